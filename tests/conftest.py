@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+def load_golden(name):
+    """-> dict of torch tensors / python scalars from tests/golden/<name>."""
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        a = z[k]
+        if a.dtype.kind in "US":
+            out[k] = [str(s) for s in a.tolist()] if a.ndim else str(a)
+        elif a.ndim == 0:
+            out[k] = a.item()
+        else:
+            out[k] = torch.from_numpy(a)
+    return out
+
+
+def golden_weights(fx, prefix="w."):
+    """Rebuild the deterministic weights a fixture was generated with (manifest + seed stored in it)."""
+    from mvsformerplusplus_amd import synth
+    keys = fx[prefix + "keys"]
+    shapes = [tuple(json.loads(s)) for s in fx[prefix + "shapes"]]
+    return synth.seeded_state_dict(dict(zip(keys, shapes)), int(fx[prefix + "seed"]))
+
+
+def rel_l1(a, b):
+    return float((a - b).abs().div(b.abs().clamp_min(1e-12)).mean())
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

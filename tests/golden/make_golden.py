@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+``/root/reference`` is a read-only mount that exists only in the build container; it never travels
+to the GPU box.  What is committed is DATA: inputs, weights (reference state-dict naming) and the
+reference's outputs as ``.npz`` - no reference source.  Fixture list = SURVEY.md §8c F1-F6.
+"""
+import io
+import json
+import os
+import sys
+
+import numpy as np
+
+REF = os.environ.get("MVS_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+
+from models.cost_volume import StageNet  # noqa: E402  (reference)
+from models.module import (CostRegNet, CostRegNet3D, conf_regression, depth_regression, init_inverse_range,  # noqa: E402
+                           init_range, schedule_inverse_range, schedule_range)
+from models.warping import homo_warping_3D_with_mask  # noqa: E402
+
+from mvsformerplusplus_amd import synth  # noqa: E402
+
+torch.set_num_threads(8)
+ARGS = {"base_ch": [8, 8, 8, 8], "depth_type": ["ce"] * 4, "fusion_type": "cnn", "cost_reg_type": ["Normal"] * 4}
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("%-36s %8.1f KB  %s" % (name, os.path.getsize(path) / 1024, sorted(out)[:6]))
+
+
+def seed_weights(module, seed, prefix="w."):
+    """Load deterministic weights (synth.seeded_state_dict) into a reference module; return the manifest
+    arrays to store in the fixture (keys + shapes + seed), not the weights themselves."""
+    man = synth.state_dict_manifest(module.state_dict())
+    module.load_state_dict(synth.seeded_state_dict(man, seed), strict=True)
+    keys = list(man)
+    return {prefix + "keys": np.array(keys), prefix + "shapes": np.array([json.dumps(list(man[k])) for k in keys]),
+            prefix + "seed": np.int64(seed)}
+
+
+def rand_cams(B, V, H, W, seed, rot_deg, baseline, scale=1.0):
+    cams = synth.make_cameras(V, H, W, baseline=baseline, rot_deg=rot_deg, seed=seed, batch=B)
+    cams[:, :, 1, :2, :] *= scale
+    return cams
+
+
+def compose(p):
+    o = p[:, 0].clone()
+    o[:, :3, :4] = torch.matmul(p[:, 1, :3, :3], p[:, 0, :3, :4])
+    return o
+
+
+@torch.no_grad()
+def f1_warp():
+    for tag, (B, C, H, W, D), rot, base in (("a", (1, 8, 16, 20, 4), 3.0, 40.0), ("b", (2, 16, 12, 16, 6), 8.0, 120.0)):
+        g = torch.Generator().manual_seed(11 + B)
+        cams = rand_cams(B, 2, H * 8, W * 8, 5 + B, rot, base, scale=1 / 8)
+        # make a slice of hypotheses sit behind the source camera / far out of frame
+        cams[:, 1, 0, 2, 3] = -300.0 if tag == "b" else 0.0
+        src_fea = torch.randn(B, C, H, W, generator=g)
+        ref_p, src_p = compose(cams[:, 0]), compose(cams[:, 1])
+        dv2 = torch.linspace(200.0, 900.0, D)[None].repeat(B, 1).contiguous()
+        dv4 = (dv2[:, :, None, None] * (1 + 0.1 * torch.rand(B, D, H, W, generator=g))).contiguous()
+        w2, m2 = homo_warping_3D_with_mask(src_fea, src_p, ref_p, dv2)
+        w4, m4 = homo_warping_3D_with_mask(src_fea, src_p, ref_p, dv4)
+        npz("f1_warp_%s.npz" % tag, src_fea=src_fea, src_proj=src_p, ref_proj=ref_p, dv2=dv2, dv4=dv4,
+            warped2=w2, mask2=m2, warped4=w4, mask4=m4)
+
+
+def stage_inputs(C, D, H, W, V, seed, dmin=425.0, dmax=935.0, down=1):
+    cams = rand_cams(1, V, H * down, W * down, seed, 2.0, 30.0, scale=1.0 / down)
+    feats = synth.make_features(cams, C, H, W, dmin=dmin + 60, dmax=dmax - 60, seed=seed, noise=0.1)
+    g = torch.Generator().manual_seed(seed)
+    base = 1.0 / torch.linspace(1.0 / dmax, 1.0 / dmin, D)            # far -> near like init_inverse_range
+    hyp = (base[None, :, None, None] * (1 + 0.02 * torch.rand(1, D, H, W, generator=g))).contiguous()
+    return feats, cams, hyp
+
+
+@torch.no_grad()
+def f2_stage():
+    for tag, stage_idx, C, D in (("s1", 1, 32, 16), ("s3", 3, 8, 4)):
+        torch.manual_seed(20 + stage_idx)
+        net = StageNet(dict(ARGS), D, stage_idx).eval()
+        wman = seed_weights(net, 200 + stage_idx)
+        feats, cams, hyp = stage_inputs(C, D, 32, 40, 3, 30 + stage_idx, down=2 ** (3 - stage_idx))
+        cap = {}
+        h = net.cost_reg.register_forward_hook(lambda m, i, o: cap.__setitem__("vol", i[0].detach().clone()))
+        out = net(feats, cams, hyp, tmp=5.0 if stage_idx < 3 else 1.0)
+        h.remove()
+        npz("f2_stage_%s.npz" % tag, features=feats, proj=cams, hyp=hyp, tmp=np.float32(5.0 if stage_idx < 3 else 1.0),
+            stage_idx=np.int32(stage_idx), volume_mean=cap["vol"], depth=out["depth"], prob_volume=out["prob_volume"],
+            photometric_confidence=out["photometric_confidence"], prob_volume_pre=out["prob_volume_pre"],
+            **wman)
+
+
+@torch.no_grad()
+def f3_regnets():
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(3)
+    net = CostRegNet(8, 8).eval()
+    wman = seed_weights(net, 31)
+    x = torch.randn(1, 8, 16, 16, 24, generator=g)
+    npz("f3_costregnet.npz", x=x, y=net.forward_once(x), **wman)
+    for D in (4, 8):
+        net = CostRegNet3D(8, 8).eval()
+        wman = seed_weights(net, 32 + D)
+        x = torch.randn(1, 8, D, 16, 24, generator=g)
+        npz("f3_costregnet3d_d%d.npz" % D, x=x, y=net.forward_once(x), **wman)
+
+
+@torch.no_grad()
+def f4_cascade():
+    """4-stage cascade from features, 64x128, V=4, all-"Normal" (logic of DINOv2_mvsformer_model.py:120-179)."""
+    import torch.nn.functional as F
+    H, W, V = 64, 128, 4
+    ndepths, ratios, tmp = [32, 16, 8, 4], [4.0, 2.67, 1.5, 1.0], [5.0, 5.0, 5.0, 1.0]
+    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=4, baseline=30.0, rot_deg=1.0)
+    torch.manual_seed(40)
+    nets = [StageNet(dict(ARGS), ndepths[i], i).eval() for i in range(4)]
+    arrs = {"depth_values": dv}
+    for i, n in enumerate(nets):
+        arrs.update(seed_weights(n, 40 + i, "w%d." % (i + 1)))
+    prob_maps = torch.zeros(1, H, W)
+    st = None
+    for s in range(4):
+        f, p = feats["stage%d" % (s + 1)], projs["stage%d" % (s + 1)]
+        h, w = f.shape[-2:]
+        if s == 0:
+            hyp = init_inverse_range(dv, ndepths[s], dv.device, dv.dtype, h, w)
+        else:
+            hyp = schedule_inverse_range(st["depth"].detach(), st["depth_values"], ndepths[s], ratios[s], h, w)
+        st = nets[s](f, p, hyp, tmp=tmp[s])
+        conf = st["photometric_confidence"]
+        if conf.shape[1] != H or conf.shape[2] != W:
+            conf = F.interpolate(conf.unsqueeze(1), [H, W], mode="nearest").squeeze(1)
+        prob_maps += conf
+        arrs["features%d" % (s + 1)] = f
+        arrs["proj%d" % (s + 1)] = p
+        arrs["hyp%d" % (s + 1)] = hyp
+        arrs["depth%d" % (s + 1)] = st["depth"]
+        arrs["conf%d" % (s + 1)] = st["photometric_confidence"]
+    arrs["refined_depth"] = st["depth"]
+    arrs["photometric_confidence"] = prob_maps / 4
+    # features dominate the size: keep them fp16-representable so the .npz compresses well but stays exact
+    npz("f4_cascade.npz", **arrs)
+
+
+@torch.no_grad()
+def f5_small_fns():
+    g = torch.Generator().manual_seed(5)
+    arrs = {}
+    for D, n in ((32, 4), (16, 3), (8, 2)):
+        p = torch.softmax(3 * torch.randn(2, D, 6, 7, generator=g), 1)
+        dv = torch.sort(torch.rand(2, D, 6, 7, generator=g) * 500 + 400, dim=1, descending=True)[0]
+        arrs["p%d" % D] = p
+        arrs["dv%d" % D] = dv
+        arrs["dreg%d" % D] = depth_regression(p, dv)
+        arrs["conf%d_n%d" % (D, n)] = conf_regression(p, n=n)
+    dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None].repeat(2, 1)
+    dv[1] = dv[1] * 1.3
+    arrs["depth_values"] = dv
+    arrs["init_range"] = init_range(dv, 8, dv.device, dv.dtype, 5, 6)
+    arrs["init_inverse_range"] = init_inverse_range(dv, 8, dv.device, dv.dtype, 5, 6)
+    prev_hyp = init_inverse_range(dv, 8, dv.device, dv.dtype, 5, 6) * (1 + 0.01 * torch.rand(2, 8, 5, 6, generator=g))
+    prev_depth = prev_hyp[:, 3] * (1 + 0.02 * torch.rand(2, 5, 6, generator=g))
+    arrs["prev_hyp"] = prev_hyp
+    arrs["prev_depth"] = prev_depth
+    arrs["schedule_inverse_range"] = schedule_inverse_range(prev_depth, prev_hyp, 4, 2.67, 10, 12)
+    itv = (dv[:, 1] - dv[:, 0]) * 1.5
+    arrs["schedule_range_itv"] = itv
+    arrs["schedule_range"] = schedule_range(prev_depth, 4, itv, 10, 12)
+    npz("f5_small_fns.npz", **arrs)
+
+
+@torch.no_grad()
+def f6_train_mode():
+    torch.manual_seed(6)
+    net = StageNet(dict(ARGS), 8, 2)
+    wman = seed_weights(net, 6)
+    feats, cams, hyp = stage_inputs(16, 8, 16, 24, 3, 36, down=2)
+    # train-mode BN would use batch statistics; the 'ce' argmax branch (cost_volume.py:109-112) is what this
+    # fixture pins, so BN layers are put in eval mode while self.training stays True on StageNet.
+    net.train()
+    for m in net.modules():
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+            m.eval()
+    out = net(feats, cams, hyp, tmp=5.0)
+    npz("f6_stage_train_ce.npz", features=feats, proj=cams, hyp=hyp, depth=out["depth"],
+        photometric_confidence=out["photometric_confidence"], prob_volume=out["prob_volume"], **wman)
+
+    # 'reg' depth type, eval (cost_volume.py:119-128) for D = 8 (conf_regression n=2)
+    args = dict(ARGS)
+    args["depth_type"] = ["reg"] * 4
+    net = StageNet(args, 8, 2).eval()
+    wman = seed_weights(net, 7)
+    out = net(feats, cams, hyp, tmp=1.0)
+    npz("f6_stage_reg.npz", features=feats, proj=cams, hyp=hyp, depth=out["depth"],
+        photometric_confidence=out["photometric_confidence"], **wman)
+
+
+if __name__ == "__main__":
+    f1_warp()
+    f2_stage()
+    f3_regnets()
+    f4_cascade()
+    f5_small_fns()
+    f6_train_mode()

@@ -1,0 +1,83 @@
+"""CPU: pin the oracle (oracle/ref_path.py) against golden vectors generated from the imported reference
+(tests/golden/make_golden.py).  This is what licenses using the oracle as the parity checker on the GPU box."""
+import pytest
+import torch
+
+from conftest import golden_weights, load_golden, rel_l1
+from oracle import ref_path as O
+
+TOL = 2e-6   # fp32 op-for-op restatement; observed <= 1e-6 (values O(1))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_f1_warp(tag):
+    fx = load_golden("f1_warp_%s.npz" % tag)
+    for dv, wk, mk in (("dv2", "warped2", "mask2"), ("dv4", "warped4", "mask4")):
+        w, m = O.homo_warping_3D_with_mask(fx["src_fea"], fx["src_proj"], fx["ref_proj"], fx[dv])
+        assert torch.equal(m, fx[mk])
+        assert (w - fx[wk]).abs().max() <= TOL
+    # the fixture must really exercise out-of-frame / behind-camera voxels
+    assert fx["mask4"].float().mean() > 0.02
+
+
+@pytest.mark.parametrize("tag", ["s1", "s3"])
+def test_f2_stage(tag):
+    fx = load_golden("f2_stage_%s.npz" % tag)
+    sd = golden_weights(fx)
+    out = O.stage_forward(fx["features"], fx["proj"], fx["hyp"], float(fx["tmp"]), sd, G=8, return_intermediates=True)
+    assert (out["volume_mean"] - fx["volume_mean"]).abs().max() <= 1e-5
+    assert (out["prob_volume_pre"] - fx["prob_volume_pre"]).abs().max() <= 1e-4
+    assert (out["prob_volume"] - fx["prob_volume"]).abs().max() <= 1e-5
+    assert (out["photometric_confidence"] - fx["photometric_confidence"]).abs().max() <= 1e-5
+    assert rel_l1(out["depth"], fx["depth"]) <= 1e-6
+
+
+@pytest.mark.parametrize("name,fn", [("f3_costregnet.npz", O.cost_regnet), ("f3_costregnet3d_d4.npz", O.cost_regnet3d),
+                                     ("f3_costregnet3d_d8.npz", O.cost_regnet3d)])
+def test_f3_regnets(name, fn):
+    fx = load_golden(name)
+    sd = {"cost_reg." + k: v for k, v in golden_weights(fx).items()}
+    y = fn(fx["x"], sd)
+    assert y.shape == fx["y"].shape
+    assert (y - fx["y"]).abs().max() <= 1e-4 * max(1.0, float(fx["y"].abs().max()))
+
+
+def test_f4_cascade():
+    fx = load_golden("f4_cascade.npz")
+    feats = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
+    projs = {"stage%d" % s: fx["proj%d" % s] for s in range(1, 5)}
+    sds = [golden_weights(fx, "w%d." % s) for s in range(1, 5)]
+    out = O.cascade_forward(feats, projs, fx["depth_values"], sds, ndepths=[32, 16, 8, 4],
+                            depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], base_ch=[8, 8, 8, 8])
+    for s in range(1, 5):
+        st = out["stage%d" % s]
+        assert rel_l1(st["depth_values"], fx["hyp%d" % s]) <= 1e-6
+        assert rel_l1(st["depth"], fx["depth%d" % s]) <= 1e-6
+        assert (st["photometric_confidence"] - fx["conf%d" % s]).abs().max() <= 1e-4
+    assert rel_l1(out["refined_depth"], fx["refined_depth"]) <= 1e-6
+    assert (out["photometric_confidence"] - fx["photometric_confidence"]).abs().max() <= 1e-4
+
+
+def test_f5_small_fns():
+    fx = load_golden("f5_small_fns.npz")
+    for D, n in ((32, 4), (16, 3), (8, 2)):
+        assert torch.allclose(O.depth_regression(fx["p%d" % D], fx["dv%d" % D]), fx["dreg%d" % D], rtol=1e-6, atol=0)
+        assert torch.allclose(O.conf_regression(fx["p%d" % D], n=n), fx["conf%d_n%d" % (D, n)], rtol=1e-6, atol=1e-7)
+    dv = fx["depth_values"]
+    assert torch.equal(O.init_range(dv, 8, 5, 6), fx["init_range"])
+    assert torch.equal(O.init_inverse_range(dv, 8, 5, 6), fx["init_inverse_range"])
+    got = O.schedule_inverse_range(fx["prev_depth"], fx["prev_hyp"], 4, 2.67, 10, 12)
+    assert torch.allclose(got, fx["schedule_inverse_range"], rtol=1e-6, atol=0)
+    got = O.schedule_range(fx["prev_depth"], 4, fx["schedule_range_itv"], 10, 12)
+    assert torch.allclose(got, fx["schedule_range"], rtol=1e-6, atol=0)
+
+
+def test_f6_train_and_reg():
+    fx = load_golden("f6_stage_train_ce.npz")
+    out = O.stage_forward(fx["features"], fx["proj"], fx["hyp"], 5.0, golden_weights(fx), G=8, training=True)
+    assert (out["depth"] != fx["depth"]).float().mean() <= 0.002      # argmax ties may flip on a rounding difference
+    assert (out["prob_volume"] - fx["prob_volume"]).abs().max() <= 1e-5
+    fx = load_golden("f6_stage_reg.npz")
+    out = O.stage_forward(fx["features"], fx["proj"], fx["hyp"], 1.0, golden_weights(fx), G=8, depth_type="reg")
+    assert rel_l1(out["depth"], fx["depth"]) <= 1e-6
+    assert (out["photometric_confidence"] - fx["photometric_confidence"]).abs().max() <= 1e-5
