@@ -1,0 +1,146 @@
+/* mvs_hip.h - C ABI of libmvs_hip.so: the MI355X (gfx950) implementation of MVSFormer++'s
+ * depth-inference hot path (homography warp -> group-wise correlation cost volume ->
+ * 3D-conv regularisation -> depth regression), SURVEY.md section 8.
+ *
+ * The reference (maybeLx/MVSFormerPlusPlus @ 2025-01-14) is pure Python/PyTorch and has no
+ * FFI of its own; the seam a maintainer binds is the set of Python callables cited next to each
+ * entry point below (file:line relative to the reference tree).  INTEGRATION.md shows the ctypes
+ * stub and the `patch_model()` swap.
+ *
+ * Calling convention
+ *   - every pointer is a DEVICE pointer unless its name ends in _host
+ *   - tensors are dense row-major with the shape given in the comment; B = batch
+ *   - `stream` is a hipStream_t passed as void*; work is only enqueued, never synchronised
+ *   - return value: MVS_OK (0) or an MVS_ERR_* code; mvs_last_error() gives the message
+ *   - no hidden global state, no allocation: scratch memory is passed in by the caller
+ *     (mvs_*_workspace_bytes tells how much)
+ *
+ * Internal activation layout ("channel-last"): [B, D, H, W, C] fp32, C in {8,16,32,64}.
+ */
+#ifndef MVS_HIP_H
+#define MVS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_ABI_VERSION 1
+
+enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
+enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
+/* depth / confidence head modes, cost_volume.py:108-128 */
+enum { MVS_HEAD_CE_EVAL = 0, MVS_HEAD_CE_TRAIN = 1, MVS_HEAD_REG = 2 };
+/* regulariser kinds, cost_volume.py:41-49 */
+enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
+
+int mvs_abi_version(void);
+const char* mvs_last_error(void);
+
+/* ---- a1 + warping.py:80-82 ---------------------------------------------------------------------
+ * proj [B,V,2,4,4] (0 = extrinsic, 1 = intrinsic; datasets/general_eval.py:211-216).
+ * For every source view v>=1: P = E.clone(); P[:3,:4] = K[:3,:3] @ E[:3,:4] (cost_volume.py:68-71),
+ * M = P_v @ inverse(P_0); homography[b, v-1] = {M[:3,:3] row-major (9), M[:3,3] (3)}.          */
+int mvs_compose_homography(const float* proj, int B, int V, float* homography /*[B,V-1,12]*/, void* stream);
+/* same from already-composed 4x4 projections (the argument form of homo_warping_3D_with_mask) */
+int mvs_homography_from_proj(const float* src_proj /*[B,4,4]*/, const float* ref_proj /*[B,4,4]*/, int B,
+                             float* homography /*[B,12]*/, void* stream);
+
+/* ---- a2/a3: models/warping.py:69-109 homo_warping_3D_with_mask ---------------------------------
+ * src_fea [B,C,H,W] (dtype), depth [B,D] (depth_is_volume=0) or [B,D,H,W] (1)
+ * -> warped [B,C,D,H,W] fp32, proj_mask [B,D,H,W] uint8 (either may be NULL).                   */
+int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* homography /*[B,12]*/, const float* depth,
+                      int depth_is_volume, float* warped, uint8_t* proj_mask, int B, int C, int D, int H, int W,
+                      void* stream);
+
+/* ---- a2-a5 fused: warp + group-wise correlation + softmax-entropy, cost_volume.py:65-92 --------
+ * features [B,V,C,H,W] (dtype; view 0 = reference), hyp [B,D,H,W]
+ * -> entropy [B,V-1,H,W].  No [C,D,H,W] or [G,D,H,W] intermediate is materialised.
+ * Only source views in [view_begin, view_end) (1-based view indices) are processed.              */
+int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homography /*[B,V-1,12]*/,
+                              const float* hyp, float* entropy, int B, int V, int C, int G, int D, int H, int W,
+                              int view_begin, int view_end, void* stream);
+
+/* ---- a5: visibility CNN, cost_volume.py:36,93 + module.py:168-197 ------------------------------
+ * entropy [N,H,W] -> vis [N,H,W] = sigmoid(conv1x1(CBR(16->8)(CBR(16->16)(CBR(1->16)(entropy))))).
+ * Packed parameters are produced by the Python side (mvsformerplusplus_amd/packing.py):
+ *   w1 [9][16] + b1[16] (BN folded), w2/w3 = MFMA-packed 3x3 weights (layout below), b2[16], b3[8]
+ *   (padded to 16), w4[8], b4[1].  workspace >= mvs_vis_workspace_bytes(N,H,W).                  */
+size_t mvs_vis_workspace_bytes(int N, int H, int W);
+int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const float* w2, const float* b2,
+                       const float* w3, const float* b3, const float* w4, const float* b4, float* vis,
+                       void* workspace, size_t workspace_bytes, int N, int H, int W, void* stream);
+
+/* ---- a4 + a6: recompute warp + correlation, weight by visibility, aggregate over views ----------
+ * cost_volume.py:79-101.  vis [B,V-1,H,W].  volume_cl [B,D,H,W,G] channel-last.
+ *   normalise = 1 : volume = sum_v ip_v*vis_v / (sum_v vis_v + 1e-6)              (single GPU)
+ *   normalise = 0 : volume = partial sum over [view_begin, view_end), vis_sum [B,H,W] = partial
+ *                   sum of vis (view-sharded multi-GPU: all-reduce both, then mvs_volume_normalise) */
+int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, const float* homography, const float* hyp,
+                                const float* vis, float* volume_cl, float* vis_sum, int normalise, int B, int V,
+                                int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream);
+int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, void* stream);
+
+/* ---- a7: Conv3d + folded BatchNorm3d + ReLU, module.py:89-126 ----------------------------------
+ * x_cl [B,D,H,W,Cin] -> y_cl [B,OD,OH,OW,Cout]; kernel (kd,3,3), kd in {1,3}, padding (kd/2,1,1),
+ * stride (sd,sh,sw) in {1,2}.  Implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).
+ * w_packed: see "MFMA weight packing" in DESIGN.md (packing.pack_conv_weights); bias [max(Cout,16)].*/
+int mvs_conv3d_bn_relu_fwd(const float* x_cl, const float* w_packed, const float* bias, float* y_cl, int B, int Cin,
+                           int Cout, int D, int H, int W, int kd, int sd, int sh, int sw, int relu, void* stream);
+
+/* ---- a7: ConvTranspose3d(k3, padding 1, stride (sd,2,2), output_padding (sd-1,1,1)) + BN + ReLU,
+ * then + skip (module.py:129-165, 402-405, 467-481, 498-501).
+ * x_cl [B,D,H,W,Cin] -> y_cl [B,D*sd,2H,2W,Cout]; skip_cl has y's shape (NULL = no skip).          */
+int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const float* w_packed, const float* bias, const float* skip_cl,
+                                 float* y_cl, int B, int Cin, int Cout, int D, int H, int W, int sd, void* stream);
+
+/* ---- a8/a9: whole regulariser U-Net (CostRegNet / CostRegNet3D), module.py:367-408 / 453-504 ----
+ * volume_cl [B,D,H,W,8] -> feat_cl [B,D,H,W,8] = conv0 + relu(bn(deconv11(...))) (input of `prob`).
+ * params: 9 packed weight pointers + 9 bias pointers in layer order conv1..conv6, conv7, conv9, conv11.*/
+size_t mvs_regnet_workspace_bytes(int kind, int B, int D, int H, int W);
+int mvs_regnet_fwd(int kind, const float* volume_cl, const float* const* w_packed, const float* const* bias,
+                   float* feat_cl, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, void* stream);
+
+/* ---- a8/a9 `prob` + a10 + a11: logits, softmax, depth regression, confidence --------------------
+ * feat_cl [B,D,H,W,8]; prob_w: [8] (+ prob_b[1]) for the 1x1x1 head (CostRegNet3D, module.py:486)
+ * or [27][8] tap-major for the 3x3x3 head without bias (CostRegNet, module.py:391; prob_b = NULL).
+ * hyp [B,D,H,W].  mode: MVS_HEAD_*.  conf_n: window of conf_regression for MVS_HEAD_REG (0 = max prob).
+ * Outputs (any of prob_volume / prob_volume_pre may be NULL): depth [B,H,W], conf [B,H,W],
+ * prob_volume [B,D,H,W], prob_volume_pre [B,D,H,W].                                                */
+int mvs_prob_regress_fwd(const float* feat_cl, const float* prob_w, const float* prob_b, int prob_ksize,
+                         const float* hyp, float tmp, int mode, int conf_n, float* depth, float* conf,
+                         float* prob_volume, float* prob_volume_pre, int B, int D, int H, int W, void* stream);
+/* same head on precomputed logits [B,D,H,W] (depth_regression / conf_regression callers) */
+int mvs_softmax_regress_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth,
+                            float* conf, float* prob_volume, int B, int D, int H, int W, void* stream);
+
+/* module.py:649-671 as free functions on a probability volume p [B,D,H,W]:
+ * depth_regression: out = sum_d p*depth_values (depth_values [B,D,H,W]); conf_regression: window sum of n. */
+int mvs_depth_regression_fwd(const float* p, const float* depth_values, float* out, int B, int D, int H, int W, void* stream);
+int mvs_conf_regression_fwd(const float* p, int n, float* out, int B, int D, int H, int W, void* stream);
+
+/* ---- a13-a15: hypothesis ranges, module.py:674-741 ----------------------------------------------*/
+int mvs_init_range_fwd(const float* depth_values /*[B,N]*/, int N, int inverse, float* hyp /*[B,D,H,W]*/, int B,
+                       int D, int H, int W, void* stream);
+/* prev_depth [B,H/2,W/2], prev_hyp [B,Dprev,H/2,W/2] -> hyp [B,D,H,W]; ratio = depth_interals_ratio */
+int mvs_schedule_inverse_range_fwd(const float* prev_depth, const float* prev_hyp, int Dprev, float ratio,
+                                   float* hyp, int B, int D, int H, int W, void* stream);
+/* interval [B] = depth_interals_ratio * depth_interval (module.py:727-741) */
+int mvs_schedule_range_fwd(const float* prev_depth, const float* interval, float* hyp, int B, int D, int H, int W,
+                           void* stream);
+
+/* ---- a16: confidence fusion, DINOv2_mvsformer_model.py:167-177 -----------------------------------
+ * out[b,y,x] = mean_s conf_s[b, y >> shift_s, x >> shift_s] (nearest upsample), n_stages <= 8.      */
+int mvs_confidence_average(const float* const* conf_host_ptrs, const int* shifts_host, int n_stages, float* out,
+                           int B, int H, int W, void* stream);
+
+/* ---- layout helpers for the nn.Module-level API (NCDHW <-> channel-last) -------------------------*/
+int mvs_ncdhw_to_cl(const float* x, float* y_cl, int B, int C, int D, int H, int W, void* stream);
+int mvs_cl_to_ncdhw(const float* x_cl, float* y, int B, int C, int D, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of libmvs_hip.so (C ABI: include/mvs_hip.h).
+
+There is NO fallback: if the gfx950 library has not been built (``python -m mvsformerplusplus_amd.build``)
+importing an op raises, and every op refuses tensors that are not on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
+
+OK = 0
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
+REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mvs_hip.h one to one
+SIGNATURES = {
+    "mvs_abi_version": (_i, []),
+    "mvs_last_error": (C.c_char_p, []),
+    "mvs_compose_homography": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mvs_homography_from_proj": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mvs_homo_warp_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "mvs_vis_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _vp]),
+    "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i] + [_i] * 9 + [_vp]),
+    "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+    "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
+    "mvs_regnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "mvs_regnet_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "mvs_prob_regress_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_softmax_regress_fwd": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_depth_regression_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_conf_regression_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_init_range_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_schedule_inverse_range_fwd": (_i, [_vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_schedule_range_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_confidence_average": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "mvs_ncdhw_to_cl": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_cl_to_ncdhw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+}
+
+
+class MvsHipError(RuntimeError):
+    pass
+
+
+def bind(path: str) -> C.CDLL:
+    """Load a build of the C ABI and attach prototypes for every symbol the header declares."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvs_abi_version() != 1:
+        raise MvsHipError("libmvs_hip ABI version mismatch: %d" % lib.mvs_abi_version())
+    return lib
+
+
+_LIB: Optional[C.CDLL] = None
+_REQUIRE_DEVICE = True        # product behaviour; only tests/hipemu flips this for host-emulated kernels
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MvsHipError("%s not found: build the gfx950 HIP library first (python -m mvsformerplusplus_amd.build). "
+                              "There is no CPU/PyTorch fallback for this path." % LIB_PATH)
+        _LIB = bind(LIB_PATH)
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        msg = lib().mvs_last_error()
+        raise MvsHipError("%s failed (code %d): %s" % (what or "libmvs_hip call", rc, msg.decode() if msg else "?"))
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Raw address of a dense tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise MvsHipError("internal: non-contiguous tensor handed to the C ABI")
+    if _REQUIRE_DEVICE and not t.is_cuda:
+        raise MvsHipError("libmvs_hip needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+    return t.data_ptr()
+
+
+def stream_of(t: torch.Tensor) -> Optional[int]:
+    """The caller's current HIP stream (work is enqueued there, like any torch op)."""
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None

@@ -1,0 +1,56 @@
+"""Build libmvs_hip.so (gfx950) in-tree with hipcc.  `python -m mvsformerplusplus_amd.build`.
+
+hipcc cross-compiles without a GPU.  The shared object lands next to the sources
+(mvsformerplusplus_amd/csrc/libmvs_hip.so) so that it travels with a repo snapshot to the GPU box; it is
+git-ignored.  No CPU fallback exists: the package refuses to work without this library.
+"""
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libmvs_hip.so")
+STAMP = os.path.join(CSRC, ".libmvs_hip.stamp")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
+
+
+def _digest():
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                   glob.glob(os.path.join(HERE, "..", "include", "*.h")))
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+        return LIB
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    objs, procs = [], []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(o)
+    for cmd, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
+        if verbose and out.strip():
+            print(out)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    for o in objs:
+        os.remove(o)
+    with open(STAMP, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,82 @@
+"""The cascade driver of the depth hot path and the drop-in helper.
+
+The reference keeps this loop inside its top-level model (``models/networks/DINOv2_mvsformer_model.py:120-179``,
+copy in ``casmvs_model.py:68-130``), interleaved with the image backbone.  The reference's Python never reaches the
+GPU box, so the hot path ships its own driver: ``CascadeDepthHead`` consumes the per-stage feature maps the
+backbone would produce and returns the same output dictionary (``stageK`` dicts, ``refined_depth``,
+``photometric_confidence``).  ``patch_model`` swaps ``model.fusions[i]`` of a reference model in place.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import module as M
+from . import ops
+from .cost_volume import StageNet
+
+
+class CascadeDepthHead(nn.Module):
+    """features{stageK:[B,V,C,H,W]}, proj_matrices{stageK:[B,V,2,4,4]}, depth_values[B,N], tmp -> outputs dict.
+
+    ``args`` are the reference's ``arch.args`` (config/mvsformer++.json): ``ndepths``, ``depth_interals_ratio``,
+    ``inverse_depth``, ``base_ch``, ``depth_type``, ``cost_reg_type`` (only "Normal" is built here), ``model_th``.
+    """
+
+    def __init__(self, args: dict):
+        super().__init__()
+        self.args = args
+        self.ndepths = list(args["ndepths"])
+        self.depth_interals_ratio = list(args["depth_interals_ratio"])
+        self.inverse_depth = args.get("inverse_depth", False)
+        self.fusions = nn.ModuleList([StageNet(args, self.ndepths[i], i) for i in range(len(self.ndepths))])
+
+    def set_view_group(self, group) -> None:
+        """Shard source views over the ranks of `group` (RCCL all-reduce of partial cost volumes per stage)."""
+        for f in self.fusions:
+            f.view_group = group
+
+    def forward(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
+                tmp: Sequence[float] = (5.0, 5.0, 5.0, 1.0)) -> Dict[str, torch.Tensor]:
+        n = len(self.ndepths)
+        depth_interval = depth_values[:, 1] - depth_values[:, 0]
+        outputs: Dict[str, torch.Tensor] = {}
+        stage_out: Optional[Dict[str, torch.Tensor]] = None
+        confs: List[torch.Tensor] = []
+        for s in range(n):
+            key = "stage%d" % (s + 1)
+            feat, proj = features[key], proj_matrices[key]
+            H, W = feat.shape[-2:]
+            if s == 0:
+                hyp = ops.init_range(depth_values, self.ndepths[s], H, W, inverse=self.inverse_depth)
+            elif self.inverse_depth:
+                hyp = ops.schedule_inverse_range(stage_out["depth"], stage_out["depth_values"], self.ndepths[s],
+                                                 self.depth_interals_ratio[s], H, W)
+            else:
+                hyp = ops.schedule_range(stage_out["depth"], self.ndepths[s], self.depth_interals_ratio[s] * depth_interval, H, W)
+            stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s])
+            outputs[key] = stage_out
+            confs.append(stage_out["photometric_confidence"])
+            outputs.update(stage_out)
+        Hf, Wf = features["stage%d" % n].shape[-2:]
+        outputs["refined_depth"] = stage_out["depth"]
+        outputs["photometric_confidence"] = ops.confidence_average(confs, Hf, Wf)
+        return outputs
+
+
+def patch_model(model: nn.Module) -> nn.Module:
+    """Swap every ``model.fusions[i]`` (a reference ``models.cost_volume.StageNet``) for the HIP ``StageNet``.
+
+    Parameters are carried over with ``load_state_dict(strict=True)``; device and train/eval mode are preserved.
+    The rest of the reference model (backbone, FMT, cascade loop) keeps calling ``fusions[i].forward(...)`` as before.
+    """
+    for i, old in enumerate(model.fusions):
+        new = StageNet(old.args, old.ndepth, old.stage_idx)
+        new.load_state_dict(old.state_dict(), strict=True)
+        p = next(old.parameters())
+        new = new.to(p.device)
+        new.train(old.training)
+        model.fusions[i] = new
+    return model

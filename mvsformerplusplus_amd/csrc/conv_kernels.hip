@@ -1,0 +1,467 @@
+// 3D-conv regulariser kernels: implicit-GEMM Conv3d / ConvTranspose3d
+// with folded BatchNorm + ReLU (+ skip add) on v_mfma_f32_16x16x4_f32, i.e. exact fp32 contraction - bf16
+// inputs can break the 1e-3 depth bar when the logits are peaky.
+//
+// GEMM view of one workgroup (256 threads = 4 waves):
+//     D[cout, voxel] += W[cout, k] * X[k, voxel],    k = (tap, cin)
+//   * A operand = packed weights (rows = 16 output channels), read straight from global/L2 in the
+//     exact per-lane order the MFMA wants (1 KiB contiguous per wave-instruction, see packing.py)
+//   * B operand = activations of 16 consecutive output x-positions ("n-block"), read from an LDS copy of the
+//     input tile + halo, channel-last with the voxel stride padded to CH+4 floats so that the 16 lanes of
+//     a ds_read_b128 group fall into different 16-byte bank slots
+//   * one ds_read_b128 / global_load_dwordx4 feeds FOUR MFMAs: lane group g = lane>>4 supplies k-quad
+//     kq = 4*step + g and component s of its float4 is used by MFMA s (the MFMA's k index is only a label:
+//     any bijection works as long as A and B agree)
+//   * D fragment: lane (voxel = lane&15, g) holds output channels 16*mb + 4*g + 0..3 -> one float4 store into
+//     the channel-last output, fused with bias (folded BN), ReLU and the U-Net skip add
+// Activations are channel-last fp32 [B, D, H, W, C].
+#include "mvs_common.h"
+
+namespace mvs {
+
+// ------------------------------------------------------------------------------------------------
+// Conv3d (kd,3,3), padding (kd/2,1,1), stride (SD,SH,SW)                      module.py:89-126
+// ------------------------------------------------------------------------------------------------
+template <int CIN_, int COUT_, int KD_, int SD_, int SH_, int SW_, int TD_, int TH_, int CH_>
+struct ConvCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_, SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, CH = CH_;
+    static constexpr int TW = 16;
+    static constexpr int PD = KD / 2;
+    static constexpr int ID = (TD - 1) * SD + KD, IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
+    static constexpr int NVOX = ID * IH * IW;
+    static constexpr int S = CH + 4;                 // padded voxel stride (floats)
+    static constexpr int QC = CH / 4;                // channel quads per tap and pass
+    static constexpr int NPASS = CIN / CH;
+    static constexpr int NTAP = KD * 9;
+    static constexpr int NSTEP = (NTAP * QC + 3) / 4;
+    static constexpr int MREP = (COUT + 15) / 16;
+    static constexpr int NB = TD * TH;
+    static constexpr int NREP = NB / 4;
+    static constexpr size_t LDS_BYTES = (size_t)NVOX * S * sizeof(float);
+    static_assert(CIN % CH == 0 && CH % 4 == 0 && NB % 4 == 0, "bad conv tile configuration");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W,
+                                                          int OD, int OH, int OW, int relu, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, SH = Cfg::SH, SW = Cfg::SW, TD = Cfg::TD, TH = Cfg::TH, CH = Cfg::CH;
+    constexpr int IH = Cfg::IH, IW = Cfg::IW, S = Cfg::S, QC = Cfg::QC, NSTEP = Cfg::NSTEP, MREP = Cfg::MREP, NREP = Cfg::NREP;
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
+    const int b = (int)blockIdx.y;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y, tz = tile / tiles_y;
+    const int oz0 = tz * TD, oy0 = ty * TH, ox0 = tx * 16;
+    const int iz0 = oz0 * SD - Cfg::PD, iy0 = oy0 * SH - 1, ix0 = ox0 * SW - 1;
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int mb = 0; mb < MREP; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NREP; ++nb) acc[mb][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    int voxbase[NREP];
+#pragma unroll
+    for (int nb = 0; nb < NREP; ++nb) {
+        const int nbg = wave * NREP + nb;
+        const int oz = nbg / TH, oy = nbg % TH;
+        voxbase[nb] = (((oz * SD) * IH + oy * SH) * IW + li * SW) * S;
+    }
+
+    const float* xb = x + (size_t)b * D * H * W * CIN;
+    for (int pass = 0; pass < Cfg::NPASS; ++pass) {
+        if (pass > 0) __syncthreads();                       // everyone is done reading the previous chunk
+        // ---- stage the input tile (+halo) of channel chunk `pass` into LDS, zero-filled outside the volume ----
+        for (int e = tid; e < Cfg::NVOX * QC; e += 256) {
+            const int vox = e / QC, cq = e - vox * QC;
+            const int dx = vox % IW;
+            const int t2 = vox / IW;
+            const int dy = t2 % IH, dz = t2 / IH;
+            const int z = iz0 + dz, yy = iy0 + dy, xx = ix0 + dx;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v = *reinterpret_cast<const float4*>(xb + (((size_t)z * H + yy) * W + xx) * CIN + pass * CH + cq * 4);
+            *reinterpret_cast<float4*>(lds + vox * S + cq * 4) = v;
+        }
+        __syncthreads();
+        // ---- contraction over (tap, cin) of this chunk ----
+        const float* wpass = wp + (size_t)pass * NSTEP * MREP * 256;
+#pragma unroll 2
+        for (int t = 0; t < NSTEP; ++t) {
+            const int kq = 4 * t + g;
+            int tap = kq / QC;
+            const int cq = kq - tap * QC;
+            tap = tap < Cfg::NTAP ? tap : Cfg::NTAP - 1;        // padded quads carry zero weights
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int tapoff = ((kd * IH + kh) * IW + kw) * S + cq * 4;
+            float4 a[MREP];
+#pragma unroll
+            for (int mb = 0; mb < MREP; ++mb) a[mb] = *reinterpret_cast<const float4*>(wpass + ((size_t)(t * MREP + mb) * 64 + lane) * 4);
+            float4 bv[NREP];
+#pragma unroll
+            for (int nb = 0; nb < NREP; ++nb) bv[nb] = *reinterpret_cast<const float4*>(lds + voxbase[nb] + tapoff);
+#pragma unroll
+            for (int mb = 0; mb < MREP; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NREP; ++nb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, bv[nb].x, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, bv[nb].y, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, bv[nb].z, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, bv[nb].w, acc[mb][nb], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: + bias (folded BN), ReLU, channel-last float4 store ----
+    float* yb = y + (size_t)b * OD * OH * OW * COUT;
+#pragma unroll
+    for (int nb = 0; nb < NREP; ++nb) {
+        const int nbg = wave * NREP + nb;
+        const int oz = oz0 + nbg / TH, oy = oy0 + nbg % TH, ox = ox0 + li;
+        if (oz >= OD || oy >= OH || ox >= OW) continue;
+        float* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
+#pragma unroll
+        for (int mb = 0; mb < MREP; ++mb) {
+            const int co = 16 * mb + 4 * g;
+            if (co >= COUT) continue;
+            const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+            float4 v = make_float4(acc[mb][nb][0] + bb.x, acc[mb][nb][1] + bb.y, acc[mb][nb][2] + bb.z, acc[mb][nb][3] + bb.w);
+            if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+            *reinterpret_cast<float4*>(o + co) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose3d k=3, padding 1, stride (SD,2,2), output_padding (SD-1,1,1) + BN + ReLU (+ skip)
+//                                                          module.py:129-165, 381-383, 466-481
+// Output voxel o = stride*m + parity.  Per axis with stride 2: parity 0 <- (k=1, input m); parity 1 <-
+// (k=0, input m+1) and (k=2, input m).  Depth axis with stride 1: o = m <- (k=0, m+1), (k=1, m), (k=2, m-1).
+// The input tile (all CIN channels, +1 halo) is staged once and reused by the 4 / 8 parity classes.
+// ------------------------------------------------------------------------------------------------
+template <int CIN_, int COUT_, int SD_, int TDM_, int THM_>
+struct DeconvCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, SD = SD_, TDM = TDM_, THM = THM_;
+    static constexpr int LD = (SD == 2) ? TDM + 1 : TDM + 2;
+    static constexpr int ZO = (SD == 2) ? 0 : 1;          // LDS z index of tile-local m = 0
+    static constexpr int LH = THM + 1, LW = 17;
+    static constexpr int NVOX = LD * LH * LW;
+    static constexpr int S = CIN + 4;
+    static constexpr int QC = CIN / 4;
+    static constexpr int NQ = CIN / 16;
+    static constexpr int MREP = (COUT + 15) / 16;
+    static constexpr int NB = TDM * THM;
+    static constexpr int NREP = NB / 4;
+    static constexpr size_t LDS_BYTES = (size_t)NVOX * S * sizeof(float);
+    static_assert(CIN % 16 == 0 && NB % 4 == 0, "bad deconv tile configuration");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                            const float* __restrict__ bias, const float* __restrict__ skip,
+                                                            float* __restrict__ y, int D, int H, int W, int tiles_x, int tiles_y,
+                                                            int ntiles) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, TDM = Cfg::TDM, THM = Cfg::THM;
+    constexpr int LH = Cfg::LH, LW = Cfg::LW, S = Cfg::S, QC = Cfg::QC, NQ = Cfg::NQ, MREP = Cfg::MREP, NREP = Cfg::NREP;
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
+    const int b = (int)blockIdx.y;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y, tz = tile / tiles_y;
+    const int mz0 = tz * TDM, my0 = ty * THM, mx0 = tx * 16;
+    const int OD = D * SD, OH = 2 * H, OW = 2 * W;
+
+    // ---- stage input tile: z in [mz0 - ZO, ...), y in [my0, my0 + THM], x in [mx0, mx0 + 16] ----
+    const float* xb = x + (size_t)b * D * H * W * CIN;
+    for (int e = tid; e < Cfg::NVOX * QC; e += 256) {
+        const int vox = e / QC, cq = e - vox * QC;
+        const int dx = vox % LW;
+        const int t2 = vox / LW;
+        const int dy = t2 % LH, dz = t2 / LH;
+        const int z = mz0 - Cfg::ZO + dz, yy = my0 + dy, xx = mx0 + dx;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (z >= 0 && z < D && yy < H && xx < W)
+            v = *reinterpret_cast<const float4*>(xb + (((size_t)z * H + yy) * W + xx) * CIN + cq * 4);
+        *reinterpret_cast<float4*>(lds + vox * S + cq * 4) = v;
+    }
+    __syncthreads();
+
+    int voxbase[NREP];
+#pragma unroll
+    for (int nb = 0; nb < NREP; ++nb) {
+        const int nbg = wave * NREP + nb;
+        const int mz = nbg / THM, my = nbg % THM;
+        voxbase[nb] = (((mz + Cfg::ZO) * LH + my) * LW + li) * S + g * 4;
+    }
+    float* yb = y + (size_t)b * OD * OH * OW * COUT;
+    const float* sb = skip ? skip + (size_t)b * OD * OH * OW * COUT : nullptr;
+
+    constexpr int NCLS = (SD == 2 ? 2 : 1) * 4;
+    for (int cls = 0; cls < NCLS; ++cls) {
+        const int pw = cls & 1, ph = (cls >> 1) & 1, pd = (SD == 2) ? (cls >> 2) : 0;
+        f32x4 acc[MREP][NREP];
+#pragma unroll
+        for (int mb = 0; mb < MREP; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NREP; ++nb) acc[mb][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+        const int nkd = (SD == 2) ? (pd ? 2 : 1) : 3;
+        const int nkh = ph ? 2 : 1, nkw = pw ? 2 : 1;
+        for (int a_d = 0; a_d < nkd; ++a_d) {
+            // (kernel index, input offset) along depth
+            const int kd = (SD == 2) ? (pd ? 2 * a_d : 1) : a_d;
+            const int od = (SD == 2) ? (pd ? 1 - a_d : 0) : 1 - a_d;
+            for (int a_h = 0; a_h < nkh; ++a_h) {
+                const int kh = ph ? 2 * a_h : 1, oh = ph ? 1 - a_h : 0;
+                for (int a_w = 0; a_w < nkw; ++a_w) {
+                    const int kw = pw ? 2 * a_w : 1, ow = pw ? 1 - a_w : 0;
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+                    const int ldsoff = ((od * LH + oh) * LW + ow) * S;
+                    const float* wtap = wp + (size_t)tap * NQ * MREP * 256;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float4 a[MREP];
+#pragma unroll
+                        for (int mb = 0; mb < MREP; ++mb) a[mb] = *reinterpret_cast<const float4*>(wtap + ((size_t)(q * MREP + mb) * 64 + lane) * 4);
+                        float4 bv[NREP];
+#pragma unroll
+                        for (int nb = 0; nb < NREP; ++nb) bv[nb] = *reinterpret_cast<const float4*>(lds + voxbase[nb] + ldsoff + q * 16);
+#pragma unroll
+                        for (int mb = 0; mb < MREP; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NREP; ++nb) {
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, bv[nb].x, acc[mb][nb], 0, 0, 0);
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, bv[nb].y, acc[mb][nb], 0, 0, 0);
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, bv[nb].z, acc[mb][nb], 0, 0, 0);
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, bv[nb].w, acc[mb][nb], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+        }
+        // ---- epilogue of this parity class: relu(acc + bias) + skip ----
+#pragma unroll
+        for (int nb = 0; nb < NREP; ++nb) {
+            const int nbg = wave * NREP + nb;
+            const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
+            if (mz >= D || my >= H || mx >= W) continue;
+            const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + pw;
+            const size_t off = (((size_t)oz * OH + oy) * OW + ox) * COUT;
+#pragma unroll
+            for (int mb = 0; mb < MREP; ++mb) {
+                const int co = 16 * mb + 4 * g;
+                if (co >= COUT) continue;
+                const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+                float4 v = make_float4(fmaxf(acc[mb][nb][0] + bb.x, 0.0f), fmaxf(acc[mb][nb][1] + bb.y, 0.0f),
+                                       fmaxf(acc[mb][nb][2] + bb.z, 0.0f), fmaxf(acc[mb][nb][3] + bb.w, 0.0f));
+                if (sb) {
+                    const float4 sk = *reinterpret_cast<const float4*>(sb + off + co);
+                    v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;     // skip is added AFTER the ReLU (module.py:402-405)
+                }
+                *reinterpret_cast<float4*>(yb + off + co) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// visibility CNN ends (cost_volume.py:36): 1 -> 16 3x3 conv + BN + ReLU, and 8 -> 1 1x1 conv + sigmoid
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vis_conv1_kernel(const float* __restrict__ ent, const float* __restrict__ w1 /*[9][16]*/,
+                                                        const float* __restrict__ b1 /*[16]*/, float* __restrict__ out /*[N,H,W,16]*/,
+                                                        int H, int W) {
+    const int HW = H * W;
+    const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int n = (int)blockIdx.y;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    const float* e = ent + (size_t)n * HW;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int yy = y + kh - 1, xx = x + kw - 1;
+            const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? e[yy * W + xx] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] += v * w1[(kh * 3 + kw) * 16 + c];
+        }
+    float4* o = reinterpret_cast<float4*>(out + ((size_t)n * HW + p) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        o[q] = make_float4(fmaxf(acc[4 * q] + b1[4 * q], 0.0f), fmaxf(acc[4 * q + 1] + b1[4 * q + 1], 0.0f),
+                           fmaxf(acc[4 * q + 2] + b1[4 * q + 2], 0.0f), fmaxf(acc[4 * q + 3] + b1[4 * q + 3], 0.0f));
+}
+
+__global__ __launch_bounds__(256) void vis_out_kernel(const float* __restrict__ x /*[N,H,W,8]*/, const float* __restrict__ w4,
+                                                      const float* __restrict__ b4, float* __restrict__ vis, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float4* f = reinterpret_cast<const float4*>(x + i * 8);
+    const float4 a = f[0], c = f[1];
+    float v = a.x * w4[0];
+    v += a.y * w4[1]; v += a.z * w4[2]; v += a.w * w4[3];
+    v += c.x * w4[4]; v += c.y * w4[5]; v += c.z * w4[6]; v += c.w * w4[7];
+    v += b4[0];
+    vis[i] = 1.0f / (1.0f + expf(-v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+template <class Cfg>
+static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int D, int H, int W, int relu, hipStream_t st) {
+    const int OD = (D + 2 * Cfg::PD - Cfg::KD) / Cfg::SD + 1, OH = (H - 1) / Cfg::SH + 1, OW = (W - 1) / Cfg::SW + 1;
+    const int tx = (int)ceil_div(OW, 16), ty = (int)ceil_div(OH, Cfg::TH), tz = (int)ceil_div(OD, Cfg::TD);
+    const int ntiles = tx * ty * tz;
+    if (Cfg::LDS_BYTES > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((conv3d_mfma_kernel<Cfg>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
+    return check_launch("conv3d_mfma_kernel");
+}
+
+template <class Cfg>
+static int launch_deconv(const float* x, const float* wp, const float* bias, const float* skip, float* y, int B, int D, int H, int W, hipStream_t st) {
+    const int tx = (int)ceil_div(W, 16), ty = (int)ceil_div(H, Cfg::THM), tz = (int)ceil_div(D, Cfg::TDM);
+    const int ntiles = tx * ty * tz;
+    if (Cfg::LDS_BYTES > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((deconv3d_mfma_kernel<Cfg>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, skip, y, D, H, W, tx, ty, ntiles);
+    return check_launch("deconv3d_mfma_kernel");
+}
+
+// Tile configurations.  stride-1: 4x4x16 outputs, 16-channel chunks (648-voxel halo tile, 51 KiB -> 3 blocks/CU);
+// strided: 2x4x16 outputs, 8-channel chunks (57-71 KiB -> 2 blocks/CU); 2-D (vis CNN): 1x16x16 outputs.
+int conv3d_dispatch(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
+                    int sd, int sh, int sw, int relu, hipStream_t st) {
+#define MVS_CONV(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                  \
+    if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW)                      \
+        return launch_conv<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>(x, wp, bias, y, B, D, H, W, relu, st);
+    MVS_CONV(16, 16, 3, 1, 1, 1, 4, 4, 16)
+    MVS_CONV(32, 32, 3, 1, 1, 1, 4, 4, 16)
+    MVS_CONV(64, 64, 3, 1, 1, 1, 4, 4, 16)
+    MVS_CONV(8, 16, 3, 2, 2, 2, 2, 4, 8)
+    MVS_CONV(16, 32, 3, 2, 2, 2, 2, 4, 8)
+    MVS_CONV(32, 64, 3, 2, 2, 2, 2, 4, 8)
+    MVS_CONV(8, 16, 3, 1, 2, 2, 2, 4, 8)
+    MVS_CONV(16, 32, 3, 1, 2, 2, 2, 4, 8)
+    MVS_CONV(32, 64, 3, 1, 2, 2, 2, 4, 8)
+    MVS_CONV(16, 16, 1, 1, 1, 1, 1, 16, 16)
+    MVS_CONV(16, 8, 1, 1, 1, 1, 1, 16, 16)
+#undef MVS_CONV
+    set_error("conv3d: no kernel for Cin=%d Cout=%d kernel=(%d,3,3) stride=(%d,%d,%d)", Cin, Cout, kd, sd, sh, sw);
+    return MVS_ERR_UNSUPPORTED;
+}
+
+int deconv3d_dispatch(const float* x, const float* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout, int D,
+                      int H, int W, int sd, hipStream_t st) {
+#define MVS_DECONV(CI, CO, SD, TDM, THM)                                                                \
+    if (Cin == CI && Cout == CO && sd == SD) return launch_deconv<DeconvCfg<CI, CO, SD, TDM, THM>>(x, wp, bias, skip, y, B, D, H, W, st);
+    MVS_DECONV(64, 32, 2, 2, 4)
+    MVS_DECONV(32, 16, 2, 4, 4)
+    MVS_DECONV(16, 8, 2, 4, 4)
+    MVS_DECONV(64, 32, 1, 2, 2)
+    MVS_DECONV(32, 16, 1, 4, 4)
+    MVS_DECONV(16, 8, 1, 4, 4)
+#undef MVS_DECONV
+    set_error("deconv3d: no kernel for Cin=%d Cout=%d stride=(%d,2,2)", Cin, Cout, sd);
+    return MVS_ERR_UNSUPPORTED;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_conv3d_bn_relu_fwd(const float* x_cl, const float* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout,
+                                      int D, int H, int W, int kd, int sd, int sh, int sw, int relu, void* stream) {
+    if (!x_cl || !w_packed || !bias || !y_cl || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_conv3d_bn_relu_fwd: bad arguments"); return MVS_ERR_ARG; }
+    return conv3d_dispatch(x_cl, w_packed, bias, y_cl, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, (hipStream_t)stream);
+}
+
+extern "C" int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const float* w_packed, const float* bias, const float* skip_cl, float* y_cl,
+                                            int B, int Cin, int Cout, int D, int H, int W, int sd, void* stream) {
+    if (!x_cl || !w_packed || !bias || !y_cl || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_deconv3d_bn_relu_add_fwd: bad arguments"); return MVS_ERR_ARG; }
+    return deconv3d_dispatch(x_cl, w_packed, bias, skip_cl, y_cl, B, Cin, Cout, D, H, W, sd, (hipStream_t)stream);
+}
+
+extern "C" size_t mvs_vis_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * 32 * sizeof(float); }
+
+extern "C" int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                  const float* b3, const float* w4, const float* b4, float* vis, void* workspace, size_t workspace_bytes,
+                                  int N, int H, int W, void* stream) {
+    if (!entropy || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4 || !vis || !workspace || N < 1 || H < 1 || W < 1) { set_error("mvs_vis_weight_fwd: bad arguments"); return MVS_ERR_ARG; }
+    if (workspace_bytes < mvs_vis_workspace_bytes(N, H, W)) { set_error("mvs_vis_weight_fwd: workspace too small (%zu < %zu)", workspace_bytes, mvs_vis_workspace_bytes(N, H, W)); return MVS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t HW = (size_t)H * W;
+    float* t1 = static_cast<float*>(workspace);          // [N,H,W,16]
+    float* t2 = t1 + (size_t)N * HW * 16;                // [N,H,W,16]
+    hipLaunchKernelGGL(vis_conv1_kernel, dim3(ceil_div((long long)HW, 256), N), dim3(256), 0, st, entropy, w1, b1, t1, H, W);
+    int rc = check_launch("vis_conv1_kernel");
+    if (rc != MVS_OK) return rc;
+    rc = conv3d_dispatch(t1, w2, b2, t2, 1, 16, 16, N, H, W, 1, 1, 1, 1, 1, st);      // views ride on the depth axis, kd = 1
+    if (rc != MVS_OK) return rc;
+    rc = conv3d_dispatch(t2, w3, b3, t1, 1, 16, 8, N, H, W, 1, 1, 1, 1, 1, st);       // -> [N,H,W,8] in t1
+    if (rc != MVS_OK) return rc;
+    const size_t total = (size_t)N * HW;
+    hipLaunchKernelGGL(vis_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, t1, w4, b4, vis, total);
+    return check_launch("vis_out_kernel");
+}
+
+// level sizes of the U-Net: CostRegNet halves D,H,W per level, CostRegNet3D halves H,W only
+static void regnet_level(int kind, int lvl, int D, int H, int W, int* d, int* h, int* w) {
+    *d = (kind == MVS_REG_COSTREGNET) ? (D >> lvl) : D;
+    *h = H >> lvl;
+    *w = W >> lvl;
+}
+
+extern "C" size_t mvs_regnet_workspace_bytes(int kind, int B, int D, int H, int W) {
+    size_t total = 0;
+    for (int lvl = 1; lvl <= 3; ++lvl) {
+        int d, h, w;
+        regnet_level(kind, lvl, D, H, W, &d, &h, &w);
+        total += (size_t)2 * B * d * h * w * (8u << lvl);
+    }
+    return total * sizeof(float);
+}
+
+extern "C" int mvs_regnet_fwd(int kind, const float* volume_cl, const float* const* w_packed, const float* const* bias, float* feat_cl,
+                              void* workspace, size_t workspace_bytes, int B, int D, int H, int W, void* stream) {
+    if (!volume_cl || !w_packed || !bias || !feat_cl || !workspace || B < 1) { set_error("mvs_regnet_fwd: bad arguments"); return MVS_ERR_ARG; }
+    if (kind != MVS_REG_COSTREGNET && kind != MVS_REG_COSTREGNET3D) { set_error("mvs_regnet_fwd: unknown regulariser kind %d", kind); return MVS_ERR_ARG; }
+    if ((H % 8) || (W % 8) || (kind == MVS_REG_COSTREGNET && (D % 8))) {
+        set_error("mvs_regnet_fwd: spatial size %dx%dx%d must be divisible by 8 (U-Net skip adds, module.py:403-405)", D, H, W);
+        return MVS_ERR_ARG;
+    }
+    if (workspace_bytes < mvs_regnet_workspace_bytes(kind, B, D, H, W)) { set_error("mvs_regnet_fwd: workspace too small"); return MVS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int sd = (kind == MVS_REG_COSTREGNET) ? 2 : 1;
+    int d1, h1, w1, d2, h2, w2, d3, h3, w3;
+    regnet_level(kind, 1, D, H, W, &d1, &h1, &w1);
+    regnet_level(kind, 2, D, H, W, &d2, &h2, &w2);
+    regnet_level(kind, 3, D, H, W, &d3, &h3, &w3);
+    float* ws = static_cast<float*>(workspace);
+    const size_t n1 = (size_t)B * d1 * h1 * w1 * 16, n2 = (size_t)B * d2 * h2 * w2 * 32, n3 = (size_t)B * d3 * h3 * w3 * 64;
+    float *c1 = ws, *c2 = c1 + n1, *c3 = c2 + n1, *c4 = c3 + n2, *c5 = c4 + n2, *c6 = c5 + n3;
+    int rc;
+#define MVS_TRY(expr) do { rc = (expr); if (rc != MVS_OK) return rc; } while (0)
+    MVS_TRY(conv3d_dispatch(volume_cl, w_packed[0], bias[0], c1, B, 8, 16, D, H, W, 3, sd, 2, 2, 1, st));       // conv1
+    MVS_TRY(conv3d_dispatch(c1, w_packed[1], bias[1], c2, B, 16, 16, d1, h1, w1, 3, 1, 1, 1, 1, st));           // conv2
+    MVS_TRY(conv3d_dispatch(c2, w_packed[2], bias[2], c3, B, 16, 32, d1, h1, w1, 3, sd, 2, 2, 1, st));          // conv3
+    MVS_TRY(conv3d_dispatch(c3, w_packed[3], bias[3], c4, B, 32, 32, d2, h2, w2, 3, 1, 1, 1, 1, st));           // conv4
+    MVS_TRY(conv3d_dispatch(c4, w_packed[4], bias[4], c5, B, 32, 64, d2, h2, w2, 3, sd, 2, 2, 1, st));          // conv5
+    MVS_TRY(conv3d_dispatch(c5, w_packed[5], bias[5], c6, B, 64, 64, d3, h3, w3, 3, 1, 1, 1, 1, st));           // conv6
+    MVS_TRY(deconv3d_dispatch(c6, w_packed[6], bias[6], c4, c3, B, 64, 32, d3, h3, w3, sd, st));                // conv4 + conv7 -> c3
+    MVS_TRY(deconv3d_dispatch(c3, w_packed[7], bias[7], c2, c1, B, 32, 16, d2, h2, w2, sd, st));                // conv2 + conv9 -> c1
+    MVS_TRY(deconv3d_dispatch(c1, w_packed[8], bias[8], volume_cl, feat_cl, B, 16, 8, d1, h1, w1, sd, st));     // conv0 + conv11
+#undef MVS_TRY
+    return MVS_OK;
+}

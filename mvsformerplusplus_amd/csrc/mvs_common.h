@@ -1,0 +1,104 @@
+// Shared declarations for the gfx950 kernels of the MVSFormer++ depth hot path.
+//
+// Conventions
+//   * one wavefront = 64 lanes; every workgroup is 1-D with 256 threads (4 waves) unless stated
+//   * feature maps arrive in the caller's layout [B, V, C, H, W] (fp32 / bf16 / fp16, upcast in-kernel,
+//     reference: cost_volume.py:67,81,84)
+//   * everything the library produces for itself (cost volume, U-Net activations) is channel-last
+//     fp32 [B, D, H, W, C] so that one voxel's channels are one contiguous 16-byte-aligned run
+//   * hypotheses, entropy / visibility maps, logits, depth, confidence are planar fp32
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "../../include/mvs_hip.h"
+
+namespace mvs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kMaxSrcViews = 16;   // source views handled by one aggregate launch
+
+// ---- error plumbing (host) ----
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- feature element access (device) ----
+template <int DT> struct FeatT;
+template <> struct FeatT<MVS_DTYPE_F32> { typedef float type; };
+template <> struct FeatT<MVS_DTYPE_BF16> { typedef uint16_t type; };
+template <> struct FeatT<MVS_DTYPE_F16> { typedef _Float16 type; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(uint16_t bf16_bits) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)bf16_bits) << 16;
+    return c.f;
+}
+
+// 3x4 homography of one source view: p = R * [x, y, 1] * depth + t   (warping.py:80-92)
+struct Homography {
+    float r[9];
+    float t[3];
+};
+
+// Bilinear tap set of one projected point, ATen grid_sampler_2d semantics (bilinear, zeros padding,
+// align_corners=True), reached through the same normalise / un-normalise round trip the reference
+// performs (warping.py:93-95 then grid_sampler_unnormalize).
+struct Taps {
+    int off[4];      // y*W + x of nw, ne, sw, se (clamped to a valid address)
+    float w[4];      // bilinear weight, 0 for an out-of-bounds tap
+};
+
+__device__ __forceinline__ Taps make_taps(const Homography& hm, float qx, float qy, float qz, float depth, int H, int W,
+                                          float half_w, float half_h, bool* out_of_frame) {
+    const float px = qx * depth + hm.t[0];
+    const float py = qy * depth + hm.t[1];
+    const float pz = qz * depth + hm.t[2];
+    const float zz = pz + 1e-6f;
+    const float u = px / zz;
+    const float v = py / zz;
+    const float xn = u / half_w - 1.0f;                  // warping.py:94
+    const float yn = v / half_h - 1.0f;                  // warping.py:95
+    if (out_of_frame) *out_of_frame = (xn > 1.0f) || (xn < -1.0f) || (yn > 1.0f) || (yn < -1.0f) || (pz <= 0.0f);
+    const float ix = ((xn + 1.0f) / 2.0f) * (float)(W - 1);   // grid_sampler_unnormalize, align_corners
+    const float iy = ((yn + 1.0f) / 2.0f) * (float)(H - 1);
+    Taps tp;
+    // Non-finite or far-away coordinates contribute nothing (every tap fails the bounds test in ATen).
+    const bool sane = (ix > -2.0f) && (ix < (float)(W + 1)) && (iy > -2.0f) && (iy < (float)(H + 1));
+    if (!sane) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tp.off[k] = 0; tp.w[k] = 0.0f; }
+        return tp;
+    }
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx0, wy1 = iy - fy0;           // weight of the +1 neighbour
+    const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+    const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x1 >= 0) && (x1 < W);
+    const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y1 >= 0) && (y1 < H);
+    const int cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : 0, cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : 0;
+    tp.off[0] = cy0 * W + cx0; tp.w[0] = (vx0 && vy0) ? wx0 * wy0 : 0.0f;   // nw
+    tp.off[1] = cy0 * W + cx1; tp.w[1] = (vx1 && vy0) ? wx1 * wy0 : 0.0f;   // ne
+    tp.off[2] = cy1 * W + cx0; tp.w[2] = (vx0 && vy1) ? wx0 * wy1 : 0.0f;   // sw
+    tp.off[3] = cy1 * W + cx1; tp.w[3] = (vx1 && vy1) ? wx1 * wy1 : 0.0f;   // se
+    return tp;
+}
+
+// XCD-aware work-group remap: the dispatcher places block b on XCD b % 8, so consecutive logical tiles
+// (which share feature rows / halo voxels) are handed to the same XCD and hit its private L2.
+// Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7u, xcd = b & 7u, idx = b >> 3;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline unsigned ceil_div(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace mvs

@@ -1,0 +1,306 @@
+"""Host-side mirror of the hot-path part of the reference's ``models/module.py``.
+
+Same class / function names, constructor arguments, parameter names and shapes as the reference, so a reference
+checkpoint loads with ``strict=True`` (SURVEY.md section 8b state-dict contract):
+
+    Conv3d / Deconv3d          module.py:89-165    .conv.weight, .bn.{weight,bias,running_mean,running_var,num_batches_tracked}
+    ConvBnReLU                 module.py:168-197   .conv.weight, .bn.*
+    CostRegNet                 module.py:367-408   conv1..6, conv7/9/11 (Deconv3d), prob.weight [1,8,3,3,3]
+    CostRegNet3D               module.py:453-504   conv1..6, conv7/9/11 = Sequential(ConvTranspose3d, BatchNorm3d, ReLU), prob.{weight,bias}
+    depth_regression, conf_regression, init_range, init_inverse_range, schedule_inverse_range, schedule_range
+
+The torch sub-modules are parameter containers only: every forward runs hand-written HIP kernels through
+``ops`` (implicit-GEMM MFMA convs with BatchNorm folded at eval time).  Training-mode BatchNorm and backward
+are not part of this round and raise instead of silently falling back.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops, packing
+
+
+def _bn_dict(bn: nn.Module) -> Dict[str, torch.Tensor]:
+    if bn.training:
+        raise NotImplementedError("train-mode BatchNorm (batch statistics) is not implemented in the HIP path yet "
+                                  "(SURVEY.md section 8f #2); call .eval() on the BatchNorm layers")
+    return {"weight": bn.weight.detach().cpu(), "bias": bn.bias.detach().cpu(),
+            "running_mean": bn.running_mean.detach().cpu(), "running_var": bn.running_var.detach().cpu()}
+
+
+class _PackedCache:
+    """Folded + packed parameters on the module's device, rebuilt when any parameter/buffer changes."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, module: nn.Module, builder):
+        ts = list(module.parameters()) + list(module.buffers())
+        bn_modes = tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+        key = (ts[0].device, sum(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]), bn_modes)
+        if key != self._key:
+            self._val = builder(ts[0].device)
+            self._key = key
+        return self._val
+
+
+def _no_grad_path(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError("backward through the HIP hot path is not implemented yet (SURVEY.md section 8f #2); "
+                                  "run under torch.no_grad()")
+
+
+# --------------------------------------------------------------------------------------------------
+# layer wrappers (parameter containers + single-layer forwards for API parity)
+# --------------------------------------------------------------------------------------------------
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+class Conv3d(nn.Module):
+    """3D convolution + optional BatchNorm3d + optional ReLU (reference module.py:89-126)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+        self._cache = _PackedCache()
+
+    def packed(self, device):
+        def build(dev):
+            w = self.conv.weight.detach().cpu().float()
+            if self.bn is not None:
+                w, b = packing.fold_bn(w, _bn_dict(self.bn), 0)
+            else:
+                b = self.conv.bias.detach().cpu().float() if self.conv.bias is not None else torch.zeros(w.shape[0])
+            ch = packing.conv_chunk(w.shape[1], _triple(self.conv.stride))
+            return packing.pack_conv_weights(w, ch).to(dev), packing.pad_bias(b).to(dev)
+        return self._cache.get(self, build)
+
+    def forward_cl(self, x_cl):
+        w, b = self.packed(x_cl.device)
+        k = _triple(self.conv.kernel_size)
+        if k[1:] != (3, 3) or _triple(self.conv.padding) != (k[0] // 2, 1, 1):
+            raise NotImplementedError("HIP Conv3d supports kernel (1|3,3,3) with 'same' padding only")
+        return ops.conv3d_bn_relu(x_cl, w, b, self.conv.out_channels, k[0], _triple(self.conv.stride), self.relu)
+
+    def forward(self, x):
+        _no_grad_path(x)
+        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x)))
+
+
+class Deconv3d(nn.Module):
+    """3D transposed convolution + optional BatchNorm3d + optional ReLU (reference module.py:129-165)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.out_channels = out_channels
+        self.conv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+        self._cache = _PackedCache()
+
+    def packed(self, device):
+        return self._cache.get(self, lambda dev: _pack_deconv(self.conv, self.bn, dev))
+
+    def forward_cl(self, x_cl, skip_cl=None):
+        if not self.relu or self.bn is None:
+            raise NotImplementedError("HIP Deconv3d implements the BN + ReLU form used by the regularisers")
+        w, b = self.packed(x_cl.device)
+        return ops.deconv3d_bn_relu_add(x_cl, w, b, self.conv.out_channels, _deconv_sd(self.conv), skip_cl)
+
+    def forward(self, x):
+        _no_grad_path(x)
+        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x)))
+
+
+def _deconv_sd(conv: nn.ConvTranspose3d) -> int:
+    s, p, op, k = _triple(conv.stride), _triple(conv.padding), _triple(conv.output_padding), _triple(conv.kernel_size)
+    if k != (3, 3, 3) or p != (1, 1, 1) or s[1:] != (2, 2) or op != (s[0] - 1, 1, 1) or s[0] not in (1, 2):
+        raise NotImplementedError("HIP ConvTranspose3d supports k=3, padding=1, stride (1|2,2,2), output_padding (stride-1)")
+    return s[0]
+
+
+def _pack_deconv(conv: nn.ConvTranspose3d, bn: Optional[nn.Module], dev):
+    w = conv.weight.detach().cpu().float()
+    if bn is not None:
+        w, b = packing.fold_bn(w, _bn_dict(bn), 1)
+    else:
+        b = conv.bias.detach().cpu().float()
+    return packing.pack_deconv_weights(w).to(dev), packing.pad_bias(b).to(dev)
+
+
+class ConvBnReLU(nn.Module):
+    """2D convolution + BatchNorm2d + ReLU (reference module.py:168-197); container for the visibility CNN."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, dilation=dilation, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        raise NotImplementedError("ConvBnReLU is evaluated inside the fused visibility kernel (StageNet.vis); "
+                                  "a standalone 2D conv is outside the hot path")
+
+
+# --------------------------------------------------------------------------------------------------
+# regularisers
+# --------------------------------------------------------------------------------------------------
+class _RegNetBase(nn.Module):
+    kind = -1
+    prob_ksize = 0
+
+    def _layers(self) -> List[Tuple[str, nn.Module]]:
+        raise NotImplementedError
+
+    def _build(self, dev):
+        ws, bs = [], []
+        for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6"):
+            w, b = getattr(self, name).packed(dev)
+            ws.append(w)
+            bs.append(b)
+        for name in ("conv7", "conv9", "conv11"):
+            w, b = self._deconv_packed(getattr(self, name), dev)
+            ws.append(w)
+            bs.append(b)
+        pw = self.prob.weight.detach().cpu().float()
+        if self.prob_ksize == 3:
+            prob_w = pw[0].permute(1, 2, 3, 0).reshape(27, 8).contiguous().to(dev)     # [tap][cin]
+            prob_b = None
+        else:
+            prob_w = pw.reshape(-1)[:8].contiguous().to(dev)
+            prob_b = self.prob.bias.detach().cpu().float().reshape(-1)[:1].contiguous().to(dev)
+        return ws, bs, prob_w, prob_b
+
+    def packed_all(self, device):
+        if not isinstance(self.inner, nn.Identity):
+            raise NotImplementedError("in_channels != base_channels (1x1x1 `inner` conv) is not used by any shipped config")
+        if self.prob.weight.shape[0] != 1 or self.prob.weight.shape[1] != 8:
+            raise NotImplementedError("HIP head supports an 8 -> 1 channel `prob` layer")
+        return self._cache.get(self, self._build)
+
+    def forward_cl(self, volume_cl: torch.Tensor) -> torch.Tensor:
+        """[B,D,H,W,8] channel-last cost volume -> [B,D,H,W,8] features that feed `prob`."""
+        ws, bs, _, _ = self.packed_all(volume_cl.device)
+        return ops.regnet(self.kind, volume_cl, ws, bs)
+
+    def forward(self, x, *kwargs):
+        """NCDHW in, logits [B,1,D,H,W] out - the reference's call form (module.py:393-396 / 488-492)."""
+        _no_grad_path(x)
+        vol = ops.ncdhw_to_cl(x)
+        feat = self.forward_cl(vol)
+        _, _, prob_w, prob_b = self.packed_all(x.device)
+        B, D, H, W, _ = feat.shape
+        dummy_hyp = torch.ones(B, D, H, W, dtype=torch.float32, device=x.device)
+        _, _, _, pre = ops.prob_regress(feat, prob_w, prob_b, self.prob_ksize, dummy_hyp, 1.0, _lib.HEAD_CE_EVAL, 0, True)
+        return pre.unsqueeze(1)
+
+    forward_once = forward
+
+
+class CostRegNet(_RegNetBase):
+    """3D U-Net that halves D, H, W per level (reference module.py:367-408)."""
+    kind = _lib.REG_COSTREGNET
+    prob_ksize = 3
+
+    def __init__(self, in_channels, base_channels, last_layer=True):
+        super().__init__()
+        if not last_layer:
+            raise NotImplementedError("last_layer=False is unused by the hot path")
+        self.last_layer = last_layer
+        c = base_channels
+        plan = [("conv1", in_channels, 2 * c, 2), ("conv2", 2 * c, 2 * c, 1), ("conv3", 2 * c, 4 * c, 2),
+                ("conv4", 4 * c, 4 * c, 1), ("conv5", 4 * c, 8 * c, 2), ("conv6", 8 * c, 8 * c, 1)]
+        for name, ci, co, s in plan:
+            setattr(self, name, Conv3d(ci, co, stride=s, padding=1))
+        for name, ci, co in (("conv7", 8 * c, 4 * c), ("conv9", 4 * c, 2 * c), ("conv11", 2 * c, c)):
+            setattr(self, name, Deconv3d(ci, co, stride=2, padding=1, output_padding=1))
+        self.inner = nn.Conv3d(in_channels, c, 1, 1) if in_channels != c else nn.Identity()
+        self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
+        self._cache = _PackedCache()
+
+    @staticmethod
+    def _deconv_packed(layer, dev):
+        return layer.packed(dev)
+
+
+class CostRegNet3D(_RegNetBase):
+    """3D U-Net that keeps D and halves H, W per level; used when ndepth <= model_th (reference module.py:453-504)."""
+    kind = _lib.REG_COSTREGNET3D
+    prob_ksize = 1
+
+    def __init__(self, in_channels, base_channel=8, log_var=False):
+        super().__init__()
+        if log_var:
+            raise NotImplementedError("log_var=True is unused by the hot path")
+        self.log_var = log_var
+        c = base_channel
+        s = (1, 2, 2)
+        plan = [("conv1", in_channels, 2 * c, s), ("conv2", 2 * c, 2 * c, 1), ("conv3", 2 * c, 4 * c, s),
+                ("conv4", 4 * c, 4 * c, 1), ("conv5", 4 * c, 8 * c, s), ("conv6", 8 * c, 8 * c, 1)]
+        for name, ci, co, st in plan:
+            setattr(self, name, Conv3d(ci, co, kernel_size=3, stride=st, padding=1))
+        for name, ci, co in (("conv7", 8 * c, 4 * c), ("conv9", 4 * c, 2 * c), ("conv11", 2 * c, c)):
+            setattr(self, name, nn.Sequential(
+                nn.ConvTranspose3d(ci, co, kernel_size=3, padding=1, output_padding=(0, 1, 1), stride=s, bias=False),
+                nn.BatchNorm3d(co), nn.ReLU(inplace=True)))
+        self.inner = nn.Conv3d(in_channels, c, 1, 1) if in_channels != c else nn.Identity()
+        self.prob = nn.Conv3d(c, 1, 1, stride=1, padding=0)
+        self._cache = _PackedCache()
+
+    @staticmethod
+    def _deconv_packed(seq, dev):
+        _deconv_sd(seq[0])
+        return _pack_deconv(seq[0], seq[1], dev)
+
+
+# --------------------------------------------------------------------------------------------------
+# functional API (reference module.py:649-741)
+# --------------------------------------------------------------------------------------------------
+def depth_regression(p: torch.Tensor, depth_values: torch.Tensor) -> torch.Tensor:
+    """sum_d p[:, d] * depth_values[:, d]; depth_values [B,D] or [B,D,H,W] (reference module.py:649-655)."""
+    _no_grad_path(p, depth_values)
+    if depth_values.dim() <= 2:
+        depth_values = depth_values.reshape(*depth_values.shape, 1, 1).expand(-1, -1, p.shape[2], p.shape[3])
+    return ops.depth_regression(p, depth_values)
+
+
+def conf_regression(p: torch.Tensor, n: int = 4) -> torch.Tensor:
+    """Sum of the n probabilities around floor(E[index]) (reference module.py:658-671)."""
+    _no_grad_path(p)
+    return ops.conf_regression(p, n)
+
+
+def init_range(cur_depth, ndepths, device, dtype, H, W):
+    if cur_depth.dim() != 2:
+        raise NotImplementedError("per-pixel [B,H,W,n] initial ranges are unused by the shipped configs")
+    return ops.init_range(cur_depth.to(device), ndepths, H, W, inverse=False).to(dtype)
+
+
+def init_inverse_range(cur_depth, ndepths, device, dtype, H, W):
+    if cur_depth.dim() != 2:
+        raise NotImplementedError("per-pixel [B,H,W,n] initial ranges are unused by the shipped configs")
+    return ops.init_range(cur_depth.to(device), ndepths, H, W, inverse=True).to(dtype)
+
+
+def schedule_inverse_range(depth, depth_hypo, ndepths, split_itv, H, W, shift=False):
+    if shift:
+        raise NotImplementedError("shift=True is never enabled by the reference (module.py:712-715)")
+    return ops.schedule_inverse_range(depth, depth_hypo, ndepths, float(split_itv), H, W)
+
+
+def schedule_range(cur_depth, ndepth, depth_inteval_pixel, H, W):
+    if not torch.is_tensor(depth_inteval_pixel):
+        depth_inteval_pixel = torch.tensor([float(depth_inteval_pixel)], device=cur_depth.device)
+    if depth_inteval_pixel.dim() == 3:
+        raise NotImplementedError("per-pixel depth intervals are unused by the shipped configs")
+    return ops.schedule_range(cur_depth, ndepth, depth_inteval_pixel.to(cur_depth.device), H, W)

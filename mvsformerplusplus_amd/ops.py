@@ -1,0 +1,248 @@
+"""Tensor-level wrappers over the C ABI (include/mvs_hip.h).  Each function allocates its outputs with torch
+(so the caching allocator owns them), enqueues the HIP kernels on the caller's current stream and returns
+fresh tensors.  No autograd: this is the inference path (SURVEY.md section 8f #2 lists backward as next).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_of
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _feat(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    if t.dtype not in _lib.DTYPE_CODE:
+        t = t.float()
+    return t.contiguous(), _lib.DTYPE_CODE[t.dtype]
+
+
+# ---- a1 + warping.py:80 -------------------------------------------------------------------------
+def compose_homography(proj_matrices: torch.Tensor) -> torch.Tensor:
+    """proj_matrices [B,V,2,4,4] -> per-source-view homographies [B,V-1,12] (R row-major, then t)."""
+    p = _f32c(proj_matrices)
+    B, V = p.shape[:2]
+    assert p.shape[2:] == (2, 4, 4), "proj_matrices must be [B,V,2,4,4]"
+    out = torch.empty(B, V - 1, 12, dtype=torch.float32, device=p.device)
+    check(lib().mvs_compose_homography(ptr(p), B, V, ptr(out), stream_of(p)), "mvs_compose_homography")
+    return out
+
+
+def homography_from_proj(src_proj: torch.Tensor, ref_proj: torch.Tensor) -> torch.Tensor:
+    s, r = _f32c(src_proj), _f32c(ref_proj)
+    B = s.shape[0]
+    out = torch.empty(B, 12, dtype=torch.float32, device=s.device)
+    check(lib().mvs_homography_from_proj(ptr(s), ptr(r), B, ptr(out), stream_of(s)), "mvs_homography_from_proj")
+    return out
+
+
+def homo_warp(src_fea: torch.Tensor, homography: torch.Tensor, depth_values: torch.Tensor,
+              want_warped: bool = True, want_mask: bool = True):
+    f, code = _feat(src_fea)
+    B, Cc, H, W = f.shape
+    dv = _f32c(depth_values)
+    D = dv.shape[1]
+    is_vol = 1 if dv.dim() == 4 else 0
+    warped = torch.empty(B, Cc, D, H, W, dtype=torch.float32, device=f.device) if want_warped else None
+    mask = torch.empty(B, D, H, W, dtype=torch.uint8, device=f.device) if want_mask else None
+    check(lib().mvs_homo_warp_fwd(ptr(f), code, ptr(homography.contiguous()), ptr(dv), is_vol, ptr(warped), ptr(mask),
+                                  B, Cc, D, H, W, stream_of(f)), "mvs_homo_warp_fwd")
+    return warped, (mask.bool() if mask is not None else None)
+
+
+# ---- a2-a6 --------------------------------------------------------------------------------------
+def warp_corr_entropy(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, G: int,
+                      view_begin: int = 1, view_end: Optional[int] = None) -> torch.Tensor:
+    """features [B,V,C,H,W] contiguous; -> entropy [B,V-1,H,W] (only views in [view_begin, view_end) are written)."""
+    B, V, Cc, H, W = features.shape
+    D = hyp.shape[1]
+    view_end = V if view_end is None else view_end
+    ent = torch.zeros(B, V - 1, H, W, dtype=torch.float32, device=features.device)
+    check(lib().mvs_warp_corr_entropy_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(ent), B, V, Cc, G, D, H, W,
+                                          view_begin, view_end, stream_of(features)), "mvs_warp_corr_entropy_fwd")
+    return ent
+
+
+def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """entropy [..., H, W] -> sigmoid(vis CNN) of the same shape.  params = packed (w1,b1,w2,b2,w3,b3,w4,b4)."""
+    e = _f32c(entropy)
+    H, W = e.shape[-2:]
+    N = e.numel() // (H * W)
+    vis = torch.empty_like(e)
+    nbytes = lib().mvs_vis_workspace_bytes(N, H, W)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=e.device)
+    check(lib().mvs_vis_weight_fwd(ptr(e), *[ptr(p) for p in params], ptr(vis), ptr(ws), nbytes, N, H, W, stream_of(e)),
+          "mvs_vis_weight_fwd")
+    return vis
+
+
+def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, vis: torch.Tensor,
+                        G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None):
+    """-> (volume_cl [B,D,H,W,G], vis_sum [B,H,W] or None).  `out` = preallocated (volume, vis_sum) to fill."""
+    B, V, Cc, H, W = features.shape
+    D = hyp.shape[1]
+    view_end = V if view_end is None else view_end
+    if out is not None:
+        vol, vsum = out
+    else:
+        vol = torch.empty(B, D, H, W, G, dtype=torch.float32, device=features.device)
+        vsum = None if normalise else torch.empty(B, H, W, dtype=torch.float32, device=features.device)
+    check(lib().mvs_warp_corr_aggregate_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(vis), ptr(vol), ptr(vsum),
+                                            1 if normalise else 0, B, V, Cc, G, D, H, W, view_begin, view_end,
+                                            stream_of(features)), "mvs_warp_corr_aggregate_fwd")
+    return vol, vsum
+
+
+def volume_normalise_(vol_cl: torch.Tensor, vis_sum: torch.Tensor) -> torch.Tensor:
+    B, D, H, W, G = vol_cl.shape
+    check(lib().mvs_volume_normalise(ptr(vol_cl), ptr(vis_sum), B, D, H, W, G, stream_of(vol_cl)), "mvs_volume_normalise")
+    return vol_cl
+
+
+# ---- a7-a9 --------------------------------------------------------------------------------------
+def conv3d_bn_relu(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, kd: int,
+                   stride: Tuple[int, int, int], relu: bool = True) -> torch.Tensor:
+    B, D, H, W, cin = x_cl.shape
+    sd, sh, sw = stride
+    pd = kd // 2
+    od, oh, ow = (D + 2 * pd - kd) // sd + 1, (H - 1) // sh + 1, (W - 1) // sw + 1
+    y = torch.empty(B, od, oh, ow, cout, dtype=torch.float32, device=x_cl.device)
+    check(lib().mvs_conv3d_bn_relu_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(y), B, cin, cout, D, H, W, kd, sd, sh, sw,
+                                       1 if relu else 0, stream_of(x_cl)), "mvs_conv3d_bn_relu_fwd")
+    return y
+
+
+def deconv3d_bn_relu_add(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, sd: int,
+                         skip_cl: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, D, H, W, cin = x_cl.shape
+    y = torch.empty(B, D * sd, 2 * H, 2 * W, cout, dtype=torch.float32, device=x_cl.device)
+    if skip_cl is not None:
+        assert tuple(skip_cl.shape) == tuple(y.shape), "skip tensor shape mismatch"
+    check(lib().mvs_deconv3d_bn_relu_add_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(skip_cl), ptr(y), B, cin, cout, D, H, W,
+                                             sd, stream_of(x_cl)), "mvs_deconv3d_bn_relu_add_fwd")
+    return y
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    return (C.c_void_p * len(ts))(*[ptr(t) for t in ts])
+
+
+def regnet(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.Tensor], bias: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Whole U-Net up to (not including) `prob`: volume_cl [B,D,H,W,8] -> feat_cl [B,D,H,W,8]."""
+    B, D, H, W, c = volume_cl.shape
+    assert c == 8 and len(w_packed) == 9 and len(bias) == 9
+    out = torch.empty_like(volume_cl)
+    nbytes = lib().mvs_regnet_workspace_bytes(kind, B, D, H, W)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=volume_cl.device)
+    wa, ba = _ptr_array(w_packed), _ptr_array(bias)
+    check(lib().mvs_regnet_fwd(kind, ptr(volume_cl), C.cast(wa, C.c_void_p), C.cast(ba, C.c_void_p), ptr(out), ptr(ws), nbytes,
+                               B, D, H, W, stream_of(volume_cl)), "mvs_regnet_fwd")
+    return out
+
+
+# ---- a10/a11 ------------------------------------------------------------------------------------
+def prob_regress(feat_cl: torch.Tensor, prob_w: torch.Tensor, prob_b: Optional[torch.Tensor], ksize: int, hyp: torch.Tensor,
+                 tmp: float, mode: int, conf_n: int = 0, want_volumes: bool = True):
+    B, D, H, W, _ = feat_cl.shape
+    dev = feat_cl.device
+    depth = torch.empty(B, H, W, dtype=torch.float32, device=dev)
+    conf = torch.empty(B, H, W, dtype=torch.float32, device=dev)
+    need_pre = want_volumes or D not in (4, 8, 16, 32, 48)
+    pv = torch.empty(B, D, H, W, dtype=torch.float32, device=dev) if want_volumes else None
+    pre = torch.empty(B, D, H, W, dtype=torch.float32, device=dev) if need_pre else None
+    check(lib().mvs_prob_regress_fwd(ptr(feat_cl), ptr(prob_w), ptr(prob_b), ksize, ptr(hyp), float(tmp), mode, conf_n,
+                                     ptr(depth), ptr(conf), ptr(pv), ptr(pre), B, D, H, W, stream_of(feat_cl)),
+          "mvs_prob_regress_fwd")
+    return depth, conf, pv, pre
+
+
+def softmax_regress(logits: torch.Tensor, hyp: torch.Tensor, tmp: float, mode: int, conf_n: int = 0, want_prob: bool = True):
+    lg, hp = _f32c(logits), _f32c(hyp)
+    B, D, H, W = lg.shape
+    depth = torch.empty(B, H, W, dtype=torch.float32, device=lg.device)
+    conf = torch.empty(B, H, W, dtype=torch.float32, device=lg.device)
+    pv = torch.empty_like(lg) if want_prob else None
+    check(lib().mvs_softmax_regress_fwd(ptr(lg), ptr(hp), float(tmp), mode, conf_n, ptr(depth), ptr(conf), ptr(pv), B, D, H, W,
+                                        stream_of(lg)), "mvs_softmax_regress_fwd")
+    return depth, conf, pv
+
+
+# ---- a13-a16 ------------------------------------------------------------------------------------
+def depth_regression(p: torch.Tensor, depth_values: torch.Tensor) -> torch.Tensor:
+    pp, dv = _f32c(p), _f32c(depth_values)
+    B, D, H, W = pp.shape
+    out = torch.empty(B, H, W, dtype=torch.float32, device=pp.device)
+    check(lib().mvs_depth_regression_fwd(ptr(pp), ptr(dv), ptr(out), B, D, H, W, stream_of(pp)), "mvs_depth_regression_fwd")
+    return out
+
+
+def conf_regression(p: torch.Tensor, n: int) -> torch.Tensor:
+    pp = _f32c(p)
+    B, D, H, W = pp.shape
+    out = torch.empty(B, H, W, dtype=torch.float32, device=pp.device)
+    check(lib().mvs_conf_regression_fwd(ptr(pp), int(n), ptr(out), B, D, H, W, stream_of(pp)), "mvs_conf_regression_fwd")
+    return out
+
+
+def init_range(depth_values: torch.Tensor, ndepths: int, H: int, W: int, inverse: bool) -> torch.Tensor:
+    dv = _f32c(depth_values)
+    B, N = dv.shape
+    hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=dv.device)
+    check(lib().mvs_init_range_fwd(ptr(dv), N, 1 if inverse else 0, ptr(hyp), B, ndepths, H, W, stream_of(dv)), "mvs_init_range_fwd")
+    return hyp
+
+
+def schedule_inverse_range(prev_depth: torch.Tensor, prev_hyp: torch.Tensor, ndepths: int, ratio: float, H: int, W: int) -> torch.Tensor:
+    d, h = _f32c(prev_depth), _f32c(prev_hyp)
+    B, Dp = h.shape[:2]
+    assert tuple(d.shape[-2:]) == (H // 2, W // 2) and tuple(h.shape[-2:]) == (H // 2, W // 2)
+    hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=d.device)
+    check(lib().mvs_schedule_inverse_range_fwd(ptr(d), ptr(h), Dp, float(ratio), ptr(hyp), B, ndepths, H, W, stream_of(d)),
+          "mvs_schedule_inverse_range_fwd")
+    return hyp
+
+
+def schedule_range(prev_depth: torch.Tensor, ndepths: int, interval: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    d = _f32c(prev_depth)
+    B = d.shape[0]
+    itv = _f32c(interval.reshape(-1).expand(B) if interval.numel() == 1 else interval.reshape(B))
+    hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=d.device)
+    check(lib().mvs_schedule_range_fwd(ptr(d), ptr(itv), ptr(hyp), B, ndepths, H, W, stream_of(d)), "mvs_schedule_range_fwd")
+    return hyp
+
+
+def confidence_average(confs: Sequence[torch.Tensor], H: int, W: int) -> torch.Tensor:
+    confs = [_f32c(c) for c in confs]
+    B = confs[0].shape[0]
+    shifts = []
+    for c in confs:
+        s = (H // c.shape[1]).bit_length() - 1
+        assert c.shape[1] << s == H and c.shape[2] << s == W, "confidence maps must be power-of-two downsamplings"
+        shifts.append(s)
+    out = torch.empty(B, H, W, dtype=torch.float32, device=confs[0].device)
+    pa = _ptr_array(confs)
+    sa = (C.c_int * len(shifts))(*shifts)
+    check(lib().mvs_confidence_average(C.cast(pa, C.c_void_p), C.cast(sa, C.c_void_p), len(confs), ptr(out), B, H, W,
+                                       stream_of(out)), "mvs_confidence_average")
+    return out
+
+
+def ncdhw_to_cl(x: torch.Tensor) -> torch.Tensor:
+    x = _f32c(x)
+    B, Cc, D, H, W = x.shape
+    y = torch.empty(B, D, H, W, Cc, dtype=torch.float32, device=x.device)
+    check(lib().mvs_ncdhw_to_cl(ptr(x), ptr(y), B, Cc, D, H, W, stream_of(x)), "mvs_ncdhw_to_cl")
+    return y
+
+
+def cl_to_ncdhw(x_cl: torch.Tensor) -> torch.Tensor:
+    B, D, H, W, Cc = x_cl.shape
+    y = torch.empty(B, Cc, D, H, W, dtype=torch.float32, device=x_cl.device)
+    check(lib().mvs_cl_to_ncdhw(ptr(x_cl), ptr(y), B, Cc, D, H, W, stream_of(x_cl)), "mvs_cl_to_ncdhw")
+    return y

@@ -1,0 +1,72 @@
+"""Host-side parameter preparation for the HIP kernels: BatchNorm folding and MFMA weight packing.
+
+Packed conv layout (read by ``conv3d_mfma_kernel``; DESIGN.md "MFMA weight packing"):
+
+    K-quads are enumerated per channel chunk ("pass", CH input channels) tap-major:
+        kq = tap * (CH/4) + cq,   tap = (kd*3 + kh)*3 + kw,   cq = channel quad inside the chunk
+    and consumed four at a time ("step"); lane group g = lane >> 4 of the wave owns quad 4*step + g.
+    packed[pass][step][mb][lane = g*16 + j][s] = W'[cout = 16*mb + j][cin = pass*CH + 4*cq + s][tap]
+    (zero where the quad index or cout runs past the end).  W' = W * gamma / sqrt(var + eps).
+
+Packed deconv layout (``deconv3d_mfma_kernel``): all 27 taps, 16-channel blocks q:
+    packed[tap][q][mb][lane = g*16 + j][s] = Wt'[cin = 16*q + 4*g + s][cout = 16*mb + j][tap]
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+BN_EPS = 1e-5
+
+
+def fold_bn(weight: torch.Tensor, bn: Dict[str, torch.Tensor], out_dim: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fold eval-mode BatchNorm into the preceding bias-free conv.  ``out_dim`` = axis of ``weight`` that is Cout."""
+    scale = bn["weight"].double() / torch.sqrt(bn["running_var"].double() + BN_EPS)
+    shift = bn["bias"].double() - bn["running_mean"].double() * scale
+    shape = [1] * weight.dim()
+    shape[out_dim] = -1
+    return (weight.double() * scale.reshape(shape)).float(), shift.float()
+
+
+def conv_chunk(cin: int, stride: Tuple[int, int, int]) -> int:
+    """Channel chunk staged per LDS pass - must match the ConvCfg table in csrc/conv_kernels.hip."""
+    return 16 if tuple(stride) == (1, 1, 1) else 8
+
+
+def pack_conv_weights(w: torch.Tensor, ch: int) -> torch.Tensor:
+    """w [Cout, Cin, kd, 3, 3] (BN already folded) -> packed fp32 1-D tensor."""
+    cout, cin = w.shape[:2]
+    ntap = w.shape[2] * w.shape[3] * w.shape[4]
+    assert cin % ch == 0 and ch % 4 == 0
+    qc = ch // 4
+    npass = cin // ch
+    nquad = ntap * qc
+    nstep = (nquad + 3) // 4
+    mrep = (cout + 15) // 16
+    wt = w.reshape(cout, npass, qc, 4, ntap).float()                       # [co, pass, cq, s, tap]
+    wt = wt.permute(1, 4, 2, 0, 3).reshape(npass, nquad, cout, 4)          # [pass, kq = tap*qc + cq, co, s]
+    full = torch.zeros(npass, nstep * 4, mrep * 16, 4, dtype=torch.float32)
+    full[:, :nquad, :cout] = wt
+    full = full.reshape(npass, nstep, 4, mrep, 16, 4)                      # [pass, step, g, mb, j, s]
+    return full.permute(0, 1, 3, 2, 4, 5).contiguous().reshape(-1)         # [pass, step, mb, g, j, s]
+
+
+def pack_deconv_weights(w: torch.Tensor) -> torch.Tensor:
+    """w [Cin, Cout, 3, 3, 3] (ConvTranspose3d layout, BN folded over Cout) -> packed fp32 1-D tensor."""
+    cin, cout = w.shape[:2]
+    assert cin % 16 == 0 and tuple(w.shape[2:]) == (3, 3, 3)
+    nq = cin // 16
+    mrep = (cout + 15) // 16
+    wt = w.reshape(nq, 4, 4, cout, 27).float()                             # [q, g, s, co, tap]
+    full = torch.zeros(nq, 4, 4, mrep * 16, 27, dtype=torch.float32)
+    full[:, :, :, :cout] = wt
+    full = full.reshape(nq, 4, 4, mrep, 16, 27)                            # [q, g, s, mb, j, tap]
+    return full.permute(5, 0, 3, 1, 4, 2).contiguous().reshape(-1)         # [tap, q, mb, g, j, s]
+
+
+def pad_bias(b: torch.Tensor) -> torch.Tensor:
+    n = max(16, ((b.numel() + 15) // 16) * 16)
+    out = torch.zeros(n, dtype=torch.float32)
+    out[: b.numel()] = b.float()
+    return out

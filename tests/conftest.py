@@ -48,3 +48,20 @@ def rel_l1(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """Host-emulated twin of libmvs_hip.so (tests/hipemu): the same kernel sources compiled for x86."""
+    import hipemu_build
+    from mvsformerplusplus_amd import _lib
+    return _lib.bind(hipemu_build.build())
+
+
+@pytest.fixture
+def emu(monkeypatch, emu_lib):
+    """Route the package's C-ABI calls to the emulated library for one test (CPU tensors allowed)."""
+    from mvsformerplusplus_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", emu_lib)
+    monkeypatch.setattr(_lib, "_REQUIRE_DEVICE", False)
+    return "cpu"

@@ -1,0 +1,159 @@
+// TEST INFRASTRUCTURE ONLY - never part of the product build.
+//
+// A tiny host-side stand-in for <hip/hip_runtime.h> that lets the *unchanged* kernel sources under
+// mvsformerplusplus_amd/csrc/ be compiled for x86 (clang++ -x c++ -I tests/hipemu) and executed on
+// the CPU of the GPU-less build container.  Each workgroup runs as a set of cooperative fibers
+// (one per work-item) scheduled round-robin in lane order on one OS thread:
+//   * __syncthreads()             -> workgroup barrier over the fibers
+//   * __shfl* / MFMA builtins     -> wave-level (64 lanes) exchange through a per-wave buffer, using
+//                                    the gfx950 operand/result lane maps documented in
+//                                    cdna_hip_programming.md section 3
+// It exists to check index arithmetic, tiling, fragment layouts and barrier placement of the
+// real kernels against the oracle before spending GPU minutes.  The package never loads the
+// resulting library; only tests/ do (tests/hipemu_build.py).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <utility>
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) ushort4 { unsigned short x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+namespace hipemu {
+struct Ids { dim3 tid, bid, bdim, gdim; };
+extern Ids cur;                      // ids of the fiber that is running right now
+void syncthreads();
+int lane_id();
+// every live lane of the calling wave deposits `size` bytes; returns once all have, with all[64*size]
+// holding every lane's deposit (dead lanes: zeros)
+void wave_gather(const void* mine, void* all, size_t size);
+void* dyn_smem();
+void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur.tid)
+#define blockIdx (hipemu::cur.bid)
+#define blockDim (hipemu::cur.bdim)
+#define gridDim (hipemu::cur.gdim)
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_smem());
+#define __syncthreads() hipemu::syncthreads()
+
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu: no error"; }
+template <class F>
+static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+
+template <class... KArgs, class... Args>
+static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+    std::function<void()> body = [=]() { kernel(args...); };
+    hipemu::run_grid(grid, block, shmem, body);
+}
+
+// ---- wave-level data movement -------------------------------------------------------------
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+    T all[64];
+    hipemu::wave_gather(&v, all, sizeof(T));
+    int l = hipemu::lane_id();
+    int base = l & ~(width - 1);
+    return all[base + (src & (width - 1))];
+}
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    T all[64];
+    hipemu::wave_gather(&v, all, sizeof(T));
+    int l = hipemu::lane_id();
+    int t = l ^ mask;
+    if ((t & ~(width - 1)) != (l & ~(width - 1))) t = l;
+    return all[t];
+}
+template <class T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    T all[64];
+    hipemu::wave_gather(&v, all, sizeof(T));
+    int l = hipemu::lane_id();
+    int t = l + (int)delta;
+    if ((t & ~(width - 1)) != (l & ~(width - 1))) t = l;
+    return all[t];
+}
+
+// ---- MFMA (gfx950 lane maps; f32 result is a k-ordered fmaf chain, bitwise like the hardware) ----
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
+// D: col = l&15, row = 4*(l>>4) + r.
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+    struct AB { float a, b; } mine{a, b}, all[64];
+    hipemu::wave_gather(&mine, all, sizeof(AB));
+    const int l = hipemu::lane_id(), col = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(all[row + 16 * k].a, all[col + 16 * k].b, acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col = l&31,
+// row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16).
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+    struct AB { float a, b; } mine{a, b}, all[64];
+    hipemu::wave_gather(&mine, all, sizeof(AB));
+    const int l = hipemu::lane_id(), col = l & 31, h = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(all[row + 32 * k].a, all[col + 32 * k].b, acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
+
+static inline int hipemu_readfirstlane(int v) {
+    int all[64];
+    hipemu::wave_gather(&v, all, sizeof(int));
+    return all[0];
+}
+#define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
+
+// ---- device math spellings used by the kernels ----
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -1,0 +1,253 @@
+"""Parity cases shared by tests/test_emu_parity.py (kernel sources run through the host emulator, CPU) and
+tests/test_gpu_parity.py (-m gpu: the real libmvs_hip.so on an MI355X).  Every case drives the product API
+(mvsformerplusplus_amd.*) on `device` and compares with the oracle / golden vectors on the CPU.
+
+Tolerances: depth within 1e-3 relative L1 is the north-star bar (BASELINE.json); the checks below are far tighter
+(fp32 MFMA is an exact fmaf chain, so differences are summation-order noise) and are written next to each assert.
+"""
+import torch
+
+from conftest import golden_weights, load_golden, rel_l1
+from mvsformerplusplus_amd import _lib, module as M, ops, packing, synth
+from mvsformerplusplus_amd.cost_volume import StageNet
+from mvsformerplusplus_amd.warping import homo_warping_3D_with_mask
+from oracle import ref_path as O
+
+ARGS = {"base_ch": [8, 8, 8, 8], "depth_type": ["ce"] * 4, "fusion_type": "cnn", "cost_reg_type": ["Normal"] * 4}
+
+
+def dev(t, device):
+    return t.to(device) if torch.is_tensor(t) else t
+
+
+def cpu(t):
+    return t.detach().cpu()
+
+
+# ---------------------------------------------------------------- a2/a3
+def case_warp_golden(device, tag):
+    fx = load_golden("f1_warp_%s.npz" % tag)
+    for dv, wk, mk in (("dv2", "warped2", "mask2"), ("dv4", "warped4", "mask4")):
+        w, m = homo_warping_3D_with_mask(dev(fx["src_fea"], device), dev(fx["src_proj"], device), dev(fx["ref_proj"], device),
+                                         dev(fx[dv], device))
+        w, m = cpu(w), cpu(m)
+        # mask flips only where a coordinate sits within rounding of the frame border
+        assert (m != fx[mk]).float().mean() <= 2e-3
+        assert (w - fx[wk]).abs().max() <= 2e-4, "warped features differ from the reference"
+        assert (w - fx[wk]).abs().mean() <= 2e-6
+
+
+def case_warp_dtypes(device):
+    fx = load_golden("f1_warp_a.npz")
+    for dt, tol in ((torch.bfloat16, 1e-6), (torch.float16, 1e-6)):
+        src = fx["src_fea"].to(dt)
+        w, _ = homo_warping_3D_with_mask(dev(src, device), dev(fx["src_proj"], device), dev(fx["ref_proj"], device), dev(fx["dv4"], device))
+        wo, _ = O.homo_warping_3D_with_mask(src.float(), fx["src_proj"], fx["ref_proj"], fx["dv4"])
+        assert (cpu(w) - wo).abs().max() <= 2e-4        # the kernel upcasts the same low-precision values exactly
+
+
+# ---------------------------------------------------------------- a7-a9
+def _load_regnet(net, sd, device):
+    net.load_state_dict(sd, strict=True)
+    return net.eval().to(device)
+
+
+def case_regnet_golden(device, name):
+    fx = load_golden(name)
+    sd = golden_weights(fx)
+    net = M.CostRegNet3D(8, 8) if "3d" in name else M.CostRegNet(8, 8)
+    net = _load_regnet(net, sd, device)
+    with torch.no_grad():
+        y = cpu(net(dev(fx["x"], device)))
+    assert y.shape == fx["y"].shape
+    scale = float(fx["y"].abs().max())
+    assert (y - fx["y"]).abs().max() <= 2e-4 * max(1.0, scale), "regulariser logits differ from the reference"
+
+
+def case_single_layers(device):
+    """Conv3d / Deconv3d wrappers one layer at a time against torch's own conv (fp32 reference of the same op)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, stride, shape in ((8, 16, (2, 2, 2), (8, 8, 24)), (8, 16, (1, 2, 2), (4, 8, 40)), (16, 16, 1, (5, 6, 20)),
+                                     (32, 64, (1, 2, 2), (3, 8, 16)), (64, 64, 1, (2, 5, 17))):
+        layer = M.Conv3d(cin, cout, stride=stride, padding=1)
+        man = synth.state_dict_manifest(layer.state_dict())
+        layer.load_state_dict(synth.seeded_state_dict(man, 5))
+        layer = layer.eval().to(device)
+        x = torch.randn(2, cin, *shape, generator=g)
+        ref = F.relu(F.batch_norm(F.conv3d(x, layer.conv.weight.cpu(), None, stride=stride, padding=1), layer.bn.running_mean.cpu(),
+                                  layer.bn.running_var.cpu(), layer.bn.weight.cpu(), layer.bn.bias.cpu(), False, 0.1, 1e-5))
+        with torch.no_grad():
+            y = cpu(layer(dev(x, device)))
+        assert y.shape == ref.shape
+        assert (y - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max())), (cin, cout, stride)
+    for cin, cout, sd, shape in ((64, 32, 2, (2, 3, 5)), (32, 16, 2, (3, 4, 18)), (16, 8, 2, (4, 5, 16)),
+                                 (64, 32, 1, (3, 2, 5)), (16, 8, 1, (4, 6, 17))):
+        layer = M.Deconv3d(cin, cout, stride=(sd, 2, 2), padding=1, output_padding=(sd - 1, 1, 1))
+        man = synth.state_dict_manifest(layer.state_dict())
+        layer.load_state_dict(synth.seeded_state_dict(man, 6))
+        layer = layer.eval().to(device)
+        x = torch.randn(1, cin, *shape, generator=g)
+        ref = F.relu(F.batch_norm(F.conv_transpose3d(x, layer.conv.weight.cpu(), None, stride=(sd, 2, 2), padding=1,
+                                                     output_padding=(sd - 1, 1, 1)), layer.bn.running_mean.cpu(),
+                                  layer.bn.running_var.cpu(), layer.bn.weight.cpu(), layer.bn.bias.cpu(), False, 0.1, 1e-5))
+        with torch.no_grad():
+            y = cpu(layer(dev(x, device)))
+        assert y.shape == ref.shape
+        assert (y - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max())), (cin, cout, sd)
+
+
+# ---------------------------------------------------------------- a1-a12 one stage
+def make_stage(fx, ndepth, stage_idx, device, depth_type="ce"):
+    args = dict(ARGS)
+    args["depth_type"] = [depth_type] * 4
+    net = StageNet(args, ndepth, stage_idx)
+    net.load_state_dict(golden_weights(fx), strict=True)      # reference state-dict names, strict
+    return net.eval().to(device)
+
+
+def case_stage_golden(device, tag):
+    fx = load_golden("f2_stage_%s.npz" % tag)
+    D = fx["hyp"].shape[1]
+    net = make_stage(fx, D, int(fx["stage_idx"]), device)
+    with torch.no_grad():
+        out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), float(fx["tmp"]))
+    assert set(out) == {"depth", "prob_volume", "photometric_confidence", "depth_values", "prob_volume_pre"}
+    assert rel_l1(cpu(out["depth"]), fx["depth"]) <= 2e-5, "stage depth vs reference (bar: 1e-3)"
+    assert (cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max() <= 5e-4
+    assert (cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max() <= 1e-4
+    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-4
+
+
+def case_stage_pieces(device):
+    """Intermediate tensors of one stage (entropy, visibility, cost volume) against the oracle's intermediates."""
+    fx = load_golden("f2_stage_s1.npz")
+    sd = golden_weights(fx)
+    feats, proj, hyp = fx["features"], fx["proj"], fx["hyp"]
+    ref = O.stage_forward(feats, proj, hyp, 5.0, sd, G=8, return_intermediates=True)
+    net = make_stage(fx, hyp.shape[1], 1, device)
+    f, code = ops._feat(dev(feats, device))
+    hom = ops.compose_homography(dev(proj, device))
+    ent = ops.warp_corr_entropy(f, code, hom, dev(hyp, device), 8)
+    assert (cpu(ent) - ref["entropy"].squeeze(2)).abs().max() <= 2e-5
+    vis = ops.vis_weight(ent, net._vis_params(f.device))
+    assert (cpu(vis) - ref["vis_weight"].squeeze(2)).abs().max() <= 2e-5
+    vol, _ = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8)
+    assert (cpu(vol).permute(0, 4, 1, 2, 3) - ref["volume_mean"]).abs().max() <= 2e-5
+    # partial (view-sharded) form: two halves summed and normalised == the fused single pass
+    v1, s1 = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, normalise=False, view_begin=1, view_end=2)
+    v2, s2 = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, normalise=False, view_begin=2, view_end=3)
+    both = ops.volume_normalise_(v1 + v2, s1 + s2)
+    assert (cpu(both) - cpu(vol)).abs().max() <= 1e-6
+
+
+def case_stage_modes(device):
+    fx = load_golden("f6_stage_train_ce.npz")
+    net = make_stage(fx, 8, 2, device)
+    net.training = True                                   # BN layers stay in eval mode, like the fixture
+    with torch.no_grad():
+        out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), 5.0)
+    assert (cpu(out["depth"]) != fx["depth"]).float().mean() <= 0.005      # argmax may flip on exact near-ties only
+    assert (cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max() <= 1e-4
+    fx = load_golden("f6_stage_reg.npz")
+    net = make_stage(fx, 8, 2, device, depth_type="reg")
+    with torch.no_grad():
+        out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
+    assert rel_l1(cpu(out["depth"]), fx["depth"]) <= 2e-5
+    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-4
+
+
+def case_stage_lowp_features(device):
+    """bf16 / fp16 feature inputs are upcast per element in-kernel (reference: cost_volume.py:67,81,84)."""
+    fx = load_golden("f2_stage_s3.npz")
+    sd = golden_weights(fx)
+    net = make_stage(fx, 4, 3, device)
+    for dt in (torch.bfloat16, torch.float16):
+        f = fx["features"].to(dt)
+        ref = O.stage_forward(f.float(), fx["proj"], fx["hyp"], 1.0, sd, G=8)
+        with torch.no_grad():
+            out = net(dev(f, device), dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
+        assert rel_l1(cpu(out["depth"]), ref["depth"]) <= 2e-5
+
+
+# ---------------------------------------------------------------- a10-a15 small functions
+def case_small_fns(device):
+    fx = load_golden("f5_small_fns.npz")
+    for D, n in ((32, 4), (16, 3), (8, 2)):
+        p, dv = dev(fx["p%d" % D], device), dev(fx["dv%d" % D], device)
+        assert torch.allclose(cpu(M.depth_regression(p, dv)), fx["dreg%d" % D], rtol=1e-5, atol=0)
+        assert torch.allclose(cpu(M.conf_regression(p, n=n)), fx["conf%d_n%d" % (D, n)], rtol=1e-5, atol=1e-6)
+    dv = dev(fx["depth_values"], device)
+    assert torch.allclose(cpu(M.init_range(dv, 8, dv.device, dv.dtype, 5, 6)), fx["init_range"], rtol=1e-6, atol=0)
+    assert torch.allclose(cpu(M.init_inverse_range(dv, 8, dv.device, dv.dtype, 5, 6)), fx["init_inverse_range"], rtol=1e-6, atol=0)
+    got = M.schedule_inverse_range(dev(fx["prev_depth"], device), dev(fx["prev_hyp"], device), 4, 2.67, 10, 12)
+    assert torch.allclose(cpu(got), fx["schedule_inverse_range"], rtol=2e-6, atol=0)
+    got = M.schedule_range(dev(fx["prev_depth"], device), 4, dev(fx["schedule_range_itv"], device), 10, 12)
+    assert torch.allclose(cpu(got), fx["schedule_range"], rtol=2e-6, atol=0)
+
+
+def case_generic_shapes(device):
+    """Ragged sizes and the run-time-shape kernel variants: HW not a multiple of 64, C/G outside the templated set,
+    D without a register-resident head, empty view ranges rejected."""
+    g = torch.Generator().manual_seed(3)
+    B, V, C, G, D, H, W = 2, 3, 12, 4, 5, 9, 13
+    cams = synth.make_cameras(V, H * 8, W * 8, baseline=40.0, rot_deg=3.0, seed=1, batch=B)
+    cams[:, :, 1, :2, :] /= 8
+    feats = torch.randn(B, V, C, H, W, generator=g)
+    hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.05 * torch.rand(B, D, H, W, generator=g))).contiguous()
+    ref_p = O.compose_proj(cams[:, 0])
+    f, code = ops._feat(dev(feats, device))
+    hom = ops.compose_homography(dev(cams, device))
+    ent = cpu(ops.warp_corr_entropy(f, code, hom, dev(hyp, device), G))
+    vis = torch.rand(B, V - 1, H, W, generator=g)
+    vol, _ = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), dev(vis, device), G)
+    vsum, acc = 0.0, 0.0
+    for v in range(1, V):
+        warped, _ = O.homo_warping_3D_with_mask(feats[:, v], O.compose_proj(cams[:, v]), ref_p, hyp)
+        ip = O.group_correlation(feats[:, 0], warped, G)
+        assert (ent[:, v - 1] - O.entropy_of_similarity(ip)[:, 0]).abs().max() <= 2e-5
+        acc = acc + ip * vis[:, v - 1][:, None, None]
+        vsum = vsum + vis[:, v - 1]
+    expect = acc / (vsum[:, None, None] + 1e-6)
+    assert (cpu(vol).permute(0, 4, 1, 2, 3) - expect).abs().max() <= 2e-5
+    # run-time-D head (D = 5 has no register variant) on given logits
+    logits = torch.randn(B, D, H, W, generator=g) * 3
+    depth, conf, pv = ops.softmax_regress(dev(logits, device), dev(hyp, device), 5.0, _lib.HEAD_CE_EVAL)
+    assert torch.allclose(cpu(depth), O.depth_regression(torch.softmax(logits * 5.0, 1), hyp), rtol=1e-5)
+    assert torch.allclose(cpu(pv), torch.softmax(logits, 1), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(cpu(conf), torch.softmax(logits, 1).max(1)[0], rtol=1e-5)
+    try:
+        ops.warp_corr_entropy(f, code, hom, dev(hyp, device), G, view_begin=2, view_end=2)
+    except _lib.MvsHipError:
+        pass
+    else:
+        raise AssertionError("an empty source-view range must be rejected")
+    try:
+        ops.warp_corr_entropy(f, code, hom, dev(hyp, device), 5)      # G does not divide C
+    except _lib.MvsHipError:
+        pass
+    else:
+        raise AssertionError("G must divide C (cost_volume.py:87)")
+
+
+# ---------------------------------------------------------------- a16 cascade
+def case_cascade_golden(device):
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    fx = load_golden("f4_cascade.npz")
+    args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True)
+    head = CascadeDepthHead(args)
+    for s in range(4):
+        head.fusions[s].load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
+    head = head.eval().to(device)
+    feats = {"stage%d" % s: dev(fx["features%d" % s], device) for s in range(1, 5)}
+    projs = {"stage%d" % s: dev(fx["proj%d" % s], device) for s in range(1, 5)}
+    with torch.no_grad():
+        out = head(feats, projs, dev(fx["depth_values"], device), tmp=[5.0, 5.0, 5.0, 1.0])
+    for s in range(1, 5):
+        st = out["stage%d" % s]
+        assert rel_l1(cpu(st["depth_values"]), fx["hyp%d" % s]) <= 2e-5, s
+        assert rel_l1(cpu(st["depth"]), fx["depth%d" % s]) <= 5e-5, "stage %d depth vs reference (bar 1e-3)" % s
+        assert (cpu(st["photometric_confidence"]) - fx["conf%d" % s]).abs().max() <= 2e-3
+    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= 5e-5
+    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-3
+    assert torch.equal(out["refined_depth"], out["stage4"]["depth"])

@@ -1,0 +1,53 @@
+"""CPU: the real kernel sources (csrc/*.hip) executed through the host emulator (tests/hipemu) against the oracle and
+the golden vectors.  This checks indexing, tiling, MFMA fragment layouts and barrier placement without a GPU; the
+numbers that count are produced by tests/test_gpu_parity.py on the MI355X."""
+import pytest
+
+import parity_cases as P
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_warp_golden(emu, tag):
+    P.case_warp_golden(emu, tag)
+
+
+def test_warp_dtypes(emu):
+    P.case_warp_dtypes(emu)
+
+
+def test_single_layers(emu):
+    P.case_single_layers(emu)
+
+
+@pytest.mark.parametrize("name", ["f3_costregnet.npz", "f3_costregnet3d_d4.npz", "f3_costregnet3d_d8.npz"])
+def test_regnet_golden(emu, name):
+    P.case_regnet_golden(emu, name)
+
+
+def test_stage_pieces(emu):
+    P.case_stage_pieces(emu)
+
+
+@pytest.mark.parametrize("tag", ["s1", "s3"])
+def test_stage_golden(emu, tag):
+    P.case_stage_golden(emu, tag)
+
+
+def test_stage_modes(emu):
+    P.case_stage_modes(emu)
+
+
+def test_stage_lowp_features(emu):
+    P.case_stage_lowp_features(emu)
+
+
+def test_small_fns(emu):
+    P.case_small_fns(emu)
+
+
+def test_generic_shapes(emu):
+    P.case_generic_shapes(emu)
+
+
+def test_cascade_golden(emu):
+    P.case_cascade_golden(emu)
