@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X depth hot path (BASELINE.json: "ref-views/sec at 1152x1536 N=5 D=192 4-stage;
+achieved HBM GB/s vs peak").
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+
+One "step" = one reference view through the whole 4-stage cascade (features in HBM -> refined depth + confidence):
+hypothesis scheduling, fused warp + group-wise correlation + visibility weighting for the 4 source views, the
+3D-conv regulariser and the depth head of every stage.  Workload = BASELINE.json configs[1]: 1152x1536, V=5,
+numdepth 192 (-> cascade ndepths 32/16/8/4), fp32 features, all-"Normal" regularisers,
+synthetic features / cameras and seeded random weights with randomised BatchNorm statistics (no dataset or
+checkpoint exists offline).
+
+N > 1: one process per GPU; reference views are independent, so every rank runs its own stream of reference views
+(data parallel over reference views, no data-path collective; "scaling": "weak").  The view-sharded latency mode
+with the RCCL all-reduce of partial cost volumes is timed afterwards and reported in the
+extra `view_sharded` object.
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, HIP-event timing on the launch stream) and
+`cpu_baseline` (the oracle - a CPU restatement of the reference path - timed on this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = "DTU 1152x1536 N=5 numdepth=192 4-stage cascade (ndepths 32/16/8/4, all-Normal CostRegNet/CostRegNet3D)"
+ARGS = {"base_ch": [8, 8, 8, 8], "depth_type": ["ce"] * 4, "fusion_type": "cnn", "cost_reg_type": ["Normal"] * 4,
+        "ndepths": [32, 16, 8, 4], "depth_interals_ratio": [4.0, 2.67, 1.5, 1.0], "inverse_depth": True}
+TMP = [5.0, 5.0, 5.0, 1.0]
+ALGO_BYTES_PER_VIEW = 5.03e9
+
+
+def build_head(device):
+    from mvsformerplusplus_amd import synth
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    head = CascadeDepthHead(dict(ARGS))
+    for i, st in enumerate(head.fusions):
+        st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 100 + i), strict=True)
+        st.return_prob_volumes = True       # reference-faithful outputs (a12): prob_volume / prob_volume_pre are written
+    return head.eval().to(device)
+
+
+def cpu_baseline(head, feats, projs, dv, max_threads=None):
+    """The oracle (CPU restatement of the reference PyTorch path, fp32) on the host cores; second of two passes."""
+    from oracle import ref_path as O
+    n = max_threads or os.cpu_count() or 1
+    torch.set_num_threads(n)
+    sds = [{k: v.detach().cpu() for k, v in st.state_dict().items()} for st in head.fusions]
+    f = {k: v.cpu() for k, v in feats.items()}
+    p = {k: v.cpu() for k, v in projs.items()}
+    d = dv.cpu()
+    times = []
+    out = None
+    with torch.no_grad():
+        for _ in range(2):
+            t0 = time.time()
+            out = O.cascade_forward(f, p, d, sds, ndepths=ARGS["ndepths"], depth_interals_ratio=ARGS["depth_interals_ratio"],
+                                    base_ch=ARGS["base_ch"], tmp=TMP)
+            times.append(time.time() - t0)
+    return {"value": 1.0 / times[-1], "unit": "ref-views/s", "cores": n, "kind": "port",
+            "sample": "1 reference view of the bench workload (full 4-stage cascade, fp32), second of two passes; "
+                      "first pass %.1f s, timed pass %.1f s" % (times[0], times[-1])}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1152)
+    ap.add_argument("--width", type=int, default=1536)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            print("bench.py --gpus %d must be launched with torch.distributed.run (see docstring)" % a.gpus, file=sys.stderr)
+            sys.exit(2)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mvsformerplusplus_amd import profiling, synth
+    head = build_head(device)
+    feats, projs, dv = synth.make_cascade_inputs(a.height, a.width, a.views, seed=rank, device=device)
+    torch.cuda.synchronize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    out = None
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out = head(feats, projs, dv, tmp=TMP)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = head(feats, projs, dv, tmp=TMP)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * a.steps / elapsed
+    is_cfg2 = (a.height, a.width, a.views) == (1152, 1536, 5)
+
+    result = {
+        "metric": "ref-views/sec at 1152x1536 N=5 D=192 4-stage; achieved HBM GB/s vs peak",
+        "value": value, "unit": "ref-views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": WORKLOAD if is_cfg2 else "%dx%d V=%d 4-stage cascade" % (a.height, a.width, a.views),
+                   "height": a.height, "width": a.width, "views": a.views, "global_batch": world,
+                   "parallelism": "dp%d over reference views" % world, "features": "fp32 resident in HBM"},
+        "hbm_algorithmic_gbs_per_gpu": (ALGO_BYTES_PER_VIEW * value / world / 1e9) if is_cfg2 else None,
+        "hbm_algorithmic_frac_of_8TBs": (ALGO_BYTES_PER_VIEW * value / world / 8.0e12) if is_cfg2 else None,
+    }
+
+    # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
+    if not a.no_profile:
+        reps = 3
+        allruns = []
+        for _ in range(reps):
+            _, launches = profiling.profile_cascade(head, feats, projs, dv, TMP)
+            allruns.append(launches)
+        agg = profiling.summarize([l for run in allruns for l in run])
+        dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        mfma = dom_name.startswith("conv3d") or dom_name.startswith("deconv3d")
+        per_launch = dom["flops" if mfma else "bytes"] / dom["calls"]
+        achieved = (dom["tflops"] if mfma else dom["gbs"])
+        peak = profiling.PEAK_F32_MFMA_TFLOPS if mfma else profiling.PEAK_HBM_GBS
+        result["roofline"] = {"kernel": dom_name, "bound": "mfma" if mfma else "hbm", "achieved": achieved, "peak": peak,
+                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": achieved / peak, "traffic": None,
+                              "avg_launch_ms": dom["avg_ms"], "algorithmic_per_launch": per_launch,
+                              "share_of_step": dom["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-9),
+                              "launches_per_step": dom["calls"] / reps,
+                              "note": "fp32-exact contraction on v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense peak)" if mfma else ""}
+        result["kernels"] = {k: {"calls_per_step": v["calls"] / reps, "ms_per_step": v["ms"] / reps, "gbs": v["gbs"], "tflops": v["tflops"]}
+                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if a.profile_table and rank == 0:
+            tot = sum(v["ms"] for v in agg.values()) / reps
+            print("%-34s %6s %9s %9s %9s" % ("kernel", "calls", "ms/step", "GB/s", "TFLOP/s"), file=sys.stderr)
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                print("%-34s %6.0f %9.3f %9.0f %9.1f" % (k, v["calls"] / reps, v["ms"] / reps, v["gbs"], v["tflops"]), file=sys.stderr)
+            print("sum of kernel times %.3f ms/step; wall %.3f ms/step" % (tot, ms_per_step), file=sys.stderr)
+
+    # ---- view-sharded latency mode (N > 1): source views over ranks + RCCL all-reduce per stage ----
+    if world > 1:
+        try:
+            head.set_view_group(dist.group.WORLD)
+            f0 = {k: v.clone() for k, v in feats.items()}
+            for k in f0:
+                dist.broadcast(f0[k], 0)
+            with torch.no_grad():
+                for _ in range(2):
+                    head(f0, projs, dv, tmp=TMP)
+                sync_all()
+                t0 = time.perf_counter()
+                n_lat = max(3, a.steps // 4)
+                for _ in range(n_lat):
+                    head(f0, projs, dv, tmp=TMP)
+                sync_all()
+                lat = (time.perf_counter() - t0) / n_lat
+            tl = torch.tensor([lat], dtype=torch.float64, device=device)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            result["view_sharded"] = {"ms_per_ref_view": float(tl.item()) * 1e3, "ref_views_per_s": 1.0 / float(tl.item()),
+                                      "note": "ONE reference view at a time, %d source views sharded over %d ranks, "
+                                              "all-reduce(sum) of [8*D*H*W + H*W] fp32 per stage" % (a.views - 1, world)}
+            head.set_view_group(None)
+        except Exception as e:  # the headline number above is already measured; report the failure instead of dying
+            result["view_sharded"] = {"error": repr(e)}
+
+    # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) + a parity read-out ----
+    if world == 1 and not a.no_cpu_baseline:
+        cb, ref = cpu_baseline(head, feats, projs, dv)
+        result["cpu_baseline"] = cb
+        d, r = out["refined_depth"].cpu(), ref["refined_depth"]
+        result["parity"] = {"refined_depth_rel_l1_vs_oracle": float(((d - r).abs() / r.abs()).mean()),
+                            "confidence_max_abs_vs_oracle": float((out["photometric_confidence"].cpu() - ref["photometric_confidence"]).abs().max()),
+                            "bar": 1e-3}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""Per-kernel timing of one cascade pass with HIP events (for bench.py's `roofline` object and DESIGN.md).
+
+``profile_cascade`` replays exactly the launches ``CascadeDepthHead.forward`` makes, but one C-ABI call per kernel
+launch, each bracketed by a pair of events recorded on torch's current stream - the stream the kernels are launched
+on.  Every launch is labelled with the kernel it runs and with its ALGORITHMIC work:
+
+  bytes   what the launch must move through HBM at least once (inputs read once + outputs written once; halo
+          re-reads, weights and L2-resident re-use are NOT counted)
+  flops   2 * MACs of the mathematical operator (padding taps on the volume border included, MFMA padding of
+          8-channel outputs to 16 rows NOT included)
+
+so that achieved = work / time is comparable with the 8 TB/s HBM and 157.3 TFLOP/s fp32-MFMA peaks of
+MI355X_MICROARCH.md.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+from .cascade import CascadeDepthHead
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 dense peak
+
+
+class Launch:
+    __slots__ = ("kernel", "stage", "flops", "bytes", "start", "end", "ms")
+
+    def __init__(self, kernel, stage, flops, nbytes):
+        self.kernel, self.stage, self.flops, self.bytes = kernel, stage, float(flops), float(nbytes)
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.end = torch.cuda.Event(enable_timing=True)
+        self.ms = 0.0
+
+
+def _conv_name(cin, cout, kd, stride):
+    return "conv3d_mfma<%d,%d,k%d,s%d%d%d>" % (cin, cout, kd, stride[0], stride[1], stride[2])
+
+
+def _timed(launches: List[Launch], kernel: str, stage: int, flops: float, nbytes: float, fn):
+    rec = Launch(kernel, stage, flops, nbytes)
+    rec.start.record()
+    out = fn()
+    rec.end.record()
+    launches.append(rec)
+    return out
+
+
+def _regnet_layers(net, vol, stage, launches):
+    """The nine U-Net launches of mvs_regnet_fwd, one C-ABI call each (same kernels, same order)."""
+    ws, bs, _, _ = net.packed_all(vol.device)
+    three_d = net.kind == _lib.REG_COSTREGNET3D
+    s2 = (1, 2, 2) if three_d else (2, 2, 2)
+    sd = 1 if three_d else 2
+
+    def conv(x, i, cout, stride):
+        B, D, H, W, cin = x.shape
+        od = (D - 1) // stride[0] + 1
+        oh, ow = (H - 1) // stride[1] + 1, (W - 1) // stride[2] + 1
+        nout = B * od * oh * ow
+        return _timed(launches, _conv_name(cin, cout, 3, stride), stage, 2.0 * 27 * cin * cout * nout,
+                      4.0 * (x.numel() + nout * cout), lambda: ops.conv3d_bn_relu(x, ws[i], bs[i], cout, 3, stride, True))
+
+    def deconv(x, i, cout, skip):
+        B, D, H, W, cin = x.shape
+        nout = B * D * sd * 4 * H * W
+        return _timed(launches, "deconv3d_mfma<%d,%d,s%d22>" % (cin, cout, sd), stage, 2.0 * 27 * cin * cout * (B * D * H * W),
+                      4.0 * (x.numel() + 2 * nout * cout), lambda: ops.deconv3d_bn_relu_add(x, ws[i], bs[i], cout, sd, skip))
+
+    c1 = conv(vol, 0, 16, s2)
+    c2 = conv(c1, 1, 16, (1, 1, 1))
+    c3 = conv(c2, 2, 32, s2)
+    c4 = conv(c3, 3, 32, (1, 1, 1))
+    c5 = conv(c4, 4, 64, s2)
+    c6 = conv(c5, 5, 64, (1, 1, 1))
+    x = deconv(c6, 6, 32, c4)
+    x = deconv(x, 7, 16, c2)
+    return deconv(x, 8, 8, vol)
+
+
+@torch.no_grad()
+def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_values, tmp=(5.0, 5.0, 5.0, 1.0)) -> Tuple[dict, List[Launch]]:
+    launches: List[Launch] = []
+    n = len(head.ndepths)
+    out = None
+    confs = []
+    for s in range(n):
+        key = "stage%d" % (s + 1)
+        net = head.fusions[s]
+        feats, code = ops._feat(features[key])
+        proj = proj_matrices[key]
+        B, V, C, H, W = feats.shape
+        D = head.ndepths[s]
+        HW = H * W
+        esz = feats.element_size()
+        if s == 0:
+            hyp = _timed(launches, "init_range", s, 0, 4.0 * B * D * HW,
+                         lambda: ops.init_range(depth_values, D, H, W, inverse=head.inverse_depth))
+        else:
+            pd, ph = out["depth"], out["depth_values"]
+            hyp = _timed(launches, "schedule_range", s, 0, 4.0 * (B * D * HW + 3 * B * HW / 4),
+                         lambda: ops.schedule_inverse_range(pd, ph, D, head.depth_interals_ratio[s], H, W))
+        hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
+        corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
+        ent = _timed(launches, "warp_corr_entropy<C%d>" % C, s, corr_flops,
+                     B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)), lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
+        vp = net._vis_params(feats.device)
+        # the vis CNN is four launches inside one C call; it is timed as a unit
+        vis = _timed(launches, "vis_cnn(4 launches)", s, 2.0 * B * (V - 1) * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8),
+                     4.0 * B * (V - 1) * HW * (1 + 16 + 16 + 16 + 16 + 8 + 8 + 1), lambda: ops.vis_weight(ent, vp))
+        vol = _timed(launches, "warp_corr_aggregate<C%d>" % C, s, corr_flops,
+                     B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
+                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
+        feat_cl = _regnet_layers(net.cost_reg, vol, s, launches)
+        ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device)
+        ks = net.cost_reg.prob_ksize
+        res = _timed(launches, "prob_regress<k%d>" % ks, s, 2.0 * B * D * HW * 8 * (27 if ks == 3 else 1),
+                     4.0 * B * (8 * D * HW + D * HW + 2 * D * HW + 2 * HW),
+                     lambda: ops.prob_regress(feat_cl, prob_w, prob_b, ks, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
+        out = {"depth": res[0], "photometric_confidence": res[1], "depth_values": hyp}
+        confs.append(res[1])
+    Hf, Wf = features["stage%d" % n].shape[-2:]
+    final_conf = _timed(launches, "confidence_average", n - 1, 0, 4.0 * Hf * Wf * 2, lambda: ops.confidence_average(confs, Hf, Wf))
+    torch.cuda.synchronize()
+    for l in launches:
+        l.ms = l.start.elapsed_time(l.end)
+    return {"refined_depth": out["depth"], "photometric_confidence": final_conf}, launches
+
+
+def summarize(launches: Sequence[Launch]) -> "OrderedDict[str, dict]":
+    """Aggregate by kernel name: calls, total ms, average ms, achieved GB/s and TFLOP/s."""
+    agg: "OrderedDict[str, dict]" = OrderedDict()
+    for l in launches:
+        a = agg.setdefault(l.kernel, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        a["calls"] += 1
+        a["ms"] += l.ms
+        a["flops"] += l.flops
+        a["bytes"] += l.bytes
+    for a in agg.values():
+        t = max(a["ms"], 1e-9) * 1e-3
+        a["avg_ms"] = a["ms"] / a["calls"]
+        a["gbs"] = a["bytes"] / t / 1e9
+        a["tflops"] = a["flops"] / t / 1e12
+    return agg

@@ -92,8 +92,9 @@ def _texture(X: torch.Tensor, Y: torch.Tensor, C: int, wavelength: float, seed: 
     a = (torch.rand(C, 3, generator=g, dtype=torch.float64) * 2 - 1) * k
     b = (torch.rand(C, 3, generator=g, dtype=torch.float64) * 2 - 1) * k
     ph = torch.rand(C, 3, generator=g, dtype=torch.float64) * 2 * math.pi
-    amp = torch.tensor([1.0, 0.6, 0.35], dtype=torch.float64)
-    out = torch.zeros((C,) + tuple(X.shape), dtype=torch.float64)
+    amp = (1.0, 0.6, 0.35)
+    a, b, ph = a.to(X.device), b.to(X.device), ph.to(X.device)
+    out = torch.zeros((C,) + tuple(X.shape), dtype=torch.float64, device=X.device)
     for j in range(3):
         mult = float(2 ** j)
         out += amp[j] * torch.sin(mult * (a[:, j, None, None] * X + b[:, j, None, None] * Y) + ph[:, j, None, None])
@@ -101,7 +102,7 @@ def _texture(X: torch.Tensor, Y: torch.Tensor, C: int, wavelength: float, seed: 
 
 
 def make_features(proj_stage: torch.Tensor, C: int, H: int, W: int, *, dmin: float, dmax: float,
-                  noise: float = 0.05, seed: int = 0, dtype=torch.float32) -> torch.Tensor:
+                  noise: float = 0.05, seed: int = 0, dtype=torch.float32, device=None) -> torch.Tensor:
     """Geometrically consistent features ``[B, V, C, H, W]`` for one stage.
 
     The scene is the depth surface ``_surface_depth`` seen from the reference camera.  For a
@@ -110,9 +111,12 @@ def make_features(proj_stage: torch.Tensor, C: int, H: int, W: int, *, dmin: flo
     benchmark texture; a little white noise decorrelates the views.
     """
     B, V = proj_stage.shape[:2]
-    g = torch.Generator().manual_seed(seed)
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
-    feats = torch.zeros(B, V, C, H, W, dtype=torch.float32)
+    device = torch.device("cpu") if device is None else torch.device(device)
+    on_cpu = device.type == "cpu"
+    g = torch.Generator(device=device).manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=device), torch.arange(W, dtype=torch.float64, device=device), indexing="ij")
+    feats = torch.zeros(B, V, C, H, W, dtype=torch.float32, device=device)
+    proj_stage = proj_stage.to(device)
     for b in range(B):
         K0 = proj_stage[b, 0, 1, :3, :3].double()
         E0 = proj_stage[b, 0, 0].double()
@@ -122,7 +126,7 @@ def make_features(proj_stage: torch.Tensor, C: int, H: int, W: int, *, dmin: flo
             K = proj_stage[b, v, 1, :3, :3].double()
             E = proj_stage[b, v, 0].double()
             # relative pose view v -> ref
-            T = E0 @ torch.inverse(E)          # X_ref = T @ X_v
+            T = (E0.cpu() @ torch.inverse(E.cpu())).to(device)          # X_ref = T @ X_v
             rx = (xs - K[0, 2]) / K[0, 0]
             ry = (ys - K[1, 2]) / K[1, 1]
             z = torch.full_like(xs, 0.5 * (dmin + dmax))
@@ -136,9 +140,9 @@ def make_features(proj_stage: torch.Tensor, C: int, H: int, W: int, *, dmin: flo
                 z = z + (zr - Xr[2])
             Xv = torch.stack([rx * z, ry * z, z, torch.ones_like(z)], 0).reshape(4, -1)
             Xr = (T @ Xv).reshape(4, H, W)
-            Xw = (torch.inverse(E0) @ Xr.reshape(4, -1)).reshape(4, H, W)
+            Xw = (torch.inverse(E0.cpu()).to(device) @ Xr.reshape(4, -1)).reshape(4, H, W)
             tex = _texture(Xw[0], Xw[1], C, wl, seed)
-            tex = tex + noise * torch.randn(tex.shape, generator=g, dtype=torch.float64)
+            tex = tex + noise * torch.randn(tex.shape, generator=g, dtype=torch.float64, device=device)
             feats[b, v] = tex.float()
     return feats.to(dtype)
 
@@ -152,7 +156,7 @@ def true_depth(proj_stage: torch.Tensor, H: int, W: int, dmin: float, dmax: floa
 def make_cascade_inputs(H: int, W: int, V: int, *, numdepth: int = 192, depth_min: float = 425.0,
                         depth_interval: float = 2.65, baseline: float = 25.0, rot_deg: float = 0.0,
                         seed: int = 0, batch: int = 1, feat_dtype=torch.float32,
-                        stage_ch: Tuple[int, ...] = STAGE_CH) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor], torch.Tensor]:
+                        stage_ch: Tuple[int, ...] = STAGE_CH, device=None) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor], torch.Tensor]:
     """(features, proj_matrices, depth_values) for a 4-stage cascade at full resolution HxW.
 
     ``depth_values`` mirrors ``general_eval.py:223``: arange(dmin, interval*(nd-0.5)+dmin, interval).
@@ -171,7 +175,10 @@ def make_cascade_inputs(H: int, W: int, V: int, *, numdepth: int = 192, depth_mi
     for s, C in enumerate(stage_ch):
         down = 2 ** (len(stage_ch) - 1 - s)
         feats["stage%d" % (s + 1)] = make_features(projs["stage%d" % (s + 1)], C, H // down, W // down,
-                                                   dmin=lo, dmax=hi, seed=seed + s, dtype=feat_dtype)
+                                                   dmin=lo, dmax=hi, seed=seed + s, dtype=feat_dtype, device=device)
+    if device is not None:
+        projs = {k: v.to(device) for k, v in projs.items()}
+        depth_values = depth_values.to(device)
     return feats, projs, depth_values
 
 

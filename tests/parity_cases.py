@@ -251,3 +251,59 @@ def case_cascade_golden(device):
     assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= 5e-5
     assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-3
     assert torch.equal(out["refined_depth"], out["stage4"]["depth"])
+
+
+# ---------------------------------------------------------------- larger sizes (GPU only)
+def _seeded_head(device, seed=11, peaky=False):
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True)
+    head = CascadeDepthHead(args)
+    for i, st in enumerate(head.fusions):
+        sd = synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), seed + i)
+        if peaky:
+            sd["cost_reg.prob.weight"] = sd["cost_reg.prob.weight"] * 30.0      # SURVEY.md section 8d "peaky" set
+        st.load_state_dict(sd, strict=True)
+    return head.eval().to(device), args
+
+
+def case_cascade_vs_oracle(device, H, W, V, peaky=False):
+    head, args = _seeded_head(device, peaky=peaky)
+    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=2, rot_deg=1.0)
+    sds = [{k: v.cpu() for k, v in st.state_dict().items()} for st in head.fusions]
+    with torch.no_grad():
+        ref = O.cascade_forward(feats, projs, dv, sds, ndepths=args["ndepths"], depth_interals_ratio=args["depth_interals_ratio"],
+                                base_ch=args["base_ch"])
+        out = head({k: dev(v, device) for k, v in feats.items()}, {k: dev(v, device) for k, v in projs.items()}, dev(dv, device))
+    for s in range(1, 5):
+        r = rel_l1(cpu(out["stage%d" % s]["depth"]), ref["stage%d" % s]["depth"])
+        assert r <= 1e-3, "stage %d depth rel-L1 %g > 1e-3" % (s, r)
+    r = rel_l1(cpu(out["refined_depth"]), ref["refined_depth"])
+    assert r <= 1e-3, "refined depth rel-L1 %g > 1e-3 (north-star bar)" % r
+    assert (cpu(out["photometric_confidence"]) - ref["photometric_confidence"]).abs().max() <= 5e-2
+    return r
+
+
+def case_cascade_fullsize_properties(device, H=1152, W=1536, V=5):
+    head, args = _seeded_head(device)
+    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=0, device=device)
+    with torch.no_grad():
+        a = head(feats, projs, dv)
+        b = head(feats, projs, dv)
+        assert torch.equal(a["refined_depth"], b["refined_depth"]), "the path must be deterministic run to run"
+        d = a["refined_depth"]
+        assert torch.isfinite(d).all() and torch.isfinite(a["photometric_confidence"]).all()
+        assert float(d.min()) >= float(dv.min()) * 0.9 and float(d.max()) <= float(dv.max()) * 1.1
+        c = a["photometric_confidence"]
+        assert float(c.min()) >= 0.0 and float(c.max()) <= 1.0 + 1e-5
+        for s in range(1, 5):
+            pv = a["stage%d" % s]["prob_volume"]
+            assert (pv.sum(1) - 1).abs().max() <= 1e-4                      # softmax over depth sums to one
+            hyp = a["stage%d" % s]["depth_values"]
+            assert (hyp[:, :-1] >= hyp[:, 1:]).all()                         # inverse-depth hypotheses run far -> near
+        # permuting the source views permutes nothing but the summation order of the aggregation
+        perm = [0, 3, 1, 4, 2]
+        fp = {k: v[:, perm].contiguous() for k, v in feats.items()}
+        pp = {k: v[:, perm].contiguous() for k, v in projs.items()}
+        c2 = head(fp, pp, dv)
+        r = rel_l1(c2["refined_depth"].cpu(), d.cpu())
+        assert r <= 1e-4, "view-order invariance violated: %g" % r
