@@ -51,7 +51,9 @@ def build_head(device):
 def cpu_baseline(head, feats, projs, dv, max_threads=None):
     """The oracle (CPU restatement of the reference PyTorch path, fp32) on the host cores; second of two passes."""
     from oracle import ref_path as O
-    n = max_threads or os.cpu_count() or 1
+    # oneDNN convolutions on these shapes get SLOWER beyond a few dozen threads (256 threads: 171 s per pass on the
+    # GPU box vs 11.5 s on 8 threads in the build container), so the baseline uses 16 threads and says so.
+    n = min(max_threads or 16, os.cpu_count() or 1)
     torch.set_num_threads(n)
     sds = [{k: v.detach().cpu() for k, v in st.state_dict().items()} for st in head.fusions]
     f = {k: v.cpu() for k, v in feats.items()}

@@ -41,13 +41,46 @@ struct ConvCfg {
     static_assert(CIN % CH == 0 && CH % 4 == 0 && NB % 4 == 0, "bad conv tile configuration");
 };
 
+// operands of contraction step t: MREP weight fragments (global, 1 KiB contiguous per wave) + NREP activation
+// fragments (LDS).  Lane group g owns k-quad 4t+g: (tap, cq) = divmod(4t+g, QC); padded quads carry zero weights.
 template <class Cfg>
-__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__device__ __forceinline__ void conv_load_step(int t, int g, const float4* wq, const float* lds, const int* voxbase,
+                                               float4* a, float4* b) {
+    constexpr int QC = Cfg::QC;
+    int tap, cq;
+    if (QC >= 4) { tap = (4 * t) / QC; cq = (4 * t) % QC + g; }       // tap is wave-uniform
+    else { const int kq = 4 * t + g; tap = kq / QC; cq = kq % QC; }
+    tap = tap < Cfg::NTAP ? tap : Cfg::NTAP - 1;
+    const int kd = tap / 9, r9 = tap - kd * 9, kh = r9 / 3, kw = r9 - kh * 3;
+    const int tapoff = ((kd * Cfg::IH + kh) * Cfg::IW + kw) * Cfg::S + cq * 4;
+#pragma unroll
+    for (int mb = 0; mb < Cfg::MREP; ++mb) a[mb] = wq[(size_t)(t * Cfg::MREP + mb) * 64];
+#pragma unroll
+    for (int nb = 0; nb < Cfg::NREP; ++nb) b[nb] = *reinterpret_cast<const float4*>(lds + voxbase[nb] + tapoff);
+}
+
+template <int MREP, int NREP>
+__device__ __forceinline__ void conv_mfma_step(const float4* a, const float4* b, f32x4 (*acc)[NREP]) {
+    // component-outer order: consecutive MFMAs target different accumulators (v_mfma_f32_16x16x4_f32 issues every
+    // 32 cycles but a dependent accumulator is ready only after 40)
+#define MVS_MFMA_ROUND(COMP)                                                                                          \
+    _Pragma("unroll") for (int mb = 0; mb < MREP; ++mb) _Pragma("unroll") for (int nb = 0; nb < NREP; ++nb)          \
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].COMP, b[nb].COMP, acc[mb][nb], 0, 0, 0);
+    MVS_MFMA_ROUND(x)
+    MVS_MFMA_ROUND(y)
+    MVS_MFMA_ROUND(z)
+    MVS_MFMA_ROUND(w)
+#undef MVS_MFMA_ROUND
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const float* __restrict__ x, const float* wp,
                                                           const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W,
                                                           int OD, int OH, int OW, int relu, int tiles_x, int tiles_y, int ntiles) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, SH = Cfg::SH, SW = Cfg::SW, TD = Cfg::TD, TH = Cfg::TH, CH = Cfg::CH;
     constexpr int IH = Cfg::IH, IW = Cfg::IW, S = Cfg::S, QC = Cfg::QC, NSTEP = Cfg::NSTEP, MREP = Cfg::MREP, NREP = Cfg::NREP;
-    HIP_DYNAMIC_SHARED(float, lds)
+    HIP_DYNAMIC_SHARED(float4, lds4)                          // float4 => the LDS base is known 16-byte aligned (ds_read_b128)
+    float* lds = reinterpret_cast<float*>(lds4);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
@@ -89,31 +122,22 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const float* __restric
         }
         __syncthreads();
         // ---- contraction over (tap, cin) of this chunk ----
-        const float* wpass = wp + (size_t)pass * NSTEP * MREP * 256;
-#pragma unroll 2
-        for (int t = 0; t < NSTEP; ++t) {
-            const int kq = 4 * t + g;
-            int tap = kq / QC;
-            const int cq = kq - tap * QC;
-            tap = tap < Cfg::NTAP ? tap : Cfg::NTAP - 1;        // padded quads carry zero weights
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int tapoff = ((kd * IH + kh) * IW + kw) * S + cq * 4;
-            float4 a[MREP];
-#pragma unroll
-            for (int mb = 0; mb < MREP; ++mb) a[mb] = *reinterpret_cast<const float4*>(wpass + ((size_t)(t * MREP + mb) * 64 + lane) * 4);
-            float4 bv[NREP];
-#pragma unroll
-            for (int nb = 0; nb < NREP; ++nb) bv[nb] = *reinterpret_cast<const float4*>(lds + voxbase[nb] + tapoff);
-#pragma unroll
-            for (int mb = 0; mb < MREP; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NREP; ++nb) {
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, bv[nb].x, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, bv[nb].y, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, bv[nb].z, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, bv[nb].w, acc[mb][nb], 0, 0, 0);
-                }
+        // Software pipeline with two named register sets (no copies): the weight (global/L2) and activation (LDS)
+        // operands of step t+1 are requested before the MFMAs of step t are issued, so their latency hides under
+        // 4*MREP*NREP MFMAs (>= 512 cycles) instead of being exposed in front of every step.
+        const float4* wq = reinterpret_cast<const float4*>(wp) + (size_t)pass * NSTEP * MREP * 64 + lane;
+        float4 a0[MREP], b0[NREP], a1[MREP], b1[NREP];
+        conv_load_step<Cfg>(0, g, wq, lds, voxbase, a0, b0);
+#pragma unroll 1
+        for (int t = 0; t + 1 < NSTEP; t += 2) {
+            conv_load_step<Cfg>(t + 1, g, wq, lds, voxbase, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);                 // keep the prefetch ABOVE the MFMAs it hides under
+            conv_mfma_step<MREP, NREP>(a0, b0, acc);
+            conv_load_step<Cfg>(t + 2 < NSTEP ? t + 2 : NSTEP - 1, g, wq, lds, voxbase, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            conv_mfma_step<MREP, NREP>(a1, b1, acc);
         }
+        if (NSTEP & 1) conv_mfma_step<MREP, NREP>(a0, b0, acc);    // odd step count: the last prefetched step
     }
 
     // ---- epilogue: + bias (folded BN), ReLU, channel-last float4 store ----
@@ -160,14 +184,39 @@ struct DeconvCfg {
     static_assert(CIN % 16 == 0 && NB % 4 == 0, "bad deconv tile configuration");
 };
 
+// operands of step `st` of parity class (pd,ph,pw): decode (tap, q), then MREP weight + NREP activation fragments
 template <class Cfg>
-__global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__device__ __forceinline__ void deconv_load_step(int st, int pd, int ph, int pw, const float4* wq, const float* lds, const int* voxbase,
+                                                 float4* a, float4* b) {
+    constexpr int SD = Cfg::SD, NQ = Cfg::NQ;
+    const int q = st % NQ;
+    int ti = st / NQ;
+    const int nkw = pw ? 2 : 1, nkh = ph ? 2 : 1;
+    const int a_w = ti % nkw;
+    ti /= nkw;
+    const int a_h = ti % nkh, a_d = ti / nkh;
+    // (kernel index, input offset) per axis: stride 2 parity 0 <- (1, 0); parity 1 <- (0, +1), (2, 0); stride 1 <- (k, 1 - k)
+    const int kd = (SD == 2) ? (pd ? 2 * a_d : 1) : a_d;
+    const int od = (SD == 2) ? (pd ? 1 - a_d : 0) : 1 - a_d;
+    const int kh = ph ? 2 * a_h : 1, oh = ph ? 1 - a_h : 0;
+    const int kw = pw ? 2 * a_w : 1, ow = pw ? 1 - a_w : 0;
+    const int tap = (kd * 3 + kh) * 3 + kw;
+    const int ldsoff = ((od * Cfg::LH + oh) * Cfg::LW + ow) * Cfg::S + q * 16;
+#pragma unroll
+    for (int mb = 0; mb < Cfg::MREP; ++mb) a[mb] = wq[(size_t)((tap * NQ + q) * Cfg::MREP + mb) * 64];
+#pragma unroll
+    for (int nb = 0; nb < Cfg::NREP; ++nb) b[nb] = *reinterpret_cast<const float4*>(lds + voxbase[nb] + ldsoff);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const float* __restrict__ x, const float* wp,
                                                             const float* __restrict__ bias, const float* __restrict__ skip,
                                                             float* __restrict__ y, int D, int H, int W, int tiles_x, int tiles_y,
                                                             int ntiles) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, TDM = Cfg::TDM, THM = Cfg::THM;
     constexpr int LH = Cfg::LH, LW = Cfg::LW, S = Cfg::S, QC = Cfg::QC, NQ = Cfg::NQ, MREP = Cfg::MREP, NREP = Cfg::NREP;
-    HIP_DYNAMIC_SHARED(float, lds)
+    HIP_DYNAMIC_SHARED(float4, lds4)
+    float* lds = reinterpret_cast<float*>(lds4);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
@@ -212,40 +261,23 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(const float* __restr
 #pragma unroll
             for (int nb = 0; nb < NREP; ++nb) acc[mb][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+        // flat, software-pipelined step list of this class: step = (tap of the class, 16-channel block q)
         const int nkd = (SD == 2) ? (pd ? 2 : 1) : 3;
         const int nkh = ph ? 2 : 1, nkw = pw ? 2 : 1;
-        for (int a_d = 0; a_d < nkd; ++a_d) {
-            // (kernel index, input offset) along depth
-            const int kd = (SD == 2) ? (pd ? 2 * a_d : 1) : a_d;
-            const int od = (SD == 2) ? (pd ? 1 - a_d : 0) : 1 - a_d;
-            for (int a_h = 0; a_h < nkh; ++a_h) {
-                const int kh = ph ? 2 * a_h : 1, oh = ph ? 1 - a_h : 0;
-                for (int a_w = 0; a_w < nkw; ++a_w) {
-                    const int kw = pw ? 2 * a_w : 1, ow = pw ? 1 - a_w : 0;
-                    const int tap = (kd * 3 + kh) * 3 + kw;
-                    const int ldsoff = ((od * LH + oh) * LW + ow) * S;
-                    const float* wtap = wp + (size_t)tap * NQ * MREP * 256;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        float4 a[MREP];
-#pragma unroll
-                        for (int mb = 0; mb < MREP; ++mb) a[mb] = *reinterpret_cast<const float4*>(wtap + ((size_t)(q * MREP + mb) * 64 + lane) * 4);
-                        float4 bv[NREP];
-#pragma unroll
-                        for (int nb = 0; nb < NREP; ++nb) bv[nb] = *reinterpret_cast<const float4*>(lds + voxbase[nb] + ldsoff + q * 16);
-#pragma unroll
-                        for (int mb = 0; mb < MREP; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NREP; ++nb) {
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, bv[nb].x, acc[mb][nb], 0, 0, 0);
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, bv[nb].y, acc[mb][nb], 0, 0, 0);
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, bv[nb].z, acc[mb][nb], 0, 0, 0);
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, bv[nb].w, acc[mb][nb], 0, 0, 0);
-                            }
-                    }
-                }
-            }
+        const int nst = nkd * nkh * nkw * NQ;
+        const float4* wq = reinterpret_cast<const float4*>(wp) + lane;
+        float4 a0[MREP], b0[NREP], a1[MREP], b1[NREP];
+        deconv_load_step<Cfg>(0, pd, ph, pw, wq, lds, voxbase, a0, b0);
+#pragma unroll 1
+        for (int st = 0; st + 1 < nst; st += 2) {
+            deconv_load_step<Cfg>(st + 1, pd, ph, pw, wq, lds, voxbase, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            conv_mfma_step<MREP, NREP>(a0, b0, acc);
+            deconv_load_step<Cfg>(st + 2 < nst ? st + 2 : nst - 1, pd, ph, pw, wq, lds, voxbase, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            conv_mfma_step<MREP, NREP>(a1, b1, acc);
         }
+        if (nst & 1) conv_mfma_step<MREP, NREP>(a0, b0, acc);
         // ---- epilogue of this parity class: relu(acc + bias) + skip ----
 #pragma unroll
         for (int nb = 0; nb < NREP; ++nb) {
@@ -348,7 +380,7 @@ int conv3d_dispatch(const float* x, const float* wp, const float* bias, float* y
         return launch_conv<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>(x, wp, bias, y, B, D, H, W, relu, st);
     MVS_CONV(16, 16, 3, 1, 1, 1, 4, 4, 16)
     MVS_CONV(32, 32, 3, 1, 1, 1, 4, 4, 16)
-    MVS_CONV(64, 64, 3, 1, 1, 1, 4, 4, 16)
+    MVS_CONV(64, 64, 3, 1, 1, 1, 2, 4, 16)      // coarsest U-Net level: few voxels, so smaller tiles (2x4x16) keep all CUs busy
     MVS_CONV(8, 16, 3, 2, 2, 2, 2, 4, 8)
     MVS_CONV(16, 32, 3, 2, 2, 2, 2, 4, 8)
     MVS_CONV(32, 64, 3, 2, 2, 2, 2, 4, 8)

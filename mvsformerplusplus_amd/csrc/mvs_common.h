@@ -90,6 +90,57 @@ __device__ __forceinline__ Taps make_taps(const Homography& hm, float qx, float 
     return tp;
 }
 
+// The same four taps expressed as TWO horizontally adjacent pairs (top row, bottom row): one unaligned
+// 8-byte (fp32) / 4-byte (bf16, fp16) load per row instead of two 4-/2-byte loads.  `top`/`bot` address the
+// LEFT element of an in-bounds pair (x clamped to [0, W-2]); the bilinear weights are routed to whichever pair
+// slot the valid tap landed in, so border handling (per-tap zero padding) is bit-identical to make_taps.
+// Needs W >= 2.
+struct PairTaps {
+    int top, bot;
+    float w00, w01, w10, w11;    // weights of top.x, top.y, bot.x, bot.y
+};
+
+template <typename T> struct PairOf;
+template <> struct PairOf<float> { struct __attribute__((packed, aligned(4))) type { float x, y; }; };
+template <> struct PairOf<uint16_t> { struct __attribute__((packed, aligned(2))) type { uint16_t x, y; }; };
+template <> struct PairOf<_Float16> { struct __attribute__((packed, aligned(2))) type { _Float16 x, y; }; };
+
+__device__ __forceinline__ PairTaps make_pair_taps(const Homography& hm, float qx, float qy, float qz, float depth, int H, int W,
+                                                   float half_w, float half_h) {
+    const float px = qx * depth + hm.t[0];
+    const float py = qy * depth + hm.t[1];
+    const float pz = qz * depth + hm.t[2];
+    const float zz = pz + 1e-6f;
+    const float u = px / zz;
+    const float v = py / zz;
+    const float xn = u / half_w - 1.0f;
+    const float yn = v / half_h - 1.0f;
+    const float ix = ((xn + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((yn + 1.0f) / 2.0f) * (float)(H - 1);
+    PairTaps tp;
+    const bool sane = (ix > -2.0f) && (ix < (float)(W + 1)) && (iy > -2.0f) && (iy < (float)(H + 1));
+    if (!sane) {
+        tp.top = 0; tp.bot = 0; tp.w00 = 0.0f; tp.w01 = 0.0f; tp.w10 = 0.0f; tp.w11 = 0.0f;
+        return tp;
+    }
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float wx1 = ix - fx0, wy1 = iy - fy0;
+    const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+    const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x0 >= -1) && (x0 < W - 1);
+    const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y0 >= -1) && (y0 < H - 1);
+    const int xb = x0 < 0 ? 0 : (x0 > W - 2 ? W - 2 : x0);
+    // slot 0 holds column xb, slot 1 column xb + 1
+    const float wa = (vx0 && x0 <= W - 2 ? wx0 : 0.0f) + (vx1 && x0 < 0 ? wx1 : 0.0f);
+    const float wb = (vx0 && x0 > W - 2 ? wx0 : 0.0f) + (vx1 && x0 >= 0 ? wx1 : 0.0f);
+    const float wyt = vy0 ? wy0 : 0.0f, wyb = vy1 ? wy1 : 0.0f;
+    const int yt = vy0 ? y0 : 0, yb = vy1 ? y0 + 1 : 0;
+    tp.top = yt * W + xb;
+    tp.bot = yb * W + xb;
+    tp.w00 = wa * wyt; tp.w01 = wb * wyt; tp.w10 = wa * wyb; tp.w11 = wb * wyb;
+    return tp;
+}
+
 // XCD-aware work-group remap: the dispatcher places block b on XCD b % 8, so consecutive logical tiles
 // (which share feature rows / halo voxels) are handed to the same XCD and hit its private L2.
 // Bijective for any grid size (cdna_hip_programming.md T1).

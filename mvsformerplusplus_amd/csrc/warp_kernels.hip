@@ -95,109 +95,186 @@ __device__ __forceinline__ Homography load_homography(const float* p) {
     return hm;
 }
 
-// group-wise correlation of one voxel with one source view: ip[g] = mean_{c in g} ref[c] * bilinear(src[c])
-template <typename T, int CT, int GT>
-__device__ __forceinline__ void correlate(const T* __restrict__ src, const T* __restrict__ ref_g, const float* r_cached,
-                                          const Taps& tp, int HW, int pc, int C, int G, float* ip) {
-    const int cpg = C / G;
+// ------------------------------------------------------------------------------------------------
+// Work decomposition shared by both passes.  One work-item owns one pixel and a chunk of DCH = 4 consecutive
+// depth hypotheses: the DCH tap sets are computed once and every channel is then gathered for all DCH planes
+// back to back - neighbouring hypotheses project within a pixel or two of each other, so the 2*DCH pair loads of
+// a channel fall into the same few cache lines (L1-resident re-use instead of one L2 trip per plane) and the
+// reference feature is loaded once per DCH planes.  A 256-thread block = 4 waves = (64*SP pixels) x (SD depth
+// chunk slots), SD = min(4, #chunks); lanes are 64 consecutive pixels so every load is a near-contiguous span.
+// ------------------------------------------------------------------------------------------------
+constexpr int DCH = 4;
+
+struct ChunkMap {
+    int nch, sd, sp, ppb;     // #depth chunks, chunk slots per block, pixel sub-blocks per block, pixels per block
+};
+__host__ __device__ inline ChunkMap chunk_map(int D) {
+    ChunkMap m;
+    m.nch = (D + DCH - 1) / DCH;
+    m.sd = m.nch >= 4 ? 4 : (m.nch >= 2 ? 2 : 1);
+    m.sp = 4 / m.sd;
+    m.ppb = 64 * m.sp;
+    return m;
+}
+
+// Correlation of the DCH planes of one work-item with one source view, GT channel groups of `cpg` channels each:
+//   SUM_GROUPS  out[dd]       += sum_g mean_{c in g} ref[c] * bilinear(src[c])      (sim_vol, cost_volume.py:90)
+//   otherwise   out[dd*GT+g]   = mean_{c in g} ref[c] * bilinear(src[c])            (in_prod_vol, cost_volume.py:79-87)
+// The group loop is unrolled (accumulators are statically indexed registers) but the channel loop inside a group is
+// a REAL loop with a run-time trip count: the feature loads are invariant loads, which neither a memory clobber nor
+// sched_barrier pins, so a fully unrolled body issues every load of every channel up front and needs > 512
+// registers.  One iteration = one channel = 1 + 2*DCH independent loads in flight per work-item.
+template <typename T, int GT, bool SUM_GROUPS>
+__device__ __forceinline__ void correlate_chunk(const T* __restrict__ src, const T* __restrict__ ref, const PairTaps* tp, unsigned HW,
+                                                unsigned pc, int cpg, float* out) {
+    typedef typename PairOf<T>::type P2;
     const float inv_cpg = 1.0f / (float)cpg;
-    if (CT > 0) {
+    unsigned plane = 0;                                        // c * HW, uniform
 #pragma unroll
-        for (int g = 0; g < (GT > 0 ? GT : 1); ++g) {
-            float acc = 0.0f;
+    for (int g = 0; g < GT; ++g) {
+        float acc[DCH];
 #pragma unroll
-            for (int cc = 0; cc < (CT > 0 && GT > 0 ? CT / GT : 1); ++cc) {
-                const int c = g * (CT / (GT > 0 ? GT : 1)) + cc;
-                const T* sp = src + (size_t)c * HW;
-                float wv = tp.w[0] * to_f32(sp[tp.off[0]]);
-                wv += tp.w[1] * to_f32(sp[tp.off[1]]);
-                wv += tp.w[2] * to_f32(sp[tp.off[2]]);
-                wv += tp.w[3] * to_f32(sp[tp.off[3]]);
-                acc += r_cached[c] * wv;
+        for (int dd = 0; dd < DCH; ++dd) acc[dd] = 0.0f;
+#pragma unroll 1
+        for (int cc = 0; cc < cpg; ++cc) {
+            const T* sp = src + plane;
+            const float r = to_f32(ref[plane + pc]);
+#pragma unroll
+            for (int dd = 0; dd < DCH; ++dd) {
+                const P2 t = *reinterpret_cast<const P2*>(sp + (unsigned)tp[dd].top);
+                const P2 b = *reinterpret_cast<const P2*>(sp + (unsigned)tp[dd].bot);
+                float wv = tp[dd].w00 * to_f32(t.x);
+                wv += tp[dd].w01 * to_f32(t.y);
+                wv += tp[dd].w10 * to_f32(b.x);
+                wv += tp[dd].w11 * to_f32(b.y);
+                acc[dd] += r * wv;
             }
-            ip[g] = acc * inv_cpg;
+            plane += HW;
         }
-    } else {
-        for (int g = 0; g < G; ++g) {
-            float acc = 0.0f;
-            for (int cc = 0; cc < cpg; ++cc) {
-                const int c = g * cpg + cc;
-                const T* sp = src + (size_t)c * HW;
-                float wv = tp.w[0] * to_f32(sp[tp.off[0]]);
-                wv += tp.w[1] * to_f32(sp[tp.off[1]]);
-                wv += tp.w[2] * to_f32(sp[tp.off[2]]);
-                wv += tp.w[3] * to_f32(sp[tp.off[3]]);
-                acc += to_f32(ref_g[(size_t)c * HW + pc]) * wv;
-            }
-            ip[g] = acc * inv_cpg;
+#pragma unroll
+        for (int dd = 0; dd < DCH; ++dd) {
+            if (SUM_GROUPS) out[dd] += acc[dd] * inv_cpg;
+            else out[dd * GT + g] = acc[dd] * inv_cpg;
         }
     }
 }
 
+// generic (run-time C, G) single-voxel correlation used by the fallback kernels
+template <typename T>
+__device__ __forceinline__ void correlate_generic(const T* __restrict__ src, const T* __restrict__ ref, const Taps& tp, int HW, int pc, int C,
+                                                  int G, float* ip) {
+    const int cpg = C / G;
+    const float inv_cpg = 1.0f / (float)cpg;
+    for (int g = 0; g < G; ++g) {
+        float acc = 0.0f;
+        for (int cc = 0; cc < cpg; ++cc) {
+            const int c = g * cpg + cc;
+            const T* sp = src + (size_t)c * HW;
+            float wv = tp.w[0] * to_f32(sp[tp.off[0]]);
+            wv += tp.w[1] * to_f32(sp[tp.off[1]]);
+            wv += tp.w[2] * to_f32(sp[tp.off[2]]);
+            wv += tp.w[3] * to_f32(sp[tp.off[3]]);
+            acc += to_f32(ref[(size_t)c * HW + pc]) * wv;
+        }
+        ip[g] = acc * inv_cpg;
+    }
+}
+
+__device__ __forceinline__ void softmax_entropy_store(const float* sim, int stride, int D, float* dst) {
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, sim[d * stride]);
+    float den = 0.0f;
+    for (int d = 0; d < D; ++d) den += expf(sim[d * stride] - m);
+    float ent = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float pr = expf(sim[d * stride] - m) / den;
+        ent += -pr * logf(pr + 1e-7f);                      // cost_volume.py:92
+    }
+    *dst = ent;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pass 1: entropy of the depth-softmax of the group-summed correlation        cost_volume.py:79-92
-// grid = (pixel blocks of 64, views in launch, B); block = 64 pixels x 4 depth slots.
-// dynamic LDS: sim[D][64] floats.
+// grid = (pixel blocks, views in launch, B).  dynamic LDS: sim[D][pixels per block] floats.
 // ------------------------------------------------------------------------------------------------
 template <int DT, int CT, int GT>
 __global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                                 const float* __restrict__ hyp, float* __restrict__ entropy,
                                                                 int V, int C_, int G_, int D, int H, int W, int view_begin, int nblk) {
     typedef typename FeatT<DT>::type T;
-    const int C = CT > 0 ? CT : C_;
-    const int G = GT > 0 ? GT : G_;
     HIP_DYNAMIC_SHARED(float, sim)
     const int HW = H * W;
-    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
-    const int blk = (int)xcd_remap(blockIdx.x, (unsigned)nblk);
-    const int p = blk * 64 + lane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v = view_begin + (int)blockIdx.y;
     const int b = (int)blockIdx.z;
-    const bool valid = p < HW;
-    const int pc = valid ? p : HW - 1;
-    const int y = pc / W, x = pc - y * W;
+    const int blk = (int)xcd_remap(blockIdx.x, (unsigned)nblk);
     const Homography hm = load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
-    const float fx = (float)x, fy = (float)y;
-    const float qx = hm.r[0] * fx + hm.r[1] * fy + hm.r[2];
-    const float qy = hm.r[3] * fx + hm.r[4] * fy + hm.r[5];
-    const float qz = hm.r[6] * fx + hm.r[7] * fy + hm.r[8];
     const float half_w = (float)((double)(W - 1) / 2.0), half_h = (float)((double)(H - 1) / 2.0);
     const T* feat = reinterpret_cast<const T*>(feat_);
-    const T* ref = feat + (size_t)(b * V) * C * HW;
-    const T* src = feat + (size_t)(b * V + v) * C * HW;
-    float r[CT > 0 ? CT : 1];
     if (CT > 0) {
+        const ChunkMap cm = chunk_map(D);
+        const int psub = wave / cm.sd, cslot = wave % cm.sd;
+        const int pl = psub * 64 + lane;                     // pixel inside the block
+        const int p = blk * cm.ppb + pl;
+        const bool valid = p < HW;
+        const int pc = valid ? p : HW - 1;
+        const int y = pc / W, x = pc - y * W;
+        const float fx = (float)x, fy = (float)y;
+        const float qx = hm.r[0] * fx + hm.r[1] * fy + hm.r[2];
+        const float qy = hm.r[3] * fx + hm.r[4] * fy + hm.r[5];
+        const float qz = hm.r[6] * fx + hm.r[7] * fy + hm.r[8];
+        const T* ref = feat + (size_t)(b * V) * C_ * HW;
+        const T* src = feat + (size_t)(b * V + v) * C_ * HW;
+        const float* hp = hyp + (size_t)b * D * HW + pc;
+        const int cpg = C_ / GT;
+        for (int ch = cslot; ch < cm.nch; ch += cm.sd) {
+            const int d0 = ch * DCH;
+            PairTaps tp[DCH];
 #pragma unroll
-        for (int c = 0; c < (CT > 0 ? CT : 1); ++c) r[c] = to_f32(ref[(size_t)c * HW + pc]);
-    }
-    const float* hp = hyp + (size_t)b * D * HW + pc;
-    for (int d = slot; d < D; d += 4) {
-        const float depth = hp[(size_t)d * HW];
-        const Taps tp = make_taps(hm, qx, qy, qz, depth, H, W, half_w, half_h, nullptr);
-        float ip[GT > 0 ? GT : 64];
-        correlate<T, CT, GT>(src, ref, r, tp, HW, pc, C, G, ip);
-        float s = 0.0f;
-        for (int g = 0; g < G; ++g) s += ip[g];                 // sim_vol = in_prod_vol.sum(dim=1)
-        sim[d * 64 + lane] = s;
-    }
-    __syncthreads();
-    if (slot == 0 && valid) {
-        float m = -INFINITY;
-        for (int d = 0; d < D; ++d) m = fmaxf(m, sim[d * 64 + lane]);
-        float den = 0.0f;
-        for (int d = 0; d < D; ++d) den += expf(sim[d * 64 + lane] - m);
-        float ent = 0.0f;
-        for (int d = 0; d < D; ++d) {
-            const float pr = expf(sim[d * 64 + lane] - m) / den;
-            ent += -pr * logf(pr + 1e-7f);                      // cost_volume.py:92
+            for (int dd = 0; dd < DCH; ++dd) {
+                const int d = d0 + dd < D ? d0 + dd : D - 1;
+                tp[dd] = make_pair_taps(hm, qx, qy, qz, hp[(size_t)d * HW], H, W, half_w, half_h);
+            }
+            float s[DCH];
+#pragma unroll
+            for (int dd = 0; dd < DCH; ++dd) s[dd] = 0.0f;
+            correlate_chunk<T, (GT > 0 ? GT : 8), true>(src, ref, tp, (unsigned)HW, (unsigned)pc, cpg, s);
+#pragma unroll
+            for (int dd = 0; dd < DCH; ++dd)
+                if (d0 + dd < D) sim[(d0 + dd) * cm.ppb + pl] = s[dd];
         }
-        entropy[(size_t)(b * (V - 1) + (v - 1)) * HW + p] = ent;
+        __syncthreads();
+        if (cslot == 0 && valid) softmax_entropy_store(sim + pl, cm.ppb, D, entropy + (size_t)(b * (V - 1) + (v - 1)) * HW + p);
+    } else {
+        // run-time C / G fallback: 64 pixels x 4 depth slots, one voxel at a time
+        const int C = C_, G = G_;
+        const int p = blk * 64 + lane;
+        const bool valid = p < HW;
+        const int pc = valid ? p : HW - 1;
+        const int y = pc / W, x = pc - y * W;
+        const float fx = (float)x, fy = (float)y;
+        const float qx = hm.r[0] * fx + hm.r[1] * fy + hm.r[2];
+        const float qy = hm.r[3] * fx + hm.r[4] * fy + hm.r[5];
+        const float qz = hm.r[6] * fx + hm.r[7] * fy + hm.r[8];
+        const T* ref = feat + (size_t)(b * V) * C * HW;
+        const T* src = feat + (size_t)(b * V + v) * C * HW;
+        const float* hp = hyp + (size_t)b * D * HW + pc;
+        for (int d = wave; d < D; d += 4) {
+            const Taps tp = make_taps(hm, qx, qy, qz, hp[(size_t)d * HW], H, W, half_w, half_h, nullptr);
+            float ip[64];
+            correlate_generic<T>(src, ref, tp, HW, pc, C, G, ip);
+            float s = 0.0f;
+            for (int g = 0; g < G; ++g) s += ip[g];
+            sim[d * 64 + lane] = s;
+        }
+        __syncthreads();
+        if (wave == 0 && valid) softmax_entropy_store(sim + lane, 64, D, entropy + (size_t)(b * (V - 1) + (v - 1)) * HW + p);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // pass 2: visibility-weighted aggregation over the source views of the launch    cost_volume.py:97-101
-// grid = (pixel blocks of 64, 1, B); block = 64 pixels x 4 depth slots; output channel-last [D,HW,G].
+// grid = (pixel blocks, 1, B); output channel-last [D,HW,G].
 // ------------------------------------------------------------------------------------------------
 template <int DT, int CT, int GT>
 __global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
@@ -206,54 +283,89 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __
                                                                   int V, int C_, int G_, int D, int H, int W, int view_begin,
                                                                   int view_end, int nblk) {
     typedef typename FeatT<DT>::type T;
-    const int C = CT > 0 ? CT : C_;
-    const int G = GT > 0 ? GT : G_;
     const int HW = H * W;
-    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
-    const int blk = (int)xcd_remap(blockIdx.x, (unsigned)nblk);
-    const int p = blk * 64 + lane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = (int)blockIdx.z;
+    const int blk = (int)xcd_remap(blockIdx.x, (unsigned)nblk);
+    const float half_w = (float)((double)(W - 1) / 2.0), half_h = (float)((double)(H - 1) / 2.0);
+    const T* feat = reinterpret_cast<const T*>(feat_);
+    ChunkMap cm;
+    if (CT > 0) cm = chunk_map(D); else { cm.nch = D; cm.sd = 4; cm.sp = 1; cm.ppb = 64; }
+    const int psub = wave / cm.sd, cslot = wave % cm.sd;
+    const int p = blk * cm.ppb + psub * 64 + lane;
     const bool valid = p < HW;
     const int pc = valid ? p : HW - 1;
     const int y = pc / W, x = pc - y * W;
     const float fx = (float)x, fy = (float)y;
-    const float half_w = (float)((double)(W - 1) / 2.0), half_h = (float)((double)(H - 1) / 2.0);
-    const T* feat = reinterpret_cast<const T*>(feat_);
-    const T* ref = feat + (size_t)(b * V) * C * HW;
-    float r[CT > 0 ? CT : 1];
-    if (CT > 0) {
-#pragma unroll
-        for (int c = 0; c < (CT > 0 ? CT : 1); ++c) r[c] = to_f32(ref[(size_t)c * HW + pc]);
-    }
     float vsum = 0.0f;
     for (int v = view_begin; v < view_end; ++v) vsum += vis[(size_t)(b * (V - 1) + (v - 1)) * HW + pc];   // cost_volume.py:98
-    if (vis_sum != nullptr && slot == 0 && valid) vis_sum[(size_t)b * HW + p] = vsum;
+    if (vis_sum != nullptr && cslot == 0 && valid) vis_sum[(size_t)b * HW + p] = vsum;
     const float denom = vsum + 1e-6f;                                                                     // cost_volume.py:101
     const float* hp = hyp + (size_t)b * D * HW + pc;
-    for (int d = slot; d < D; d += 4) {
-        const float depth = hp[(size_t)d * HW];
-        float acc[GT > 0 ? GT : 64];
-        for (int g = 0; g < G; ++g) acc[g] = 0.0f;
-        for (int v = view_begin; v < view_end; ++v) {
-            const Homography hm = load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
-            const float qx = hm.r[0] * fx + hm.r[1] * fy + hm.r[2];
-            const float qy = hm.r[3] * fx + hm.r[4] * fy + hm.r[5];
-            const float qz = hm.r[6] * fx + hm.r[7] * fy + hm.r[8];
-            const Taps tp = make_taps(hm, qx, qy, qz, depth, H, W, half_w, half_h, nullptr);
-            const T* src = feat + (size_t)(b * V + v) * C * HW;
-            float ip[GT > 0 ? GT : 64];
-            correlate<T, CT, GT>(src, ref, r, tp, HW, pc, C, G, ip);
-            const float w = vis[(size_t)(b * (V - 1) + (v - 1)) * HW + pc];
-            for (int g = 0; g < G; ++g) acc[g] += ip[g] * w;                                             // cost_volume.py:97
+    if (CT > 0) {
+        constexpr int GG = GT > 0 ? GT : 8;
+        const int CC = C_, cpg = C_ / GG;
+        const T* ref = feat + (size_t)(b * V) * CC * HW;
+        for (int ch = cslot; ch < cm.nch; ch += cm.sd) {
+            const int d0 = ch * DCH;
+            float depth[DCH];
+#pragma unroll
+            for (int dd = 0; dd < DCH; ++dd) depth[dd] = hp[(size_t)(d0 + dd < D ? d0 + dd : D - 1) * HW];
+            float acc[DCH * GG];
+#pragma unroll
+            for (int i = 0; i < DCH * GG; ++i) acc[i] = 0.0f;
+            for (int v = view_begin; v < view_end; ++v) {
+                const Homography hm = load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
+                const float qx = hm.r[0] * fx + hm.r[1] * fy + hm.r[2];
+                const float qy = hm.r[3] * fx + hm.r[4] * fy + hm.r[5];
+                const float qz = hm.r[6] * fx + hm.r[7] * fy + hm.r[8];
+                PairTaps tp[DCH];
+#pragma unroll
+                for (int dd = 0; dd < DCH; ++dd) tp[dd] = make_pair_taps(hm, qx, qy, qz, depth[dd], H, W, half_w, half_h);
+                float ip[DCH * GG];
+                correlate_chunk<T, GG, false>(feat + (size_t)(b * V + v) * CC * HW, ref, tp, (unsigned)HW, (unsigned)pc, cpg, ip);
+                const float w = vis[(size_t)(b * (V - 1) + (v - 1)) * HW + pc];
+#pragma unroll
+                for (int i = 0; i < DCH * GG; ++i) acc[i] += ip[i] * w;                                   // cost_volume.py:97
+            }
+            if (valid) {
+#pragma unroll
+                for (int dd = 0; dd < DCH; ++dd) {
+                    if (d0 + dd >= D) continue;
+                    float* o = vol + ((size_t)(b * D + d0 + dd) * HW + p) * GG;
+                    float r[GG];
+#pragma unroll
+                    for (int g = 0; g < GG; ++g) r[g] = normalise ? acc[dd * GG + g] / denom : acc[dd * GG + g];
+                    if (GG == 8) {
+                        reinterpret_cast<float4*>(o)[0] = make_float4(r[0], r[1], r[2], r[3]);
+                        reinterpret_cast<float4*>(o)[1] = make_float4(r[4 % GG], r[5 % GG], r[6 % GG], r[7 % GG]);
+                    } else {
+                        for (int g = 0; g < GG; ++g) o[g] = r[g];
+                    }
+                }
+            }
         }
-        if (valid) {
-            float* o = vol + ((size_t)(b * D + d) * HW + p) * G;
-            if (normalise) for (int g = 0; g < G; ++g) acc[g] = acc[g] / denom;
-            if (GT == 8) {
-                reinterpret_cast<float4*>(o)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                reinterpret_cast<float4*>(o)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            } else {
-                for (int g = 0; g < G; ++g) o[g] = acc[g];
+    } else {
+        const int C = C_, G = G_;
+        const T* ref = feat + (size_t)(b * V) * C * HW;
+        for (int d = cslot; d < D; d += 4) {
+            const float depth = hp[(size_t)d * HW];
+            float acc[64];
+            for (int g = 0; g < G; ++g) acc[g] = 0.0f;
+            for (int v = view_begin; v < view_end; ++v) {
+                const Homography hm = load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
+                const float qx = hm.r[0] * fx + hm.r[1] * fy + hm.r[2];
+                const float qy = hm.r[3] * fx + hm.r[4] * fy + hm.r[5];
+                const float qz = hm.r[6] * fx + hm.r[7] * fy + hm.r[8];
+                const Taps tp = make_taps(hm, qx, qy, qz, depth, H, W, half_w, half_h, nullptr);
+                float ip[64];
+                correlate_generic<T>(feat + (size_t)(b * V + v) * C * HW, ref, tp, HW, pc, C, G, ip);
+                const float w = vis[(size_t)(b * (V - 1) + (v - 1)) * HW + pc];
+                for (int g = 0; g < G; ++g) acc[g] += ip[g] * w;
+            }
+            if (valid) {
+                float* o = vol + ((size_t)(b * D + d) * HW + p) * G;
+                for (int g = 0; g < G; ++g) o[g] = normalise ? acc[g] / denom : acc[g];
             }
         }
     }
@@ -316,8 +428,9 @@ template <int DT, int CT, int GT>
 static int launch_entropy(const void* feat, const float* hom, const float* hyp, float* ent, int B, int V, int C, int G, int D,
                           int H, int W, int vb, int ve, hipStream_t st) {
     const int HW = H * W;
-    const int nblk = (int)ceil_div(HW, 64);
-    const size_t lds = (size_t)D * 64 * sizeof(float);
+    const int ppb = CT > 0 ? chunk_map(D).ppb : 64;
+    const int nblk = (int)ceil_div(HW, ppb);
+    const size_t lds = (size_t)D * ppb * sizeof(float);
     if (lds > 160 * 1024) { set_error("warp_corr_entropy: D=%d needs %zu B of LDS (> 160 KiB)", D, lds); return MVS_ERR_UNSUPPORTED; }
     if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_corr_entropy_kernel<DT, CT, GT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -329,18 +442,17 @@ static int launch_entropy(const void* feat, const float* hom, const float* hyp, 
 template <int DT, int CT, int GT>
 static int launch_aggregate(const void* feat, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
                             int normalise, int B, int V, int C, int G, int D, int H, int W, int vb, int ve, hipStream_t st) {
-    const int nblk = (int)ceil_div((long long)H * W, 64);
+    const int nblk = (int)ceil_div((long long)H * W, CT > 0 ? chunk_map(D).ppb : 64);
     hipLaunchKernelGGL((warp_corr_aggregate_kernel<DT, CT, GT>), dim3(nblk, 1, B), dim3(256), 0, st, feat, hom, hyp, vis, vol, vis_sum,
                        normalise, V, C, G, D, H, W, vb, ve, nblk);
     return check_launch("warp_corr_aggregate_kernel");
 }
 
+// fast path (pair loads, DCH planes per work-item): G == 8 (every shipped config), any C divisible by 8, W >= 2;
+// the template's CT is only the fast/generic switch now (1 = fast), C itself is a run-time value
 #define MVS_DISPATCH_CG(FN, DT, ...)                                              \
     do {                                                                          \
-        if (G == 8 && C == 64) return FN<DT, 64, 8>(__VA_ARGS__);                 \
-        if (G == 8 && C == 32) return FN<DT, 32, 8>(__VA_ARGS__);                 \
-        if (G == 8 && C == 16) return FN<DT, 16, 8>(__VA_ARGS__);                 \
-        if (G == 8 && C == 8) return FN<DT, 8, 8>(__VA_ARGS__);                   \
+        if (G == 8 && W >= 2) return FN<DT, 1, 8>(__VA_ARGS__);                   \
         return FN<DT, 0, 0>(__VA_ARGS__);                                         \
     } while (0)
 

@@ -152,6 +152,8 @@ static inline int hipemu_readfirstlane(int v) {
 }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+
 // ---- device math spellings used by the kernels ----
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
