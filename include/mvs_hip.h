@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 1
+#define MVS_ABI_VERSION 2
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -35,6 +35,11 @@ enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
 enum { MVS_HEAD_CE_EVAL = 0, MVS_HEAD_CE_TRAIN = 1, MVS_HEAD_REG = 2 };
 /* regulariser kinds, cost_volume.py:41-49 */
 enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
+/* contraction precision of the MFMA convolutions:
+ *   MVS_PREC_FP32    v_mfma_f32_16x16x4_f32, bit-exact fp32 fmaf chain (weights packed fp32)
+ *   MVS_PREC_BF16X3  three-term split-bf16 product on v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32
+ *                    accumulate, ~2^-16 relative product error; weights packed as hi/lo bf16)                 */
+enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1 };
 
 int mvs_abi_version(void);
 const char* mvs_last_error(void);
@@ -69,9 +74,9 @@ int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homo
  *   w1 [9][16] + b1[16] (BN folded), w2/w3 = MFMA-packed 3x3 weights (layout below), b2[16], b3[8]
  *   (padded to 16), w4[8], b4[1].  workspace >= mvs_vis_workspace_bytes(N,H,W).                  */
 size_t mvs_vis_workspace_bytes(int N, int H, int W);
-int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const float* w2, const float* b2,
-                       const float* w3, const float* b3, const float* w4, const float* b4, float* vis,
-                       void* workspace, size_t workspace_bytes, int N, int H, int W, void* stream);
+int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2,
+                       const void* w3, const float* b3, const float* w4, const float* b4, float* vis,
+                       void* workspace, size_t workspace_bytes, int N, int H, int W, int precision, void* stream);
 
 /* ---- a4 + a6: recompute warp + correlation, weight by visibility, aggregate over views ----------
  * cost_volume.py:79-101.  vis [B,V-1,H,W].  volume_cl [B,D,H,W,G] channel-last.
@@ -85,23 +90,27 @@ int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, i
 
 /* ---- a7: Conv3d + folded BatchNorm3d + ReLU, module.py:89-126 ----------------------------------
  * x_cl [B,D,H,W,Cin] -> y_cl [B,OD,OH,OW,Cout]; kernel (kd,3,3), kd in {1,3}, padding (kd/2,1,1),
- * stride (sd,sh,sw) in {1,2}.  Implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).
- * w_packed: see "MFMA weight packing" in DESIGN.md (packing.pack_conv_weights); bias [max(Cout,16)].*/
-int mvs_conv3d_bn_relu_fwd(const float* x_cl, const float* w_packed, const float* bias, float* y_cl, int B, int Cin,
-                           int Cout, int D, int H, int W, int kd, int sd, int sh, int sw, int relu, void* stream);
+ * stride (sd,sh,sw) in {1,2}.  Implicit GEMM on MFMA; `precision` = MVS_PREC_* selects the contraction and the
+ * packed-weight format (packing.pack_conv_weights / pack_conv_weights_bf16x3, DESIGN.md "MFMA weight packing");
+ * bias [max(Cout,16)] fp32.                                                                                */
+int mvs_conv3d_bn_relu_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin,
+                           int Cout, int D, int H, int W, int kd, int sd, int sh, int sw, int relu, int precision,
+                           void* stream);
 
 /* ---- a7: ConvTranspose3d(k3, padding 1, stride (sd,2,2), output_padding (sd-1,1,1)) + BN + ReLU,
  * then + skip (module.py:129-165, 402-405, 467-481, 498-501).
  * x_cl [B,D,H,W,Cin] -> y_cl [B,D*sd,2H,2W,Cout]; skip_cl has y's shape (NULL = no skip).          */
-int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const float* w_packed, const float* bias, const float* skip_cl,
-                                 float* y_cl, int B, int Cin, int Cout, int D, int H, int W, int sd, void* stream);
+int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const void* w_packed, const float* bias, const float* skip_cl,
+                                 float* y_cl, int B, int Cin, int Cout, int D, int H, int W, int sd, int precision,
+                                 void* stream);
 
 /* ---- a8/a9: whole regulariser U-Net (CostRegNet / CostRegNet3D), module.py:367-408 / 453-504 ----
  * volume_cl [B,D,H,W,8] -> feat_cl [B,D,H,W,8] = conv0 + relu(bn(deconv11(...))) (input of `prob`).
  * params: 9 packed weight pointers + 9 bias pointers in layer order conv1..conv6, conv7, conv9, conv11.*/
 size_t mvs_regnet_workspace_bytes(int kind, int B, int D, int H, int W);
-int mvs_regnet_fwd(int kind, const float* volume_cl, const float* const* w_packed, const float* const* bias,
-                   float* feat_cl, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, void* stream);
+int mvs_regnet_fwd(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias,
+                   float* feat_cl, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int precision,
+                   void* stream);
 
 /* ---- a8/a9 `prob` + a10 + a11: logits, softmax, depth regression, confidence --------------------
  * feat_cl [B,D,H,W,8]; prob_w: [8] (+ prob_b[1]) for the 1x1x1 head (CostRegNet3D, module.py:486)

@@ -18,6 +18,8 @@ OK = 0
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
+PREC_FP32, PREC_BF16X3 = 0, 1
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -30,13 +32,13 @@ SIGNATURES = {
     "mvs_homo_warp_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mvs_vis_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _vp]),
+    "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _i, _vp]),
     "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i] + [_i] * 9 + [_vp]),
     "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
-    "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
+    "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mvs_regnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "mvs_regnet_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "mvs_regnet_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "mvs_prob_regress_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_softmax_regress_fwd": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_depth_regression_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -61,7 +63,7 @@ def bind(path: str) -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.mvs_abi_version() != 1:
+    if lib.mvs_abi_version() != 2:
         raise MvsHipError("libmvs_hip ABI version mismatch: %d" % lib.mvs_abi_version())
     return lib
 

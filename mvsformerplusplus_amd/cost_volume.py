@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops, packing
-from .module import ConvBnReLU, CostRegNet, CostRegNet3D, _bn_dict, _no_grad_path, _PackedCache
+from .module import DEFAULT_PRECISION, ConvBnReLU, CostRegNet, CostRegNet3D, _bn_dict, _no_grad_path, _PackedCache, precision_code
 
 
 def shard_views(n_src: int, world: int, rank: int):
@@ -53,10 +53,16 @@ class StageNet(nn.Module):
             self.cost_reg = CostRegNet(self.in_channels, self.in_channels)
         self.view_group = None            # torch.distributed group for view sharding (None = single GPU)
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
+        # contraction of every MFMA convolution of the stage: "bf16x3" (3-term split bf16, ~2^-16 relative) or "fp32"
+        self.conv_precision = args.get("conv_precision", DEFAULT_PRECISION)
         self._vis_cache = _PackedCache()
 
     # ---- packed parameters ----
     def _vis_params(self, device):
+        prec = self.conv_precision
+        pack = packing.pack_conv_weights_bf16x3 if prec == "bf16x3" else packing.pack_conv_weights
+        precision_code(prec)
+
         def build(dev):
             out = []
             for i, ch in ((0, None), (1, 16), (2, 16)):
@@ -65,11 +71,11 @@ class StageNet(nn.Module):
                 if i == 0:
                     out += [w[:, 0].permute(1, 2, 0).reshape(9, 16).contiguous().to(dev), b.contiguous().to(dev)]
                 else:
-                    out += [packing.pack_conv_weights(w.unsqueeze(2), 16).to(dev), packing.pad_bias(b).to(dev)]
+                    out += [pack(w.unsqueeze(2), 16).to(dev), packing.pad_bias(b).to(dev)]
             last = self.vis[3]
             out += [last.weight.detach().float().reshape(8).contiguous().to(dev), last.bias.detach().float().reshape(1).contiguous().to(dev)]
             return out
-        return self._vis_cache.get(self.vis, build)
+        return self._vis_cache.get(self.vis, build, prec)
 
     def forward(self, features, proj_matrices, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
         _no_grad_path(features, depth_values)
@@ -87,15 +93,16 @@ class StageNet(nn.Module):
         hom = ops.compose_homography(proj_matrices)
         vis_params = self._vis_params(feats.device)
 
+        prec = precision_code(self.conv_precision)
         if self.view_group is None:
             entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
-            vis = ops.vis_weight(entropy, vis_params)
+            vis = ops.vis_weight(entropy, vis_params, prec)
             volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
         else:
             volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
 
-        ws, bs, prob_w, prob_b = self.cost_reg.packed_all(feats.device)
-        feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs)
+        ws, bs, prob_w, prob_b = self.cost_reg.packed_all(feats.device, self.conv_precision)
+        feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, prec)
 
         D = hyp.shape[1]
         conf_n = 0
@@ -122,7 +129,7 @@ class StageNet(nn.Module):
         if ve > vb:
             entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, vb, ve)
             vis = entropy.clone()
-            vis[:, vb - 1: ve - 1] = ops.vis_weight(entropy[:, vb - 1: ve - 1].contiguous(), vis_params)
+            vis[:, vb - 1: ve - 1] = ops.vis_weight(entropy[:, vb - 1: ve - 1].contiguous(), vis_params, precision_code(self.conv_precision))
             ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=False, view_begin=vb, view_end=ve, out=(vol, vsum))
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.view_group)
         return ops.volume_normalise_(vol, vsum)

@@ -15,31 +15,9 @@
 //   * D fragment: lane (voxel = lane&15, g) holds output channels 16*mb + 4*g + 0..3 -> one float4 store into
 //     the channel-last output, fused with bias (folded BN), ReLU and the U-Net skip add
 // Activations are channel-last fp32 [B, D, H, W, C].
-#include "mvs_common.h"
+#include "conv_cfg.h"
 
 namespace mvs {
-
-// ------------------------------------------------------------------------------------------------
-// Conv3d (kd,3,3), padding (kd/2,1,1), stride (SD,SH,SW)                      module.py:89-126
-// ------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int KD_, int SD_, int SH_, int SW_, int TD_, int TH_, int CH_>
-struct ConvCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_, SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, CH = CH_;
-    static constexpr int TW = 16;
-    static constexpr int PD = KD / 2;
-    static constexpr int ID = (TD - 1) * SD + KD, IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
-    static constexpr int NVOX = ID * IH * IW;
-    static constexpr int S = CH + 4;                 // padded voxel stride (floats)
-    static constexpr int QC = CH / 4;                // channel quads per tap and pass
-    static constexpr int NPASS = CIN / CH;
-    static constexpr int NTAP = KD * 9;
-    static constexpr int NSTEP = (NTAP * QC + 3) / 4;
-    static constexpr int MREP = (COUT + 15) / 16;
-    static constexpr int NB = TD * TH;
-    static constexpr int NREP = NB / 4;
-    static constexpr size_t LDS_BYTES = (size_t)NVOX * S * sizeof(float);
-    static_assert(CIN % CH == 0 && CH % 4 == 0 && NB % 4 == 0, "bad conv tile configuration");
-};
 
 // operands of contraction step t: MREP weight fragments (global, 1 KiB contiguous per wave) + NREP activation
 // fragments (LDS).  Lane group g owns k-quad 4t+g: (tap, cq) = divmod(4t+g, QC); padded quads carry zero weights.
@@ -167,23 +145,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const float* __restric
 // (k=0, input m+1) and (k=2, input m).  Depth axis with stride 1: o = m <- (k=0, m+1), (k=1, m), (k=2, m-1).
 // The input tile (all CIN channels, +1 halo) is staged once and reused by the 4 / 8 parity classes.
 // ------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int SD_, int TDM_, int THM_>
-struct DeconvCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, SD = SD_, TDM = TDM_, THM = THM_;
-    static constexpr int LD = (SD == 2) ? TDM + 1 : TDM + 2;
-    static constexpr int ZO = (SD == 2) ? 0 : 1;          // LDS z index of tile-local m = 0
-    static constexpr int LH = THM + 1, LW = 17;
-    static constexpr int NVOX = LD * LH * LW;
-    static constexpr int S = CIN + 4;
-    static constexpr int QC = CIN / 4;
-    static constexpr int NQ = CIN / 16;
-    static constexpr int MREP = (COUT + 15) / 16;
-    static constexpr int NB = TDM * THM;
-    static constexpr int NREP = NB / 4;
-    static constexpr size_t LDS_BYTES = (size_t)NVOX * S * sizeof(float);
-    static_assert(CIN % 16 == 0 && NB % 4 == 0, "bad deconv tile configuration");
-};
-
 // operands of step `st` of parity class (pd,ph,pw): decode (tap, q), then MREP weight + NREP activation fragments
 template <class Cfg>
 __device__ __forceinline__ void deconv_load_step(int st, int pd, int ph, int pw, const float4* wq, const float* lds, const int* voxbase,
@@ -371,40 +332,28 @@ static int launch_deconv(const float* x, const float* wp, const float* bias, con
     return check_launch("deconv3d_mfma_kernel");
 }
 
-// Tile configurations.  stride-1: 4x4x16 outputs, 16-channel chunks (648-voxel halo tile, 51 KiB -> 3 blocks/CU);
-// strided: 2x4x16 outputs, 8-channel chunks (57-71 KiB -> 2 blocks/CU); 2-D (vis CNN): 1x16x16 outputs.
-int conv3d_dispatch(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
-                    int sd, int sh, int sw, int relu, hipStream_t st) {
-#define MVS_CONV(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                  \
+int conv3d_dispatch(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
+                    int sd, int sh, int sw, int relu, int prec, hipStream_t st) {
+    if (prec == MVS_PREC_BF16X3) return conv3d_dispatch_bf16x3(x, wp, bias, y, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, st);
+    if (prec != MVS_PREC_FP32) { set_error("conv3d: unknown precision %d", prec); return MVS_ERR_ARG; }
+#define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW)                      \
-        return launch_conv<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>(x, wp, bias, y, B, D, H, W, relu, st);
-    MVS_CONV(16, 16, 3, 1, 1, 1, 4, 4, 16)
-    MVS_CONV(32, 32, 3, 1, 1, 1, 4, 4, 16)
-    MVS_CONV(64, 64, 3, 1, 1, 1, 2, 4, 16)      // coarsest U-Net level: few voxels, so smaller tiles (2x4x16) keep all CUs busy
-    MVS_CONV(8, 16, 3, 2, 2, 2, 2, 4, 8)
-    MVS_CONV(16, 32, 3, 2, 2, 2, 2, 4, 8)
-    MVS_CONV(32, 64, 3, 2, 2, 2, 2, 4, 8)
-    MVS_CONV(8, 16, 3, 1, 2, 2, 2, 4, 8)
-    MVS_CONV(16, 32, 3, 1, 2, 2, 2, 4, 8)
-    MVS_CONV(32, 64, 3, 1, 2, 2, 2, 4, 8)
-    MVS_CONV(16, 16, 1, 1, 1, 1, 1, 16, 16)
-    MVS_CONV(16, 8, 1, 1, 1, 1, 1, 16, 16)
-#undef MVS_CONV
+        return launch_conv<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>(x, static_cast<const float*>(wp), bias, y, B, D, H, W, relu, st);
+    MVS_CONV_TABLE(MVS_X)
+#undef MVS_X
     set_error("conv3d: no kernel for Cin=%d Cout=%d kernel=(%d,3,3) stride=(%d,%d,%d)", Cin, Cout, kd, sd, sh, sw);
     return MVS_ERR_UNSUPPORTED;
 }
 
-int deconv3d_dispatch(const float* x, const float* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout, int D,
-                      int H, int W, int sd, hipStream_t st) {
-#define MVS_DECONV(CI, CO, SD, TDM, THM)                                                                \
-    if (Cin == CI && Cout == CO && sd == SD) return launch_deconv<DeconvCfg<CI, CO, SD, TDM, THM>>(x, wp, bias, skip, y, B, D, H, W, st);
-    MVS_DECONV(64, 32, 2, 2, 4)
-    MVS_DECONV(32, 16, 2, 4, 4)
-    MVS_DECONV(16, 8, 2, 4, 4)
-    MVS_DECONV(64, 32, 1, 2, 2)
-    MVS_DECONV(32, 16, 1, 4, 4)
-    MVS_DECONV(16, 8, 1, 4, 4)
-#undef MVS_DECONV
+int deconv3d_dispatch(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout, int D,
+                      int H, int W, int sd, int prec, hipStream_t st) {
+    if (prec == MVS_PREC_BF16X3) return deconv3d_dispatch_bf16x3(x, wp, bias, skip, y, B, Cin, Cout, D, H, W, sd, st);
+    if (prec != MVS_PREC_FP32) { set_error("deconv3d: unknown precision %d", prec); return MVS_ERR_ARG; }
+#define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
+    if (Cin == CI && Cout == CO && sd == SD)                                                            \
+        return launch_deconv<DeconvCfg<CI, CO, SD, TDM, THM>>(x, static_cast<const float*>(wp), bias, skip, y, B, D, H, W, st);
+    MVS_DECONV_TABLE(MVS_X)
+#undef MVS_X
     set_error("deconv3d: no kernel for Cin=%d Cout=%d stride=(%d,2,2)", Cin, Cout, sd);
     return MVS_ERR_UNSUPPORTED;
 }
@@ -413,23 +362,23 @@ int deconv3d_dispatch(const float* x, const float* wp, const float* bias, const 
 
 using namespace mvs;
 
-extern "C" int mvs_conv3d_bn_relu_fwd(const float* x_cl, const float* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout,
-                                      int D, int H, int W, int kd, int sd, int sh, int sw, int relu, void* stream) {
+extern "C" int mvs_conv3d_bn_relu_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout,
+                                      int D, int H, int W, int kd, int sd, int sh, int sw, int relu, int precision, void* stream) {
     if (!x_cl || !w_packed || !bias || !y_cl || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_conv3d_bn_relu_fwd: bad arguments"); return MVS_ERR_ARG; }
-    return conv3d_dispatch(x_cl, w_packed, bias, y_cl, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, (hipStream_t)stream);
+    return conv3d_dispatch(x_cl, w_packed, bias, y_cl, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, precision, (hipStream_t)stream);
 }
 
-extern "C" int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const float* w_packed, const float* bias, const float* skip_cl, float* y_cl,
-                                            int B, int Cin, int Cout, int D, int H, int W, int sd, void* stream) {
+extern "C" int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const void* w_packed, const float* bias, const float* skip_cl, float* y_cl,
+                                            int B, int Cin, int Cout, int D, int H, int W, int sd, int precision, void* stream) {
     if (!x_cl || !w_packed || !bias || !y_cl || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_deconv3d_bn_relu_add_fwd: bad arguments"); return MVS_ERR_ARG; }
-    return deconv3d_dispatch(x_cl, w_packed, bias, skip_cl, y_cl, B, Cin, Cout, D, H, W, sd, (hipStream_t)stream);
+    return deconv3d_dispatch(x_cl, w_packed, bias, skip_cl, y_cl, B, Cin, Cout, D, H, W, sd, precision, (hipStream_t)stream);
 }
 
 extern "C" size_t mvs_vis_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * 32 * sizeof(float); }
 
-extern "C" int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+extern "C" int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                                   const float* b3, const float* w4, const float* b4, float* vis, void* workspace, size_t workspace_bytes,
-                                  int N, int H, int W, void* stream) {
+                                  int N, int H, int W, int precision, void* stream) {
     if (!entropy || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4 || !vis || !workspace || N < 1 || H < 1 || W < 1) { set_error("mvs_vis_weight_fwd: bad arguments"); return MVS_ERR_ARG; }
     if (workspace_bytes < mvs_vis_workspace_bytes(N, H, W)) { set_error("mvs_vis_weight_fwd: workspace too small (%zu < %zu)", workspace_bytes, mvs_vis_workspace_bytes(N, H, W)); return MVS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
@@ -439,9 +388,9 @@ extern "C" int mvs_vis_weight_fwd(const float* entropy, const float* w1, const f
     hipLaunchKernelGGL(vis_conv1_kernel, dim3(ceil_div((long long)HW, 256), N), dim3(256), 0, st, entropy, w1, b1, t1, H, W);
     int rc = check_launch("vis_conv1_kernel");
     if (rc != MVS_OK) return rc;
-    rc = conv3d_dispatch(t1, w2, b2, t2, 1, 16, 16, N, H, W, 1, 1, 1, 1, 1, st);      // views ride on the depth axis, kd = 1
+    rc = conv3d_dispatch(t1, w2, b2, t2, 1, 16, 16, N, H, W, 1, 1, 1, 1, 1, precision, st);      // views ride on the depth axis, kd = 1
     if (rc != MVS_OK) return rc;
-    rc = conv3d_dispatch(t2, w3, b3, t1, 1, 16, 8, N, H, W, 1, 1, 1, 1, 1, st);       // -> [N,H,W,8] in t1
+    rc = conv3d_dispatch(t2, w3, b3, t1, 1, 16, 8, N, H, W, 1, 1, 1, 1, 1, precision, st);       // -> [N,H,W,8] in t1
     if (rc != MVS_OK) return rc;
     const size_t total = (size_t)N * HW;
     hipLaunchKernelGGL(vis_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, t1, w4, b4, vis, total);
@@ -465,8 +414,8 @@ extern "C" size_t mvs_regnet_workspace_bytes(int kind, int B, int D, int H, int 
     return total * sizeof(float);
 }
 
-extern "C" int mvs_regnet_fwd(int kind, const float* volume_cl, const float* const* w_packed, const float* const* bias, float* feat_cl,
-                              void* workspace, size_t workspace_bytes, int B, int D, int H, int W, void* stream) {
+extern "C" int mvs_regnet_fwd(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias, float* feat_cl,
+                              void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int precision, void* stream) {
     if (!volume_cl || !w_packed || !bias || !feat_cl || !workspace || B < 1) { set_error("mvs_regnet_fwd: bad arguments"); return MVS_ERR_ARG; }
     if (kind != MVS_REG_COSTREGNET && kind != MVS_REG_COSTREGNET3D) { set_error("mvs_regnet_fwd: unknown regulariser kind %d", kind); return MVS_ERR_ARG; }
     if ((H % 8) || (W % 8) || (kind == MVS_REG_COSTREGNET && (D % 8))) {
@@ -485,15 +434,15 @@ extern "C" int mvs_regnet_fwd(int kind, const float* volume_cl, const float* con
     float *c1 = ws, *c2 = c1 + n1, *c3 = c2 + n1, *c4 = c3 + n2, *c5 = c4 + n2, *c6 = c5 + n3;
     int rc;
 #define MVS_TRY(expr) do { rc = (expr); if (rc != MVS_OK) return rc; } while (0)
-    MVS_TRY(conv3d_dispatch(volume_cl, w_packed[0], bias[0], c1, B, 8, 16, D, H, W, 3, sd, 2, 2, 1, st));       // conv1
-    MVS_TRY(conv3d_dispatch(c1, w_packed[1], bias[1], c2, B, 16, 16, d1, h1, w1, 3, 1, 1, 1, 1, st));           // conv2
-    MVS_TRY(conv3d_dispatch(c2, w_packed[2], bias[2], c3, B, 16, 32, d1, h1, w1, 3, sd, 2, 2, 1, st));          // conv3
-    MVS_TRY(conv3d_dispatch(c3, w_packed[3], bias[3], c4, B, 32, 32, d2, h2, w2, 3, 1, 1, 1, 1, st));           // conv4
-    MVS_TRY(conv3d_dispatch(c4, w_packed[4], bias[4], c5, B, 32, 64, d2, h2, w2, 3, sd, 2, 2, 1, st));          // conv5
-    MVS_TRY(conv3d_dispatch(c5, w_packed[5], bias[5], c6, B, 64, 64, d3, h3, w3, 3, 1, 1, 1, 1, st));           // conv6
-    MVS_TRY(deconv3d_dispatch(c6, w_packed[6], bias[6], c4, c3, B, 64, 32, d3, h3, w3, sd, st));                // conv4 + conv7 -> c3
-    MVS_TRY(deconv3d_dispatch(c3, w_packed[7], bias[7], c2, c1, B, 32, 16, d2, h2, w2, sd, st));                // conv2 + conv9 -> c1
-    MVS_TRY(deconv3d_dispatch(c1, w_packed[8], bias[8], volume_cl, feat_cl, B, 16, 8, d1, h1, w1, sd, st));     // conv0 + conv11
+    MVS_TRY(conv3d_dispatch(volume_cl, w_packed[0], bias[0], c1, B, 8, 16, D, H, W, 3, sd, 2, 2, 1, precision, st));       // conv1
+    MVS_TRY(conv3d_dispatch(c1, w_packed[1], bias[1], c2, B, 16, 16, d1, h1, w1, 3, 1, 1, 1, 1, precision, st));           // conv2
+    MVS_TRY(conv3d_dispatch(c2, w_packed[2], bias[2], c3, B, 16, 32, d1, h1, w1, 3, sd, 2, 2, 1, precision, st));          // conv3
+    MVS_TRY(conv3d_dispatch(c3, w_packed[3], bias[3], c4, B, 32, 32, d2, h2, w2, 3, 1, 1, 1, 1, precision, st));           // conv4
+    MVS_TRY(conv3d_dispatch(c4, w_packed[4], bias[4], c5, B, 32, 64, d2, h2, w2, 3, sd, 2, 2, 1, precision, st));          // conv5
+    MVS_TRY(conv3d_dispatch(c5, w_packed[5], bias[5], c6, B, 64, 64, d3, h3, w3, 3, 1, 1, 1, 1, precision, st));           // conv6
+    MVS_TRY(deconv3d_dispatch(c6, w_packed[6], bias[6], c4, c3, B, 64, 32, d3, h3, w3, sd, precision, st));                // conv4 + conv7 -> c3
+    MVS_TRY(deconv3d_dispatch(c3, w_packed[7], bias[7], c2, c1, B, 32, 16, d2, h2, w2, sd, precision, st));                // conv2 + conv9 -> c1
+    MVS_TRY(deconv3d_dispatch(c1, w_packed[8], bias[8], volume_cl, feat_cl, B, 16, 8, d1, h1, w1, sd, precision, st));     // conv0 + conv11
 #undef MVS_TRY
     return MVS_OK;
 }

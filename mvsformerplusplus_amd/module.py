@@ -31,21 +31,31 @@ def _bn_dict(bn: nn.Module) -> Dict[str, torch.Tensor]:
             "running_mean": bn.running_mean.detach().cpu(), "running_var": bn.running_var.detach().cpu()}
 
 
+DEFAULT_PRECISION = "bf16x3"      # contraction of the MFMA convolutions: "bf16x3" (3-term split bf16) or "fp32" (exact)
+
+
+def precision_code(name: str) -> int:
+    if name not in _lib.PRECISIONS:
+        raise ValueError("conv precision must be one of %s, got %r" % (sorted(_lib.PRECISIONS), name))
+    return _lib.PRECISIONS[name]
+
+
 class _PackedCache:
-    """Folded + packed parameters on the module's device, rebuilt when any parameter/buffer changes."""
+    """Folded + packed parameters on the module's device, rebuilt when any parameter/buffer changes.
+    One entry per `tag` (the contraction precision: the packed weight format depends on it)."""
 
     def __init__(self):
-        self._key = None
-        self._val = None
+        self._entries = {}
 
-    def get(self, module: nn.Module, builder):
+    def get(self, module: nn.Module, builder, tag=None):
         ts = list(module.parameters()) + list(module.buffers())
         bn_modes = tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
         key = (ts[0].device, sum(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]), bn_modes)
-        if key != self._key:
-            self._val = builder(ts[0].device)
-            self._key = key
-        return self._val
+        hit = self._entries.get(tag)
+        if hit is None or hit[0] != key:
+            hit = (key, builder(ts[0].device))
+            self._entries[tag] = hit
+        return hit[1]
 
 
 def _no_grad_path(*tensors):
@@ -74,7 +84,7 @@ class Conv3d(nn.Module):
         self.relu = relu
         self._cache = _PackedCache()
 
-    def packed(self, device):
+    def packed(self, device, precision=DEFAULT_PRECISION):
         def build(dev):
             w = self.conv.weight.detach().cpu().float()
             if self.bn is not None:
@@ -82,19 +92,21 @@ class Conv3d(nn.Module):
             else:
                 b = self.conv.bias.detach().cpu().float() if self.conv.bias is not None else torch.zeros(w.shape[0])
             ch = packing.conv_chunk(w.shape[1], _triple(self.conv.stride))
-            return packing.pack_conv_weights(w, ch).to(dev), packing.pad_bias(b).to(dev)
-        return self._cache.get(self, build)
+            pack = packing.pack_conv_weights_bf16x3 if precision == "bf16x3" else packing.pack_conv_weights
+            return pack(w, ch).to(dev), packing.pad_bias(b).to(dev)
+        precision_code(precision)
+        return self._cache.get(self, build, precision)
 
-    def forward_cl(self, x_cl):
-        w, b = self.packed(x_cl.device)
+    def forward_cl(self, x_cl, precision=DEFAULT_PRECISION):
+        w, b = self.packed(x_cl.device, precision)
         k = _triple(self.conv.kernel_size)
         if k[1:] != (3, 3) or _triple(self.conv.padding) != (k[0] // 2, 1, 1):
             raise NotImplementedError("HIP Conv3d supports kernel (1|3,3,3) with 'same' padding only")
-        return ops.conv3d_bn_relu(x_cl, w, b, self.conv.out_channels, k[0], _triple(self.conv.stride), self.relu)
+        return ops.conv3d_bn_relu(x_cl, w, b, self.conv.out_channels, k[0], _triple(self.conv.stride), self.relu, precision_code(precision))
 
     def forward(self, x):
         _no_grad_path(x)
-        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x)))
+        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x), getattr(self, "conv_precision", DEFAULT_PRECISION)))
 
 
 class Deconv3d(nn.Module):
@@ -109,18 +121,19 @@ class Deconv3d(nn.Module):
         self.relu = relu
         self._cache = _PackedCache()
 
-    def packed(self, device):
-        return self._cache.get(self, lambda dev: _pack_deconv(self.conv, self.bn, dev))
+    def packed(self, device, precision=DEFAULT_PRECISION):
+        precision_code(precision)
+        return self._cache.get(self, lambda dev: _pack_deconv(self.conv, self.bn, dev, precision), precision)
 
-    def forward_cl(self, x_cl, skip_cl=None):
+    def forward_cl(self, x_cl, skip_cl=None, precision=DEFAULT_PRECISION):
         if not self.relu or self.bn is None:
             raise NotImplementedError("HIP Deconv3d implements the BN + ReLU form used by the regularisers")
-        w, b = self.packed(x_cl.device)
-        return ops.deconv3d_bn_relu_add(x_cl, w, b, self.conv.out_channels, _deconv_sd(self.conv), skip_cl)
+        w, b = self.packed(x_cl.device, precision)
+        return ops.deconv3d_bn_relu_add(x_cl, w, b, self.conv.out_channels, _deconv_sd(self.conv), skip_cl, precision_code(precision))
 
     def forward(self, x):
         _no_grad_path(x)
-        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x)))
+        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x), None, getattr(self, "conv_precision", DEFAULT_PRECISION)))
 
 
 def _deconv_sd(conv: nn.ConvTranspose3d) -> int:
@@ -130,12 +143,14 @@ def _deconv_sd(conv: nn.ConvTranspose3d) -> int:
     return s[0]
 
 
-def _pack_deconv(conv: nn.ConvTranspose3d, bn: Optional[nn.Module], dev):
+def _pack_deconv(conv: nn.ConvTranspose3d, bn: Optional[nn.Module], dev, precision=DEFAULT_PRECISION):
     w = conv.weight.detach().cpu().float()
     if bn is not None:
         w, b = packing.fold_bn(w, _bn_dict(bn), 1)
     else:
         b = conv.bias.detach().cpu().float()
+    if precision == "bf16x3":
+        return packing.pack_deconv_weights_bf16x3(w, _deconv_sd(conv)).to(dev), packing.pad_bias(b).to(dev)
     return packing.pack_deconv_weights(w).to(dev), packing.pad_bias(b).to(dev)
 
 
@@ -162,14 +177,16 @@ class _RegNetBase(nn.Module):
     def _layers(self) -> List[Tuple[str, nn.Module]]:
         raise NotImplementedError
 
-    def _build(self, dev):
+    conv_precision = DEFAULT_PRECISION
+
+    def _build(self, dev, precision):
         ws, bs = [], []
         for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6"):
-            w, b = getattr(self, name).packed(dev)
+            w, b = getattr(self, name).packed(dev, precision)
             ws.append(w)
             bs.append(b)
         for name in ("conv7", "conv9", "conv11"):
-            w, b = self._deconv_packed(getattr(self, name), dev)
+            w, b = self._deconv_packed(getattr(self, name), dev, precision)
             ws.append(w)
             bs.append(b)
         pw = self.prob.weight.detach().cpu().float()
@@ -181,17 +198,20 @@ class _RegNetBase(nn.Module):
             prob_b = self.prob.bias.detach().cpu().float().reshape(-1)[:1].contiguous().to(dev)
         return ws, bs, prob_w, prob_b
 
-    def packed_all(self, device):
+    def packed_all(self, device, precision=None):
+        precision = precision or self.conv_precision
+        precision_code(precision)
         if not isinstance(self.inner, nn.Identity):
             raise NotImplementedError("in_channels != base_channels (1x1x1 `inner` conv) is not used by any shipped config")
         if self.prob.weight.shape[0] != 1 or self.prob.weight.shape[1] != 8:
             raise NotImplementedError("HIP head supports an 8 -> 1 channel `prob` layer")
-        return self._cache.get(self, self._build)
+        return self._cache.get(self, lambda dev: self._build(dev, precision), precision)
 
-    def forward_cl(self, volume_cl: torch.Tensor) -> torch.Tensor:
+    def forward_cl(self, volume_cl: torch.Tensor, precision=None) -> torch.Tensor:
         """[B,D,H,W,8] channel-last cost volume -> [B,D,H,W,8] features that feed `prob`."""
-        ws, bs, _, _ = self.packed_all(volume_cl.device)
-        return ops.regnet(self.kind, volume_cl, ws, bs)
+        precision = precision or self.conv_precision
+        ws, bs, _, _ = self.packed_all(volume_cl.device, precision)
+        return ops.regnet(self.kind, volume_cl, ws, bs, precision_code(precision))
 
     def forward(self, x, *kwargs):
         """NCDHW in, logits [B,1,D,H,W] out - the reference's call form (module.py:393-396 / 488-492)."""
@@ -229,8 +249,8 @@ class CostRegNet(_RegNetBase):
         self._cache = _PackedCache()
 
     @staticmethod
-    def _deconv_packed(layer, dev):
-        return layer.packed(dev)
+    def _deconv_packed(layer, dev, precision):
+        return layer.packed(dev, precision)
 
 
 class CostRegNet3D(_RegNetBase):
@@ -258,9 +278,9 @@ class CostRegNet3D(_RegNetBase):
         self._cache = _PackedCache()
 
     @staticmethod
-    def _deconv_packed(seq, dev):
+    def _deconv_packed(seq, dev, precision):
         _deconv_sd(seq[0])
-        return _pack_deconv(seq[0], seq[1], dev)
+        return _pack_deconv(seq[0], seq[1], dev, precision)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -69,7 +69,7 @@ def warp_corr_entropy(features: torch.Tensor, code: int, homography: torch.Tenso
     return ent
 
 
-def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor]) -> torch.Tensor:
+def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor], precision: int = 0) -> torch.Tensor:
     """entropy [..., H, W] -> sigmoid(vis CNN) of the same shape.  params = packed (w1,b1,w2,b2,w3,b3,w4,b4)."""
     e = _f32c(entropy)
     H, W = e.shape[-2:]
@@ -77,7 +77,7 @@ def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor]) -> torch.T
     vis = torch.empty_like(e)
     nbytes = lib().mvs_vis_workspace_bytes(N, H, W)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=e.device)
-    check(lib().mvs_vis_weight_fwd(ptr(e), *[ptr(p) for p in params], ptr(vis), ptr(ws), nbytes, N, H, W, stream_of(e)),
+    check(lib().mvs_vis_weight_fwd(ptr(e), *[ptr(p) for p in params], ptr(vis), ptr(ws), nbytes, N, H, W, precision, stream_of(e)),
           "mvs_vis_weight_fwd")
     return vis
 
@@ -107,25 +107,25 @@ def volume_normalise_(vol_cl: torch.Tensor, vis_sum: torch.Tensor) -> torch.Tens
 
 # ---- a7-a9 --------------------------------------------------------------------------------------
 def conv3d_bn_relu(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, kd: int,
-                   stride: Tuple[int, int, int], relu: bool = True) -> torch.Tensor:
+                   stride: Tuple[int, int, int], relu: bool = True, precision: int = 0) -> torch.Tensor:
     B, D, H, W, cin = x_cl.shape
     sd, sh, sw = stride
     pd = kd // 2
     od, oh, ow = (D + 2 * pd - kd) // sd + 1, (H - 1) // sh + 1, (W - 1) // sw + 1
     y = torch.empty(B, od, oh, ow, cout, dtype=torch.float32, device=x_cl.device)
     check(lib().mvs_conv3d_bn_relu_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(y), B, cin, cout, D, H, W, kd, sd, sh, sw,
-                                       1 if relu else 0, stream_of(x_cl)), "mvs_conv3d_bn_relu_fwd")
+                                       1 if relu else 0, precision, stream_of(x_cl)), "mvs_conv3d_bn_relu_fwd")
     return y
 
 
 def deconv3d_bn_relu_add(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, sd: int,
-                         skip_cl: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         skip_cl: Optional[torch.Tensor] = None, precision: int = 0) -> torch.Tensor:
     B, D, H, W, cin = x_cl.shape
     y = torch.empty(B, D * sd, 2 * H, 2 * W, cout, dtype=torch.float32, device=x_cl.device)
     if skip_cl is not None:
         assert tuple(skip_cl.shape) == tuple(y.shape), "skip tensor shape mismatch"
     check(lib().mvs_deconv3d_bn_relu_add_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(skip_cl), ptr(y), B, cin, cout, D, H, W,
-                                             sd, stream_of(x_cl)), "mvs_deconv3d_bn_relu_add_fwd")
+                                             sd, precision, stream_of(x_cl)), "mvs_deconv3d_bn_relu_add_fwd")
     return y
 
 
@@ -133,7 +133,8 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return (C.c_void_p * len(ts))(*[ptr(t) for t in ts])
 
 
-def regnet(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.Tensor], bias: Sequence[torch.Tensor]) -> torch.Tensor:
+def regnet(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.Tensor], bias: Sequence[torch.Tensor],
+           precision: int = 0) -> torch.Tensor:
     """Whole U-Net up to (not including) `prob`: volume_cl [B,D,H,W,8] -> feat_cl [B,D,H,W,8]."""
     B, D, H, W, c = volume_cl.shape
     assert c == 8 and len(w_packed) == 9 and len(bias) == 9
@@ -142,7 +143,7 @@ def regnet(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.Tensor],
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=volume_cl.device)
     wa, ba = _ptr_array(w_packed), _ptr_array(bias)
     check(lib().mvs_regnet_fwd(kind, ptr(volume_cl), C.cast(wa, C.c_void_p), C.cast(ba, C.c_void_p), ptr(out), ptr(ws), nbytes,
-                               B, D, H, W, stream_of(volume_cl)), "mvs_regnet_fwd")
+                               B, D, H, W, precision, stream_of(volume_cl)), "mvs_regnet_fwd")
     return out
 
 

@@ -65,6 +65,67 @@ def pack_deconv_weights(w: torch.Tensor) -> torch.Tensor:
     return full.permute(5, 0, 3, 1, 4, 2).contiguous().reshape(-1)         # [tap, q, mb, g, j, s]
 
 
+def _split_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [...] -> bf16 [2, ...] with x ~= hi + lo (both round-to-nearest-even), the operand format of the bf16x3 kernels."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo])
+
+
+def pack_conv_weights_bf16x3(w: torch.Tensor, ch: int) -> torch.Tensor:
+    """w [Cout, Cin, kd, 3, 3] (BN folded) -> bf16 1-D tensor for ``conv3d_mfma_bf16x3_kernel``:
+
+        packed[pass][step][mb][hi|lo][lane = g*16 + j][e] = W'[16*mb + j][pass*CH + 8*oc + e][tap],
+        (tap, oc) = divmod(4*step + g, CH/8)      (channel octets enumerated tap-major, four per step)
+    """
+    cout, cin = w.shape[:2]
+    ntap = w.shape[2] * w.shape[3] * w.shape[4]
+    assert cin % ch == 0 and ch % 8 == 0
+    opt = ch // 8
+    npass = cin // ch
+    noct = ntap * opt
+    nstep = (noct + 3) // 4
+    mrep = (cout + 15) // 16
+    wt = w.reshape(cout, npass, opt, 8, ntap).float().permute(1, 4, 2, 0, 3).reshape(npass, noct, cout, 8)   # [pass, o, co, e]
+    full = torch.zeros(npass, nstep * 4, mrep * 16, 8, dtype=torch.float32)
+    full[:, :noct, :cout] = wt
+    full = full.reshape(npass, nstep, 4, mrep, 16, 8).permute(0, 1, 3, 2, 4, 5)                              # [pass, step, mb, g, j, e]
+    return _split_bf16(full).permute(1, 2, 3, 0, 4, 5, 6).contiguous().reshape(-1)                           # [pass, step, mb, 2, g, j, e]
+
+
+def deconv_class_taps(sd: int):
+    """Parity classes of ConvTranspose3d(k3, stride (sd,2,2)) in the kernels' order, each a list of tap indices
+    (kd*3 + kh)*3 + kw ordered (a_d, a_h, a_w) with a_w fastest - mirrors ``bf_deconv_load_step``."""
+    out = []
+    for cls in range((2 if sd == 2 else 1) * 4):
+        pw, ph, pd = cls & 1, (cls >> 1) & 1, (cls >> 2) if sd == 2 else 0
+        kds = ([0, 2] if pd else [1]) if sd == 2 else [0, 1, 2]
+        khs = [0, 2] if ph else [1]
+        kws = [0, 2] if pw else [1]
+        out.append([(kd * 3 + kh) * 3 + kw for kd in kds for kh in khs for kw in kws])
+    return out
+
+
+def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
+    """w [Cin, Cout, 3, 3, 3] (BN folded over Cout) -> bf16 1-D tensor for ``deconv3d_mfma_bf16x3_kernel``: per parity
+    class, packed[step][mb][hi|lo][lane = g*16 + j][e] = Wt'[8*oc + e][16*mb + j][taps[ti]], (ti, oc) = divmod(4*step + g, Cin/8)."""
+    cin, cout = w.shape[:2]
+    assert cin % 8 == 0 and tuple(w.shape[2:]) == (3, 3, 3)
+    opt = cin // 8
+    mrep = (cout + 15) // 16
+    wf = w.reshape(opt, 8, cout, 27).float()                                       # [oc, e, co, tap]
+    chunks = []
+    for taps in deconv_class_taps(sd):
+        noct = len(taps) * opt
+        nst = (noct + 3) // 4
+        sel = wf[:, :, :, taps].permute(3, 0, 2, 1).reshape(noct, cout, 8)         # [o = ti*opt + oc, co, e]
+        full = torch.zeros(nst * 4, mrep * 16, 8, dtype=torch.float32)
+        full[:noct, :cout] = sel
+        full = full.reshape(nst, 4, mrep, 16, 8).permute(0, 2, 1, 3, 4)             # [step, mb, g, j, e]
+        chunks.append(_split_bf16(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1))   # [step, mb, 2, g, j, e]
+    return torch.cat(chunks)
+
+
 def pad_bias(b: torch.Tensor) -> torch.Tensor:
     n = max(16, ((b.numel() + 15) // 16) * 16)
     out = torch.zeros(n, dtype=torch.float32)

@@ -49,9 +49,10 @@ def _timed(launches: List[Launch], kernel: str, stage: int, flops: float, nbytes
     return out
 
 
-def _regnet_layers(net, vol, stage, launches):
+def _regnet_layers(net, vol, stage, launches, precision):
     """The nine U-Net launches of mvs_regnet_fwd, one C-ABI call each (same kernels, same order)."""
-    ws, bs, _, _ = net.packed_all(vol.device)
+    ws, bs, _, _ = net.packed_all(vol.device, precision)
+    prec = _lib.PRECISIONS[precision]
     three_d = net.kind == _lib.REG_COSTREGNET3D
     s2 = (1, 2, 2) if three_d else (2, 2, 2)
     sd = 1 if three_d else 2
@@ -62,13 +63,13 @@ def _regnet_layers(net, vol, stage, launches):
         oh, ow = (H - 1) // stride[1] + 1, (W - 1) // stride[2] + 1
         nout = B * od * oh * ow
         return _timed(launches, _conv_name(cin, cout, 3, stride), stage, 2.0 * 27 * cin * cout * nout,
-                      4.0 * (x.numel() + nout * cout), lambda: ops.conv3d_bn_relu(x, ws[i], bs[i], cout, 3, stride, True))
+                      4.0 * (x.numel() + nout * cout), lambda: ops.conv3d_bn_relu(x, ws[i], bs[i], cout, 3, stride, True, prec))
 
     def deconv(x, i, cout, skip):
         B, D, H, W, cin = x.shape
         nout = B * D * sd * 4 * H * W
         return _timed(launches, "deconv3d_mfma<%d,%d,s%d22>" % (cin, cout, sd), stage, 2.0 * 27 * cin * cout * (B * D * H * W),
-                      4.0 * (x.numel() + 2 * nout * cout), lambda: ops.deconv3d_bn_relu_add(x, ws[i], bs[i], cout, sd, skip))
+                      4.0 * (x.numel() + 2 * nout * cout), lambda: ops.deconv3d_bn_relu_add(x, ws[i], bs[i], cout, sd, skip, prec))
 
     c1 = conv(vol, 0, 16, s2)
     c2 = conv(c1, 1, 16, (1, 1, 1))
@@ -110,12 +111,12 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         vp = net._vis_params(feats.device)
         # the vis CNN is four launches inside one C call; it is timed as a unit
         vis = _timed(launches, "vis_cnn(4 launches)", s, 2.0 * B * (V - 1) * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8),
-                     4.0 * B * (V - 1) * HW * (1 + 16 + 16 + 16 + 16 + 8 + 8 + 1), lambda: ops.vis_weight(ent, vp))
+                     4.0 * B * (V - 1) * HW * (1 + 16 + 16 + 16 + 16 + 8 + 8 + 1), lambda: ops.vis_weight(ent, vp, _lib.PRECISIONS[net.conv_precision]))
         vol = _timed(launches, "warp_corr_aggregate<C%d>" % C, s, corr_flops,
                      B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
                      lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
-        feat_cl = _regnet_layers(net.cost_reg, vol, s, launches)
-        ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device)
+        feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
+        ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
         ks = net.cost_reg.prob_ksize
         res = _timed(launches, "prob_regress<k%d>" % ks, s, 2.0 * B * D * HW * 8 * (27 if ks == 3 else 1),
                      4.0 * B * (8 * D * HW + D * HW + 2 * D * HW + 2 * HW),

@@ -145,6 +145,23 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[i=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][col=l&15], j<8; D as 16x16 above.
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
+    struct AB { hipemu_bf16x8 a, b; } mine{a, b}, all[64];
+    hipemu::wave_gather(&mine, all, sizeof(AB));
+    const int l = hipemu::lane_id(), col = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < 8; ++j) acc += (float)all[row + 16 * k].a[j] * (float)all[col + 16 * k].b[j];   // bf16 products are exact in fp32
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
+
 static inline int hipemu_readfirstlane(int v) {
     int all[64];
     hipemu::wave_gather(&v, all, sizeof(int));

@@ -64,6 +64,39 @@ def case_regnet_golden(device, name):
     assert (y - fx["y"]).abs().max() <= 2e-4 * max(1.0, scale), "regulariser logits differ from the reference"
 
 
+def case_precisions(device):
+    """Both contraction modes of the MFMA convolutions against the reference's regulariser output:
+    fp32 (v_mfma_f32_16x16x4_f32, an exact fmaf chain) and bf16x3 (3-term split bf16, ~2^-16 per product)."""
+    for name in ("f3_costregnet.npz", "f3_costregnet3d_d8.npz"):
+        fx = load_golden(name)
+        sd = golden_weights(fx)
+        errs = {}
+        for prec in ("fp32", "bf16x3"):
+            net = M.CostRegNet3D(8, 8) if "3d" in name else M.CostRegNet(8, 8)
+            net = _load_regnet(net, sd, device)
+            net.conv_precision = prec
+            with torch.no_grad():
+                y = cpu(net(dev(fx["x"], device)))
+            errs[prec] = float((y - fx["y"]).norm() / fx["y"].norm())
+        assert errs["fp32"] <= 2e-6, errs            # summation-order noise only
+        assert errs["bf16x3"] <= 5e-5, errs          # 2^-16-class product error, 10 layers deep
+    fx = load_golden("f2_stage_s1.npz")
+    for prec, tol in (("fp32", 5e-6), ("bf16x3", 2e-5)):
+        net = make_stage(fx, fx["hyp"].shape[1], 1, device)
+        net.conv_precision = prec
+        with torch.no_grad():
+            out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), float(fx["tmp"]))
+        assert rel_l1(cpu(out["depth"]), fx["depth"]) <= tol, prec
+    try:
+        net.conv_precision = "fp8"
+        with torch.no_grad():
+            net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), 5.0)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("unknown precision names must be rejected")
+
+
 def case_single_layers(device):
     """Conv3d / Deconv3d wrappers one layer at a time against torch's own conv (fp32 reference of the same op)."""
     import torch.nn.functional as F
@@ -130,8 +163,10 @@ def case_stage_pieces(device):
     hom = ops.compose_homography(dev(proj, device))
     ent = ops.warp_corr_entropy(f, code, hom, dev(hyp, device), 8)
     assert (cpu(ent) - ref["entropy"].squeeze(2)).abs().max() <= 2e-5
-    vis = ops.vis_weight(ent, net._vis_params(f.device))
-    assert (cpu(vis) - ref["vis_weight"].squeeze(2)).abs().max() <= 2e-5
+    for prec in ("fp32", "bf16x3"):
+        net.conv_precision = prec
+        vis = ops.vis_weight(ent, net._vis_params(f.device), _lib.PRECISIONS[prec])
+        assert (cpu(vis) - ref["vis_weight"].squeeze(2)).abs().max() <= 2e-5, prec
     vol, _ = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8)
     assert (cpu(vol).permute(0, 4, 1, 2, 3) - ref["volume_mean"]).abs().max() <= 2e-5
     # partial (view-sharded) form: two halves summed and normalised == the fused single pass

@@ -15,6 +15,10 @@ def test_warp_dtypes(emu):
     P.case_warp_dtypes(emu)
 
 
+def test_precisions(emu):
+    P.case_precisions(emu)
+
+
 def test_single_layers(emu):
     P.case_single_layers(emu)
 

@@ -30,6 +30,10 @@ def test_warp_dtypes():
     P.case_warp_dtypes(DEV)
 
 
+def test_precisions():
+    P.case_precisions(DEV)
+
+
 def test_single_layers():
     P.case_single_layers(DEV)
 
