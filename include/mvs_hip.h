@@ -64,14 +64,9 @@ int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* homography /*
  * features [B,V,C,H,W] (dtype; view 0 = reference), hyp [B,D,H,W]
  * -> entropy [B,V-1,H,W].  No [C,D,H,W] or [G,D,H,W] intermediate is materialised.
  * Only source views in [view_begin, view_end) (1-based view indices) are processed.              */
-int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* src_cl, const float* homography /*[B,V-1,12]*/,
+int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homography /*[B,V-1,12]*/,
                               const float* hyp, float* entropy, int B, int V, int C, int G, int D, int H, int W,
                               int view_begin, int view_end, void* stream);
-/* Optional accelerator for the two warp_corr passes: source views [view_begin, view_end) of features transposed to
- * channel-last fp32, src_cl [B,V-1,H*W,C] (slot v-1).  With it (G == 8, C in {8,16,32,64}) every bilinear tap pair is
- * one run of aligned 16-byte loads (2x the gather rate of the planar layout on MI355X); NULL selects the planar path. */
-int mvs_features_to_cl(const void* features, int dtype, float* src_cl, int B, int V, int C, int H, int W,
-                       int view_begin, int view_end, void* stream);
 
 /* ---- a5: visibility CNN, cost_volume.py:36,93 + module.py:168-197 ------------------------------
  * entropy [N,H,W] -> vis [N,H,W] = sigmoid(conv1x1(CBR(16->8)(CBR(16->16)(CBR(1->16)(entropy))))).
@@ -88,7 +83,7 @@ int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, c
  *   normalise = 1 : volume = sum_v ip_v*vis_v / (sum_v vis_v + 1e-6)              (single GPU)
  *   normalise = 0 : volume = partial sum over [view_begin, view_end), vis_sum [B,H,W] = partial
  *                   sum of vis (view-sharded multi-GPU: all-reduce both, then mvs_volume_normalise) */
-int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, const float* src_cl, const float* homography, const float* hyp,
+int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, const float* homography, const float* hyp,
                                 const float* vis, float* volume_cl, float* vis_sum, int normalise, int B, int V,
                                 int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream);
 int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, void* stream);

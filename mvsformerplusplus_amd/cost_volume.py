@@ -95,10 +95,9 @@ class StageNet(nn.Module):
 
         prec = precision_code(self.conv_precision)
         if self.view_group is None:
-            src_cl = ops.features_to_cl(feats, code, G)        # channel-last copy of the source views: aligned 16-B gathers
-            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, src_cl=src_cl)
+            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
             vis = ops.vis_weight(entropy, vis_params, prec)
-            volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, src_cl=src_cl)
+            volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
         else:
             volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
 
@@ -128,10 +127,9 @@ class StageNet(nn.Module):
         vol = flat[: B * D * H * W * G].view(B, D, H, W, G)
         vsum = flat[B * D * H * W * G:].view(B, H, W)
         if ve > vb:
-            src_cl = ops.features_to_cl(feats, code, G, vb, ve)
-            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, vb, ve, src_cl=src_cl)
+            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, vb, ve)
             vis = entropy.clone()
             vis[:, vb - 1: ve - 1] = ops.vis_weight(entropy[:, vb - 1: ve - 1].contiguous(), vis_params, precision_code(self.conv_precision))
-            ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=False, view_begin=vb, view_end=ve, out=(vol, vsum), src_cl=src_cl)
+            ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=False, view_begin=vb, view_end=ve, out=(vol, vsum))
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.view_group)
         return ops.volume_normalise_(vol, vsum)

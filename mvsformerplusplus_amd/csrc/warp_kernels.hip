@@ -159,114 +159,128 @@ __device__ __forceinline__ void correlate_chunk(const T* __restrict__ src, const
     }
 }
 
-// Channel-last variant (fastest): the source view has been transposed to [HW][C] fp32 (features_to_cl_kernel), so the
-// two x-taps of a row are 2*C contiguous floats and every load is an ALIGNED 16-byte float4 of four channels.  Measured
-// on MI355X (scripts/gather_ubench.hip): aligned 16-B gathers deliver 51-53 tap-bytes/clk/CU, planar 4-/8-byte gathers
-// 22-26 (unaligned wide loads are split by the memory pipeline and gain nothing).  CPG = C/8 is a template parameter
-// so that every accumulator index is static; quads of channels are separated by scheduling barriers to bound the loads
-// in flight (4 reference + 4*DCH float4 per quad).
-// one quad (4 channels) of one source view for the DCH planes: wv[dd][j] = bilinear value of channel 4q+j, r[j] = ref
-template <typename TR, int NQ>
-__device__ __forceinline__ void cl_quad(const float4* src, const TR* __restrict__ ref, const PairTaps* tp, unsigned HW, unsigned pc,
-                                        unsigned q, float (*wv)[4], float* r) {
+// ------------------------------------------------------------------------------------------------
+// Per-wave LDS staging of the source window.
+// rocprofv3 counters on MI355X show the direct gathers above pinned at TD_TD_BUSY ~ 90 % (the L1 data-return path)
+// at ~30 tap-bytes/clk/CU whatever the layout (planar 4/8-byte or channel-last aligned 16-byte loads): every tap
+// value crosses the L1 return path once per (pixel, plane, view, pass).  A wave covers 64 consecutive pixels and
+// only DCH adjacent depth planes, so all its taps of one source view fall in a box of a few rows x (64 + a few)
+// columns.  The wave copies that box of 8 channels into its own LDS region with coalesced row loads (each source
+// element crosses L1 once per wave) and takes the 4-tap gathers from LDS (ds_read2_b32, 128 B/clk/CU, separate
+// pipe).  No workgroup barrier: the region is private to the wave.  Boxes that do not fit (strong rotation / zoom)
+// fall back to the direct gather, wave-uniformly.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStageFloats = 2304;          // per wave: 8 channels x (rows x columns <= 288), 9 KiB
+
+struct StageBox {
+    int xmin, ymin, bw, bh;
+    bool fits;
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = to_f32(ref[(size_t)(4 * q + j) * HW + pc]);
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+
+__device__ __forceinline__ StageBox stage_box(const PairTaps* tp) {
+    int x0 = 0x3fffffff, x1 = -1, y0 = 0x3fffffff, y1 = -1;
 #pragma unroll
     for (int dd = 0; dd < DCH; ++dd) {
-        const float4* t = src + (unsigned)tp[dd].top * NQ + q;
-        const float4* b = src + (unsigned)tp[dd].bot * NQ + q;
-        const float4 t0 = t[0], t1 = t[NQ], b0 = b[0], b1 = b[NQ];
-        wv[dd][0] = tp[dd].w00 * t0.x; wv[dd][0] += tp[dd].w01 * t1.x; wv[dd][0] += tp[dd].w10 * b0.x; wv[dd][0] += tp[dd].w11 * b1.x;
-        wv[dd][1] = tp[dd].w00 * t0.y; wv[dd][1] += tp[dd].w01 * t1.y; wv[dd][1] += tp[dd].w10 * b0.y; wv[dd][1] += tp[dd].w11 * b1.y;
-        wv[dd][2] = tp[dd].w00 * t0.z; wv[dd][2] += tp[dd].w01 * t1.z; wv[dd][2] += tp[dd].w10 * b0.z; wv[dd][2] += tp[dd].w11 * b1.z;
-        wv[dd][3] = tp[dd].w00 * t0.w; wv[dd][3] += tp[dd].w01 * t1.w; wv[dd][3] += tp[dd].w10 * b0.w; wv[dd][3] += tp[dd].w11 * b1.w;
+        if (tp[dd].xb < 0) continue;                        // no valid tap: does not constrain the box
+        x0 = tp[dd].xb < x0 ? tp[dd].xb : x0;
+        x1 = tp[dd].xb > x1 ? tp[dd].xb : x1;
+        const int ya = tp[dd].yt < tp[dd].yb ? tp[dd].yt : tp[dd].yb, yc = tp[dd].yt < tp[dd].yb ? tp[dd].yb : tp[dd].yt;
+        y0 = ya < y0 ? ya : y0;
+        y1 = yc > y1 ? yc : y1;
     }
+    StageBox bx;
+    bx.xmin = wave_min_i(x0);
+    const int xmax = wave_max_i(x1);
+    bx.ymin = wave_min_i(y0);
+    const int ymax = wave_max_i(y1);
+    if (xmax < 0) { bx.xmin = 0; bx.ymin = 0; bx.bw = 2; bx.bh = 1; bx.fits = true; return bx; }   // nothing valid in the wave
+    bx.bw = xmax - bx.xmin + 2;                             // pairs read xb and xb + 1
+    bx.bh = ymax - bx.ymin + 1;
+    bx.fits = bx.bw * bx.bh * 8 <= kStageFloats;
+    return bx;
 }
 
-// CPG = C/8 channels per group (template: accumulator indices stay static).  Every quad is processed inside a REAL
-// loop whose trip count is only known at run time (derived from the kernel argument C), so its 4 + 4*DCH loads cannot
-// be hoisted across quads - the same register-pressure guard as in correlate_chunk.
-template <typename TR, int CPG, bool SUM_GROUPS>
-__device__ __forceinline__ void correlate_chunk_cl(const float4* src, const TR* __restrict__ ref, const PairTaps* tp, unsigned HW, unsigned pc,
-                                                   int c_rt, float* out) {
-    constexpr int C = 8 * CPG, NQ = C / 4;
-    const float inv_cpg = 1.0f / (float)CPG;
-    float wv[DCH][4], r[4];
-    if (SUM_GROUPS) {
-        // sim = sum_g mean_{c in g} = (1/cpg) * sum_c : one rolled loop over all quads
-        const int nq = c_rt / 4;
+// out[dd*8 + g] = v[dd] for a WAVE-UNIFORM run-time g: a scalar branch selects one of eight statically indexed stores,
+// so the accumulators stay in registers although the channel loop is a real (rolled) loop
+__device__ __forceinline__ void put_group(float* out, int g, const float* v) {
+#define MVS_PUT(G) case G: _Pragma("unroll") for (int dd = 0; dd < DCH; ++dd) out[dd * 8 + G] = v[dd]; break;
+    switch (g) { MVS_PUT(0) MVS_PUT(1) MVS_PUT(2) MVS_PUT(3) MVS_PUT(4) MVS_PUT(5) MVS_PUT(6) default: MVS_PUT(7) }
+#undef MVS_PUT
+}
+
+// All C channels (8 groups of cpg) of one source view for the DCH planes of this work-item, 8 channels at a time through
+// the wave's LDS copy of the source box.  Channel loop rolled: per iteration 1 reference load + 4*DCH LDS reads.
+template <typename T, bool SUM_GROUPS>
+__device__ __forceinline__ void correlate_chunk_lds(const T* __restrict__ src, const T* __restrict__ ref, const PairTaps* tp, float* stg,
+                                                    unsigned HW, unsigned W, unsigned pc, int lane, int C, float* out) {
+    const int cpg = C >> 3;
+    const StageBox bx = stage_box(tp);
+    if (!bx.fits) {                                             // wave-uniform fallback: direct gather
+        correlate_chunk<T, 8, SUM_GROUPS>(src, ref, tp, HW, pc, cpg, out);
+        return;
+    }
+    const float inv_cpg = 1.0f / (float)cpg;
+    int ot[DCH], ob[DCH];
+#pragma unroll
+    for (int dd = 0; dd < DCH; ++dd) {
+        const bool ok = tp[dd].xb >= 0;
+        ot[dd] = ok ? (tp[dd].yt - bx.ymin) * bx.bw + (tp[dd].xb - bx.xmin) : 0;
+        ob[dd] = ok ? (tp[dd].yb - bx.ymin) * bx.bw + (tp[dd].xb - bx.xmin) : 0;
+    }
+    const int plane = bx.bh * bx.bw, nrow = 8 * bx.bh;
+    float cur[DCH];
+#pragma unroll
+    for (int dd = 0; dd < DCH; ++dd) cur[dd] = 0.0f;
+    int in_group = 0, g = 0;
 #pragma unroll 1
-        for (int q = 0; q < nq; ++q) {
-            cl_quad<TR, NQ>(src, ref, tp, HW, pc, (unsigned)q, wv, r);
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        // ---- stage 8 channels: 8 * bh rows of bw floats, coalesced along x ----
+#pragma unroll 1
+        for (int row = 0; row < nrow; ++row) {
+            const int cc = row / bx.bh, yy = row - cc * bx.bh;
+            const T* sp = src + (size_t)(c0 + cc) * HW + (unsigned)(bx.ymin + yy) * W + (unsigned)bx.xmin;
+            for (int xx = lane; xx < bx.bw; xx += 64) stg[row * bx.bw + xx] = to_f32(sp[xx]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- gather from LDS ----
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+            const float r = to_f32(ref[(size_t)(c0 + j) * HW + pc]);
+            const float* sj = stg + j * plane;
 #pragma unroll
             for (int dd = 0; dd < DCH; ++dd) {
-                float t = r[0] * wv[dd][0];
-                t += r[1] * wv[dd][1]; t += r[2] * wv[dd][2]; t += r[3] * wv[dd][3];
-                out[dd] += t * inv_cpg;
+                float wv = tp[dd].w00 * sj[ot[dd]];
+                wv += tp[dd].w01 * sj[ot[dd] + 1];
+                wv += tp[dd].w10 * sj[ob[dd]];
+                wv += tp[dd].w11 * sj[ob[dd] + 1];
+                cur[dd] += r * wv;
             }
-        }
-    } else if (CPG >= 4) {
-        const int qpg = c_rt / 32;                               // quads per group (run-time value of CPG/4)
+            if (++in_group == cpg) {                             // wave-uniform: a channel group is complete
+                float m[DCH];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            float cur[DCH];
+                for (int dd = 0; dd < DCH; ++dd) { m[dd] = cur[dd] * inv_cpg; cur[dd] = 0.0f; }
+                if (SUM_GROUPS) {
 #pragma unroll
-            for (int dd = 0; dd < DCH; ++dd) cur[dd] = 0.0f;
-#pragma unroll 1
-            for (int qq = 0; qq < qpg; ++qq) {
-                cl_quad<TR, NQ>(src, ref, tp, HW, pc, (unsigned)(g * (CPG / 4) + qq), wv, r);
-#pragma unroll
-                for (int dd = 0; dd < DCH; ++dd) {
-                    cur[dd] += r[0] * wv[dd][0]; cur[dd] += r[1] * wv[dd][1]; cur[dd] += r[2] * wv[dd][2]; cur[dd] += r[3] * wv[dd][3];
+                    for (int dd = 0; dd < DCH; ++dd) out[dd] += m[dd];
+                } else {
+                    put_group(out, g, m);
                 }
-            }
-#pragma unroll
-            for (int dd = 0; dd < DCH; ++dd) out[dd * 8 + g] = cur[dd] * inv_cpg;
-        }
-    } else {
-        const int reps = c_rt / C;                               // == 1; opaque to the compiler
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-#pragma unroll 1
-            for (int it = 0; it < reps; ++it) {
-                cl_quad<TR, NQ>(src, ref, tp, HW, pc, (unsigned)q, wv, r);
-#pragma unroll
-                for (int dd = 0; dd < DCH; ++dd) {
-                    if (CPG == 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) out[dd * 8 + 4 * q + j] = r[j] * wv[dd][j];
-                    } else {                                     // CPG == 2
-                        out[dd * 8 + 2 * q] = (r[0] * wv[dd][0] + r[1] * wv[dd][1]) * inv_cpg;
-                        out[dd * 8 + 2 * q + 1] = (r[2] * wv[dd][2] + r[3] * wv[dd][3]) * inv_cpg;
-                    }
-                }
+                in_group = 0;
+                ++g;
             }
         }
-    }
-}
-
-// [B,V,C,HW] (any feature dtype) -> [B,V-1,HW,C] fp32 for the source views, through an LDS tile so that both the
-// planar reads and the channel-last writes are coalesced.  grid = (HW/64, views, B), C <= 64.
-template <int DT>
-__global__ __launch_bounds__(256) void features_to_cl_kernel(const void* __restrict__ feat_, float* __restrict__ out, int V, int C, int HW,
-                                                             int view_begin) {
-    typedef typename FeatT<DT>::type T;
-    __shared__ float tile[64 * 65];
-    const int tid = (int)threadIdx.x;
-    const int p0 = (int)blockIdx.x * 64;
-    const int v = view_begin + (int)blockIdx.y, b = (int)blockIdx.z;
-    const T* src = reinterpret_cast<const T*>(feat_) + (size_t)(b * V + v) * C * HW;
-    for (int i = tid; i < C * 64; i += 256) {
-        const int c = i >> 6, px = i & 63;
-        const int p = p0 + px < HW ? p0 + px : HW - 1;
-        tile[c * 65 + px] = to_f32(src[(size_t)c * HW + p]);
-    }
-    __syncthreads();
-    float* dst = out + ((size_t)(b * (V - 1) + (v - 1)) * HW + p0) * C;
-    const int npx = HW - p0 < 64 ? HW - p0 : 64;
-    for (int i = tid; i < npx * C; i += 256) {
-        const int px = i / C, c = i - px * C;
-        dst[i] = tile[c * 65 + px];
+        __builtin_amdgcn_wave_barrier();                        // the region is reused by the next 8 channels
     }
 }
 
@@ -309,10 +323,9 @@ __device__ __forceinline__ void softmax_entropy_store(const float* sim, int stri
 // grid = (pixel blocks, views in launch, B).  dynamic LDS: sim[D][pixels per block] floats.
 // ------------------------------------------------------------------------------------------------
 template <int DT, int CT, int GT>
-__global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __restrict__ feat_, const float* src_cl,
-                                                                const float* __restrict__ hom, const float* __restrict__ hyp,
-                                                                float* __restrict__ entropy, int V, int C_, int G_, int D, int H, int W,
-                                                                int view_begin, int nblk) {
+__global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
+                                                                const float* __restrict__ hyp, float* __restrict__ entropy,
+                                                                int V, int C_, int G_, int D, int H, int W, int view_begin, int nblk) {
     typedef typename FeatT<DT>::type T;
     HIP_DYNAMIC_SHARED(float, sim)
     const int HW = H * W;
@@ -351,8 +364,8 @@ __global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __re
 #pragma unroll
             for (int dd = 0; dd < DCH; ++dd) s[dd] = 0.0f;
             if (CT >= 10)
-                correlate_chunk_cl<T, (CT >= 10 ? CT - 10 : 1), true>(
-                    reinterpret_cast<const float4*>(src_cl + (size_t)(b * (V - 1) + (v - 1)) * HW * C_), ref, tp, (unsigned)HW, (unsigned)pc, C_, s);
+                correlate_chunk_lds<T, true>(src, ref, tp, sim + D * cm.ppb + wave * kStageFloats, (unsigned)HW, (unsigned)W, (unsigned)pc,
+                                             lane, C_, s);
             else
                 correlate_chunk<T, (GT > 0 ? GT : 8), true>(src, ref, tp, (unsigned)HW, (unsigned)pc, cpg, s);
 #pragma unroll
@@ -393,13 +406,13 @@ __global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __re
 // grid = (pixel blocks, 1, B); output channel-last [D,HW,G].
 // ------------------------------------------------------------------------------------------------
 template <int DT, int CT, int GT>
-__global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __restrict__ feat_, const float* src_cl,
-                                                                  const float* __restrict__ hom,
+__global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                                   const float* __restrict__ hyp, const float* __restrict__ vis,
                                                                   float* __restrict__ vol, float* __restrict__ vis_sum, int normalise,
                                                                   int V, int C_, int G_, int D, int H, int W, int view_begin,
                                                                   int view_end, int nblk) {
     typedef typename FeatT<DT>::type T;
+    HIP_DYNAMIC_SHARED(float, stage_lds)
     const int HW = H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = (int)blockIdx.z;
@@ -441,8 +454,8 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __
                 for (int dd = 0; dd < DCH; ++dd) tp[dd] = make_pair_taps(hm, qx, qy, qz, depth[dd], H, W, half_w, half_h);
                 float ip[DCH * GG];
                 if (CT >= 10)
-                    correlate_chunk_cl<T, (CT >= 10 ? CT - 10 : 1), false>(
-                        reinterpret_cast<const float4*>(src_cl + (size_t)(b * (V - 1) + (v - 1)) * HW * CC), ref, tp, (unsigned)HW, (unsigned)pc, CC, ip);
+                    correlate_chunk_lds<T, false>(feat + (size_t)(b * V + v) * CC * HW, ref, tp, stage_lds + wave * kStageFloats,
+                                                  (unsigned)HW, (unsigned)W, (unsigned)pc, lane, CC, ip);
                 else
                     correlate_chunk<T, GG, false>(feat + (size_t)(b * V + v) * CC * HW, ref, tp, (unsigned)HW, (unsigned)pc, cpg, ip);
                 const float w = vis[(size_t)(b * (V - 1) + (v - 1)) * HW + pc];
@@ -546,40 +559,35 @@ __global__ __launch_bounds__(256) void homo_warp_kernel(const void* __restrict__
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
 template <int DT, int CT, int GT>
-static int launch_entropy(const void* feat, const float* src_cl, const float* hom, const float* hyp, float* ent, int B, int V, int C, int G,
-                          int D, int H, int W, int vb, int ve, hipStream_t st) {
+static int launch_entropy(const void* feat, const float* hom, const float* hyp, float* ent, int B, int V, int C, int G, int D,
+                          int H, int W, int vb, int ve, hipStream_t st) {
     const int HW = H * W;
     const int ppb = CT > 0 ? chunk_map(D).ppb : 64;
     const int nblk = (int)ceil_div(HW, ppb);
-    const size_t lds = (size_t)D * ppb * sizeof(float);
+    const size_t lds = ((size_t)D * ppb + (CT >= 10 ? 4 * kStageFloats : 0)) * sizeof(float);
     if (lds > 160 * 1024) { set_error("warp_corr_entropy: D=%d needs %zu B of LDS (> 160 KiB)", D, lds); return MVS_ERR_UNSUPPORTED; }
     if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_corr_entropy_kernel<DT, CT, GT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((warp_corr_entropy_kernel<DT, CT, GT>), dim3(nblk, ve - vb, B), dim3(256), lds, st, feat, src_cl, hom, hyp, ent, V,
-                       C, G, D, H, W, vb, nblk);
+    hipLaunchKernelGGL((warp_corr_entropy_kernel<DT, CT, GT>), dim3(nblk, ve - vb, B), dim3(256), lds, st, feat, hom, hyp, ent, V, C,
+                       G, D, H, W, vb, nblk);
     return check_launch("warp_corr_entropy_kernel");
 }
 
 template <int DT, int CT, int GT>
-static int launch_aggregate(const void* feat, const float* src_cl, const float* hom, const float* hyp, const float* vis, float* vol,
-                            float* vis_sum, int normalise, int B, int V, int C, int G, int D, int H, int W, int vb, int ve, hipStream_t st) {
+static int launch_aggregate(const void* feat, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
+                            int normalise, int B, int V, int C, int G, int D, int H, int W, int vb, int ve, hipStream_t st) {
     const int nblk = (int)ceil_div((long long)H * W, CT > 0 ? chunk_map(D).ppb : 64);
-    hipLaunchKernelGGL((warp_corr_aggregate_kernel<DT, CT, GT>), dim3(nblk, 1, B), dim3(256), 0, st, feat, src_cl, hom, hyp, vis, vol,
-                       vis_sum, normalise, V, C, G, D, H, W, vb, ve, nblk);
+    const size_t lds = CT >= 10 ? 4 * kStageFloats * sizeof(float) : 0;
+    hipLaunchKernelGGL((warp_corr_aggregate_kernel<DT, CT, GT>), dim3(nblk, 1, B), dim3(256), lds, st, feat, hom, hyp, vis, vol, vis_sum,
+                       normalise, V, C, G, D, H, W, vb, ve, nblk);
     return check_launch("warp_corr_aggregate_kernel");
 }
 
-// kernel variants (template CT): 0 = run-time C/G fallback; 1 = planar source, unaligned pair loads (G == 8, W >= 2);
-// 10 + C/8 = channel-last source copy present (G == 8, C in {8,16,32,64}, W >= 2) - the fast path
+// kernel variants (template CT): 0 = run-time C/G fallback; 1 = direct gather with unaligned pair loads (kept for
+// A/B measurements); 10 = per-wave LDS staging of the source window (G == 8, C % 8 == 0, W >= 2) - the fast path
 #define MVS_DISPATCH_CG(FN, DT, ...)                                              \
     do {                                                                          \
-        if (G == 8 && W >= 2 && src_cl != nullptr) {                              \
-            if (C == 8) return FN<DT, 11, 8>(__VA_ARGS__);                        \
-            if (C == 16) return FN<DT, 12, 8>(__VA_ARGS__);                       \
-            if (C == 32) return FN<DT, 14, 8>(__VA_ARGS__);                       \
-            if (C == 64) return FN<DT, 18, 8>(__VA_ARGS__);                       \
-        }                                                                         \
-        if (G == 8 && W >= 2) return FN<DT, 1, 8>(__VA_ARGS__);                   \
+        if (G == 8 && W >= 2) return FN<DT, 10, 8>(__VA_ARGS__);                  \
         return FN<DT, 0, 0>(__VA_ARGS__);                                         \
     } while (0)
 
@@ -626,37 +634,20 @@ extern "C" int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* ho
     return check_launch("homo_warp_kernel");
 }
 
-extern "C" int mvs_features_to_cl(const void* features, int dtype, float* src_cl, int B, int V, int C, int H, int W, int view_begin,
-                                  int view_end, void* stream) {
-    if (!features || !src_cl || B < 1 || V < 2 || C < 1 || H < 1 || W < 1 || view_begin < 1 || view_end > V || view_begin >= view_end) { set_error("mvs_features_to_cl: bad arguments"); return MVS_ERR_ARG; }
-    if (C > 64) { set_error("mvs_features_to_cl: C=%d > 64 unsupported", C); return MVS_ERR_UNSUPPORTED; }
-    const int HW = H * W;
-    const dim3 grid(ceil_div(HW, 64), view_end - view_begin, B);
-    hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case MVS_DTYPE_F32: hipLaunchKernelGGL((features_to_cl_kernel<MVS_DTYPE_F32>), grid, dim3(256), 0, st, features, src_cl, V, C, HW, view_begin); break;
-        case MVS_DTYPE_BF16: hipLaunchKernelGGL((features_to_cl_kernel<MVS_DTYPE_BF16>), grid, dim3(256), 0, st, features, src_cl, V, C, HW, view_begin); break;
-        case MVS_DTYPE_F16: hipLaunchKernelGGL((features_to_cl_kernel<MVS_DTYPE_F16>), grid, dim3(256), 0, st, features, src_cl, V, C, HW, view_begin); break;
-        default: set_error("mvs_features_to_cl: bad dtype %d", dtype); return MVS_ERR_ARG;
-    }
-    return check_launch("features_to_cl_kernel");
-}
-
-extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* src_cl, const float* homography, const float* hyp,
-                                         float* entropy, int B, int V, int C, int G, int D, int H, int W, int view_begin, int view_end,
-                                         void* stream) {
+extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homography, const float* hyp, float* entropy,
+                                         int B, int V, int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream) {
     int rc = check_corr_args("mvs_warp_corr_entropy_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, view_begin, view_end);
     if (rc != MVS_OK) return rc;
     if (!entropy) { set_error("mvs_warp_corr_entropy_fwd: null output"); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, src_cl, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
-        case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, src_cl, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
-        default: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F16, features, src_cl, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
+        case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
+        case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
+        default: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
     }
 }
 
-extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, const float* src_cl, const float* homography, const float* hyp, const float* vis,
+extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, const float* homography, const float* hyp, const float* vis,
                                            float* volume_cl, float* vis_sum, int normalise, int B, int V, int C, int G, int D, int H,
                                            int W, int view_begin, int view_end, void* stream) {
     int rc = check_corr_args("mvs_warp_corr_aggregate_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, view_begin, view_end);
@@ -665,9 +656,9 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, cons
     if (!normalise && !vis_sum) { set_error("mvs_warp_corr_aggregate_fwd: partial mode needs vis_sum"); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F32, features, src_cl, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
-        case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_BF16, features, src_cl, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
-        default: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F16, features, src_cl, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
+        case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F32, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
+        case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_BF16, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
+        default: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F16, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
     }
 }
 

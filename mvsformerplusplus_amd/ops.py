@@ -57,25 +57,14 @@ def homo_warp(src_fea: torch.Tensor, homography: torch.Tensor, depth_values: tor
 
 
 # ---- a2-a6 --------------------------------------------------------------------------------------
-def features_to_cl(features: torch.Tensor, code: int, G: int, view_begin: int = 1, view_end: Optional[int] = None) -> Optional[torch.Tensor]:
-    """Channel-last fp32 copy [B,V-1,H*W,C] of the source views (gather accelerator); None where the fast path does not apply."""
-    B, V, Cc, H, W = features.shape
-    if G != 8 or Cc not in (8, 16, 32, 64) or W < 2:
-        return None
-    view_end = V if view_end is None else view_end
-    out = torch.empty(B, V - 1, H * W, Cc, dtype=torch.float32, device=features.device)
-    check(lib().mvs_features_to_cl(ptr(features), code, ptr(out), B, V, Cc, H, W, view_begin, view_end, stream_of(features)), "mvs_features_to_cl")
-    return out
-
-
 def warp_corr_entropy(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, G: int,
-                      view_begin: int = 1, view_end: Optional[int] = None, src_cl: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      view_begin: int = 1, view_end: Optional[int] = None) -> torch.Tensor:
     """features [B,V,C,H,W] contiguous; -> entropy [B,V-1,H,W] (only views in [view_begin, view_end) are written)."""
     B, V, Cc, H, W = features.shape
     D = hyp.shape[1]
     view_end = V if view_end is None else view_end
     ent = torch.zeros(B, V - 1, H, W, dtype=torch.float32, device=features.device)
-    check(lib().mvs_warp_corr_entropy_fwd(ptr(features), code, ptr(src_cl), ptr(homography), ptr(hyp), ptr(ent), B, V, Cc, G, D, H, W,
+    check(lib().mvs_warp_corr_entropy_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(ent), B, V, Cc, G, D, H, W,
                                           view_begin, view_end, stream_of(features)), "mvs_warp_corr_entropy_fwd")
     return ent
 
@@ -94,8 +83,7 @@ def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor], precision:
 
 
 def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, vis: torch.Tensor,
-                        G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None,
-                        src_cl: Optional[torch.Tensor] = None):
+                        G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None):
     """-> (volume_cl [B,D,H,W,G], vis_sum [B,H,W] or None).  `out` = preallocated (volume, vis_sum) to fill."""
     B, V, Cc, H, W = features.shape
     D = hyp.shape[1]
@@ -105,7 +93,7 @@ def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Ten
     else:
         vol = torch.empty(B, D, H, W, G, dtype=torch.float32, device=features.device)
         vsum = None if normalise else torch.empty(B, H, W, dtype=torch.float32, device=features.device)
-    check(lib().mvs_warp_corr_aggregate_fwd(ptr(features), code, ptr(src_cl), ptr(homography), ptr(hyp), ptr(vis), ptr(vol), ptr(vsum),
+    check(lib().mvs_warp_corr_aggregate_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(vis), ptr(vol), ptr(vsum),
                                             1 if normalise else 0, B, V, Cc, G, D, H, W, view_begin, view_end,
                                             stream_of(features)), "mvs_warp_corr_aggregate_fwd")
     return vol, vsum

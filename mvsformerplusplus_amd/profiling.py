@@ -106,16 +106,15 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.schedule_inverse_range(pd, ph, D, head.depth_interals_ratio[s], H, W))
         hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
-        src_cl = _timed(launches, "features_to_cl", s, 0, B * (V - 1) * C * HW * (esz + 4), lambda: ops.features_to_cl(feats, code, 8))
         ent = _timed(launches, "warp_corr_entropy<C%d>" % C, s, corr_flops,
-                     B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)), lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8, src_cl=src_cl))
+                     B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)), lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
         vp = net._vis_params(feats.device)
         # the vis CNN is four launches inside one C call; it is timed as a unit
         vis = _timed(launches, "vis_cnn(4 launches)", s, 2.0 * B * (V - 1) * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8),
                      4.0 * B * (V - 1) * HW * (1 + 16 + 16 + 16 + 16 + 8 + 8 + 1), lambda: ops.vis_weight(ent, vp, _lib.PRECISIONS[net.conv_precision]))
         vol = _timed(launches, "warp_corr_aggregate<C%d>" % C, s, corr_flops,
                      B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
-                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8, src_cl=src_cl)[0])
+                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
         ks = net.cost_reg.prob_ksize

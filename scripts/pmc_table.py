@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Merge rocprofv3 counter_collection CSVs (one per --pmc pass) into a per-kernel table: scripts/pmc_table.py gpurun_out/pmc_x [filter]"""
+import csv, glob, re, sys, collections
+root = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else ""
+agg = collections.OrderedDict()
+for f in sorted(glob.glob(root + "/p*/p*_counter_collection.csv")):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(f)):
+        name = row["Kernel_Name"]
+        if filt and not re.search(filt, name): continue
+        m = re.search(r"(warp_corr_\w+|conv3d_mfma\w*|deconv3d_mfma\w*|\w+_kernel)<?([^>]*)", name)
+        short = (m.group(1) + "<" + m.group(2)[:28] + ">") if m else name[:50]
+        per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, cs in per.items():
+        for c, vals in cs.items():
+            agg.setdefault(k, collections.OrderedDict())[c] = sum(vals) / len(vals)
+cols = []
+for k in agg:
+    for c in agg[k]:
+        if c not in cols: cols.append(c)
+for k in agg:
+    print(k)
+    for c in cols:
+        if c in agg[k]: print("    %-34s %16.0f" % (c, agg[k][c]))

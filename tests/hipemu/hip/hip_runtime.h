@@ -50,6 +50,7 @@ int lane_id();
 // holding every lane's deposit (dead lanes: zeros)
 void wave_gather(const void* mine, void* all, size_t size);
 void* dyn_smem();
+void wave_sync();            // all live lanes of the calling wave rendezvous (the emulated lanes are not lock-step)
 void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 }  // namespace hipemu
 
@@ -170,6 +171,7 @@ static inline int hipemu_readfirstlane(int v) {
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 
 // ---- device math spellings used by the kernels ----
 static inline float __fdividef(float a, float b) { return a / b; }

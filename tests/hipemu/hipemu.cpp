@@ -97,6 +97,8 @@ static void wave_barrier(Wave& wv) {
 
 int lane_id() { return cur_t & 63; }
 
+void wave_sync() { wave_barrier(waves[cur_t / 64]); }
+
 void wave_gather(const void* mine, void* all, size_t size) {
     if (size > 128) { fprintf(stderr, "hipemu: wave_gather payload too large\n"); abort(); }
     Wave& wv = waves[cur_t / 64];
