@@ -96,8 +96,7 @@ __device__ __forceinline__ Taps make_taps(const Homography& hm, float qx, float 
 // slot the valid tap landed in, so border handling (per-tap zero padding) is bit-identical to make_taps.
 // Needs W >= 2.
 struct PairTaps {
-    int top, bot;                // y*W + x of the left element of the top / bottom pair
-    int xb, yt, yb;              // the same as coordinates (for the per-wave LDS staging box); xb < 0 <=> no valid tap
+    int top, bot;
     float w00, w01, w10, w11;    // weights of top.x, top.y, bot.x, bot.y
 };
 
@@ -121,7 +120,7 @@ __device__ __forceinline__ PairTaps make_pair_taps(const Homography& hm, float q
     PairTaps tp;
     const bool sane = (ix > -2.0f) && (ix < (float)(W + 1)) && (iy > -2.0f) && (iy < (float)(H + 1));
     if (!sane) {
-        tp.top = 0; tp.bot = 0; tp.xb = -1; tp.yt = 0; tp.yb = 0; tp.w00 = 0.0f; tp.w01 = 0.0f; tp.w10 = 0.0f; tp.w11 = 0.0f;
+        tp.top = 0; tp.bot = 0; tp.w00 = 0.0f; tp.w01 = 0.0f; tp.w10 = 0.0f; tp.w11 = 0.0f;
         return tp;
     }
     const float fx0 = floorf(ix), fy0 = floorf(iy);
@@ -135,11 +134,9 @@ __device__ __forceinline__ PairTaps make_pair_taps(const Homography& hm, float q
     const float wa = (vx0 && x0 <= W - 2 ? wx0 : 0.0f) + (vx1 && x0 < 0 ? wx1 : 0.0f);
     const float wb = (vx0 && x0 > W - 2 ? wx0 : 0.0f) + (vx1 && x0 >= 0 ? wx1 : 0.0f);
     const float wyt = vy0 ? wy0 : 0.0f, wyb = vy1 ? wy1 : 0.0f;
-    // an invalid row (weight 0) aliases the valid one so that it does not stretch the LDS staging box
-    const int yt = vy0 ? y0 : (vy1 ? y0 + 1 : 0), yb = vy1 ? y0 + 1 : yt;
+    const int yt = vy0 ? y0 : 0, yb = vy1 ? y0 + 1 : 0;
     tp.top = yt * W + xb;
     tp.bot = yb * W + xb;
-    tp.xb = xb; tp.yt = yt; tp.yb = yb;
     tp.w00 = wa * wyt; tp.w01 = wb * wyt; tp.w10 = wa * wyb; tp.w11 = wb * wyb;
     return tp;
 }

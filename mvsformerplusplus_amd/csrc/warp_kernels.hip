@@ -159,131 +159,6 @@ __device__ __forceinline__ void correlate_chunk(const T* __restrict__ src, const
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Per-wave LDS staging of the source window.
-// rocprofv3 counters on MI355X show the direct gathers above pinned at TD_TD_BUSY ~ 90 % (the L1 data-return path)
-// at ~30 tap-bytes/clk/CU whatever the layout (planar 4/8-byte or channel-last aligned 16-byte loads): every tap
-// value crosses the L1 return path once per (pixel, plane, view, pass).  A wave covers 64 consecutive pixels and
-// only DCH adjacent depth planes, so all its taps of one source view fall in a box of a few rows x (64 + a few)
-// columns.  The wave copies that box of 8 channels into its own LDS region with coalesced row loads (each source
-// element crosses L1 once per wave) and takes the 4-tap gathers from LDS (ds_read2_b32, 128 B/clk/CU, separate
-// pipe).  No workgroup barrier: the region is private to the wave.  Boxes that do not fit (strong rotation / zoom)
-// fall back to the direct gather, wave-uniformly.
-// ------------------------------------------------------------------------------------------------
-constexpr int kStageFloats = 2304;          // per wave: 8 channels x (rows x columns <= 288), 9 KiB
-
-struct StageBox {
-    int xmin, ymin, bw, bh;
-    bool fits;
-};
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o > v ? o : v; }
-    return v;
-}
-
-__device__ __forceinline__ StageBox stage_box(const PairTaps* tp) {
-    int x0 = 0x3fffffff, x1 = -1, y0 = 0x3fffffff, y1 = -1;
-#pragma unroll
-    for (int dd = 0; dd < DCH; ++dd) {
-        if (tp[dd].xb < 0) continue;                        // no valid tap: does not constrain the box
-        x0 = tp[dd].xb < x0 ? tp[dd].xb : x0;
-        x1 = tp[dd].xb > x1 ? tp[dd].xb : x1;
-        const int ya = tp[dd].yt < tp[dd].yb ? tp[dd].yt : tp[dd].yb, yc = tp[dd].yt < tp[dd].yb ? tp[dd].yb : tp[dd].yt;
-        y0 = ya < y0 ? ya : y0;
-        y1 = yc > y1 ? yc : y1;
-    }
-    StageBox bx;
-    bx.xmin = wave_min_i(x0);
-    const int xmax = wave_max_i(x1);
-    bx.ymin = wave_min_i(y0);
-    const int ymax = wave_max_i(y1);
-    if (xmax < 0) { bx.xmin = 0; bx.ymin = 0; bx.bw = 2; bx.bh = 1; bx.fits = true; return bx; }   // nothing valid in the wave
-    bx.bw = xmax - bx.xmin + 2;                             // pairs read xb and xb + 1
-    bx.bh = ymax - bx.ymin + 1;
-    bx.fits = bx.bw * bx.bh * 8 <= kStageFloats;
-    return bx;
-}
-
-// out[dd*8 + g] = v[dd] for a WAVE-UNIFORM run-time g: a scalar branch selects one of eight statically indexed stores,
-// so the accumulators stay in registers although the channel loop is a real (rolled) loop
-__device__ __forceinline__ void put_group(float* out, int g, const float* v) {
-#define MVS_PUT(G) case G: _Pragma("unroll") for (int dd = 0; dd < DCH; ++dd) out[dd * 8 + G] = v[dd]; break;
-    switch (g) { MVS_PUT(0) MVS_PUT(1) MVS_PUT(2) MVS_PUT(3) MVS_PUT(4) MVS_PUT(5) MVS_PUT(6) default: MVS_PUT(7) }
-#undef MVS_PUT
-}
-
-// All C channels (8 groups of cpg) of one source view for the DCH planes of this work-item, 8 channels at a time through
-// the wave's LDS copy of the source box.  Channel loop rolled: per iteration 1 reference load + 4*DCH LDS reads.
-template <typename T, bool SUM_GROUPS>
-__device__ __forceinline__ void correlate_chunk_lds(const T* __restrict__ src, const T* __restrict__ ref, const PairTaps* tp, float* stg,
-                                                    unsigned HW, unsigned W, unsigned pc, int lane, int C, float* out) {
-    const int cpg = C >> 3;
-    const StageBox bx = stage_box(tp);
-    if (!bx.fits) {                                             // wave-uniform fallback: direct gather
-        correlate_chunk<T, 8, SUM_GROUPS>(src, ref, tp, HW, pc, cpg, out);
-        return;
-    }
-    const float inv_cpg = 1.0f / (float)cpg;
-    int ot[DCH], ob[DCH];
-#pragma unroll
-    for (int dd = 0; dd < DCH; ++dd) {
-        const bool ok = tp[dd].xb >= 0;
-        ot[dd] = ok ? (tp[dd].yt - bx.ymin) * bx.bw + (tp[dd].xb - bx.xmin) : 0;
-        ob[dd] = ok ? (tp[dd].yb - bx.ymin) * bx.bw + (tp[dd].xb - bx.xmin) : 0;
-    }
-    const int plane = bx.bh * bx.bw, nrow = 8 * bx.bh;
-    float cur[DCH];
-#pragma unroll
-    for (int dd = 0; dd < DCH; ++dd) cur[dd] = 0.0f;
-    int in_group = 0, g = 0;
-#pragma unroll 1
-    for (int c0 = 0; c0 < C; c0 += 8) {
-        // ---- stage 8 channels: 8 * bh rows of bw floats, coalesced along x ----
-#pragma unroll 1
-        for (int row = 0; row < nrow; ++row) {
-            const int cc = row / bx.bh, yy = row - cc * bx.bh;
-            const T* sp = src + (size_t)(c0 + cc) * HW + (unsigned)(bx.ymin + yy) * W + (unsigned)bx.xmin;
-            for (int xx = lane; xx < bx.bw; xx += 64) stg[row * bx.bw + xx] = to_f32(sp[xx]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- gather from LDS ----
-#pragma unroll 1
-        for (int j = 0; j < 8; ++j) {
-            const float r = to_f32(ref[(size_t)(c0 + j) * HW + pc]);
-            const float* sj = stg + j * plane;
-#pragma unroll
-            for (int dd = 0; dd < DCH; ++dd) {
-                float wv = tp[dd].w00 * sj[ot[dd]];
-                wv += tp[dd].w01 * sj[ot[dd] + 1];
-                wv += tp[dd].w10 * sj[ob[dd]];
-                wv += tp[dd].w11 * sj[ob[dd] + 1];
-                cur[dd] += r * wv;
-            }
-            if (++in_group == cpg) {                             // wave-uniform: a channel group is complete
-                float m[DCH];
-#pragma unroll
-                for (int dd = 0; dd < DCH; ++dd) { m[dd] = cur[dd] * inv_cpg; cur[dd] = 0.0f; }
-                if (SUM_GROUPS) {
-#pragma unroll
-                    for (int dd = 0; dd < DCH; ++dd) out[dd] += m[dd];
-                } else {
-                    put_group(out, g, m);
-                }
-                in_group = 0;
-                ++g;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                        // the region is reused by the next 8 channels
-    }
-}
-
 // generic (run-time C, G) single-voxel correlation used by the fallback kernels
 template <typename T>
 __device__ __forceinline__ void correlate_generic(const T* __restrict__ src, const T* __restrict__ ref, const Taps& tp, int HW, int pc, int C,
@@ -363,11 +238,7 @@ __global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __re
             float s[DCH];
 #pragma unroll
             for (int dd = 0; dd < DCH; ++dd) s[dd] = 0.0f;
-            if (CT >= 10)
-                correlate_chunk_lds<T, true>(src, ref, tp, sim + D * cm.ppb + wave * kStageFloats, (unsigned)HW, (unsigned)W, (unsigned)pc,
-                                             lane, C_, s);
-            else
-                correlate_chunk<T, (GT > 0 ? GT : 8), true>(src, ref, tp, (unsigned)HW, (unsigned)pc, cpg, s);
+            correlate_chunk<T, (GT > 0 ? GT : 8), true>(src, ref, tp, (unsigned)HW, (unsigned)pc, cpg, s);
 #pragma unroll
             for (int dd = 0; dd < DCH; ++dd)
                 if (d0 + dd < D) sim[(d0 + dd) * cm.ppb + pl] = s[dd];
@@ -412,7 +283,6 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __
                                                                   int V, int C_, int G_, int D, int H, int W, int view_begin,
                                                                   int view_end, int nblk) {
     typedef typename FeatT<DT>::type T;
-    HIP_DYNAMIC_SHARED(float, stage_lds)
     const int HW = H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = (int)blockIdx.z;
@@ -453,11 +323,7 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __
 #pragma unroll
                 for (int dd = 0; dd < DCH; ++dd) tp[dd] = make_pair_taps(hm, qx, qy, qz, depth[dd], H, W, half_w, half_h);
                 float ip[DCH * GG];
-                if (CT >= 10)
-                    correlate_chunk_lds<T, false>(feat + (size_t)(b * V + v) * CC * HW, ref, tp, stage_lds + wave * kStageFloats,
-                                                  (unsigned)HW, (unsigned)W, (unsigned)pc, lane, CC, ip);
-                else
-                    correlate_chunk<T, GG, false>(feat + (size_t)(b * V + v) * CC * HW, ref, tp, (unsigned)HW, (unsigned)pc, cpg, ip);
+                correlate_chunk<T, GG, false>(feat + (size_t)(b * V + v) * CC * HW, ref, tp, (unsigned)HW, (unsigned)pc, cpg, ip);
                 const float w = vis[(size_t)(b * (V - 1) + (v - 1)) * HW + pc];
 #pragma unroll
                 for (int i = 0; i < DCH * GG; ++i) acc[i] += ip[i] * w;                                   // cost_volume.py:97
@@ -564,7 +430,7 @@ static int launch_entropy(const void* feat, const float* hom, const float* hyp, 
     const int HW = H * W;
     const int ppb = CT > 0 ? chunk_map(D).ppb : 64;
     const int nblk = (int)ceil_div(HW, ppb);
-    const size_t lds = ((size_t)D * ppb + (CT >= 10 ? 4 * kStageFloats : 0)) * sizeof(float);
+    const size_t lds = (size_t)D * ppb * sizeof(float);
     if (lds > 160 * 1024) { set_error("warp_corr_entropy: D=%d needs %zu B of LDS (> 160 KiB)", D, lds); return MVS_ERR_UNSUPPORTED; }
     if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_corr_entropy_kernel<DT, CT, GT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -577,17 +443,16 @@ template <int DT, int CT, int GT>
 static int launch_aggregate(const void* feat, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
                             int normalise, int B, int V, int C, int G, int D, int H, int W, int vb, int ve, hipStream_t st) {
     const int nblk = (int)ceil_div((long long)H * W, CT > 0 ? chunk_map(D).ppb : 64);
-    const size_t lds = CT >= 10 ? 4 * kStageFloats * sizeof(float) : 0;
-    hipLaunchKernelGGL((warp_corr_aggregate_kernel<DT, CT, GT>), dim3(nblk, 1, B), dim3(256), lds, st, feat, hom, hyp, vis, vol, vis_sum,
+    hipLaunchKernelGGL((warp_corr_aggregate_kernel<DT, CT, GT>), dim3(nblk, 1, B), dim3(256), 0, st, feat, hom, hyp, vis, vol, vis_sum,
                        normalise, V, C, G, D, H, W, vb, ve, nblk);
     return check_launch("warp_corr_aggregate_kernel");
 }
 
-// kernel variants (template CT): 0 = run-time C/G fallback; 1 = direct gather with unaligned pair loads (kept for
-// A/B measurements); 10 = per-wave LDS staging of the source window (G == 8, C % 8 == 0, W >= 2) - the fast path
+// fast path (pair loads, DCH planes per work-item): G == 8 (every shipped config), any C divisible by 8, W >= 2;
+// the template's CT is only the fast/generic switch now (1 = fast), C itself is a run-time value
 #define MVS_DISPATCH_CG(FN, DT, ...)                                              \
     do {                                                                          \
-        if (G == 8 && W >= 2) return FN<DT, 10, 8>(__VA_ARGS__);                  \
+        if (G == 8 && W >= 2) return FN<DT, 1, 8>(__VA_ARGS__);                   \
         return FN<DT, 0, 0>(__VA_ARGS__);                                         \
     } while (0)
 

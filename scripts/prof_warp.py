@@ -1,5 +1,5 @@
 """Driver for counter collection on the warp kernels: runs warp_corr_entropy / warp_corr_aggregate of stage 1 (C=64, D=32)
-and stage 4 (C=8, D=4) of the bench workload, planar and channel-last, 3 times each."""
+and stage 4 (C=8, D=4) of the bench workload, 3 times each."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,10 +15,8 @@ for stage, D in ((1, 32), (4, 4)):
     if stage == 4:      # narrow hypothesis window like the real stage 4 (~0.8 % of depth)
         hyp = (600.0 * (1 + 0.002 * torch.arange(D, device=dev).float()))[None, :, None, None].expand(1, D, H, W).contiguous()
     vis = torch.rand(B, V - 1, H, W, device=dev)
-    cl = ops.features_to_cl(f, code, 8)
     for rep in range(3):
-        for src_cl in (None, cl):
-            ops.warp_corr_entropy(f, code, hom, hyp, 8, src_cl=src_cl)
-            ops.warp_corr_aggregate(f, code, hom, hyp, vis, 8, src_cl=src_cl)
+        ops.warp_corr_entropy(f, code, hom, hyp, 8)
+        ops.warp_corr_aggregate(f, code, hom, hyp, vis, 8)
 torch.cuda.synchronize()
 print("done")
