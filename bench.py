@@ -140,6 +140,8 @@ def main():
         "hbm_algorithmic_frac_of_8TBs": (ALGO_BYTES_PER_VIEW * value / world / 8.0e12) if is_cfg2 else None,
     }
 
+    result["config"]["conv_precision"] = ("%s MFMA contraction, fp32 activations and accumulation" % head.fusions[0].conv_precision)
+
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
     if not a.no_profile:
         reps = 3
@@ -152,13 +154,23 @@ def main():
         mfma = dom_name.startswith("conv3d") or dom_name.startswith("deconv3d")
         per_launch = dom["flops" if mfma else "bytes"] / dom["calls"]
         achieved = (dom["tflops"] if mfma else dom["gbs"])
-        peak = profiling.PEAK_F32_MFMA_TFLOPS if mfma else profiling.PEAK_HBM_GBS
+        prec = head.fusions[0].conv_precision
+        if not mfma:
+            peak, note = profiling.PEAK_HBM_GBS, "gather kernel: algorithmic HBM bytes; rocprofv3 shows it TD (L1 data-return) bound, DESIGN.md"
+        elif prec == "bf16x3":
+            # every algorithmic product is three bf16 MFMA products: peak for algorithmic FLOPs = dense bf16 peak / 3
+            peak, note = 2500.0 / 3.0, "3-term split-bf16 contraction on v_mfma_f32_16x16x32_bf16: dense bf16 peak 2500 TFLOP/s / 3 passes"
+        else:
+            peak, note = profiling.PEAK_F32_MFMA_TFLOPS, "fp32-exact contraction on v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense peak)"
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # PMC-derived HBM bytes per launch, committed per round
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(dom_name, {}).get("hbm_bytes_per_launch")
         result["roofline"] = {"kernel": dom_name, "bound": "mfma" if mfma else "hbm", "achieved": achieved, "peak": peak,
-                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": achieved / peak, "traffic": None,
+                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": achieved / peak, "traffic": traffic,
                               "avg_launch_ms": dom["avg_ms"], "algorithmic_per_launch": per_launch,
                               "share_of_step": dom["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-9),
-                              "launches_per_step": dom["calls"] / reps,
-                              "note": "fp32-exact contraction on v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense peak)" if mfma else ""}
+                              "launches_per_step": dom["calls"] / reps, "note": note}
         result["kernels"] = {k: {"calls_per_step": v["calls"] / reps, "ms_per_step": v["ms"] / reps, "gbs": v["gbs"], "tflops": v["tflops"]}
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         if a.profile_table and rank == 0:

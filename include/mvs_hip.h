@@ -78,6 +78,11 @@ int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, c
                        const void* w3, const float* b3, const float* w4, const float* b4, float* vis,
                        void* workspace, size_t workspace_bytes, int N, int H, int W, int precision, void* stream);
 
+/* the first (1->16 3x3 + BN + ReLU -> [N,H,W,16] channel-last) and last (8->1 1x1 + sigmoid) layer of the chain above
+ * on their own; the two middle layers are mvs_conv3d_bn_relu_fwd with kd = 1 */
+int mvs_vis_conv1_fwd(const float* entropy, const float* w1, const float* b1, float* out_cl16, int N, int H, int W, void* stream);
+int mvs_vis_out_fwd(const float* x_cl8, const float* w4, const float* b4, float* vis, int N, int H, int W, void* stream);
+
 /* ---- a4 + a6: recompute warp + correlation, weight by visibility, aggregate over views ----------
  * cost_volume.py:79-101.  vis [B,V-1,H,W].  volume_cl [B,D,H,W,G] channel-last.
  *   normalise = 1 : volume = sum_v ip_v*vis_v / (sum_v vis_v + 1e-6)              (single GPU)

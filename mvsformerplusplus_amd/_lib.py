@@ -33,6 +33,8 @@ SIGNATURES = {
     "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mvs_vis_workspace_bytes": (_sz, [_i, _i, _i]),
     "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _i, _vp]),
+    "mvs_vis_conv1_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mvs_vis_out_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i] + [_i] * 9 + [_vp]),
     "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),

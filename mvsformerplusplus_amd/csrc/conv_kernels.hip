@@ -374,6 +374,20 @@ extern "C" int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const void* w_pac
     return deconv3d_dispatch(x_cl, w_packed, bias, skip_cl, y_cl, B, Cin, Cout, D, H, W, sd, precision, (hipStream_t)stream);
 }
 
+// the two ends of the visibility CNN as separate entry points (mvs_vis_weight_fwd chains them with the MFMA convs)
+extern "C" int mvs_vis_conv1_fwd(const float* entropy, const float* w1, const float* b1, float* out_cl16, int N, int H, int W, void* stream) {
+    if (!entropy || !w1 || !b1 || !out_cl16 || N < 1 || H < 1 || W < 1) { set_error("mvs_vis_conv1_fwd: bad arguments"); return MVS_ERR_ARG; }
+    hipLaunchKernelGGL(vis_conv1_kernel, dim3(ceil_div((long long)H * W, 256), N), dim3(256), 0, (hipStream_t)stream, entropy, w1, b1, out_cl16, H, W);
+    return check_launch("vis_conv1_kernel");
+}
+
+extern "C" int mvs_vis_out_fwd(const float* x_cl8, const float* w4, const float* b4, float* vis, int N, int H, int W, void* stream) {
+    if (!x_cl8 || !w4 || !b4 || !vis || N < 1 || H < 1 || W < 1) { set_error("mvs_vis_out_fwd: bad arguments"); return MVS_ERR_ARG; }
+    const size_t total = (size_t)N * H * W;
+    hipLaunchKernelGGL(vis_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_cl8, w4, b4, vis, total);
+    return check_launch("vis_out_kernel");
+}
+
 extern "C" size_t mvs_vis_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * 32 * sizeof(float); }
 
 extern "C" int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,

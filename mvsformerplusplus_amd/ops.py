@@ -82,6 +82,22 @@ def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor], precision:
     return vis
 
 
+def vis_conv1(entropy: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
+    e = _f32c(entropy)
+    H, W = e.shape[-2:]
+    N = e.numel() // (H * W)
+    out = torch.empty(N, H, W, 16, dtype=torch.float32, device=e.device)
+    check(lib().mvs_vis_conv1_fwd(ptr(e), ptr(w1), ptr(b1), ptr(out), N, H, W, stream_of(e)), "mvs_vis_conv1_fwd")
+    return out
+
+
+def vis_out(x_cl8: torch.Tensor, w4: torch.Tensor, b4: torch.Tensor, shape) -> torch.Tensor:
+    N, H, W, _ = x_cl8.shape
+    vis = torch.empty(shape, dtype=torch.float32, device=x_cl8.device)
+    check(lib().mvs_vis_out_fwd(ptr(x_cl8), ptr(w4), ptr(b4), ptr(vis), N, H, W, stream_of(x_cl8)), "mvs_vis_out_fwd")
+    return vis
+
+
 def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, vis: torch.Tensor,
                         G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None):
     """-> (volume_cl [B,D,H,W,G], vis_sum [B,H,W] or None).  `out` = preallocated (volume, vis_sum) to fill."""

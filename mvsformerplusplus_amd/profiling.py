@@ -109,9 +109,17 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         ent = _timed(launches, "warp_corr_entropy<C%d>" % C, s, corr_flops,
                      B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)), lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
         vp = net._vis_params(feats.device)
-        # the vis CNN is four launches inside one C call; it is timed as a unit
-        vis = _timed(launches, "vis_cnn(4 launches)", s, 2.0 * B * (V - 1) * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8),
-                     4.0 * B * (V - 1) * HW * (1 + 16 + 16 + 16 + 16 + 8 + 8 + 1), lambda: ops.vis_weight(ent, vp, _lib.PRECISIONS[net.conv_precision]))
+        # the visibility CNN launch by launch (same four kernels as mvs_vis_weight_fwd)
+        prec = _lib.PRECISIONS[net.conv_precision]
+        N = B * (V - 1)
+        t1 = _timed(launches, "vis_conv1", s, 2.0 * N * HW * 9 * 16, 4.0 * N * HW * 17, lambda: ops.vis_conv1(ent, vp[0], vp[1]))
+        t1 = t1.reshape(1, N, H, W, 16)
+        t2 = _timed(launches, _conv_name(16, 16, 1, (1, 1, 1)), s, 2.0 * N * HW * 9 * 16 * 16, 4.0 * N * HW * 32,
+                    lambda: ops.conv3d_bn_relu(t1, vp[2], vp[3], 16, 1, (1, 1, 1), True, prec))
+        t3 = _timed(launches, _conv_name(16, 8, 1, (1, 1, 1)), s, 2.0 * N * HW * 9 * 16 * 8, 4.0 * N * HW * 24,
+                    lambda: ops.conv3d_bn_relu(t2, vp[4], vp[5], 8, 1, (1, 1, 1), True, prec))
+        vis = _timed(launches, "vis_out", s, 2.0 * N * HW * 8, 4.0 * N * HW * 9,
+                     lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
         vol = _timed(launches, "warp_corr_aggregate<C%d>" % C, s, corr_flops,
                      B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
                      lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
