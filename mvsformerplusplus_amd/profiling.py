@@ -9,8 +9,9 @@ on.  Every launch is labelled with the kernel it runs and with its ALGORITHMIC w
   flops   2 * MACs of the mathematical operator (padding taps on the volume border included, MFMA padding of
           8-channel outputs to 16 rows NOT included)
 
-so that achieved = work / time is comparable with the 8 TB/s HBM and 157.3 TFLOP/s fp32-MFMA peaks of
-MI355X_MICROARCH.md.
+so that achieved = work / time is comparable with the 8 TB/s HBM and MFMA peaks of MI355X_MICROARCH.md.  Labels follow the
+kernel symbols rocprofv3 reports (one label per template instantiation; the two warp kernels are ONE instantiation each
+for all four stages), so `avg_ms` here and the average duration in profiles/*_kernel_stats.csv can be compared directly.
 """
 from __future__ import annotations
 
@@ -106,7 +107,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.schedule_inverse_range(pd, ph, D, head.depth_interals_ratio[s], H, W))
         hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
-        ent = _timed(launches, "warp_corr_entropy<C%d>" % C, s, corr_flops,
+        ent = _timed(launches, "warp_corr_entropy_kernel", s, corr_flops,
                      B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)), lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
         vp = net._vis_params(feats.device)
         # the visibility CNN launch by launch (same four kernels as mvs_vis_weight_fwd)
@@ -120,13 +121,13 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                     lambda: ops.conv3d_bn_relu(t2, vp[4], vp[5], 8, 1, (1, 1, 1), True, prec))
         vis = _timed(launches, "vis_out", s, 2.0 * N * HW * 8, 4.0 * N * HW * 9,
                      lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
-        vol = _timed(launches, "warp_corr_aggregate<C%d>" % C, s, corr_flops,
+        vol = _timed(launches, "warp_corr_aggregate_kernel", s, corr_flops,
                      B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
                      lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
         ks = net.cost_reg.prob_ksize
-        res = _timed(launches, "prob_regress<k%d>" % ks, s, 2.0 * B * D * HW * 8 * (27 if ks == 3 else 1),
+        res = _timed(launches, "prob_regress_kernel<%d,%d>" % (D, ks), s, 2.0 * B * D * HW * 8 * (27 if ks == 3 else 1),
                      4.0 * B * (8 * D * HW + D * HW + 2 * D * HW + 2 * HW),
                      lambda: ops.prob_regress(feat_cl, prob_w, prob_b, ks, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
         out = {"depth": res[0], "photometric_confidence": res[1], "depth_values": hyp}
