@@ -1,0 +1,17 @@
+"""MI355X (gfx950) implementation of MVSFormer++'s depth-inference hot path: homography warp -> group-wise correlation
+cost volume -> 3D-conv regularisation -> depth regression, behind the reference's ``nn.Module`` API.
+
+    from mvsformerplusplus_amd import patch_model, CascadeDepthHead, StageNet
+
+The HIP library (``csrc/libmvs_hip.so``, built by ``python -m mvsformerplusplus_amd.build``) is loaded on first use;
+there is no CPU or eager-PyTorch fallback.  See DESIGN.md and INTEGRATION.md.
+"""
+from .cascade import CascadeDepthHead, patch_model
+from .cost_volume import StageNet
+from .module import (Conv3d, ConvBnReLU, CostRegNet, CostRegNet3D, Deconv3d, conf_regression, depth_regression,
+                     init_inverse_range, init_range, schedule_inverse_range, schedule_range)
+from .warping import homo_warping_3D_with_mask
+
+__all__ = ["CascadeDepthHead", "patch_model", "StageNet", "Conv3d", "Deconv3d", "ConvBnReLU", "CostRegNet", "CostRegNet3D",
+           "depth_regression", "conf_regression", "init_range", "init_inverse_range", "schedule_inverse_range", "schedule_range",
+           "homo_warping_3D_with_mask"]
