@@ -53,6 +53,7 @@ class StageNet(nn.Module):
             self.cost_reg = CostRegNet(self.in_channels, self.in_channels)
         self.view_group = None            # torch.distributed group for view sharding (None = single GPU)
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
+        self.keep_correlation = None      # None = heuristic (ndepth >= 8); True / False force the pass-2 variant
         # contraction of every MFMA convolution of the stage: "bf16x3" (3-term split bf16, ~2^-16 relative) or "fp32"
         self.conv_precision = args.get("conv_precision", DEFAULT_PRECISION)
         self._vis_cache = _PackedCache()
@@ -94,10 +95,19 @@ class StageNet(nn.Module):
         vis_params = self._vis_params(feats.device)
 
         prec = precision_code(self.conv_precision)
+        # pass 2 either re-gathers (fine stages: few planes, many pixels) or streams the correlation volumes pass 1 kept
+        # (coarse stages: 2*(V-1)*32 B per voxel is cheaper than 4*C taps per voxel and view again); measured crossover D >= 8
+        keep_ip = self.keep_correlation if self.keep_correlation is not None else (hyp.shape[1] >= 8 and W >= 2)
         if self.view_group is None:
-            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
-            vis = ops.vis_weight(entropy, vis_params, prec)
-            volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
+            if keep_ip:
+                entropy, ip = ops.warp_corr_entropy(feats, code, hom, hyp, G, keep_ip=True)
+                vis = ops.vis_weight(entropy, vis_params, prec)
+                volume, _ = ops.weighted_aggregate(ip, vis, normalise=True)
+                del ip
+            else:
+                entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
+                vis = ops.vis_weight(entropy, vis_params, prec)
+                volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
         else:
             volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
 

@@ -107,8 +107,12 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.schedule_inverse_range(pd, ph, D, head.depth_interals_ratio[s], H, W))
         hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
-        ent = _timed(launches, "warp_corr_entropy_kernel", s, corr_flops,
-                     B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)), lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
+        keep_ip = net.keep_correlation if net.keep_correlation is not None else D >= 8
+        ip_bytes = B * (V - 1) * D * HW * 32 if keep_ip else 0
+        res_e = _timed(launches, "warp_corr_entropy_kernel", s, corr_flops,
+                       B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)) + ip_bytes,
+                       lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8, keep_ip=keep_ip))
+        ent, ip = res_e if keep_ip else (res_e, None)
         vp = net._vis_params(feats.device)
         # the visibility CNN launch by launch (same four kernels as mvs_vis_weight_fwd)
         prec = _lib.PRECISIONS[net.conv_precision]
@@ -121,9 +125,14 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                     lambda: ops.conv3d_bn_relu(t2, vp[4], vp[5], 8, 1, (1, 1, 1), True, prec))
         vis = _timed(launches, "vis_out", s, 2.0 * N * HW * 8, 4.0 * N * HW * 9,
                      lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
-        vol = _timed(launches, "warp_corr_aggregate_kernel", s, corr_flops,
-                     B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
-                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
+        if keep_ip:
+            vol = _timed(launches, "weighted_aggregate_kernel", s, 2.0 * B * (V - 1) * D * HW * 8,
+                         ip_bytes + B * ((V - 1) * HW * 4 + 8 * D * HW * 4), lambda: ops.weighted_aggregate(ip, vis)[0])
+            del ip
+        else:
+            vol = _timed(launches, "warp_corr_aggregate_kernel", s, corr_flops,
+                         B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
+                         lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
         ks = net.cost_reg.prob_ksize
