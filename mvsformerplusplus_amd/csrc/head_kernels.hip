@@ -37,6 +37,41 @@ __global__ __launch_bounds__(256) void prob_regress_kernel(const float* __restri
 #define MVS_LOGIT(d) (DC > 0 ? l[(DC > 0 ? (d) : 0)] : prep[(size_t)(d) * HW])
 
     // ---- logits ----
+    if (KS == 3 && DC > 0) {
+        // 3x3x3 head with the logits of the whole depth column in registers: every (kh, kw) neighbour column is read
+        // ONCE (2 float4 per plane) and plane zz feeds the three outputs zz+1, zz, zz-1 (kd = 0, 1, 2): 9*D loads of
+        // 32 bytes per pixel instead of 27*D.
+#pragma unroll
+        for (int d = 0; d < (DC > 0 ? DC : 1); ++d) l[d] = 0.0f;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = y + kh - 1;
+            if (yy < 0 || yy >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = x + kw - 1;
+                if (xx < 0 || xx >= W) continue;
+                const float* w0 = prob_w + ((0 * 3 + kh) * 3 + kw) * 8;      // kd = 0 -> output zz + 1
+                const float* w1 = prob_w + ((1 * 3 + kh) * 3 + kw) * 8;      // kd = 1 -> output zz
+                const float* w2 = prob_w + ((2 * 3 + kh) * 3 + kw) * 8;      // kd = 2 -> output zz - 1
+                const float* col = in + (((size_t)b * D) * HW + (size_t)yy * W + xx) * 8;
+#pragma unroll
+                for (int zz = 0; zz < (DC > 0 ? DC : 1); ++zz) {
+                    const float4* f = reinterpret_cast<const float4*>(col + (size_t)zz * HW * 8);
+                    const float4 a = f[0], c = f[1];
+                    const float xv[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+                    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) { s0 += xv[ch] * w0[ch]; s1 += xv[ch] * w1[ch]; s2 += xv[ch] * w2[ch]; }
+                    if (zz + 1 < DC) l[(zz + 1 < DC) ? zz + 1 : 0] += s0;
+                    l[zz] += s1;
+                    if (zz >= 1) l[(zz >= 1) ? zz - 1 : 0] += s2;
+                }
+            }
+        }
+        if (prep) {
+#pragma unroll
+            for (int d = 0; d < (DC > 0 ? DC : 1); ++d) prep[(size_t)d * HW] = l[d];
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         float v;
@@ -71,6 +106,7 @@ __global__ __launch_bounds__(256) void prob_regress_kernel(const float* __restri
         }
         if (DC > 0) l[DC > 0 ? d : 0] = v;
         if (prep && KS != 0) prep[(size_t)d * HW] = v;
+    }
     }
 
     // ---- softmax over depth (cost_volume.py:106) ----

@@ -114,17 +114,23 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                        lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8, keep_ip=keep_ip))
         ent, ip = res_e if keep_ip else (res_e, None)
         vp = net._vis_params(feats.device)
-        # the visibility CNN launch by launch (same four kernels as mvs_vis_weight_fwd)
         prec = _lib.PRECISIONS[net.conv_precision]
         N = B * (V - 1)
-        t1 = _timed(launches, "vis_conv1", s, 2.0 * N * HW * 9 * 16, 4.0 * N * HW * 17, lambda: ops.vis_conv1(ent, vp[0], vp[1]))
-        t1 = t1.reshape(1, N, H, W, 16)
-        t2 = _timed(launches, _conv_name(16, 16, 1, (1, 1, 1)), s, 2.0 * N * HW * 9 * 16 * 16, 4.0 * N * HW * 32,
-                    lambda: ops.conv3d_bn_relu(t1, vp[2], vp[3], 16, 1, (1, 1, 1), True, prec))
-        t3 = _timed(launches, _conv_name(16, 8, 1, (1, 1, 1)), s, 2.0 * N * HW * 9 * 16 * 8, 4.0 * N * HW * 24,
-                    lambda: ops.conv3d_bn_relu(t2, vp[4], vp[5], 8, 1, (1, 1, 1), True, prec))
-        vis = _timed(launches, "vis_out", s, 2.0 * N * HW * 8, 4.0 * N * HW * 9,
-                     lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
+        vis_flops = 2.0 * N * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8)
+        if net.conv_precision == "bf16x3":
+            # two fused launches inside one C call (vis_front_bf16x3_kernel, vis_back_bf16x3_kernel): timed as a bundle
+            vis = _timed(launches, "[bundle] vis_front+vis_back_bf16x3", s, vis_flops, 4.0 * N * HW * (1 + 16 + 16 + 1),
+                         lambda: ops.vis_weight(ent, vp, prec))
+        else:
+            # fp32 mode: the four launches of mvs_vis_weight_fwd one by one
+            t1 = _timed(launches, "vis_conv1", s, 2.0 * N * HW * 9 * 16, 4.0 * N * HW * 17, lambda: ops.vis_conv1(ent, vp[0], vp[1]))
+            t1 = t1.reshape(1, N, H, W, 16)
+            t2 = _timed(launches, _conv_name(16, 16, 1, (1, 1, 1)), s, 2.0 * N * HW * 9 * 16 * 16, 4.0 * N * HW * 32,
+                        lambda: ops.conv3d_bn_relu(t1, vp[2], vp[3], 16, 1, (1, 1, 1), True, prec))
+            t3 = _timed(launches, _conv_name(16, 8, 1, (1, 1, 1)), s, 2.0 * N * HW * 9 * 16 * 8, 4.0 * N * HW * 24,
+                        lambda: ops.conv3d_bn_relu(t2, vp[4], vp[5], 8, 1, (1, 1, 1), True, prec))
+            vis = _timed(launches, "vis_out", s, 2.0 * N * HW * 8, 4.0 * N * HW * 9,
+                         lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
         if keep_ip:
             vol = _timed(launches, "weighted_aggregate_kernel", s, 2.0 * B * (V - 1) * D * HW * 8,
                          ip_bytes + B * ((V - 1) * HW * 4 + 8 * D * HW * 4), lambda: ops.weighted_aggregate(ip, vis)[0])
