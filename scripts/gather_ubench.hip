@@ -59,6 +59,25 @@ __global__ __launch_bounds__(256) void k_planar_quad2px(const float* __restrict_
     }
     out[p] = acc;
 }
+// planar; only the RIGHT tap of each row is loaded (2 dword loads per channel and plane); the left tap comes from the
+// neighbouring lane through a DPP wave shift (valid wherever consecutive pixels project to consecutive columns)
+__global__ __launch_bounds__(256) void k_planar_dpp(const float* __restrict__ f, float* __restrict__ out, int shift) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW - 4 * W) return;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const unsigned o = p + d + shift;
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            const float* s = f + (size_t)c * HW;
+            const float tr = s[o + 1], br = s[o + W + 1];
+            const float tl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tr), 0x138, 0xf, 0xf, false));
+            const float bl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, br), 0x138, 0xf, 0xf, false));
+            acc += tl + tr + bl + br;
+        }
+    }
+    out[p] = acc;
+}
 // channel-last [HW][C]; lane = pixel; both x-taps of a row are 2*C contiguous floats -> 4 x 16-byte loads per row
 __global__ __launch_bounds__(256) void k_cl_lane_pixel(const float* __restrict__ f, float* __restrict__ out, int shift) {
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -135,6 +154,7 @@ int main() {
         {"planar, 4 dword taps          ", run(k_planar_dword, HW / 256, f, out, reps)},
         {"planar, 2 unaligned 8B pairs  ", run(k_planar_pair, HW / 256, f, out, reps)},
         {"planar, 16B per row, 2 px/lane", run(k_planar_quad2px, HW / 512, f, out, reps)},
+        {"planar, right taps + DPP shift", run(k_planar_dpp, HW / 256, f, out, reps)},
         {"chan-last, lane=pixel, 16B x8 ", run(k_cl_lane_pixel, HW / 256, f, out, reps)},
         {"chan-last, 4 lanes/pixel, 16B ", run(k_cl_lane_piece, HW / 64, f, out, reps)},
         {"LDS-staged rows, ds_read taps ", run(k_lds_staged, HW / 256, f, out, reps)},

