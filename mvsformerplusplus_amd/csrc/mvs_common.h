@@ -100,6 +100,11 @@ struct PairTaps {
     float w00, w01, w10, w11;    // weights of top.x, top.y, bot.x, bot.y
 };
 
+// register class for "opaque value" asm constraints (the host emulator of the tests overrides it)
+#ifndef MVS_OPAQUE_REG
+#define MVS_OPAQUE_REG "v"
+#endif
+
 template <typename T> struct PairOf;
 template <> struct PairOf<float> { struct __attribute__((packed, aligned(4))) type { float x, y; }; };
 template <> struct PairOf<uint16_t> { struct __attribute__((packed, aligned(2))) type { uint16_t x, y; }; };

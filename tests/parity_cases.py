@@ -312,9 +312,9 @@ def _seeded_head(device, seed=11, peaky=False):
     return head.eval().to(device), args
 
 
-def case_cascade_vs_oracle(device, H, W, V, peaky=False):
+def case_cascade_vs_oracle(device, H, W, V, peaky=False, **inputs):
     head, args = _seeded_head(device, peaky=peaky)
-    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=2, rot_deg=1.0)
+    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=2, rot_deg=1.0, **inputs)
     sds = [{k: v.cpu() for k, v in st.state_dict().items()} for st in head.fusions]
     with torch.no_grad():
         ref = O.cascade_forward(feats, projs, dv, sds, ndepths=args["ndepths"], depth_interals_ratio=args["depth_interals_ratio"],
@@ -332,9 +332,9 @@ def case_cascade_vs_oracle(device, H, W, V, peaky=False):
     return r
 
 
-def case_cascade_fullsize_properties(device, H=1152, W=1536, V=5):
+def case_cascade_fullsize_properties(device, H=1152, W=1536, V=5, **inputs):
     head, args = _seeded_head(device)
-    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=0, device=device)
+    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=0, device=device, **inputs)
     with torch.no_grad():
         a = head(feats, projs, dv)
         b = head(feats, projs, dv)
@@ -350,9 +350,57 @@ def case_cascade_fullsize_properties(device, H=1152, W=1536, V=5):
             hyp = a["stage%d" % s]["depth_values"]
             assert (hyp[:, :-1] >= hyp[:, 1:]).all()                         # inverse-depth hypotheses run far -> near
         # permuting the source views permutes nothing but the summation order of the aggregation
-        perm = [0, 3, 1, 4, 2]
+        perm = [0] + list(range(V - 1, 0, -1))
         fp = {k: v[:, perm].contiguous() for k, v in feats.items()}
         pp = {k: v[:, perm].contiguous() for k, v in projs.items()}
         c2 = head(fp, pp, dv)
         r = rel_l1(c2["refined_depth"].cpu(), d.cpu())
         assert r <= 1e-4, "view-order invariance violated: %g" % r
+
+
+# ---------------------------------------------------------------- BASELINE.json configs
+# configs[0] is the reference's own CPU-runnable case; [2]..[4] differ from the bench workload in view count, image size,
+# hypothesis range and feature dtype.  Each is checked against the oracle at a size it finishes in seconds and - for the
+# multi-stage ones - through size-independent properties at the full size.
+BASELINE_CFGS = {
+    "cfg3": dict(full=(1152, 1536), small=(256, 320), V=10, inputs={}),
+    # Tanks-and-Temples-like range 0.5 .. 3.0 scene units.  (A 0.5 .. 10 range makes the stage-2 inverse-depth window
+    # inv(depth) -/+ 2.67 * itv cross zero for far pixels, module.py:712-716: hypotheses jump through +-infinity there and
+    # reference and replacement agree only in being meaningless, so that range cannot carry a parity check.)
+    "cfg4": dict(full=(1088, 1920), small=(256, 448), V=11,
+                 inputs=dict(numdepth=256, depth_min=0.5, depth_interval=2.5 / 255.0, baseline=0.03)),
+    "cfg5": dict(full=(1536, 2048), small=(256, 384), V=11,
+                 inputs=dict(numdepth=384, depth_min=0.5, depth_interval=2.5 / 383.0, baseline=0.03, feat_dtype=torch.float16)),
+}
+
+
+def case_baseline_cfg1(device):
+    """configs[0] / Track S: one StageNet, stage_idx 3 (C = G = 8), 640x512, V = 3, D = 48 fronto-parallel hypotheses
+    linspace(425, 935) -> CostRegNet (D > 8) with the 3x3x3 head."""
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    H, W, V, D = 512, 640, 3, 48
+    st = StageNet(dict(ARGS), D, 3)
+    st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 5), strict=True)
+    st = st.eval().to(device)
+    cams = synth.make_cameras(V, H, W, baseline=20.0, seed=0)
+    proj = synth.stage_proj_matrices(cams, 1)["stage1"]
+    feats = synth.make_features(proj, 8, H, W, dmin=500.0, dmax=860.0, seed=0)
+    hyp = torch.linspace(425.0, 935.0, D).view(1, D, 1, 1).repeat(1, 1, H, W)
+    sd = {k: v.cpu() for k, v in st.state_dict().items()}
+    with torch.no_grad():
+        ref = O.stage_forward(feats, proj, hyp, 1.0, sd, G=8)
+        out = st(dev(feats, device), dev(proj, device), dev(hyp, device), tmp=1.0)
+    r = rel_l1(cpu(out["depth"]), ref["depth"])
+    assert r <= 1e-3, "cfg1 depth rel-L1 %g" % r
+    assert (cpu(out["prob_volume"]) - ref["prob_volume"]).abs().max() <= 2e-3
+    return r
+
+
+def case_baseline_cfg_small(device, name):
+    c = BASELINE_CFGS[name]
+    return case_cascade_vs_oracle(device, c["small"][0], c["small"][1], c["V"], **c["inputs"])
+
+
+def case_baseline_cfg_full(device, name):
+    c = BASELINE_CFGS[name]
+    case_cascade_fullsize_properties(device, c["full"][0], c["full"][1], c["V"], **c["inputs"])

@@ -88,3 +88,20 @@ def test_cascade_fullsize_properties():
     """BASELINE configs[1] size (1152x1536, V=5): run-to-run determinism, finite outputs inside the hypothesis range,
     view-order invariance of the aggregation (size-independent properties; the oracle is too slow to repeat here)."""
     P.case_cascade_fullsize_properties(DEV)
+
+
+def test_baseline_cfg1_stage4_d48():
+    """BASELINE configs[0]: 640x512, V=3, D=48, stage-4-only StageNet vs the oracle."""
+    P.case_baseline_cfg1(DEV)
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
+def test_baseline_cfgs_small_vs_oracle(name):
+    """BASELINE configs[2..4] (V=10 / 1920x1088 V=11 D=256 / 2048x1536 V=11 D=384 fp16 features) at a reduced image size."""
+    P.case_baseline_cfg_small(DEV, name)
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
+def test_baseline_cfgs_fullsize_properties(name):
+    """The same configs at their full image size through size-independent properties."""
+    P.case_baseline_cfg_full(DEV, name)
