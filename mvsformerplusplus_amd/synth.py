@@ -213,7 +213,7 @@ def seeded_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str
         if k.endswith("num_batches_tracked"):
             out[k] = torch.zeros(shp, dtype=torch.int64)
             continue
-        if k.endswith("running_var") or (len(shp) == 1 and k.endswith("weight")):
+        if k.endswith("running_var") or (len(shp) == 1 and k.endswith("weight")) or k.endswith(("gamma1", "gamma2")):
             a = rs.uniform(0.5, 1.5, size=shp)
         elif k.endswith("running_mean") or k.endswith("bias"):
             a = rs.standard_normal(size=shp) * 0.2

@@ -236,11 +236,91 @@ def schedule_range(cur_depth, ndepth, depth_interval_pixel, H, W):
 
 
 # --------------------------------------------------------------------------------------
+# stage-1 transformer regulariser
+#   PureTransformerCostReg module.py:602-646, FlashAttnBlock :535-583, FFN :507-532, LayerNorm3D :586-599,
+#   attention models/dino/layers/attention.py:76-101,141-170, Frustoconical PE position_encoding.py:138-189
+# --------------------------------------------------------------------------------------
+def get_position_3d(H: int, W: int, K: torch.Tensor, depth_values: torch.Tensor, depth_min, depth_max,
+                    height_min=None, height_max=None, width_min=None, width_max=None):
+    """position_encoding.py:138-163 (normalize=True).  K [B,3,3]; depth_values [B,D,H,W] -> ([B,3,D,H,W], 4 range scalars)."""
+    B, D = depth_values.shape[:2]
+    y, x = torch.meshgrid([torch.arange(0, H, dtype=torch.float32), torch.arange(0, W, dtype=torch.float32)], indexing="ij")
+    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(H * W)))[None].repeat(B, 1, 1)
+    xyz = torch.matmul(torch.inverse(K), xyz)                                               # :147
+    pos = xyz.unsqueeze(2).repeat(1, 1, D, 1) * depth_values.reshape(B, 1, D, -1)            # :149
+    if height_min is None or height_max is None or width_min is None or width_max is None:
+        width_min, width_max = pos[:, 0].min(), pos[:, 0].max()
+        height_min, height_max = pos[:, 1].min(), pos[:, 1].max()
+    pos[:, 0] = (pos[:, 0] - width_min) / (width_max - width_min + 1e-5)
+    pos[:, 1] = (pos[:, 1] - height_min) / (height_max - height_min + 1e-5)
+    pos[:, 2] = (torch.clamp(pos[:, 2], depth_min, depth_max) - depth_min) / (depth_max - depth_min + 1e-5)
+    return pos.reshape(B, 3, D, H, W), height_min, height_max, width_min, width_max
+
+
+def position_encoding_3d(position3d: torch.Tensor, C: int, rescale: float = 4.0) -> torch.Tensor:
+    """position_encoding.py:166-189: per axis C channels sin/cos interleaved -> [B,3C,D,H,W]."""
+    import math
+    B, _, D, H, W = position3d.shape
+    div = torch.exp(torch.arange(0, C, 2).float() * (-math.log(10000.0) / C))[None, :, None]
+    parts = []
+    for a in range(3):
+        pe = torch.zeros(B, C, D * H * W, dtype=torch.float32)
+        pos = position3d[:, a].reshape(B, 1, D * H * W)
+        pe[:, 0::2] = torch.sin(pos * rescale * div)
+        pe[:, 1::2] = torch.cos(pos * rescale * div)
+        parts.append(pe)
+    return torch.cat(parts, 1).reshape(B, 3 * C, D, H, W)
+
+
+def layer_norm_3d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    u = x.mean(1, keepdim=True)                                                               # module.py:594-598
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return w[:, None, None, None] * x + b[:, None, None, None]
+
+
+def is_transformer(sd: SD, prefix: str = "cost_reg.") -> bool:
+    return (prefix + "down.0.weight") in sd
+
+
+def pure_transformer_cost_reg(x: torch.Tensor, position3d, sd: SD, *, num_heads: int, train_avg_length,
+                              softmax_scale="entropy_invariance", prefix: str = "cost_reg.") -> torch.Tensor:
+    """PureTransformerCostReg.forward (post-norm blocks, softmax attention), module.py:629-646."""
+    import math
+    g = lambda k: sd[prefix + k]
+    if position3d is not None:
+        x = x + F.conv3d(position_encoding_3d(position3d, x.shape[1]), g("pe_proj.weight"))  # :633 (use_pe_proj)
+    rate = tuple(g("down.0.weight").shape[2:])
+    x = F.conv3d(x, g("down.0.weight"), g("down.0.bias"), stride=rate)
+    x = layer_norm_3d(x, g("down.1.weight"), g("down.1.bias"))
+    B, C, d, h, w = x.shape
+    hd = C // num_heads
+    n_layers = 1 + max(int(k[len(prefix):].split(".")[1]) for k in sd if k.startswith(prefix + "attention_layers."))
+    for i in range(n_layers):
+        L = lambda k: g("attention_layers.%d.%s" % (i, k))
+        t = x.permute(0, 3, 4, 2, 1).reshape(B, h * w * d, C)                                 # "b c d h w -> b (h w d) c"  :573
+        N = t.shape[1]
+        qkv = F.linear(t, L("attn.qkv.weight")).reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+        scale = hd ** -0.5
+        if softmax_scale == "entropy_invariance":
+            scale = scale * math.log(N, train_avg_length)                                     # attention.py:82-83,161
+        att = torch.softmax((qkv[0] * scale) @ qkv[1].transpose(-2, -1), dim=-1) @ qkv[2]    # = SDPA(q,k,v,scale)  :96
+        a = F.linear(att.transpose(1, 2).reshape(B, N, C), L("attn.proj.weight"), L("attn.proj.bias"))
+        t = F.layer_norm(t + L("gamma1") * a, (C,), L("norm1.weight"), L("norm1.bias"), 1e-5)           # :575
+        f = F.linear(F.gelu(F.linear(t, L("ffn.linear1.weight"), L("ffn.linear1.bias"))), L("ffn.linear2.weight"), L("ffn.linear2.bias"))
+        t = F.layer_norm(t + L("gamma2") * f, (C,), L("norm2.weight"), L("norm2.bias"), 1e-5)           # :576
+        x = t.reshape(B, h, w, d, C).permute(0, 4, 3, 1, 2)
+    x = F.conv_transpose3d(x, g("up.0.weight"), g("up.0.bias"), stride=rate)
+    x = layer_norm_3d(x, g("up.1.weight"), g("up.1.bias"))
+    return F.conv3d(x, g("prob.weight"), g("prob.bias"))
+
+
+# --------------------------------------------------------------------------------------
 # StageNet.forward                                               cost_volume.py:51-133
 # --------------------------------------------------------------------------------------
 def stage_forward(features: torch.Tensor, proj_matrices: torch.Tensor, depth_values: torch.Tensor, tmp: float,
                   sd: SD, *, G: int, depth_type: str = "ce", training: bool = False,
-                  return_intermediates: bool = False) -> Dict[str, torch.Tensor]:
+                  return_intermediates: bool = False, position3d=None, transformer_config=None) -> Dict[str, torch.Tensor]:
     """features [B,V,C,H,W]; proj_matrices [B,V,2,4,4]; depth_values [B,D,H,W]."""
     ref_feat = features[:, 0]
     V = features.shape[1]
@@ -262,7 +342,12 @@ def stage_forward(features: torch.Tensor, proj_matrices: torch.Tensor, depth_val
         entropies.append(ent)
         vises.append(w)
     volume_mean = volume_sum / (vis_sum.unsqueeze(1) + 1e-6)                       # :101
-    cost = cost_regnet3d(volume_mean, sd) if is_regnet3d(sd) else cost_regnet(volume_mean, sd)   # :103
+    if is_transformer(sd):
+        tc = transformer_config or {}
+        cost = pure_transformer_cost_reg(volume_mean, position3d, sd, num_heads=tc.get("num_heads", 8),
+                                         train_avg_length=tc.get("train_avg_length"), softmax_scale=tc.get("softmax_scale"))
+    else:
+        cost = cost_regnet3d(volume_mean, sd) if is_regnet3d(sd) else cost_regnet(volume_mean, sd)   # :103
     pre = cost.squeeze(1)
     prob = F.softmax(pre, dim=1)                                                   # :106
     if depth_type == "ce":
@@ -299,8 +384,9 @@ def cascade_forward(features: Dict[str, torch.Tensor], proj_matrices: Dict[str, 
                     depth_interals_ratio: Sequence[float], base_ch: Sequence[int],
                     tmp: Sequence[float] = (5.0, 5.0, 5.0, 1.0), inverse_depth: bool = True,
                     depth_type: Sequence[str] = ("ce", "ce", "ce", "ce"), training: bool = False,
-                    full_hw=None) -> Dict[str, torch.Tensor]:
-    """All-"Normal" regulariser cascade from per-stage features (no image backbone)."""
+                    full_hw=None, use_pe3d: bool = False, transformer_config=None) -> Dict[str, torch.Tensor]:
+    """Cascade from per-stage features (no image backbone); a stage whose state dict holds a transformer regulariser
+    gets the Frustoconical position encoding when ``use_pe3d`` (DINOv2_mvsformer_model.py:151-162)."""
     n = len(ndepths)
     f_last = features["stage%d" % n]
     B = f_last.shape[0]
@@ -309,6 +395,7 @@ def cascade_forward(features: Dict[str, torch.Tensor], proj_matrices: Dict[str, 
     prob_maps = torch.zeros(B, Hf, Wf, dtype=torch.float32)
     outputs: Dict[str, torch.Tensor] = {}
     st = None
+    pe_range = [None, None, None, None]                      # height_min, height_max, width_min, width_max  (:154-160)
     for s in range(n):
         proj = proj_matrices["stage%d" % (s + 1)]
         feat = features["stage%d" % (s + 1)]
@@ -319,7 +406,11 @@ def cascade_forward(features: Dict[str, torch.Tensor], proj_matrices: Dict[str, 
             hyp = schedule_inverse_range(st["depth"], st["depth_values"], ndepths[s], depth_interals_ratio[s], H, W)
         else:
             hyp = schedule_range(st["depth"], ndepths[s], depth_interals_ratio[s] * depth_interval, H, W)
-        st = stage_forward(feat, proj, hyp, tmp[s], sds[s], G=base_ch[s], depth_type=depth_type[s], training=training)
+        position3d = None
+        if is_transformer(sds[s]) and use_pe3d:
+            position3d, *pe_range = get_position_3d(H, W, proj[:, 0, 1, :3, :3], hyp, depth_values.min(), depth_values.max(), *pe_range)
+        st = stage_forward(feat, proj, hyp, tmp[s], sds[s], G=base_ch[s], depth_type=depth_type[s], training=training,
+                           position3d=position3d, transformer_config=(transformer_config or [None] * n)[min(s, len(transformer_config or [None] * n) - 1)])
         outputs["stage%d" % (s + 1)] = st
         conf = st["photometric_confidence"]
         if conf.shape[1] != Hf or conf.shape[2] != Wf:

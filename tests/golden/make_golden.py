@@ -215,7 +215,96 @@ def f6_train_mode():
         photometric_confidence=out["photometric_confidence"], **wman)
 
 
+TRANSFORMER_CFG = {"base_channel": 8, "mid_channel": 64, "num_heads": 4, "down_rate": [2, 4, 4], "mlp_ratio": 4, "layer_num": 6,
+                   "drop": 0.0, "attn_drop": 0.0, "position_encoding": True, "attention_type": "FLASH2",
+                   "softmax_scale": "entropy_invariance", "train_avg_length": 12185, "use_pe_proj": True}   # config/mvsformer++.json:94-113
+SHIPPED_ARGS = dict(ARGS, cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], use_pe3d=True,
+                    transformer_config=[TRANSFORMER_CFG])
+
+
+@torch.no_grad()
+def f7_transformer():
+    """PureTransformerCostReg alone (module.py:602-646) with the Frustoconical PE of position_encoding.py:138-189."""
+    from models.module import PureTransformerCostReg
+    from models.position_encoding import get_position_3d
+    g = torch.Generator().manual_seed(7)
+    net = PureTransformerCostReg(8, **dict(TRANSFORMER_CFG)).eval()
+    wman = seed_weights(net, 70)
+    B, D, H, W = 1, 8, 16, 24
+    x = torch.randn(B, 8, D, H, W, generator=g)
+    K = torch.tensor([[[361.5, 0.0, 12.0], [0.0, 361.5, 8.0], [0.0, 0.0, 1.0]]])
+    hyp = ((1.0 / torch.linspace(1 / 900.0, 1 / 430.0, D))[None, :, None, None] * (1 + 0.02 * torch.rand(1, D, H, W, generator=g))).contiguous()
+    dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None]
+    pos, hmin, hmax, wmin, wmax = get_position_3d(B, H, W, K, hyp, depth_min=dv.min(), depth_max=dv.max(), height_min=None,
+                                                   height_max=None, width_min=None, width_max=None, normalize=True)
+    npz("f7_transformer.npz", x=x, K=K, hyp=hyp, depth_values=dv, position3d=pos, pe_range=torch.stack([hmin, hmax, wmin, wmax]),
+        y=net(x, pos), y_nope=net(x, None), cfg=np.array(json.dumps(TRANSFORMER_CFG)), **wman)
+
+
+@torch.no_grad()
+def f8_stage_transformer():
+    """StageNet stage_idx 0 with the shipped transformer regulariser (cost_volume.py:41-43), V=3, 16x24, D=32."""
+    from models.position_encoding import get_position_3d
+    args = json.loads(json.dumps(SHIPPED_ARGS))
+    net = StageNet(args, 32, 0).eval()
+    wman = seed_weights(net, 80)
+    feats, cams, hyp = stage_inputs(64, 32, 16, 24, 3, 38, down=8)
+    feats = feats.half().float()                         # stored as fp16 (exactly representable) to keep the fixture small
+    dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None]
+    pos = get_position_3d(1, 16, 24, cams[:, 0, 1, :3, :3], hyp, depth_min=dv.min(), depth_max=dv.max(), height_min=None,
+                          height_max=None, width_min=None, width_max=None, normalize=True)[0]
+    out = net(feats, cams, hyp, tmp=5.0, position3d=pos)
+    npz("f8_stage_transformer.npz", features=feats.half(), proj=cams, hyp=hyp, position3d=pos, depth=out["depth"],
+        prob_volume=out["prob_volume"], photometric_confidence=out["photometric_confidence"], prob_volume_pre=out["prob_volume_pre"],
+        cfg=np.array(json.dumps(TRANSFORMER_CFG)), **wman)
+
+
+@torch.no_grad()
+def f9_cascade_shipped():
+    """The f4 cascade inputs through the SHIPPED regulariser mix (stage-1 transformer + PE3D), driver logic of
+    DINOv2_mvsformer_model.py:120-179.  Inputs are the ones stored in f4_cascade.npz."""
+    import torch.nn.functional as F
+    from models.position_encoding import get_position_3d
+    H, W, V = 64, 128, 4
+    ndepths, ratios, tmp = [32, 16, 8, 4], [4.0, 2.67, 1.5, 1.0], [5.0, 5.0, 5.0, 1.0]
+    feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=4, baseline=30.0, rot_deg=1.0)
+    nets = [StageNet(json.loads(json.dumps(SHIPPED_ARGS)), ndepths[i], i).eval() for i in range(4)]
+    arrs = {"cfg": np.array(json.dumps(TRANSFORMER_CFG))}
+    for i, n in enumerate(nets):
+        arrs.update(seed_weights(n, 90 + i, "w%d." % (i + 1)))
+    prob_maps = torch.zeros(1, H, W)
+    st = None
+    rng = [None] * 4
+    for s in range(4):
+        f, p = feats["stage%d" % (s + 1)], projs["stage%d" % (s + 1)]
+        h, w = f.shape[-2:]
+        hyp = init_inverse_range(dv, ndepths[s], dv.device, dv.dtype, h, w) if s == 0 else \
+            schedule_inverse_range(st["depth"].detach(), st["depth_values"], ndepths[s], ratios[s], h, w)
+        pos = None
+        if SHIPPED_ARGS["cost_reg_type"][s] != "Normal":
+            pos, *rng = get_position_3d(1, h, w, p[:, 0, 1, :3, :3], hyp, depth_min=dv.min(), depth_max=dv.max(), height_min=rng[0],
+                                        height_max=rng[1], width_min=rng[2], width_max=rng[3], normalize=True)
+        st = nets[s](f, p, hyp, tmp=tmp[s], position3d=pos)
+        conf = st["photometric_confidence"]
+        if conf.shape[1] != H or conf.shape[2] != W:
+            conf = F.interpolate(conf.unsqueeze(1), [H, W], mode="nearest").squeeze(1)
+        prob_maps += conf
+        arrs["depth%d" % (s + 1)] = st["depth"]
+        arrs["conf%d" % (s + 1)] = st["photometric_confidence"]
+    arrs["refined_depth"] = st["depth"]
+    arrs["photometric_confidence"] = prob_maps / 4
+    npz("f9_cascade_shipped.npz", **arrs)
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
+    f7_transformer()
+    f8_stage_transformer()
+    f9_cascade_shipped()
     f1_warp()
     f2_stage()
     f3_regnets()

@@ -81,3 +81,48 @@ def test_f6_train_and_reg():
     out = O.stage_forward(fx["features"], fx["proj"], fx["hyp"], 1.0, golden_weights(fx), G=8, depth_type="reg")
     assert rel_l1(out["depth"], fx["depth"]) <= 1e-6
     assert (out["photometric_confidence"] - fx["photometric_confidence"]).abs().max() <= 1e-5
+
+
+# ---------------------------------------------------------------- stage-1 transformer regulariser
+def _tcfg(fx):
+    import json
+    return json.loads(fx["cfg"])
+
+
+def test_f7_transformer():
+    fx = load_golden("f7_transformer.npz")
+    cfg = _tcfg(fx)
+    sd = {"cost_reg." + k: v for k, v in golden_weights(fx).items()}
+    dv = fx["depth_values"]
+    pos, *rng = O.get_position_3d(16, 24, fx["K"], fx["hyp"], dv.min(), dv.max())
+    assert (pos - fx["position3d"]).abs().max() <= TOL
+    assert (torch.stack(rng) - fx["pe_range"]).abs().max() <= 1e-4
+    kw = dict(num_heads=cfg["num_heads"], train_avg_length=cfg["train_avg_length"], softmax_scale=cfg["softmax_scale"])
+    y = O.pure_transformer_cost_reg(fx["x"], fx["position3d"], sd, **kw)
+    assert (y - fx["y"]).abs().max() <= 2e-5 * max(1.0, float(fx["y"].abs().max()))
+    y0 = O.pure_transformer_cost_reg(fx["x"], None, sd, **kw)
+    assert (y0 - fx["y_nope"]).abs().max() <= 2e-5 * max(1.0, float(fx["y_nope"].abs().max()))
+    assert (fx["y"] - fx["y_nope"]).abs().max() > 1e-3            # the position encoding must matter in the fixture
+
+
+def test_f8_stage_transformer():
+    fx = load_golden("f8_stage_transformer.npz")
+    sd = golden_weights(fx)
+    out = O.stage_forward(fx["features"].float(), fx["proj"], fx["hyp"], 5.0, sd, G=8, position3d=fx["position3d"],
+                          transformer_config=_tcfg(fx))
+    assert (out["prob_volume_pre"] - fx["prob_volume_pre"]).abs().max() <= 1e-4
+    assert (out["prob_volume"] - fx["prob_volume"]).abs().max() <= 1e-5
+    assert rel_l1(out["depth"], fx["depth"]) <= 1e-6
+
+
+def test_f9_cascade_shipped():
+    fx, f4 = load_golden("f9_cascade_shipped.npz"), load_golden("f4_cascade.npz")
+    feats = {"stage%d" % s: f4["features%d" % s] for s in range(1, 5)}
+    projs = {"stage%d" % s: f4["proj%d" % s] for s in range(1, 5)}
+    sds = [golden_weights(fx, "w%d." % s) for s in range(1, 5)]
+    out = O.cascade_forward(feats, projs, f4["depth_values"], sds, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0],
+                            base_ch=[8, 8, 8, 8], use_pe3d=True, transformer_config=[_tcfg(fx)])
+    for s in range(1, 5):
+        assert rel_l1(out["stage%d" % s]["depth"], fx["depth%d" % s]) <= 2e-6
+        assert (out["stage%d" % s]["photometric_confidence"] - fx["conf%d" % s]).abs().max() <= 1e-4
+    assert rel_l1(out["refined_depth"], fx["refined_depth"]) <= 2e-6
