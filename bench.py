@@ -38,17 +38,24 @@ TMP = [5.0, 5.0, 5.0, 1.0]
 ALGO_BYTES_PER_VIEW = 5.03e9
 
 
-def build_head(device):
+# stage-1 regulariser of the shipped checkpoints (config/mvsformer++.json:86-113); reported beside the all-"Normal" headline
+SHIPPED = {"cost_reg_type": ["PureTransformerCostReg", "Normal", "Normal", "Normal"], "use_pe3d": True,
+           "transformer_config": [{"base_channel": 8, "mid_channel": 64, "num_heads": 4, "down_rate": [2, 4, 4], "mlp_ratio": 4,
+                                   "layer_num": 6, "drop": 0.0, "attn_drop": 0.0, "position_encoding": True, "attention_type": "FLASH2",
+                                   "softmax_scale": "entropy_invariance", "train_avg_length": 12185, "use_pe_proj": True}]}
+
+
+def build_head(device, shipped=False):
     from mvsformerplusplus_amd import synth
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
-    head = CascadeDepthHead(dict(ARGS))
+    head = CascadeDepthHead(json.loads(json.dumps(dict(ARGS, **SHIPPED))) if shipped else dict(ARGS))
     for i, st in enumerate(head.fusions):
         st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 100 + i), strict=True)
         st.return_prob_volumes = True       # reference-faithful outputs (a12): prob_volume / prob_volume_pre are written
     return head.eval().to(device)
 
 
-def cpu_baseline(head, feats, projs, dv, max_threads=None):
+def cpu_baseline(head, feats, projs, dv, max_threads=None, shipped=False):
     """The oracle (CPU restatement of the reference PyTorch path, fp32) on the host cores; second of two passes."""
     from oracle import ref_path as O
     # oneDNN convolutions on these shapes get SLOWER beyond a few dozen threads (256 threads: 171 s per pass on the
@@ -65,7 +72,8 @@ def cpu_baseline(head, feats, projs, dv, max_threads=None):
         for _ in range(2):
             t0 = time.time()
             out = O.cascade_forward(f, p, d, sds, ndepths=ARGS["ndepths"], depth_interals_ratio=ARGS["depth_interals_ratio"],
-                                    base_ch=ARGS["base_ch"], tmp=TMP)
+                                    base_ch=ARGS["base_ch"], tmp=TMP, use_pe3d=shipped,
+                                    transformer_config=SHIPPED["transformer_config"] if shipped else None)
             times.append(time.time() - t0)
     return {"value": 1.0 / times[-1], "unit": "ref-views/s", "cores": n, "kind": "port",
             "sample": "1 reference view of the bench workload (full 4-stage cascade, fp32), second of two passes; "
@@ -83,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
+                    help="normal: all-'Normal' regularisers (Track R headline); shipped: stage-1 transformer + PE3D as in the shipped config")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +110,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from mvsformerplusplus_amd import profiling, synth
-    head = build_head(device)
+    head = build_head(device, shipped=a.cost_reg == "shipped")
     feats, projs, dv = synth.make_cascade_inputs(a.height, a.width, a.views, seed=rank, device=device)
     torch.cuda.synchronize()
 
@@ -140,6 +150,7 @@ def main():
         "hbm_algorithmic_frac_of_8TBs": (ALGO_BYTES_PER_VIEW * value / world / 8.0e12) if is_cfg2 else None,
     }
 
+    result["config"]["cost_reg_type"] = SHIPPED["cost_reg_type"] if a.cost_reg == "shipped" else ["Normal"] * 4
     result["config"]["conv_precision"] = ("%s MFMA contraction, fp32 activations and accumulation" % head.fusions[0].conv_precision)
 
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
@@ -209,7 +220,7 @@ def main():
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) + a parity read-out ----
     if world == 1 and not a.no_cpu_baseline:
-        cb, ref = cpu_baseline(head, feats, projs, dv)
+        cb, ref = cpu_baseline(head, feats, projs, dv, shipped=a.cost_reg == "shipped")
         result["cpu_baseline"] = cb
         d, r = out["refined_depth"].cpu(), ref["refined_depth"]
         result["parity"] = {"refined_depth_rel_l1_vs_oracle": float(((d - r).abs() / r.abs()).mean()),

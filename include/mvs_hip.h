@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 2
+#define MVS_ABI_VERSION 3
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -40,6 +40,8 @@ enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
  *   MVS_PREC_BF16X3  three-term split-bf16 product on v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32
  *                    accumulate, ~2^-16 relative product error; weights packed as hi/lo bf16)                 */
 enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1 };
+/* epilogues of mvs_tr_linear_fwd */
+enum { MVS_TR_EPI_BIAS = 0, MVS_TR_EPI_GELU = 1, MVS_TR_EPI_RES_LN = 2 };
 
 int mvs_abi_version(void);
 const char* mvs_last_error(void);
@@ -155,6 +157,59 @@ int mvs_schedule_range_fwd(const float* prev_depth, const float* interval, float
  * out[b,y,x] = mean_s conf_s[b, y >> shift_s, x >> shift_s] (nearest upsample), n_stages <= 8.      */
 int mvs_confidence_average(const float* const* conf_host_ptrs, const int* shifts_host, int n_stages, float* out,
                            int B, int H, int W, void* stream);
+
+/* ==== section 8f #1: stage-1 transformer regulariser of the shipped config =========================
+ * PureTransformerCostReg module.py:602-646 (FlashAttnBlock :535-583, FFN :507-532, LayerNorm3D :586-599), softmax
+ * attention models/dino/layers/attention.py:76-101,141-170, Frustoconical PE models/position_encoding.py:138-189.
+ * Tokens are rows [B, n, 64] fp32, n = (D/rd)(H/rh)(W/rw), token index (td*H/rh + th)*W/rw + tw (attention is
+ * invariant to the order; the reference's "(h w d)" order, module.py:573, is not reproduced).  All contractions
+ * are MVS_PREC_BF16X3 (fp32-equivalent); other precisions return MVS_ERR_UNSUPPORTED.  Packed weights come from
+ * packing.pack_linear_bf16x3 (layout in mvsformerplusplus_amd/packing.py).                                        */
+
+/* get_position_3d(normalize=True), position_encoding.py:138-163.  K [B,3,3] = proj[:,0,1,:3,:3] of the stage,
+ * hyp [B,D,H,W], depth_values [B*n] (only its min / max are used).  range [6] = {height_min, height_max, width_min,
+ * width_max, depth_min, depth_max}: with compute_range != 0 the first four are measured over the whole volume
+ * (stage 1) and written, otherwise they are read (later stages reuse stage 1's, DINOv2_mvsformer_model.py:152-160);
+ * the last two are always written.  -> position3d [B,3,D,H,W] in 0..1.                                            */
+size_t mvs_position3d_workspace_bytes(void);
+int mvs_position3d_fwd(const float* K, const float* hyp, const float* depth_values, int n_depth_values, float* range,
+                       int compute_range, float* workspace, size_t workspace_bytes, float* position3d, int B, int D,
+                       int H, int W, void* stream);
+
+/* x + pe_proj(PositionEncoding3D(position3d, 8)) (module.py:631-635, position_encoding.py:166-189; skipped when
+ * position3d == NULL), `down` = Conv3d(8, 64, kernel = stride = (rd,rh,rw)) + bias + LayerNorm3D(64, eps 1e-6).
+ * volume_cl [B,D,H,W,8], pe_w = pe_proj.weight [8][24], pe_div_host = the 4 frequencies exp(2k * -ln(1e4)/8) (HOST
+ * pointer), w_packed = pack_linear_bf16x3(down.0.weight as [64][patch_voxel*8 + c]) -> tokens [B,n,64].           */
+int mvs_tr_embed_fwd(const float* volume_cl, const float* position3d, const float* pe_w, const float* pe_div_host,
+                     const void* w_packed, const float* bias, const float* ln_w, const float* ln_b, float* tokens,
+                     int B, int D, int H, int W, int rd, int rh, int rw, int precision, void* stream);
+
+/* y = epilogue(x @ W^T): x [B,n,K], W [N,K] packed, y [B,n,N].
+ *   MVS_TR_EPI_BIAS    y = x W^T (+ bias)                                                K = 64
+ *   MVS_TR_EPI_GELU    y = gelu(x W^T + bias), exact erf form (FFN.linear1 + act)         K = 64
+ *   MVS_TR_EPI_RES_LN  y = LayerNorm(residual + gamma[0] * (x W^T + bias)), N = 64        K = 64 | 256
+ *                      (attn.proj / ffn.linear2 + layer scale + post-norm, module.py:575-576)                      */
+int mvs_tr_linear_fwd(const float* x, const void* w_packed, const float* bias, int epilogue, const float* residual,
+                      const float* gamma, const float* ln_w, const float* ln_b, float ln_eps, float* y, int B, int n,
+                      int K, int N, int precision, void* stream);
+
+/* attn.qkv (no bias) written as the operands of the attention kernel: q (pre-scaled by softmax_scale * log2 e) and
+ * k as [B,heads,npad,32] bf16 = [hi16 | lo16], v transposed as [B,heads,2,16,npad] bf16; npad = n rounded up to 64,
+ * each buffer mvs_tr_attention_operand_bytes(B, n, heads) bytes.  softmax_scale = head_dim^-0.5 *
+ * log(n) / log(train_avg_length) for "entropy_invariance" (attention.py:158-161).  heads = 4, head_dim = 16.        */
+size_t mvs_tr_attention_operand_bytes(int B, int n, int heads);
+int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, void* k, void* vt, float softmax_scale, int B, int n,
+                   int heads, int precision, void* stream);
+/* softmax(q k^T) v over all n tokens -> out [B,n,heads*16] (scaled_dot_product_attention, attention.py:96)          */
+int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt, float* out, int B, int n, int heads,
+                         int precision, void* stream);
+
+/* `up` = ConvTranspose3d(64, 8, kernel = stride = (rd,rh,rw)) + bias + LayerNorm3D(8, eps 1e-6), then `prob` =
+ * Conv3d(8, 1, 1) + bias (module.py:621-626, 643-644): tokens [B,n,64] -> logits [B,D,H,W].
+ * w_packed = pack_linear_bf16x3(up.0.weight as [patch_voxel*8 + co][ci]).                                          */
+int mvs_tr_up_prob_fwd(const float* tokens, const void* w_packed, const float* up_bias, const float* ln_w,
+                       const float* ln_b, const float* prob_w, const float* prob_b, float* logits, int B, int D, int H,
+                       int W, int rd, int rh, int rw, int precision, void* stream);
 
 /* ---- layout helpers for the nn.Module-level API (NCDHW <-> channel-last) -------------------------*/
 int mvs_ncdhw_to_cl(const float* x, float* y_cl, int B, int C, int D, int H, int W, void* stream);

@@ -8,10 +8,12 @@ there is no CPU or eager-PyTorch fallback.  See DESIGN.md and INTEGRATION.md.
 """
 from .cascade import CascadeDepthHead, patch_model
 from .cost_volume import StageNet
-from .module import (Conv3d, ConvBnReLU, CostRegNet, CostRegNet3D, Deconv3d, conf_regression, depth_regression,
+from .module import (Conv3d, ConvBnReLU, CostRegNet, CostRegNet3D, Deconv3d, PureTransformerCostReg, conf_regression, depth_regression,
                      init_inverse_range, init_range, schedule_inverse_range, schedule_range)
+from .position_encoding import get_position_3d
 from .warping import homo_warping_3D_with_mask
 
 __all__ = ["CascadeDepthHead", "patch_model", "StageNet", "Conv3d", "Deconv3d", "ConvBnReLU", "CostRegNet", "CostRegNet3D",
+           "PureTransformerCostReg", "get_position_3d",
            "depth_regression", "conf_regression", "init_range", "init_inverse_range", "schedule_inverse_range", "schedule_range",
            "homo_warping_3D_with_mask"]

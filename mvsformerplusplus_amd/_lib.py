@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
+ABI_VERSION = 3
+TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
@@ -50,6 +52,14 @@ SIGNATURES = {
     "mvs_schedule_inverse_range_fwd": (_i, [_vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp]),
     "mvs_schedule_range_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_confidence_average": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "mvs_position3d_workspace_bytes": (_sz, []),
+    "mvs_position3d_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_tr_embed_fwd": (_i, [_vp] * 9 + [_i] * 8 + [_vp]),
+    "mvs_tr_linear_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_tr_attention_operand_bytes": (_sz, [_i, _i, _i]),
+    "mvs_tr_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
+    "mvs_tr_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_tr_up_prob_fwd": (_i, [_vp] * 8 + [_i] * 8 + [_vp]),
     "mvs_ncdhw_to_cl": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_cl_to_ncdhw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
@@ -66,7 +76,7 @@ def bind(path: str) -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.mvs_abi_version() != 2:
+    if lib.mvs_abi_version() != ABI_VERSION:
         raise MvsHipError("libmvs_hip ABI version mismatch: %d" % lib.mvs_abi_version())
     return lib
 

@@ -22,7 +22,8 @@ class CascadeDepthHead(nn.Module):
     """features{stageK:[B,V,C,H,W]}, proj_matrices{stageK:[B,V,2,4,4]}, depth_values[B,N], tmp -> outputs dict.
 
     ``args`` are the reference's ``arch.args`` (config/mvsformer++.json): ``ndepths``, ``depth_interals_ratio``,
-    ``inverse_depth``, ``base_ch``, ``depth_type``, ``cost_reg_type`` (only "Normal" is built here), ``model_th``.
+    ``inverse_depth``, ``base_ch``, ``depth_type``, ``cost_reg_type`` ("Normal" | "PureTransformerCostReg" with its
+    ``transformer_config`` and ``use_pe3d``), ``model_th``.
     """
 
     def __init__(self, args: dict):
@@ -31,6 +32,8 @@ class CascadeDepthHead(nn.Module):
         self.ndepths = list(args["ndepths"])
         self.depth_interals_ratio = list(args["depth_interals_ratio"])
         self.inverse_depth = args.get("inverse_depth", False)
+        self.cost_reg_type = list(args.get("cost_reg_type", ["Normal"] * len(self.ndepths)))
+        self.use_pe3d = args.get("use_pe3d", False)
         self.fusions = nn.ModuleList([StageNet(args, self.ndepths[i], i) for i in range(len(self.ndepths))])
 
     def set_view_group(self, group) -> None:
@@ -45,6 +48,7 @@ class CascadeDepthHead(nn.Module):
         outputs: Dict[str, torch.Tensor] = {}
         stage_out: Optional[Dict[str, torch.Tensor]] = None
         confs: List[torch.Tensor] = []
+        pe_range = None                                  # stage 1 measures the frustum's x / y range, later stages reuse it
         for s in range(n):
             key = "stage%d" % (s + 1)
             feat, proj = features[key], proj_matrices[key]
@@ -56,7 +60,10 @@ class CascadeDepthHead(nn.Module):
                                                  self.depth_interals_ratio[s], H, W)
             else:
                 hyp = ops.schedule_range(stage_out["depth"], self.ndepths[s], self.depth_interals_ratio[s] * depth_interval, H, W)
-            stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s])
+            position3d = None
+            if self.cost_reg_type[s] != "Normal" and self.use_pe3d:                           # DINOv2_mvsformer_model.py:151-162
+                position3d, pe_range = ops.position3d(proj[:, 0, 1, :3, :3], hyp, depth_values, pe_range)
+            stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s], position3d=position3d)
             outputs[key] = stage_out
             confs.append(stage_out["photometric_confidence"])
             outputs.update(stage_out)

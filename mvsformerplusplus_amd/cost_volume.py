@@ -19,7 +19,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops, packing
-from .module import DEFAULT_PRECISION, ConvBnReLU, CostRegNet, CostRegNet3D, _bn_dict, _no_grad_path, _PackedCache, precision_code
+from .module import (DEFAULT_PRECISION, ConvBnReLU, CostRegNet, CostRegNet3D, PureTransformerCostReg, _bn_dict, _no_grad_path,
+                     _PackedCache, precision_code)
 
 
 def shard_views(n_src: int, world: int, rank: int):
@@ -44,10 +45,12 @@ class StageNet(nn.Module):
         if self.fusion_type != "cnn":
             raise NotImplementedError(f"Not implemented fusion type: {self.fusion_type}.")
         self.vis = nn.Sequential(ConvBnReLU(1, 16), ConvBnReLU(16, 16), ConvBnReLU(16, 8), nn.Conv2d(8, 1, 1), nn.Sigmoid())
-        if self.cost_reg_type != "Normal":
-            raise NotImplementedError("cost_reg_type=%r: the stage-1 transformer regulariser is the next scope row "
-                                      "(SURVEY.md section 8f #1); use 'Normal'" % self.cost_reg_type)
-        if ndepth <= args.get("model_th", 8):
+        if self.cost_reg_type == "PureTransformerCostReg":                                        # cost_volume.py:41-43
+            args["transformer_config"][stage_idx]["base_channel"] = self.in_channels
+            self.cost_reg = PureTransformerCostReg(self.in_channels, **args["transformer_config"][stage_idx])
+        elif self.cost_reg_type != "Normal":
+            raise NotImplementedError("cost_reg_type=%r" % self.cost_reg_type)
+        elif ndepth <= args.get("model_th", 8):
             self.cost_reg = CostRegNet3D(self.in_channels, self.in_channels)
         else:
             self.cost_reg = CostRegNet(self.in_channels, self.in_channels)
@@ -111,9 +114,6 @@ class StageNet(nn.Module):
         else:
             volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
 
-        ws, bs, prob_w, prob_b = self.cost_reg.packed_all(feats.device, self.conv_precision)
-        feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, prec)
-
         D = hyp.shape[1]
         conf_n = 0
         if self.depth_type == "ce":
@@ -121,8 +121,14 @@ class StageNet(nn.Module):
         else:
             mode = _lib.HEAD_REG
             conf_n = 4 if D >= 32 else (3 if D == 16 else (2 if D == 8 else 0))                    # cost_volume.py:121-128
-        depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(
-            feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, float(tmp), mode, conf_n, self.return_prob_volumes)
+        if isinstance(self.cost_reg, PureTransformerCostReg):
+            prob_volume_pre = self.cost_reg.logits_cl(volume, position3d)
+            depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, float(tmp), mode, conf_n, self.return_prob_volumes)
+        else:
+            ws, bs, prob_w, prob_b = self.cost_reg.packed_all(feats.device, self.conv_precision)
+            feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, prec)
+            depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(
+                feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, float(tmp), mode, conf_n, self.return_prob_volumes)
         return {"depth": depth, "prob_volume": prob_volume, "photometric_confidence": conf,
                 "depth_values": depth_values, "prob_volume_pre": prob_volume_pre}
 

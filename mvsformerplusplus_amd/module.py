@@ -284,6 +284,145 @@ class CostRegNet3D(_RegNetBase):
 
 
 # --------------------------------------------------------------------------------------------------
+# stage-1 transformer regulariser of the shipped config (reference module.py:507-646), SURVEY.md section 8f #1
+# --------------------------------------------------------------------------------------------------
+class FFN(nn.Module):
+    """Parameter container of the reference FFN (module.py:507-532): linear1 -> GELU -> linear2."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, bias=True):
+        super().__init__()
+        self.linear1 = nn.Linear(in_features, hidden_features or in_features, bias=bias)
+        self.act = nn.GELU()
+        self.linear2 = nn.Linear(hidden_features or in_features, out_features or in_features, bias=bias)
+
+
+class _AttentionParams(nn.Module):
+    """qkv (no bias) + proj of the reference Attention (models/dino/layers/attention.py:49-74)."""
+
+    def __init__(self, dim, qkv_bias=False, proj_bias=True):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+
+
+class FlashAttnBlock(nn.Module):
+    """Parameter container of one post-norm block (module.py:535-583): attn.{qkv,proj}, gamma1, norm1, ffn, gamma2, norm2."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, proj_bias=True, ffn_bias=True, init_values=1.0,
+                 attention_type="FLASH2", **kwargs):
+        super().__init__()
+        if attention_type not in ("FLASH2", "FLASH1"):
+            raise NotImplementedError("attention_type=%r: only softmax attention (FLASH2 / FLASH1) runs on the HIP path" % attention_type)
+        if not kwargs.get("post_norm", True):
+            raise NotImplementedError("pre-norm FlashAttnBlock (post_norm=False) is not used by the shipped transformer_config")
+        if qkv_bias:
+            raise NotImplementedError("qkv_bias=True is not used by the shipped transformer_config")
+        self.num_heads = num_heads
+        self.attn = _AttentionParams(dim, qkv_bias, proj_bias)
+        self.gamma1 = nn.Parameter(torch.tensor(init_values))
+        self.norm1 = nn.LayerNorm(dim)
+        self.ffn = FFN(dim, int(dim * mlp_ratio), bias=ffn_bias)
+        self.gamma2 = nn.Parameter(torch.tensor(init_values))
+        self.norm2 = nn.LayerNorm(dim)
+
+
+class LayerNorm3D(nn.Module):
+    """Channel LayerNorm of an NCDHW tensor (module.py:586-599); parameter container, evaluated in the GEMM epilogues."""
+
+    def __init__(self, normalized_shape, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+
+
+class PureTransformerCostReg(nn.Module):
+    """Patch embedding -> ``layer_num`` post-norm transformer blocks over all tokens -> patch expansion -> logits
+    (reference module.py:602-646).  Same constructor arguments and state-dict keys; forward = HIP kernels
+    (csrc/transformer_kernels.hip): 1 embed + 5 launches per block + 1 expand launch, all fp32-equivalent (split bf16)."""
+    kind = "transformer"
+
+    def __init__(self, in_channels, base_channel=8, mid_channel=64, num_heads=8, mlp_ratio=4, layer_num=6, drop=0.0, attn_drop=0.0,
+                 position_encoding=True, attention_type="FLASH2", down_rate=4, **kwargs):
+        super().__init__()
+        self.attention_type = attention_type
+        self.down_rate = down_rate
+        self.use_pe_proj = kwargs.get("use_pe_proj", True)
+        if not (position_encoding and self.use_pe_proj):
+            raise NotImplementedError("the HIP path implements the shipped position_encoding=True, use_pe_proj=True form")
+        if in_channels != 8 or base_channel != 8 or mid_channel != 64 or mid_channel // num_heads != 16:
+            raise NotImplementedError("HIP transformer regulariser is built for 8 -> 64 channels, heads of 16 (shipped transformer_config)")
+        self.num_heads = num_heads
+        self.softmax_scale = kwargs.get("softmax_scale", None)
+        self.train_avg_length = kwargs.get("train_avg_length", None)
+        if self.softmax_scale not in (None, "entropy_invariance"):
+            raise NotImplementedError("softmax_scale=%r" % (self.softmax_scale,))
+        self.pe_proj = nn.Conv3d(base_channel * 3, base_channel, 1, 1, bias=False)
+        self.down = nn.Sequential(nn.Conv3d(in_channels, mid_channel, kernel_size=down_rate, stride=down_rate),
+                                  LayerNorm3D(mid_channel, eps=1e-6))
+        self.attention_layers = nn.ModuleList([
+            FlashAttnBlock(mid_channel, num_heads=num_heads, mlp_ratio=mlp_ratio, attention_type=attention_type, **kwargs)
+            for _ in range(layer_num)])
+        self.up = nn.Sequential(nn.ConvTranspose3d(mid_channel, base_channel, kernel_size=down_rate, stride=down_rate),
+                                LayerNorm3D(base_channel, eps=1e-6))
+        self.prob = nn.Conv3d(base_channel, 1, 1, stride=1, padding=0)
+        self._cache = _PackedCache()
+
+    @property
+    def rate(self):
+        return _triple(self.down_rate)
+
+    def _build(self, dev):
+        import math
+        f = lambda t: t.detach().float().contiguous().to(dev)
+        pk = lambda w: packing.pack_linear_bf16x3(w.detach().cpu().float()).to(dev)
+        P = {"pe_w": f(self.pe_proj.weight.reshape(8, 24)),
+             # frequencies exactly as PositionEncoding3D builds them (fp32 exp of fp32 products), position_encoding.py:171
+             "pe_div": torch.exp(torch.arange(0, 8, 2).float() * (-math.log(10000.0) / 8)).tolist(),
+             "down_w": pk(packing.patch_embed_matrix(self.down[0].weight.detach().cpu())), "down_b": f(self.down[0].bias),
+             "down_ln": (f(self.down[1].weight), f(self.down[1].bias)),
+             "up_w": pk(packing.patch_expand_matrix(self.up[0].weight.detach().cpu())), "up_b": f(self.up[0].bias),
+             "up_ln": (f(self.up[1].weight), f(self.up[1].bias)),
+             "prob_w": f(self.prob.weight.reshape(8)), "prob_b": f(self.prob.bias.reshape(1)), "layers": []}
+        for blk in self.attention_layers:
+            P["layers"].append({
+                "qkv": pk(blk.attn.qkv.weight), "proj": pk(blk.attn.proj.weight), "proj_b": f(blk.attn.proj.bias),
+                "g1": f(blk.gamma1.reshape(1)), "n1": (f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps),
+                "l1": pk(blk.ffn.linear1.weight), "l1_b": f(blk.ffn.linear1.bias),
+                "l2": pk(blk.ffn.linear2.weight), "l2_b": f(blk.ffn.linear2.bias),
+                "g2": f(blk.gamma2.reshape(1)), "n2": (f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps)})
+        return P
+
+    def logits_cl(self, volume_cl: torch.Tensor, position3d: Optional[torch.Tensor]) -> torch.Tensor:
+        """[B,D,H,W,8] channel-last cost volume (+ position3d [B,3,D,H,W]) -> logits [B,D,H,W]."""
+        import math
+        P = self._cache.get(self, self._build, "bf16x3")
+        prec = _lib.PREC_BF16X3
+        B, D, H, W, _ = volume_cl.shape
+        rate = self.rate
+        if D % rate[0] or H % rate[1] or W % rate[2]:
+            raise ValueError("volume %dx%dx%d is not a multiple of down_rate %s" % (D, H, W, (rate,)))
+        x = ops.tr_embed(volume_cl, position3d, P["pe_w"], P["pe_div"], P["down_w"], P["down_b"], *P["down_ln"], rate, prec)
+        n = x.shape[1]
+        scale = (64 // self.num_heads) ** -0.5
+        if self.softmax_scale == "entropy_invariance":
+            scale *= math.log(n, self.train_avg_length)                                       # attention.py:82-83 / 158-161
+        for L in P["layers"]:
+            a = ops.tr_attention(x, L["qkv"], self.num_heads, scale, prec)
+            x = ops.tr_linear(a, L["proj"], L["proj_b"], _lib.TR_EPI_RES_LN, 64, prec, residual=x, gamma=L["g1"],
+                              ln_w=L["n1"][0], ln_b=L["n1"][1], ln_eps=L["n1"][2])
+            hdn = ops.tr_linear(x, L["l1"], L["l1_b"], _lib.TR_EPI_GELU, L["l1_b"].numel(), prec)
+            x = ops.tr_linear(hdn, L["l2"], L["l2_b"], _lib.TR_EPI_RES_LN, 64, prec, residual=x, gamma=L["g2"],
+                              ln_w=L["n2"][0], ln_b=L["n2"][1], ln_eps=L["n2"][2])
+        return ops.tr_up_prob(x, P["up_w"], P["up_b"], *P["up_ln"], P["prob_w"], P["prob_b"], (D, H, W), rate, prec)
+
+    def forward(self, x, position3d=None):
+        """NCDHW in, logits [B,1,D,H,W] out - the reference's call form (module.py:629-646)."""
+        _no_grad_path(x)
+        return self.logits_cl(ops.ncdhw_to_cl(x), position3d).unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------------------
 # functional API (reference module.py:649-741)
 # --------------------------------------------------------------------------------------------------
 def depth_regression(p: torch.Tensor, depth_values: torch.Tensor) -> torch.Tensor:

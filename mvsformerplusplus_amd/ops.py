@@ -208,6 +208,67 @@ def softmax_regress(logits: torch.Tensor, hyp: torch.Tensor, tmp: float, mode: i
     return depth, conf, pv
 
 
+# ---- section 8f #1: stage-1 transformer regulariser ----------------------------------------------
+def position3d(K: torch.Tensor, hyp: torch.Tensor, depth_values: torch.Tensor, pe_range: Optional[torch.Tensor] = None):
+    """get_position_3d(normalize=True): K [B,3,3], hyp [B,D,H,W], depth_values [B,n] -> (position3d [B,3,D,H,W],
+    range [6] = height_min, height_max, width_min, width_max, depth_min, depth_max).  ``pe_range`` = a previous
+    call's range tensor to reuse its first four entries (later cascade stages)."""
+    Kc, hp, dv = _f32c(K), _f32c(hyp), _f32c(depth_values)
+    B, D, H, W = hp.shape
+    compute = pe_range is None
+    rng = torch.empty(6, dtype=torch.float32, device=hp.device) if compute else pe_range.clone()
+    wsb = lib().mvs_position3d_workspace_bytes()
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=hp.device)
+    pos = torch.empty(B, 3, D, H, W, dtype=torch.float32, device=hp.device)
+    check(lib().mvs_position3d_fwd(ptr(Kc), ptr(hp), ptr(dv), dv.numel(), ptr(rng), 1 if compute else 0, ptr(ws), wsb, ptr(pos),
+                                   B, D, H, W, stream_of(hp)), "mvs_position3d_fwd")
+    return pos, rng
+
+
+def tr_embed(volume_cl: torch.Tensor, pos: Optional[torch.Tensor], pe_w, pe_div, w_packed, bias, ln_w, ln_b, rate, precision: int):
+    B, D, H, W, Cc = volume_cl.shape
+    assert Cc == 8
+    rd, rh, rw = rate
+    n = (D // rd) * (H // rh) * (W // rw)
+    tokens = torch.empty(B, n, 64, dtype=torch.float32, device=volume_cl.device)
+    div = (C.c_float * 4)(*[float(v) for v in pe_div]) if pos is not None else None
+    check(lib().mvs_tr_embed_fwd(ptr(volume_cl), ptr(_f32c(pos)) if pos is not None else None, ptr(pe_w) if pos is not None else None,
+                                 C.cast(div, C.c_void_p) if div is not None else None, ptr(w_packed), ptr(bias), ptr(ln_w), ptr(ln_b),
+                                 ptr(tokens), B, D, H, W, rd, rh, rw, precision, stream_of(volume_cl)), "mvs_tr_embed_fwd")
+    return tokens
+
+
+def tr_linear(x: torch.Tensor, w_packed, bias, epilogue: int, N: int, precision: int, residual=None, gamma=None, ln_w=None, ln_b=None,
+              ln_eps: float = 1e-5):
+    B, n, K = x.shape
+    y = torch.empty(B, n, N, dtype=torch.float32, device=x.device)
+    check(lib().mvs_tr_linear_fwd(ptr(x), ptr(w_packed), ptr(bias), epilogue, ptr(residual), ptr(gamma), ptr(ln_w), ptr(ln_b),
+                                  float(ln_eps), ptr(y), B, n, K, N, precision, stream_of(x)), "mvs_tr_linear_fwd")
+    return y
+
+
+def tr_attention(x: torch.Tensor, wqkv_packed, heads: int, softmax_scale: float, precision: int) -> torch.Tensor:
+    """x [B,n,64] -> softmax(q k^T * scale) v for all heads, [B,n,64] (qkv projection + flash attention, two launches)."""
+    B, n, Cc = x.shape
+    nb = lib().mvs_tr_attention_operand_bytes(B, n, heads)
+    buf = torch.empty(3, nb // 2, dtype=torch.bfloat16, device=x.device)
+    check(lib().mvs_tr_qkv_fwd(ptr(x), ptr(wqkv_packed), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), float(softmax_scale), B, n, heads,
+                               precision, stream_of(x)), "mvs_tr_qkv_fwd")
+    out = torch.empty(B, n, Cc, dtype=torch.float32, device=x.device)
+    check(lib().mvs_tr_attention_fwd(ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(out), B, n, heads, precision, stream_of(x)),
+          "mvs_tr_attention_fwd")
+    return out
+
+
+def tr_up_prob(tokens: torch.Tensor, w_packed, up_bias, ln_w, ln_b, prob_w, prob_b, dhw, rate, precision: int) -> torch.Tensor:
+    B = tokens.shape[0]
+    D, H, W = dhw
+    logits = torch.empty(B, D, H, W, dtype=torch.float32, device=tokens.device)
+    check(lib().mvs_tr_up_prob_fwd(ptr(tokens), ptr(w_packed), ptr(up_bias), ptr(ln_w), ptr(ln_b), ptr(prob_w), ptr(prob_b), ptr(logits),
+                                   B, D, H, W, rate[0], rate[1], rate[2], precision, stream_of(tokens)), "mvs_tr_up_prob_fwd")
+    return logits
+
+
 # ---- a13-a16 ------------------------------------------------------------------------------------
 def depth_regression(p: torch.Tensor, depth_values: torch.Tensor) -> torch.Tensor:
     pp, dv = _f32c(p), _f32c(depth_values)

@@ -93,6 +93,29 @@ def pack_conv_weights_bf16x3(w: torch.Tensor, ch: int) -> torch.Tensor:
     return _split_bf16(full).permute(1, 2, 3, 0, 4, 5, 6).contiguous().reshape(-1)                           # [pass, step, mb, 2, g, j, e]
 
 
+def pack_linear_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] (y = x @ w.T; N % 16 == 0, K % 32 == 0) -> bf16 1-D tensor for ``tr_gemm_kernel``:
+
+        packed[step][mb][hi|lo][lane = g*16 + j][e] = w[16*mb + j][32*step + 8*g + e]
+    """
+    n, k = w.shape
+    assert n % 16 == 0 and k % 32 == 0, (n, k)
+    full = w.float().reshape(n // 16, 16, k // 32, 4, 8).permute(2, 0, 3, 1, 4)                                # [step, mb, g, j, e]
+    return _split_bf16(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1)                                # [step, mb, 2, g, j, e]
+
+
+def patch_embed_matrix(w: torch.Tensor) -> torch.Tensor:
+    """Conv3d(kernel = stride) weight [Cout, Cin, rd, rh, rw] -> [Cout, patch_voxel*Cin + ci] (k order of the patch gather)."""
+    co, ci = w.shape[:2]
+    return w.float().permute(0, 2, 3, 4, 1).reshape(co, -1).contiguous()
+
+
+def patch_expand_matrix(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose3d(kernel = stride) weight [Cin, Cout, rd, rh, rw] -> [patch_voxel*Cout + co, Cin]."""
+    ci, co = w.shape[:2]
+    return w.float().permute(2, 3, 4, 1, 0).reshape(-1, ci).contiguous()
+
+
 def deconv_class_taps(sd: int):
     """Parity classes of ConvTranspose3d(k3, stride (sd,2,2)) in the kernels' order, each a list of tap indices
     (kd*3 + kh)*3 + kw ordered (a_d, a_h, a_w) with a_w fastest - mirrors ``bf_deconv_load_step``."""

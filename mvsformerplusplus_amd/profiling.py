@@ -83,12 +83,43 @@ def _regnet_layers(net, vol, stage, launches, precision):
     return deconv(x, 8, 8, vol)
 
 
+def _transformer_layers(net, vol, pos, stage, launches):
+    """The launches of PureTransformerCostReg.logits_cl one by one (same kernels, same order)."""
+    import math
+    P = net._cache.get(net, net._build, "bf16x3")
+    prec = _lib.PREC_BF16X3
+    B, D, H, W, _ = vol.shape
+    rate = net.rate
+    n = (D // rate[0]) * (H // rate[1]) * (W // rate[2])
+    kp = 8 * rate[0] * rate[1] * rate[2]
+    T = B * n
+    x = _timed(launches, "tr_gemm<embed>", stage, 2.0 * T * kp * 64, 4.0 * (vol.numel() + (3 * B * D * H * W if pos is not None else 0) + T * 64),
+               lambda: ops.tr_embed(vol, pos, P["pe_w"], P["pe_div"], P["down_w"], P["down_b"], *P["down_ln"], rate, prec))
+    scale = (64 // net.num_heads) ** -0.5
+    if net.softmax_scale == "entropy_invariance":
+        scale *= math.log(n, net.train_avg_length)
+    for L in P["layers"]:
+        a = _timed(launches, "[bundle] tr_gemm<qkv>+tr_attention", stage, 2.0 * T * 64 * 192 + 4.0 * B * n * n * 64,
+                   4.0 * T * (64 + 64) + 2.0 * T * 192 * 2, lambda: ops.tr_attention(x, L["qkv"], net.num_heads, scale, prec))
+        x = _timed(launches, "tr_gemm<res_ln,64>", stage, 2.0 * T * 64 * 64, 4.0 * T * 64 * 3,
+                   lambda: ops.tr_linear(a, L["proj"], L["proj_b"], _lib.TR_EPI_RES_LN, 64, prec, residual=x, gamma=L["g1"],
+                                         ln_w=L["n1"][0], ln_b=L["n1"][1], ln_eps=L["n1"][2]))
+        hdn = _timed(launches, "tr_gemm<gelu>", stage, 2.0 * T * 64 * 256, 4.0 * T * (64 + 256),
+                     lambda: ops.tr_linear(x, L["l1"], L["l1_b"], _lib.TR_EPI_GELU, 256, prec))
+        x = _timed(launches, "tr_gemm<res_ln,256>", stage, 2.0 * T * 256 * 64, 4.0 * T * (256 + 128),
+                   lambda: ops.tr_linear(hdn, L["l2"], L["l2_b"], _lib.TR_EPI_RES_LN, 64, prec, residual=x, gamma=L["g2"],
+                                         ln_w=L["n2"][0], ln_b=L["n2"][1], ln_eps=L["n2"][2]))
+    return _timed(launches, "tr_gemm<up>", stage, 2.0 * T * 64 * kp, 4.0 * (T * 64 + B * D * H * W),
+                  lambda: ops.tr_up_prob(x, P["up_w"], P["up_b"], *P["up_ln"], P["prob_w"], P["prob_b"], (D, H, W), rate, prec))
+
+
 @torch.no_grad()
 def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_values, tmp=(5.0, 5.0, 5.0, 1.0)) -> Tuple[dict, List[Launch]]:
     launches: List[Launch] = []
     n = len(head.ndepths)
     out = None
     confs = []
+    pe_range = None
     for s in range(n):
         key = "stage%d" % (s + 1)
         net = head.fusions[s]
@@ -139,6 +170,18 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             vol = _timed(launches, "warp_corr_aggregate_kernel", s, corr_flops,
                          B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
                          lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
+        if getattr(net.cost_reg, "kind", None) == "transformer":
+            pos = None
+            if head.use_pe3d:
+                pr = pe_range
+                pos, pe_range = _timed(launches, "[bundle] pos3d", s, 0, 4.0 * 4 * B * D * HW,
+                                       lambda: ops.position3d(proj[:, 0, 1, :3, :3], hyp, depth_values, pr))
+            logits = _transformer_layers(net.cost_reg, vol, pos, s, launches)
+            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * (3 * D * HW + 2 * HW),
+                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
+            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
+            confs.append(r3[1])
+            continue
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
         ks = net.cost_reg.prob_ksize

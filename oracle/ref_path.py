@@ -304,7 +304,7 @@ def pure_transformer_cost_reg(x: torch.Tensor, position3d, sd: SD, *, num_heads:
         scale = hd ** -0.5
         if softmax_scale == "entropy_invariance":
             scale = scale * math.log(N, train_avg_length)                                     # attention.py:82-83,161
-        att = torch.softmax((qkv[0] * scale) @ qkv[1].transpose(-2, -1), dim=-1) @ qkv[2]    # = SDPA(q,k,v,scale)  :96
+        att = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], scale=scale)            # attention.py:96 (no flash-attn on CPU)
         a = F.linear(att.transpose(1, 2).reshape(B, N, C), L("attn.proj.weight"), L("attn.proj.bias"))
         t = F.layer_norm(t + L("gamma1") * a, (C,), L("norm1.weight"), L("norm1.bias"), 1e-5)           # :575
         f = F.linear(F.gelu(F.linear(t, L("ffn.linear1.weight"), L("ffn.linear1.bias"))), L("ffn.linear2.weight"), L("ffn.linear2.bias"))

@@ -179,6 +179,7 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) 
     return l > 0 ? all[l - 1] : old;
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define MVS_OPAQUE_REG "r"      // x86 register class for the kernels' opaque-value asm
 
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

@@ -404,3 +404,67 @@ def case_baseline_cfg_small(device, name):
 def case_baseline_cfg_full(device, name):
     c = BASELINE_CFGS[name]
     case_cascade_fullsize_properties(device, c["full"][0], c["full"][1], c["V"], **c["inputs"])
+
+
+# ---------------------------------------------------------------- stage-1 transformer regulariser
+def _tcfg(fx):
+    import json
+    return json.loads(fx["cfg"])
+
+
+def case_transformer_golden(device):
+    """PureTransformerCostReg alone + get_position_3d against fixture f7 (generated from the reference)."""
+    from mvsformerplusplus_amd import PureTransformerCostReg, get_position_3d
+    fx = load_golden("f7_transformer.npz")
+    cfg = _tcfg(fx)
+    net = PureTransformerCostReg(8, **cfg)
+    net.load_state_dict(golden_weights(fx), strict=True)
+    net = net.eval().to(device)
+    dv = fx["depth_values"]
+    with torch.no_grad():
+        pos, hmin, hmax, wmin, wmax = get_position_3d(1, 16, 24, dev(fx["K"], device), dev(fx["hyp"], device), float(dv.min()), float(dv.max()),
+                                                      None, None, None, None)
+        assert (cpu(pos) - fx["position3d"]).abs().max() <= 1e-5
+        assert (torch.stack([cpu(hmin), cpu(hmax), cpu(wmin), cpu(wmax)]) - fx["pe_range"]).abs().max() <= 1e-3
+        pos2 = get_position_3d(1, 16, 24, dev(fx["K"], device), dev(fx["hyp"], device), dv.min(), dv.max(), hmin, hmax, wmin, wmax)[0]
+        assert torch.equal(cpu(pos2), cpu(pos)), "reusing the measured range must reproduce the positions"
+        y = cpu(net(dev(fx["x"], device), dev(fx["position3d"], device)))
+        y0 = cpu(net(dev(fx["x"], device), None))
+    tol = 2e-4 * max(1.0, float(fx["y"].abs().max()))
+    assert y.shape == fx["y"].shape
+    assert (y - fx["y"]).abs().max() <= tol, float((y - fx["y"]).abs().max())
+    assert (y0 - fx["y_nope"]).abs().max() <= tol, float((y0 - fx["y_nope"]).abs().max())
+
+
+def case_stage_transformer_golden(device):
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    fx = load_golden("f8_stage_transformer.npz")
+    args = dict(ARGS, cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(fx)])
+    st = StageNet(args, 32, 0)
+    st.load_state_dict(golden_weights(fx), strict=True)
+    st = st.eval().to(device)
+    with torch.no_grad():
+        out = st(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), tmp=5.0, position3d=dev(fx["position3d"], device))
+    assert (cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max() <= 1e-3
+    assert (cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max() <= 1e-4
+    assert rel_l1(cpu(out["depth"]), fx["depth"]) <= 1e-5
+
+
+def case_cascade_shipped_golden(device):
+    """Shipped regulariser mix (stage-1 transformer + Frustoconical PE, CostRegNet / CostRegNet3D after it) on the f4 inputs."""
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    fx, f4 = load_golden("f9_cascade_shipped.npz"), load_golden("f4_cascade.npz")
+    args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True, use_pe3d=True,
+                cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(fx)])
+    head = CascadeDepthHead(args)
+    for s, stn in enumerate(head.fusions):
+        stn.load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
+    head = head.eval().to(device)
+    feats = {"stage%d" % s: dev(f4["features%d" % s], device) for s in range(1, 5)}
+    projs = {"stage%d" % s: dev(f4["proj%d" % s], device) for s in range(1, 5)}
+    with torch.no_grad():
+        out = head(feats, projs, dev(f4["depth_values"], device))
+    for s in range(1, 5):
+        assert rel_l1(cpu(out["stage%d" % s]["depth"]), fx["depth%d" % s]) <= 1e-4, s
+    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= 1e-4
+    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-3

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     from mvsformerplusplus_amd import build
     path = build.build()                       # hipcc cross-compiles gfx950 without a GPU
     lib = _lib.bind(path)                      # getattr() on every symbol; raises if one is missing
-    assert lib.mvs_abi_version() == 2
+    assert lib.mvs_abi_version() == 3
     for name in header_symbols():
         assert hasattr(lib, name)
 
@@ -50,9 +50,37 @@ def test_backward_is_refused_not_faked():
 
 def test_unsupported_configs_raise():
     with pytest.raises(NotImplementedError):
-        StageNet({"base_ch": 8, "depth_type": "ce", "cost_reg_type": ["PureTransformerCostReg"] * 4}, 32, 0)
-    with pytest.raises(NotImplementedError):
         StageNet({"base_ch": 8, "depth_type": "ce", "fusion_type": "attn"}, 32, 0)
+    tc = dict(TRANSFORMER_CFG, attention_type="Linear")
+    with pytest.raises(NotImplementedError):
+        StageNet({"base_ch": 8, "depth_type": "ce", "cost_reg_type": ["PureTransformerCostReg"] * 4, "transformer_config": [tc]}, 32, 0)
+    with pytest.raises(NotImplementedError):
+        StageNet({"base_ch": 8, "depth_type": "ce", "cost_reg_type": ["PureTransformerCostReg"] * 4,
+                  "transformer_config": [dict(TRANSFORMER_CFG, post_norm=False)]}, 32, 0)
+
+
+TRANSFORMER_CFG = {"base_channel": 8, "mid_channel": 64, "num_heads": 4, "down_rate": [2, 4, 4], "mlp_ratio": 4, "layer_num": 6,
+                   "drop": 0.0, "attn_drop": 0.0, "position_encoding": True, "attention_type": "FLASH2",
+                   "softmax_scale": "entropy_invariance", "train_avg_length": 12185, "use_pe_proj": True}
+
+
+def test_transformer_state_dict_contract():
+    """Shipped stage-1 regulariser: the 89 cost_reg.* keys of the reference's PureTransformerCostReg (probed in make_golden.py)."""
+    st = StageNet({"base_ch": [8] * 4, "depth_type": ["ce"] * 4, "cost_reg_type": ["PureTransformerCostReg", "Normal", "Normal", "Normal"],
+                   "transformer_config": [dict(TRANSFORMER_CFG)]}, 32, 0)
+    sd = {k: v for k, v in st.state_dict().items() if k.startswith("cost_reg.")}
+    assert len(sd) == 89
+    shapes = {"cost_reg.pe_proj.weight": (8, 24, 1, 1, 1), "cost_reg.down.0.weight": (64, 8, 2, 4, 4), "cost_reg.down.0.bias": (64,),
+              "cost_reg.down.1.weight": (64,), "cost_reg.attention_layers.0.attn.qkv.weight": (192, 64),
+              "cost_reg.attention_layers.5.attn.proj.bias": (64,), "cost_reg.attention_layers.2.gamma1": (),
+              "cost_reg.attention_layers.3.ffn.linear1.weight": (256, 64), "cost_reg.attention_layers.3.ffn.linear2.weight": (64, 256),
+              "cost_reg.attention_layers.4.norm2.bias": (64,), "cost_reg.up.0.weight": (64, 8, 2, 4, 4), "cost_reg.up.0.bias": (8,),
+              "cost_reg.up.1.weight": (8,), "cost_reg.prob.weight": (1, 8, 1, 1, 1), "cost_reg.prob.bias": (1,)}
+    for k, shp in shapes.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert "cost_reg.attention_layers.0.attn.qkv.bias" not in sd
+    fx = __import__("conftest").load_golden("f8_stage_transformer.npz")
+    assert sorted(fx["w.keys"]) == sorted(st.state_dict().keys())          # key set of the REFERENCE module
 
 
 def test_state_dict_contract():

@@ -55,3 +55,15 @@ def test_generic_shapes(emu):
 
 def test_cascade_golden(emu):
     P.case_cascade_golden(emu)
+
+
+def test_transformer_golden(emu):
+    P.case_transformer_golden(emu)
+
+
+def test_stage_transformer_golden(emu):
+    P.case_stage_transformer_golden(emu)
+
+
+def test_cascade_shipped_golden(emu):
+    P.case_cascade_shipped_golden(emu)

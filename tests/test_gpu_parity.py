@@ -105,3 +105,17 @@ def test_baseline_cfgs_small_vs_oracle(name):
 def test_baseline_cfgs_fullsize_properties(name):
     """The same configs at their full image size through size-independent properties."""
     P.case_baseline_cfg_full(DEV, name)
+
+
+def test_transformer_golden():
+    """SURVEY.md section 8f #1: PureTransformerCostReg + get_position_3d vs fixture f7 (from the reference)."""
+    P.case_transformer_golden(DEV)
+
+
+def test_stage_transformer_golden():
+    P.case_stage_transformer_golden(DEV)
+
+
+def test_cascade_shipped_golden():
+    """The shipped regulariser mix (cost_reg_type of config/mvsformer++.json) end to end vs fixture f9."""
+    P.case_cascade_shipped_golden(DEV)
