@@ -16,10 +16,14 @@ LIB = os.path.join(CSRC, "libmvs_hip.so")
 STAMP = os.path.join(CSRC, ".libmvs_hip.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
+# per-file extras.  transformer_kernels: MFMA results are consumed by VALU code right away (scores -> softmax), so the
+# accumulators must live in VGPRs (the default AGPR form costs a v_accvgpr move per value and direction); no NaN can
+# occur in the softmax (masked scores are -inf, never inf - inf), which lets max chains fold into v_max3_f32.
+FILE_FLAGS = {"transformer_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]}
 
 
 def _digest():
-    h = hashlib.sha1(" ".join(FLAGS).encode())
+    h = hashlib.sha1((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
                    glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     for f in files:
@@ -35,7 +39,7 @@ def build(force=False, verbose=False, extra_flags=()):
     objs, procs = [], []
     for s in srcs:
         o = s[:-4] + ".o"
-        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + list(extra_flags) + ["-c", s, "-o", o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for cmd, p in procs:

@@ -282,16 +282,24 @@ __global__ __launch_bounds__(256) void tr_gemm_kernel(const TrArgs a) {
 
 // --------------------------------------------------------------------------------------------------
 // flash attention over all n tokens.  grid = (npad / 64, heads, B); wave w of a block owns queries 64*bx + 16w .. +15.
+//
+// Per 32 keys a wave issues 4 score MFMAs + 3 p.v MFMAs and ~8 v_exp_f32 per lane; everything else is kept off the
+// common path:
+//   * the running maximum m of a query is only raised when some score of the step exceeds it by more than 2^kLazy
+//     (one wave ballot per step, no cross-lane traffic otherwise); probabilities may therefore reach 2^kLazy, which the
+//     fp32 accumulators and the hi/lo split absorb.  "- m" is folded into the score MFMAs' accumulator input.
+//   * K / V^T blocks of 64 keys are double-buffered in LDS: global loads of block i+1 are issued before the math of
+//     block i and written after it, one barrier per block
+//   * K rows are stored chunk-rotated so that the 16 lanes of a group hit 16 different bank quads
 // --------------------------------------------------------------------------------------------------
 constexpr int kVRow = 64 * 2 + 16;          // bytes of one (hi|lo, dim) row of the staged V^T block, skewed
+constexpr float kLazy = 8.0f;
 
 __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restrict__ Q, const __bf16* __restrict__ Kb,
                                                            const __bf16* __restrict__ Vt, float* __restrict__ out, int n, int npad,
                                                            int heads) {
-    __shared__ float4 kl4[64 * 64 / 16];                 // 64 keys x [hi16 | lo16] bf16
-    __shared__ float4 vl4[32 * kVRow / 16];              // [hi | lo][16 dims][64 keys] bf16
-    char* kl = reinterpret_cast<char*>(kl4);
-    char* vl = reinterpret_cast<char*>(vl4);
+    __shared__ float4 kl4[2][64 * 64 / 16];              // 64 keys x [hi16 | lo16] bf16, 16-byte chunks rotated by key >> 2
+    __shared__ float4 vl4[2][32 * kVRow / 16];           // [hi | lo][16 dims][64 keys] bf16
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int hh = (int)blockIdx.y, b = (int)blockIdx.z;
@@ -303,23 +311,37 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
     const bf16x8 qh = *reinterpret_cast<const bf16x8*>(qrow + 8 * (g & 1));
     const bf16x8 ql = *reinterpret_cast<const bf16x8*>(qrow + 16 + 8 * (g & 1));
 
+    // staging roles: K chunk tid of the block (key = tid >> 2, 16-byte chunk tid & 3); V^T row tid >> 3, chunk tid & 7
+    const float4* ksrc = reinterpret_cast<const float4*>(Kb + hb * npad * 32) + tid;
+    const int kdst = 4 * (tid >> 2) + (((tid & 3) + (tid >> 4)) & 3);
+    const float4* vsrc = reinterpret_cast<const float4*>(Vt + (hb * 32 + (tid >> 3)) * (size_t)npad) + (tid & 7);
+    const int vdst = (tid >> 3) * kVRow + (tid & 7) * 16;
+    // operand addresses inside a block
+    const int koff0 = (4 * j + ((g + (j >> 2)) & 3)) * 16;                     // key j of a tile; tiles are 16 keys = 1024 bytes apart
+    const int voff = j * kVRow + 8 * g;
+
+    float4 kreg = ksrc[0], vreg = vsrc[0];
+    kl4[0][kdst] = kreg;
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(vl4[0]) + vdst) = vreg;
+    __syncthreads();
+
     f32x4 o = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float m = -INFINITY, l = 0.0f;
-    for (int kb = 0; kb < npad; kb += 64) {
-        __syncthreads();
-        kl4[tid] = reinterpret_cast<const float4*>(Kb + (hb * npad + kb) * 32)[tid];
-        {
-            const int row = tid >> 3, c = tid & 7;                               // row = hl * 16 + dim
-            *reinterpret_cast<float4*>(vl + row * kVRow + c * 16) =
-                reinterpret_cast<const float4*>(Vt + (hb * 32 + row) * (size_t)npad + kb)[c];
+    float m = 0.0f, l = 0.0f;
+    int buf = 0;
+    for (int kb = 0; kb < npad; kb += 64, buf ^= 1) {
+        const bool more = kb + 64 < npad;
+        if (more) {                                                            // in flight during this block's math
+            kreg = ksrc[(size_t)(kb + 64) * 4];
+            vreg = vsrc[(kb + 64) / 8];
         }
-        __syncthreads();
+        const char* kl = reinterpret_cast<const char*>(kl4[buf]);
+        const char* vl = reinterpret_cast<const char*>(vl4[buf]);
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
-            // S^T tiles (keys x queries): A = [k_hi | k_lo] of key 32*sb + 16*tile + j, 16 bytes at lane-group offset
-            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kl + (32 * sb + j) * 64 + g * 16);
-            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kl + (32 * sb + 16 + j) * 64 + g * 16);
-            f32x4 s0 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+            // S^T tiles (keys x queries) minus the running maximum: A = [k_hi | k_lo] of key 32*sb + 16*tile + j
+            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kl + sb * 2048 + koff0);
+            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kl + sb * 2048 + 1024 + koff0);
+            f32x4 s0 = (f32x4){-m, -m, -m, -m}, s1 = s0;
             s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qh, s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qh, s1, 0, 0, 0);
             s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, ql, s0, 0, 0, 0);
@@ -333,23 +355,29 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
                     if (key0 + 16 + r >= n) s[4 + r] = -INFINITY;
                 }
             }
-            // online softmax in base 2 (log2 e is folded into q); the running maximum is shared by the 4 lanes of a query
-            float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            const float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            const bool first = kb == 0 && sb == 0;                             // m starts at 0: the first step sets it, whatever the sign
+            if (first || __any(mx > kLazy)) {
+                // raise the maximum of every query of the wave to its step maximum (shared by the 4 lanes of the query)
+                float d = first ? mx : fmaxf(mx, 0.0f);
+                d = fmaxf(d, __shfl_xor(d, 16));
+                d = fmaxf(d, __shfl_xor(d, 32));
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+                m += d;
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] -= d;
+            }
             float p[8], ps = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { p[e] = __builtin_amdgcn_exp2f(s[e] - mn); ps += p[e]; }
-            l = l * alpha + ps;
-            m = mn;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] *= alpha;
+            for (int e = 0; e < 8; ++e) { p[e] = __builtin_amdgcn_exp2f(s[e]); ps += p[e]; }
+            l += ps;
             bf16x8 ph, pl;
             tr_split8(p, ph, pl);
             // A operand of p.v: V^T row of dim j, key slots e <-> (tile e / 4, row 4g + e % 4): the order the scores came in
-            const char* vr = vl + j * kVRow + (32 * sb + 4 * g) * 2;
+            const char* vr = vl + voff + sb * 64;
             const bf16x4 vh0 = *reinterpret_cast<const bf16x4*>(vr), vh1 = *reinterpret_cast<const bf16x4*>(vr + 32);
             const bf16x4 vl0 = *reinterpret_cast<const bf16x4*>(vr + 16 * kVRow), vl1 = *reinterpret_cast<const bf16x4*>(vr + 16 * kVRow + 32);
             const bf16x8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -358,6 +386,11 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o, 0, 0, 0);
         }
+        if (more) {
+            kl4[buf ^ 1][kdst] = kreg;
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(vl4[buf ^ 1]) + vdst) = vreg;
+        }
+        __syncthreads();
     }
     l = wave_sum_groups(l);
     const int tok = q0 + j;

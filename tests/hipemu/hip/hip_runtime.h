@@ -180,6 +180,13 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) 
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+static inline int hipemu_any(int pred) {
+    int all[64];
+    hipemu::wave_gather(&pred, all, sizeof(int));
+    for (int i = 0; i < 64; ++i) if (all[i]) return 1;
+    return 0;
+}
+#define __any(p) hipemu_any((p) ? 1 : 0)
 #define MVS_OPAQUE_REG "r"      // x86 register class for the kernels' opaque-value asm
 
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

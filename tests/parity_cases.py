@@ -468,3 +468,24 @@ def case_cascade_shipped_golden(device):
         assert rel_l1(cpu(out["stage%d" % s]["depth"]), fx["depth%d" % s]) <= 1e-4, s
     assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= 1e-4
     assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-3
+
+
+def case_attention_stress(device, n=200, gain=2.0):
+    """Flash attention alone against float64 softmax attention: token count not a multiple of the 64-key block (masked tail),
+    scores large and growing along the key axis so that the lazily raised running maximum must rescale in later blocks."""
+    from mvsformerplusplus_amd import _lib, ops, packing
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, n, 64, generator=g)
+    x = x * torch.linspace(0.2, 1.0, n).reshape(1, n, 1) * gain         # later keys carry larger scores
+    w = torch.randn(192, 64, generator=g) * 0.125
+    scale = 0.25 * 1.07
+    got = cpu(ops.tr_attention(dev(x, device), dev(packing.pack_linear_bf16x3(w), device), 4, scale, _lib.PREC_BF16X3))
+    qkv = (x.double() @ w.double().t()).reshape(2, n, 3, 4, 16).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(qkv[0] @ qkv[1].transpose(-2, -1) * scale, -1) @ qkv[2]
+    ref = att.transpose(1, 2).reshape(2, n, 64).float()
+    assert float((qkv[0] @ qkv[1].transpose(-2, -1)).abs().max() * scale * 1.4427) > 3 * 8.0, "the case must exceed the lazy threshold"
+    # the split-bf16 score product carries ~2^-17 relative error, i.e. an ABSOLUTE error proportional to the score in
+    # the exponent: measured relative output error ~ 5e-7 * max|score in log2 units| (1.6e-4 at 308, 2.8e-5 at 34)
+    err = float((got - ref).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max())), err
+    return err

@@ -67,3 +67,7 @@ def test_stage_transformer_golden(emu):
 
 def test_cascade_shipped_golden(emu):
     P.case_cascade_shipped_golden(emu)
+
+
+def test_attention_stress(emu):
+    P.case_attention_stress(emu)

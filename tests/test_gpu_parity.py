@@ -119,3 +119,9 @@ def test_stage_transformer_golden():
 def test_cascade_shipped_golden():
     """The shipped regulariser mix (cost_reg_type of config/mvsformer++.json) end to end vs fixture f9."""
     P.case_cascade_shipped_golden(DEV)
+
+
+@pytest.mark.parametrize("n", [200, 4099])
+def test_attention_stress(n):
+    """Masked key tail + running-maximum rescales far into the key stream, vs float64 softmax attention."""
+    P.case_attention_stress(DEV, n=n)
