@@ -19,10 +19,20 @@ r = json.loads(open('gpurun_out/bench.json').read().strip().splitlines()[-1])
 print({k: r[k] for k in ('value', 'ms_per_step', 'hbm_algorithmic_frac_of_8TBs') if k in r})
 print('roofline', r.get('roofline')); print('cpu_baseline', r.get('cpu_baseline')); print('parity', r.get('parity'))
 PY
+echo "== bench, shipped regulariser mix (stage-1 transformer + PE3D) =="
+timeout 900 python bench.py --steps 10 --warmup 2 --profile-table --cost-reg shipped > $OUT/bench_shipped.json 2> $OUT/bench_shipped.err
+grep -v "amdgpu.ids" $OUT/bench_shipped.err | grep -E "tr_|pos3d|softmax_regress|sum of"
+python - <<'PY'
+import json
+r = json.loads(open('gpurun_out/bench_shipped.json').read().strip().splitlines()[-1])
+print('shipped', {k: r[k] for k in ('value', 'ms_per_step') if k in r}, 'parity', r.get('parity'))
+PY
 echo "== rocprofv3 kernel trace (same bench command, 5 steps) =="
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof.log 2>&1
 tail -2 $ROOT/$OUT/rocprof.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_${TAG}_shipped -o ${TAG}_shipped -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-profile --cost-reg shipped > $ROOT/$OUT/rocprof_shipped.log 2>&1
+tail -1 $ROOT/$OUT/rocprof_shipped.log
 echo "== PMC: HBM traffic of every kernel (separate passes) =="
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/pmc_f.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/pmc_w.log 2>&1

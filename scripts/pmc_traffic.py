@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""rocprofv3 PMC passes (FETCH_SIZE in <dir>/f, WRITE_SIZE in <dir>/w, made by scripts/gpu_round.sh) -> per-kernel HBM
+traffic per launch:   python scripts/pmc_traffic.py gpurun_out/pmc_r01c profiles/pmc_traffic.json profiles/r01_pmc_fetch_write_raw.json
+hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md,
+HBM section), so the read side is doubled."""
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def load(dirname, counter):
+    agg = {}
+    for f in glob.glob(dirname + "/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = re.sub(r"\s+", " ", r["Kernel_Name"])
+            name = re.sub(r"^void ", "", name).replace("mvs::", "")
+            name = re.sub(r"\(.*$", "", name)
+            a = agg.setdefault(name, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return agg
+
+
+d, out, raw = sys.argv[1:4]
+f, w = load(d + "/f", "FETCH_SIZE"), load(d + "/w", "WRITE_SIZE")
+rawd, res = {}, {"_about": "HBM traffic per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes of bench.py --steps 2 "
+                           "--warmup 1, averaged over the launches of all stages). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
+                           "counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM section) so the read side is doubled. Reads "
+                           "below the algorithmic bytes mean the 256 MiB Infinity Cache served them."}
+for k in sorted(set(f) | set(w)):
+    if "at::native" in k or "elementwise" in k or k.startswith(("Cijk_", "__amd_")) or not k.strip():
+        continue                                   # torch / rocBLAS kernels of the synthetic input generation, runtime copies
+    fc, fv = f.get(k, [0, 0.0])
+    wc, wv = w.get(k, [0, 0.0])
+    fa, wa = fv / max(fc, 1), wv / max(wc, 1)
+    rawd[k] = {"calls": max(fc, wc), "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa}
+    short = re.sub(r"<.*$", "", k) if k.startswith("warp_corr") or k.startswith("weighted") else k
+    res[short] = {"hbm_bytes_per_launch": (2 * fa + wa) * 1024, "fetch_size_kb": fa, "write_size_kb": wa, "launches_sampled": max(fc, wc)}
+json.dump(res, open(out, "w"), indent=1)
+json.dump(rawd, open(raw, "w"), indent=1)
+print("wrote", out, raw, len(res) - 1, "kernels")

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 (ROCm 7.2) rocpd SQLite result as a kernel-stats CSV (what `--stats` prints):
-   python scripts/rocpd_stats.py gpurun_out/prof/r01_results.db > profiles/r01_kernel_stats.csv"""
+   python scripts/rocpd_stats.py gpurun_out/prof/r01_results.db [substring] > profiles/r01_kernel_stats.csv
+With a substring (e.g. "mvs::") only kernels whose name contains it are listed (percentages then refer to that subset):
+bench.py generates its synthetic inputs with torch ops on the device, which a whole-process trace also records."""
 import re
 import sqlite3
 import sys
@@ -18,6 +20,8 @@ for name, s, e in rows:
     a[1] += d
     a[2] = min(a[2], d)
     a[3] = max(a[3], d)
+if len(sys.argv) > 2:
+    agg = {k: v for k, v in agg.items() if sys.argv[2] in k}
 tot = sum(a[1] for a in agg.values()) or 1
 print("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs")
 for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
