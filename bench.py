@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--feat-dtype", choices=["fp32", "bf16", "fp16"], default="fp32",
+                    help="dtype of the feature maps handed to the path (the reference's FPN emits bf16 under test.py:250's autocast and "
+                         "StageNet upcasts per view, cost_volume.py:67); the headline keeps fp32")
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
                     help="normal: all-'Normal' regularisers (Track R headline); shipped: stage-1 transformer + PE3D as in the shipped config")
     a = ap.parse_args()
@@ -111,7 +114,8 @@ def main():
 
     from mvsformerplusplus_amd import profiling, synth
     head = build_head(device, shipped=a.cost_reg == "shipped")
-    feats, projs, dv = synth.make_cascade_inputs(a.height, a.width, a.views, seed=rank, device=device)
+    fdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.feat_dtype]
+    feats, projs, dv = synth.make_cascade_inputs(a.height, a.width, a.views, seed=rank, device=device, feat_dtype=fdt)
     torch.cuda.synchronize()
 
     def sync_all():
@@ -145,7 +149,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD if is_cfg2 else "%dx%d V=%d 4-stage cascade" % (a.height, a.width, a.views),
                    "height": a.height, "width": a.width, "views": a.views, "global_batch": world,
-                   "parallelism": "dp%d over reference views" % world, "features": "fp32 resident in HBM"},
+                   "parallelism": "dp%d over reference views" % world, "features": "%s resident in HBM" % a.feat_dtype},
         "hbm_algorithmic_gbs_per_gpu": (ALGO_BYTES_PER_VIEW * value / world / 1e9) if is_cfg2 else None,
         "hbm_algorithmic_frac_of_8TBs": (ALGO_BYTES_PER_VIEW * value / world / 8.0e12) if is_cfg2 else None,
     }
