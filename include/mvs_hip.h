@@ -211,6 +211,32 @@ int mvs_tr_up_prob_fwd(const float* tokens, const void* w_packed, const float* u
                        const float* ln_b, const float* prob_w, const float* prob_b, float* logits, int B, int D, int H,
                        int W, int rd, int rh, int rw, int precision, void* stream);
 
+/* ==== section 8f #3: depth-map filtering after inference ============================================
+ * misc/fusion.py (reprojection-consistency filters) as driven by test.py:388-409 ("pcd") and test.py:455-483 ("dpcd").
+ * Cameras: [N,2,4,4] as everywhere (0 = extrinsic world->camera, 1 = intrinsic in the top-left 3x3), first packed once per
+ * camera into mvs_fusion_campack_floats() floats {K, K^-1, E, E^-1} (the reference inverts them per call, fusion.py:24,32).
+ * Depth / confidence maps are planar fp32 [n,h,w] / [n,v,h,w]; pixel centres sit at +0.5 (fusion.py:9-10).              */
+size_t mvs_fusion_campack_floats(void);
+int mvs_fusion_prepare_cams(const float* cams /*[N,2,4,4]*/, int N, float* packed /*[N,campack]*/, void* stream);
+/* dynamic = 0: get_reproj (fusion.py:80-97) + vis_filter (:100-109) + ave_fusion (:112-114); p0 = img_dist_thresh,
+ *              p1 = depth_thresh, vthresh = view threshold; srcs_conf (nullable) zeroes source depths with conf <=
+ *              conf_thresh (test.py:389-392); vis_masks [n,v,h,w].
+ * dynamic = 1: get_reproj_dynamic (:116-153) + vis_filter_dynamic (:156-168) + test.py:463-476; p0 = dist_base,
+ *              p1 = rel_diff_base; vis_masks [n,v,v-1,h,w]; v >= 2.
+ * Either computes the reprojection from depths + cameras (xyd_in = NULL; written to xyd_out [n,v,3,h,w] / in_range_out
+ * [n,v,h,w] when non-NULL) or starts from a given one (xyd_in, in_range_in).  With depth != NULL the filter runs:
+ * depth [n,h,w] = averaged depth, geo_mask / mask [n,h,w] (mask = geo & (ref_conf > conf_thresh), ref_conf nullable),
+ * points [n,3,h,w] = world coordinates of the averaged depth (test.py:406-409); any of vis_masks / geo_mask / mask /
+ * points may be NULL.  v <= 16.                                                                                          */
+int mvs_fusion_filter_fwd(int dynamic, const float* ref_depth, const float* ref_conf, const float* srcs_depth,
+                          const float* srcs_conf, const float* ref_cam_packed, const float* srcs_cam_packed,
+                          const float* xyd_in, const float* in_range_in, float conf_thresh, float p0, float p1, float vthresh,
+                          float* xyd_out, float* in_range_out, uint8_t* vis_masks, float* depth, uint8_t* geo_mask,
+                          uint8_t* mask, float* points, int n, int v, int h, int w, void* stream);
+/* ave_fusion (fusion.py:112-114) on its own: masks [n,v,h,w] fp32 */
+int mvs_fusion_ave_fwd(const float* ref_depth, const float* reproj_xyd, const float* masks, float* out, int n, int v, int h,
+                       int w, void* stream);
+
 /* ---- layout helpers for the nn.Module-level API (NCDHW <-> channel-last) -------------------------*/
 int mvs_ncdhw_to_cl(const float* x, float* y_cl, int B, int C, int D, int H, int W, void* stream);
 int mvs_cl_to_ncdhw(const float* x_cl, float* y, int B, int C, int D, int H, int W, void* stream);

@@ -60,6 +60,10 @@ SIGNATURES = {
     "mvs_tr_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "mvs_tr_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_tr_up_prob_fwd": (_i, [_vp] * 8 + [_i] * 8 + [_vp]),
+    "mvs_fusion_campack_floats": (_sz, []),
+    "mvs_fusion_prepare_cams": (_i, [_vp, _i, _vp, _vp]),
+    "mvs_fusion_filter_fwd": (_i, [_i] + [_vp] * 8 + [_f] * 4 + [_vp] * 7 + [_i] * 4 + [_vp]),
+    "mvs_fusion_ave_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_ncdhw_to_cl": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_cl_to_ncdhw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }

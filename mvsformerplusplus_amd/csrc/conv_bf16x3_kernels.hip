@@ -205,7 +205,20 @@ __global__ __launch_bounds__(256) void vis_front_bf16x3_kernel(const float* __re
         ent_s[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? e[(size_t)yy * W + xx] : 0.0f;
     }
     __syncthreads();
-    // first layer (1 -> 16, 3x3, folded BN, ReLU) for the 18x18 tile, split into bf16 hi/lo, 8 channels per iteration
+    // first layer (1 -> 16, 3x3, folded BN, ReLU) for the 18x18 tile, split into bf16 hi/lo, 8 channels per iteration.
+    // i & 1 == tid & 1: a work-item always produces the same 8 channels, so their 72 weights + 8 biases sit in registers
+    // (indexing w1 by a lane-dependent octet made every tap a vector load: TA 79 % busy in the PMC profile)
+    float w1r[9][8], b1r[8];
+    {
+        const int oc = tid & 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(w1 + t * 16 + oc * 8), c = *reinterpret_cast<const float4*>(w1 + t * 16 + oc * 8 + 4);
+            w1r[t][0] = a.x; w1r[t][1] = a.y; w1r[t][2] = a.z; w1r[t][3] = a.w; w1r[t][4] = c.x; w1r[t][5] = c.y; w1r[t][6] = c.z; w1r[t][7] = c.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b1r[j] = b1[oc * 8 + j];
+    }
     for (int i = tid; i < Cfg::NVOX * 2; i += 256) {
         const int vox = i >> 1, oc = i & 1;
         const int dx = vox % IW, dy = vox / IW;
@@ -220,10 +233,10 @@ __global__ __launch_bounds__(256) void vis_front_bf16x3_kernel(const float* __re
                 for (int kw = 0; kw < 3; ++kw) {
                     const float ev = ent_s[(dy + kh) * EW + dx + kw];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += ev * w1[(kh * 3 + kw) * 16 + oc * 8 + j];
+                    for (int j = 0; j < 8; ++j) v[j] += ev * w1r[kh * 3 + kw][j];
                 }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] + b1[oc * 8 + j], 0.0f);
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] + b1r[j], 0.0f);
         }
         bf16x8 hi, lo;
         split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);

@@ -269,6 +269,58 @@ def tr_up_prob(tokens: torch.Tensor, w_packed, up_bias, ln_w, ln_b, prob_w, prob
     return logits
 
 
+# ---- section 8f #3: depth-map filtering ------------------------------------------------------------
+def fusion_pack_cams(cams: torch.Tensor) -> torch.Tensor:
+    """cams [..., 2, 4, 4] -> packed {K, K^-1, E, E^-1} [N, campack] for the fusion kernel."""
+    c = _f32c(cams).reshape(-1, 2, 4, 4)
+    nf = lib().mvs_fusion_campack_floats()
+    out = torch.empty(c.shape[0], nf, dtype=torch.float32, device=c.device)
+    check(lib().mvs_fusion_prepare_cams(ptr(c), c.shape[0], ptr(out), stream_of(c)), "mvs_fusion_prepare_cams")
+    return out
+
+
+def fusion_filter(dynamic: bool, ref_depth, srcs_depth, ref_cam, srcs_cam, *, ref_conf=None, srcs_conf=None, xyd_in=None, in_range_in=None,
+                  conf_thresh: float = 0.0, p0: float = 1.0, p1: float = 0.01, vthresh: float = 0.0, want_xyd: bool = False,
+                  want_filter: bool = True, want_masks: bool = False, want_points: bool = True):
+    """ref_depth [n,h,w]; srcs_depth [n,v,h,w] (or None with xyd_in [n,v,3,h,w]); cameras [n,2,4,4] / [n,v,2,4,4]."""
+    n, h, w = ref_depth.shape
+    dev = ref_depth.device
+    if xyd_in is not None:
+        xyd_in = _f32c(xyd_in)
+        v = xyd_in.shape[1]
+    else:
+        v = srcs_depth.shape[1]
+    rc = fusion_pack_cams(ref_cam) if ref_cam is not None else None
+    sc = fusion_pack_cams(srcs_cam) if srcs_cam is not None else None
+    out = {}
+    if want_xyd:
+        out["reproj_xyd"] = torch.empty(n, v, 3, h, w, dtype=torch.float32, device=dev)
+        if not dynamic:
+            out["in_range"] = torch.empty(n, v, h, w, dtype=torch.float32, device=dev)
+    if want_filter:
+        out["depth"] = torch.empty(n, h, w, dtype=torch.float32, device=dev)
+        out["geo_mask"] = torch.empty(n, h, w, dtype=torch.uint8, device=dev)
+        out["mask"] = torch.empty(n, h, w, dtype=torch.uint8, device=dev)
+        if want_masks:
+            out["vis_masks"] = torch.empty((n, v, v - 1, h, w) if dynamic else (n, v, h, w), dtype=torch.uint8, device=dev)
+        if want_points and rc is not None:
+            out["points"] = torch.empty(n, 3, h, w, dtype=torch.float32, device=dev)
+    g = out.get
+    check(lib().mvs_fusion_filter_fwd(1 if dynamic else 0, ptr(ref_depth), ptr(ref_conf), ptr(srcs_depth), ptr(srcs_conf), ptr(rc), ptr(sc),
+                                      ptr(xyd_in), ptr(in_range_in), float(conf_thresh), float(p0), float(p1), float(vthresh),
+                                      ptr(g("reproj_xyd")), ptr(g("in_range")), ptr(g("vis_masks")), ptr(g("depth")), ptr(g("geo_mask")),
+                                      ptr(g("mask")), ptr(g("points")), n, v, h, w, stream_of(ref_depth)), "mvs_fusion_filter_fwd")
+    return out
+
+
+def fusion_ave(ref_depth, reproj_xyd, masks):
+    n, h, w = ref_depth.shape
+    x = _f32c(reproj_xyd)
+    out = torch.empty(n, h, w, dtype=torch.float32, device=ref_depth.device)
+    check(lib().mvs_fusion_ave_fwd(ptr(ref_depth), ptr(x), ptr(masks), ptr(out), n, x.shape[1], h, w, stream_of(ref_depth)), "mvs_fusion_ave_fwd")
+    return out
+
+
 # ---- a13-a16 ------------------------------------------------------------------------------------
 def depth_regression(p: torch.Tensor, depth_values: torch.Tensor) -> torch.Tensor:
     pp, dv = _f32c(p), _f32c(depth_values)

@@ -296,12 +296,117 @@ def f9_cascade_shipped():
     npz("f9_cascade_shipped.npz", **arrs)
 
 
+def fusion_inputs(n_src=4, h=48, w=64, seed=10):
+    """Depth maps of one tilted plane seen from translated cameras (closed form), plus noise / outliers / holes so that every
+    mask of the filters is exercised; confidences in 0..1."""
+    g = torch.Generator().manual_seed(seed)
+    cams = synth.make_cameras(n_src + 1, h, w, baseline=30.0, rot_deg=0.0, seed=seed)          # [1,V,2,4,4], R = I
+    a, b, z0 = 0.15, -0.1, 600.0
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+    depths = []
+    for v in range(n_src + 1):
+        K, E = cams[0, v, 1, :3, :3], cams[0, v, 0]
+        C = -E[:3, 3]
+        rx, ry = (xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1]
+        depths.append((z0 + a * C[0] + b * C[1] - C[2]) / (1 - a * rx - b * ry))
+    d = torch.stack(depths)
+    d = d * (1 + 0.0008 * torch.randn(d.shape, generator=g))                                    # ~0.5 mm noise: splits the dynamic thresholds
+    out = torch.rand(d.shape, generator=g) < 0.05
+    d = torch.where(out, d * (1 + 0.05 * torch.randn(d.shape, generator=g)), d)                # 5 % outliers
+    d[1:, :, :4] = 0.0                                                                          # holes (filtered-out source depth)
+    conf = torch.rand(d.shape, generator=g)
+    return {"ref_depth": d[0][None, None].contiguous(), "srcs_depth": d[1:][None, :, None].contiguous(), "ref_conf": conf[0][None].contiguous(),
+            "srcs_conf": conf[1:][None].contiguous(), "ref_cam": cams[:, 0].contiguous(), "srcs_cam": cams[:, 1:].contiguous()}
+
+
+@torch.no_grad()
+def f10_fusion():
+    """Depth-map filtering: misc/fusion.py called the way test.py:388-409 ("pcd") and
+    test.py:455-483 ("dpcd") call it.  The reference helpers hard-code ``.cuda()`` (fusion.py:9-10); with no GPU in this
+    container the method is patched to a no-op for the duration of the call - the arithmetic is untouched."""
+    from misc import fusion as R
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        x = fusion_inputs()
+        conf_t, thres_disp, thres_view = 0.3, 1.0, 2
+        # ---- static, test.py:388-409 ----
+        sd = x["srcs_depth"].clone()
+        for i in range(sd.shape[1]):
+            sd[:, i] *= (x["srcs_conf"][:, i] > conf_t).float().unsqueeze(1)
+        prob_mask = x["ref_conf"] > conf_t
+        xyd, in_range = R.get_reproj(x["ref_depth"], sd, x["ref_cam"], x["srcs_cam"])
+        vis_masks, vis_mask = R.vis_filter(x["ref_depth"], xyd, in_range, thres_disp, 0.01, thres_view)
+        ave = R.ave_fusion(x["ref_depth"], xyd, vis_masks)
+        mask = R.bin_op_reduce([prob_mask.reshape(vis_mask.shape), vis_mask], torch.min)
+        idx_img = R.get_pixel_grids(*ave.size()[-2:]).unsqueeze(0)
+        points = R.idx_cam2world(R.idx_img2cam(idx_img, ave, x["ref_cam"]), x["ref_cam"])[..., :3, 0].permute(0, 3, 1, 2)
+        out = dict(x, conf_thresh=np.float32(conf_t), thres_disp=np.float32(thres_disp), thres_view=np.int32(thres_view),
+                   s_reproj_xyd=xyd, s_in_range=in_range, s_vis_masks=vis_masks, s_geo_mask=vis_mask, s_depth=ave, s_mask=mask, s_points=points)
+        # ---- dynamic, test.py:455-483 ----
+        v = x["srcs_depth"].shape[1]
+        dy_range = v + 1
+        xyd = R.get_reproj_dynamic(x["ref_depth"], x["srcs_depth"], x["ref_cam"], x["srcs_cam"])
+        vis_masks, vis_mask = R.vis_filter_dynamic(x["ref_depth"], xyd, dist_base=4, rel_diff_base=1300)
+        reproj_depth = xyd[:, :, -1].clone()
+        reproj_depth[~vis_mask.squeeze(2)] = 0
+        geo_mask_sums = vis_masks.sum(dim=1)
+        geo_mask_sum = vis_mask.sum(dim=1)
+        ave = (torch.sum(reproj_depth, dim=1, keepdim=True) + x["ref_depth"]) / (geo_mask_sum + 1)
+        geo_mask = geo_mask_sum >= dy_range
+        for i in range(2, dy_range):
+            geo_mask = torch.logical_or(geo_mask, geo_mask_sums[:, i - 2] >= i)
+        mask = R.bin_op_reduce([prob_mask.reshape(geo_mask.shape), geo_mask], torch.min)
+        idx_img = R.get_pixel_grids(*ave.size()[-2:]).unsqueeze(0)
+        points = R.idx_cam2world(R.idx_img2cam(idx_img, ave, x["ref_cam"]), x["ref_cam"])[..., :3, 0].permute(0, 3, 1, 2)
+        out.update(d_reproj_xyd=xyd, d_vis_masks=vis_masks, d_geo_mask=geo_mask, d_depth=ave, d_mask=mask, d_points=points)
+        print("   static: in_range %.2f geo %.2f final %.2f | dynamic: last-threshold %.2f geo %.2f final %.2f" % (
+            float(in_range.mean()), float(out["s_geo_mask"].float().mean()), float(out["s_mask"].float().mean()),
+            float(vis_mask.float().mean()), float(geo_mask.float().mean()), float(mask.float().mean())))
+        npz("f10_fusion.npz", **out)
+    finally:
+        torch.Tensor.cuda = orig
+
+
+def f11_formats():
+    """Bytes of a PFM depth map and a _cam.txt written by the reference's own writers (datasets/data_io.py:40-67, and
+    write_cam test.py:149-166 / read_camera_parameters test.py:102-112 - test.py itself is not importable here (cv2), so
+    those two small functions are executed from its source text), plus what its readers return for them."""
+    import ast
+    import tempfile
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_data_io", os.path.join(REF, "datasets", "data_io.py"))   # the package __init__ needs torchvision
+    ref_io = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_io)
+    read_pfm, save_pfm = ref_io.read_pfm, ref_io.save_pfm
+    src = open(os.path.join(REF, "test.py")).read()
+    ns = {"np": np}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("write_cam", "read_camera_parameters"):
+            exec(compile(ast.Module([node], []), "test.py", "exec"), ns)
+    rs = np.random.RandomState(11)
+    depth = (rs.rand(6, 9).astype(np.float32) * 500 + 425)
+    cam = np.zeros((2, 4, 4), np.float32)
+    cam[0] = np.eye(4, dtype=np.float32) + rs.randn(4, 4).astype(np.float32) * 0.1
+    cam[1, :3, :3] = [[361.54125, 0, 82.900625], [0, 360.3975, 66.383875], [0, 0, 1]]
+    cam[1, 3] = [425.0, 2.65, 192.0, 931.15]
+    with tempfile.TemporaryDirectory() as t:
+        save_pfm(os.path.join(t, "a.pfm"), depth)
+        ns["write_cam"](os.path.join(t, "a_cam.txt"), cam)
+        K, E = ns["read_camera_parameters"](os.path.join(t, "a_cam.txt"))
+        npz("f11_formats.npz", depth=depth, cam=cam, pfm_bytes=np.frombuffer(open(os.path.join(t, "a.pfm"), "rb").read(), np.uint8),
+            cam_bytes=np.frombuffer(open(os.path.join(t, "a_cam.txt"), "rb").read(), np.uint8),
+            depth_read_by_reference=np.ascontiguousarray(read_pfm(os.path.join(t, "a.pfm"))[0]), K_read_by_reference=K, E_read_by_reference=E)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
         for name in only:
             globals()[name]()
         sys.exit(0)
+    f10_fusion()
+    f11_formats()
     f7_transformer()
     f8_stage_transformer()
     f9_cascade_shipped()

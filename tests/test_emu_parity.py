@@ -71,3 +71,7 @@ def test_cascade_shipped_golden(emu):
 
 def test_attention_stress(emu):
     P.case_attention_stress(emu)
+
+
+def test_fusion_golden(emu):
+    P.case_fusion_golden(emu)

@@ -125,3 +125,8 @@ def test_cascade_shipped_golden():
 def test_attention_stress(n):
     """Masked key tail + running-maximum rescales far into the key stream, vs float64 softmax attention."""
     P.case_attention_stress(DEV, n=n)
+
+
+def test_fusion_golden():
+    """SURVEY.md section 8f #3: depth-map filters (static + dynamic) vs fixture f10 generated from misc/fusion.py."""
+    P.case_fusion_golden(DEV)

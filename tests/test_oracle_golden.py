@@ -126,3 +126,20 @@ def test_f9_cascade_shipped():
         assert rel_l1(out["stage%d" % s]["depth"], fx["depth%d" % s]) <= 2e-6
         assert (out["stage%d" % s]["photometric_confidence"] - fx["conf%d" % s]).abs().max() <= 1e-4
     assert rel_l1(out["refined_depth"], fx["refined_depth"]) <= 2e-6
+
+
+# ---------------------------------------------------------------- depth-map filtering
+def test_f10_fusion():
+    from oracle import fusion_ref as FR
+    fx = load_golden("f10_fusion.npz")
+    s = FR.filter_depth(fx["ref_depth"], fx["ref_conf"], fx["srcs_depth"], fx["srcs_conf"], fx["ref_cam"], fx["srcs_cam"],
+                        conf_thresh=fx["conf_thresh"], thres_disp=fx["thres_disp"], thres_view=fx["thres_view"])
+    assert (s["reproj_xyd"] - fx["s_reproj_xyd"]).abs().max() <= 1e-4
+    assert torch.equal(s["in_range"], fx["s_in_range"]) and torch.equal(s["vis_masks"], fx["s_vis_masks"])
+    assert torch.equal(s["geo_mask"], fx["s_geo_mask"]) and torch.equal(s["mask"], fx["s_mask"])
+    assert (s["depth"] - fx["s_depth"]).abs().max() <= 1e-4 and (s["points"] - fx["s_points"]).abs().max() <= 1e-3
+    d = FR.dynamic_filter_depth(fx["ref_depth"], fx["ref_conf"], fx["srcs_depth"], fx["ref_cam"], fx["srcs_cam"], conf_thresh=fx["conf_thresh"])
+    assert (d["reproj_xyd"] - fx["d_reproj_xyd"]).abs().max() <= 1e-4
+    assert torch.equal(d["vis_masks"], fx["d_vis_masks"]) and torch.equal(d["geo_mask"], fx["d_geo_mask"]) and torch.equal(d["mask"], fx["d_mask"])
+    assert (d["depth"] - fx["d_depth"]).abs().max() <= 1e-4 and (d["points"] - fx["d_points"]).abs().max() <= 1e-3
+    assert 0.2 < float(fx["s_mask"].float().mean()) < 0.8 and 0.2 < float(fx["d_mask"].float().mean()) < 0.9     # both outcomes present
