@@ -29,8 +29,8 @@ d, out, raw = sys.argv[1:4]
 f, w = load(d + "/f", "FETCH_SIZE"), load(d + "/w", "WRITE_SIZE")
 rawd, res = {}, {"_about": "HBM traffic per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes of bench.py --steps 2 "
                            "--warmup 1, averaged over the launches of all stages). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
-                           "counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM section) so the read side is doubled. Reads "
-                           "below the algorithmic bytes mean the 256 MiB Infinity Cache served them."}
+                           "counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM section) so the read side is doubled. These are the "
+                           "L2's memory-side (fabric) requests: re-use absorbed by an XCD's L2 is excluded, Infinity-Cache hits are not."}
 for k in sorted(set(f) | set(w)):
     if "at::native" in k or "elementwise" in k or k.startswith(("Cijk_", "__amd_")) or not k.strip():
         continue                                   # torch / rocBLAS kernels of the synthetic input generation, runtime copies
