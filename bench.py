@@ -223,6 +223,27 @@ def main():
         except Exception as e:
             result["batched"] = {"error": repr(e)}
 
+    # ---- shipped mix with bf16 attention probabilities (optional fast mode of the transformer stage), N = 1 ----
+    if world == 1 and a.cost_reg == "shipped" and not a.no_profile:
+        try:
+            head.fusions[0].cost_reg.attention_precision = "bf16p"
+            with torch.no_grad():
+                for _ in range(2):
+                    o2 = head(feats, projs, dv, tmp=TMP)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    o2 = head(feats, projs, dv, tmp=TMP)
+                torch.cuda.synchronize()
+                tb = (time.perf_counter() - t0) / 5
+            d1, d2 = out["refined_depth"], o2["refined_depth"]
+            result["attention_bf16p"] = {"value": a.batch / tb, "unit": "ref-views/s", "ms_per_step": tb * 1e3,
+                                         "refined_depth_rel_l1_vs_default": float(((d2 - d1).abs() / d1.abs()).mean()),
+                                         "note": "attention_precision='bf16p': softmax probabilities enter p.v as one bf16 term"}
+            head.fusions[0].cost_reg.attention_precision = "bf16x3"
+        except Exception as e:
+            result["attention_bf16p"] = {"error": repr(e)}
+
     # ---- view-sharded latency mode (N > 1): source views over ranks + RCCL all-reduce per stage ----
     if world > 1:
         try:

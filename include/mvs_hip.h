@@ -38,8 +38,10 @@ enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
 /* contraction precision of the MFMA convolutions:
  *   MVS_PREC_FP32    v_mfma_f32_16x16x4_f32, bit-exact fp32 fmaf chain (weights packed fp32)
  *   MVS_PREC_BF16X3  three-term split-bf16 product on v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32
- *                    accumulate, ~2^-16 relative product error; weights packed as hi/lo bf16)                 */
-enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1 };
+ *                    accumulate, ~2^-16 relative product error; weights packed as hi/lo bf16)
+ *   MVS_PREC_BF16P   mvs_tr_attention_fwd only: as BF16X3 (four-term scores, split v) but the softmax probabilities
+ *                    enter p.v as one bf16 term (the reference's flash-attn path keeps q, k, v and p in bf16)     */
+enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2 };
 /* epilogues of mvs_tr_linear_fwd */
 enum { MVS_TR_EPI_BIAS = 0, MVS_TR_EPI_GELU = 1, MVS_TR_EPI_RES_LN = 2 };
 
@@ -200,7 +202,8 @@ int mvs_tr_linear_fwd(const float* x, const void* w_packed, const float* bias, i
 size_t mvs_tr_attention_operand_bytes(int B, int n, int heads);
 int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, void* k, void* vt, float softmax_scale, int B, int n,
                    int heads, int precision, void* stream);
-/* softmax(q k^T) v over all n tokens -> out [B,n,heads*16] (scaled_dot_product_attention, attention.py:96)          */
+/* softmax(q k^T) v over all n tokens -> out [B,n,heads*16] (scaled_dot_product_attention, attention.py:96);
+ * precision MVS_PREC_BF16X3 or MVS_PREC_BF16P                                                                       */
 int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt, float* out, int B, int n, int heads,
                          int precision, void* stream);
 

@@ -20,7 +20,7 @@ TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
-PREC_FP32, PREC_BF16X3 = 0, 1
+PREC_FP32, PREC_BF16X3, PREC_BF16P = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

@@ -295,6 +295,9 @@ __global__ __launch_bounds__(256) void tr_gemm_kernel(const TrArgs a) {
 constexpr int kVRow = 64 * 2 + 16;          // bytes of one (hi|lo, dim) row of the staged V^T block, skewed
 constexpr float kLazy = 8.0f;
 
+// P1: probabilities enter p.v as ONE bf16 term (2^-9 relative rounding, unbiased; v keeps hi + lo, scores stay four-term):
+// -20 VALU instructions and -1 MFMA per step.  MVS_PREC_BF16P.
+template <bool P1>
 __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restrict__ Q, const __bf16* __restrict__ Kb,
                                                            const __bf16* __restrict__ Vt, float* __restrict__ out, int n, int npad,
                                                            int heads) {
@@ -375,7 +378,12 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
             for (int e = 0; e < 8; ++e) { p[e] = __builtin_amdgcn_exp2f(s[e]); ps += p[e]; }
             l += ps;
             bf16x8 ph, pl;
-            tr_split8(p, ph, pl);
+            if (P1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ph[e] = (__bf16)p[e];
+            } else {
+                tr_split8(p, ph, pl);
+            }
             // A operand of p.v: V^T row of dim j, key slots e <-> (tile e / 4, row 4g + e % 4): the order the scores came in
             const char* vr = vl + voff + sb * 64;
             const bf16x4 vh0 = *reinterpret_cast<const bf16x4*>(vr), vh1 = *reinterpret_cast<const bf16x4*>(vr + 32);
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
             const bf16x8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 vlo = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo, ph, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o, 0, 0, 0);
+            if (!P1) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o, 0, 0, 0);
         }
         if (more) {
@@ -602,10 +610,14 @@ extern "C" int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, voi
 extern "C" int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt, float* out, int B, int n, int heads, int precision,
                                     void* stream) {
     if (!q || !k || !vt || !out || B < 1 || n < 1 || heads < 1) { set_error("mvs_tr_attention_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (!only_bf16x3(precision, "mvs_tr_attention_fwd")) return MVS_ERR_UNSUPPORTED;
+    if (precision != MVS_PREC_BF16P && !only_bf16x3(precision, "mvs_tr_attention_fwd")) return MVS_ERR_UNSUPPORTED;
     const int npad = (n + 63) / 64 * 64;
-    hipLaunchKernelGGL(tr_attention_kernel, dim3(npad / 64, heads, B), dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(q),
-                       static_cast<const __bf16*>(k), static_cast<const __bf16*>(vt), out, n, npad, heads);
+    if (precision == MVS_PREC_BF16P)
+        hipLaunchKernelGGL(tr_attention_kernel<true>, dim3(npad / 64, heads, B), dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(q),
+                           static_cast<const __bf16*>(k), static_cast<const __bf16*>(vt), out, n, npad, heads);
+    else
+        hipLaunchKernelGGL(tr_attention_kernel<false>, dim3(npad / 64, heads, B), dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(q),
+                           static_cast<const __bf16*>(k), static_cast<const __bf16*>(vt), out, n, npad, heads);
     return check_launch("tr_attention_kernel");
 }
 

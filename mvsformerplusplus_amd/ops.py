@@ -247,15 +247,17 @@ def tr_linear(x: torch.Tensor, w_packed, bias, epilogue: int, N: int, precision:
     return y
 
 
-def tr_attention(x: torch.Tensor, wqkv_packed, heads: int, softmax_scale: float, precision: int) -> torch.Tensor:
-    """x [B,n,64] -> softmax(q k^T * scale) v for all heads, [B,n,64] (qkv projection + flash attention, two launches)."""
+def tr_attention(x: torch.Tensor, wqkv_packed, heads: int, softmax_scale: float, precision: int, attn_precision: Optional[int] = None) -> torch.Tensor:
+    """x [B,n,64] -> softmax(q k^T * scale) v for all heads, [B,n,64] (qkv projection + flash attention, two launches).
+    ``attn_precision`` (default = precision) may be PREC_BF16P: bf16 probabilities in the p.v product."""
     B, n, Cc = x.shape
     nb = lib().mvs_tr_attention_operand_bytes(B, n, heads)
     buf = torch.empty(3, nb // 2, dtype=torch.bfloat16, device=x.device)
     check(lib().mvs_tr_qkv_fwd(ptr(x), ptr(wqkv_packed), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), float(softmax_scale), B, n, heads,
                                precision, stream_of(x)), "mvs_tr_qkv_fwd")
     out = torch.empty(B, n, Cc, dtype=torch.float32, device=x.device)
-    check(lib().mvs_tr_attention_fwd(ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(out), B, n, heads, precision, stream_of(x)),
+    check(lib().mvs_tr_attention_fwd(ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(out), B, n, heads,
+                                     precision if attn_precision is None else attn_precision, stream_of(x)),
           "mvs_tr_attention_fwd")
     return out
 

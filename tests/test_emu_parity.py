@@ -75,3 +75,8 @@ def test_attention_stress(emu):
 
 def test_fusion_golden(emu):
     P.case_fusion_golden(emu)
+
+
+def test_attention_bf16p(emu):
+    P.case_attention_stress(emu, bf16p=True)
+    P.case_stage_transformer_bf16p(emu)

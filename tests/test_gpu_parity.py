@@ -130,3 +130,9 @@ def test_attention_stress(n):
 def test_fusion_golden():
     """SURVEY.md section 8f #3: depth-map filters (static + dynamic) vs fixture f10 generated from misc/fusion.py."""
     P.case_fusion_golden(DEV)
+
+
+def test_attention_bf16p():
+    """MVS_PREC_BF16P: bf16 softmax probabilities in p.v (optional fast mode of the transformer stage)."""
+    P.case_attention_stress(DEV, n=4099, bf16p=True)
+    P.case_stage_transformer_bf16p(DEV)
