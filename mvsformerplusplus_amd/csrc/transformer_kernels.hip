@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void tr_gemm_kernel(const TrArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------------
-// flash attention over all n tokens.  grid = (npad / 64, heads, B); wave w of a block owns queries 64*bx + 16w .. +15.
+// flash attention over all n tokens.  grid = (npad / (64 QT), heads, B); wave w of a block owns 16 QT queries.
 //
 // Per 32 keys a wave issues 4 score MFMAs + 3 p.v MFMAs and ~8 v_exp_f32 per lane; everything else is kept off the
 // common path:
@@ -297,7 +297,11 @@ constexpr float kLazy = 8.0f;
 
 // P1: probabilities enter p.v as ONE bf16 term (2^-9 relative rounding, unbiased; v keeps hi + lo, scores stay four-term):
 // -20 VALU instructions and -1 MFMA per step.  MVS_PREC_BF16P.
-template <bool P1>
+// QT: query tiles of 16 per wave; the K and V^T operands of a step are read from LDS once and used by all QT tiles, whose
+// independent score / softmax / p.v chains interleave in the issue stream.
+constexpr int kAttnQT = 1;      // measured: 2 tiles per wave 1.25 ms vs 1.12 ms per layer at 27 648 tokens (fewer, fatter waves lose more than the shared LDS reads gain)
+
+template <bool P1, int QT>
 __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restrict__ Q, const __bf16* __restrict__ Kb,
                                                            const __bf16* __restrict__ Vt, float* __restrict__ out, int n, int npad,
                                                            int heads) {
@@ -307,12 +311,16 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
     const int j = lane & 15, g = lane >> 4;
     const int hh = (int)blockIdx.y, b = (int)blockIdx.z;
     const size_t hb = (size_t)b * heads + hh;
-    const int q0 = (int)blockIdx.x * 64 + wave * 16;
+    const int q0 = ((int)blockIdx.x * 4 + wave) * 16 * QT;
 
     // B operands of the score product: lane groups 0/1 carry dims 0-7 / 8-15, groups 2/3 repeat them (they meet k_lo)
-    const __bf16* qrow = Q + (hb * npad + q0 + j) * 32;
-    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(qrow + 8 * (g & 1));
-    const bf16x8 ql = *reinterpret_cast<const bf16x8*>(qrow + 16 + 8 * (g & 1));
+    bf16x8 qh[QT], ql[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const __bf16* qrow = Q + (hb * npad + q0 + 16 * qt + j) * 32;
+        qh[qt] = *reinterpret_cast<const bf16x8*>(qrow + 8 * (g & 1));
+        ql[qt] = *reinterpret_cast<const bf16x8*>(qrow + 16 + 8 * (g & 1));
+    }
 
     // staging roles: K chunk tid of the block (key = tid >> 2, 16-byte chunk tid & 3); V^T row tid >> 3, chunk tid & 7
     const float4* ksrc = reinterpret_cast<const float4*>(Kb + hb * npad * 32) + tid;
@@ -328,8 +336,10 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
     *reinterpret_cast<float4*>(reinterpret_cast<char*>(vl4[0]) + vdst) = vreg;
     __syncthreads();
 
-    f32x4 o = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float m = 0.0f, l = 0.0f;
+    f32x4 o[QT];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { o[qt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; m[qt] = 0.0f; l[qt] = 0.0f; }
     int buf = 0;
     for (int kb = 0; kb < npad; kb += 64, buf ^= 1) {
         const bool more = kb + 64 < npad;
@@ -341,58 +351,62 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
         const char* vl = reinterpret_cast<const char*>(vl4[buf]);
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
-            // S^T tiles (keys x queries) minus the running maximum: A = [k_hi | k_lo] of key 32*sb + 16*tile + j
+            // operands shared by the wave's query tiles: A = [k_hi | k_lo] of key 32*sb + 16*tile + j; V^T row of dim j with the
+            // key slots e <-> (tile e / 4, row 4g + e % 4), the order the scores come in
             const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kl + sb * 2048 + koff0);
             const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kl + sb * 2048 + 1024 + koff0);
-            f32x4 s0 = (f32x4){-m, -m, -m, -m}, s1 = s0;
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qh, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qh, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, ql, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, ql, s1, 0, 0, 0);
-            float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            if (kb + 64 > n) {                                                   // padded keys of the last block
-                const int key0 = kb + 32 * sb + 4 * g;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (key0 + r >= n) s[r] = -INFINITY;
-                    if (key0 + 16 + r >= n) s[4 + r] = -INFINITY;
-                }
-            }
-            const float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-            const bool first = kb == 0 && sb == 0;                             // m starts at 0: the first step sets it, whatever the sign
-            if (first || __any(mx > kLazy)) {
-                // raise the maximum of every query of the wave to its step maximum (shared by the 4 lanes of the query)
-                float d = first ? mx : fmaxf(mx, 0.0f);
-                d = fmaxf(d, __shfl_xor(d, 16));
-                d = fmaxf(d, __shfl_xor(d, 32));
-                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
-                m += d;
-                l *= alpha;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] *= alpha;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s[e] -= d;
-            }
-            float p[8], ps = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { p[e] = __builtin_amdgcn_exp2f(s[e]); ps += p[e]; }
-            l += ps;
-            bf16x8 ph, pl;
-            if (P1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ph[e] = (__bf16)p[e];
-            } else {
-                tr_split8(p, ph, pl);
-            }
-            // A operand of p.v: V^T row of dim j, key slots e <-> (tile e / 4, row 4g + e % 4): the order the scores came in
             const char* vr = vl + voff + sb * 64;
             const bf16x4 vh0 = *reinterpret_cast<const bf16x4*>(vr), vh1 = *reinterpret_cast<const bf16x4*>(vr + 32);
             const bf16x4 vl0 = *reinterpret_cast<const bf16x4*>(vr + 16 * kVRow), vl1 = *reinterpret_cast<const bf16x4*>(vr + 16 * kVRow + 32);
             const bf16x8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 vlo = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo, ph, o, 0, 0, 0);
-            if (!P1) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o, 0, 0, 0);
+            const bool first = kb == 0 && sb == 0;                             // m starts at 0: the first step sets it, whatever the sign
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                // S^T tiles (keys x queries) minus the running maximum
+                f32x4 s0 = (f32x4){-m[qt], -m[qt], -m[qt], -m[qt]}, s1 = s0;
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qh[qt], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qh[qt], s1, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, ql[qt], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, ql[qt], s1, 0, 0, 0);
+                float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                if (kb + 64 > n) {                                               // padded keys of the last block
+                    const int key0 = kb + 32 * sb + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (key0 + r >= n) s[r] = -INFINITY;
+                        if (key0 + 16 + r >= n) s[4 + r] = -INFINITY;
+                    }
+                }
+                const float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+                if (first || __any(mx > kLazy)) {
+                    // raise the maximum of every query of the tile to its step maximum (shared by the 4 lanes of the query)
+                    float d = first ? mx : fmaxf(mx, 0.0f);
+                    d = fmaxf(d, __shfl_xor(d, 16));
+                    d = fmaxf(d, __shfl_xor(d, 32));
+                    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+                    m[qt] += d;
+                    l[qt] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qt][r] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[e] -= d;
+                }
+                float p[8], ps = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { p[e] = __builtin_amdgcn_exp2f(s[e]); ps += p[e]; }
+                l[qt] += ps;
+                bf16x8 ph, pl;
+                if (P1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ph[e] = (__bf16)p[e];
+                } else {
+                    tr_split8(p, ph, pl);
+                }
+                o[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo, ph, o[qt], 0, 0, 0);
+                if (!P1) o[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[qt], 0, 0, 0);
+                o[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[qt], 0, 0, 0);
+            }
         }
         if (more) {
             kl4[buf ^ 1][kdst] = kreg;
@@ -400,12 +414,15 @@ __global__ __launch_bounds__(256) void tr_attention_kernel(const __bf16* __restr
         }
         __syncthreads();
     }
-    l = wave_sum_groups(l);
-    const int tok = q0 + j;
-    if (tok < n) {
-        const float inv = 1.0f / l;
-        *reinterpret_cast<float4*>(out + (((size_t)b * n + tok) * heads + hh) * 16 + 4 * g) =
-            make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float lt = wave_sum_groups(l[qt]);
+        const int tok = q0 + 16 * qt + j;
+        if (tok < n) {
+            const float inv = 1.0f / lt;
+            *reinterpret_cast<float4*>(out + (((size_t)b * n + tok) * heads + hh) * 16 + 4 * g) =
+                make_float4(o[qt][0] * inv, o[qt][1] * inv, o[qt][2] * inv, o[qt][3] * inv);
+        }
     }
 }
 
@@ -591,7 +608,7 @@ extern "C" int mvs_tr_linear_fwd(const float* x, const void* w_packed, const flo
 }
 
 extern "C" size_t mvs_tr_attention_operand_bytes(int B, int n, int heads) {
-    const size_t npad = ((size_t)n + 63) / 64 * 64;
+    const size_t npad = ((size_t)n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT);
     return (size_t)B * heads * npad * 32 * 2;            // each of q, k, vt: 32 bf16 per (head, token)
 }
 
@@ -603,7 +620,7 @@ extern "C" int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, voi
     TrArgs a = {};
     a.x = x; a.w = w_packed; a.q = static_cast<__bf16*>(q); a.k = static_cast<__bf16*>(k); a.vt = static_cast<__bf16*>(vt);
     a.qscale = softmax_scale * 1.44269504088896340736f;    // scores in base 2
-    a.heads = heads; a.npad = (n + 63) / 64 * 64; a.n = n; a.N = 3 * 16 * heads;
+    a.heads = heads; a.npad = (n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT); a.n = n; a.N = 3 * 16 * heads;
     return launch_gemm<64, PRO_TOKENS, EPI_QKV>(a, B, (hipStream_t)stream, "tr_gemm_kernel<qkv>");
 }
 
@@ -611,12 +628,13 @@ extern "C" int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt
                                     void* stream) {
     if (!q || !k || !vt || !out || B < 1 || n < 1 || heads < 1) { set_error("mvs_tr_attention_fwd: bad arguments"); return MVS_ERR_ARG; }
     if (precision != MVS_PREC_BF16P && !only_bf16x3(precision, "mvs_tr_attention_fwd")) return MVS_ERR_UNSUPPORTED;
-    const int npad = (n + 63) / 64 * 64;
+    const int npad = (n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT);
+    const dim3 grid(npad / (64 * kAttnQT), heads, B);
     if (precision == MVS_PREC_BF16P)
-        hipLaunchKernelGGL(tr_attention_kernel<true>, dim3(npad / 64, heads, B), dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(q),
+        hipLaunchKernelGGL((tr_attention_kernel<true, kAttnQT>), grid, dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(q),
                            static_cast<const __bf16*>(k), static_cast<const __bf16*>(vt), out, n, npad, heads);
     else
-        hipLaunchKernelGGL(tr_attention_kernel<false>, dim3(npad / 64, heads, B), dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(q),
+        hipLaunchKernelGGL((tr_attention_kernel<false, kAttnQT>), grid, dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(q),
                            static_cast<const __bf16*>(k), static_cast<const __bf16*>(vt), out, n, npad, heads);
     return check_launch("tr_attention_kernel");
 }
