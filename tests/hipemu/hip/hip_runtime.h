@@ -45,6 +45,7 @@ namespace hipemu {
 struct Ids { dim3 tid, bid, bdim, gdim; };
 extern Ids cur;                      // ids of the fiber that is running right now
 void syncthreads();
+int syncthreads_and(int pred);
 int lane_id();
 // every live lane of the calling wave deposits `size` bytes; returns once all have, with all[64*size]
 // holding every lane's deposit (dead lanes: zeros)
@@ -67,6 +68,7 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& 
 #define __shared__ static
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_smem());
 #define __syncthreads() hipemu::syncthreads()
+#define __syncthreads_and(p) hipemu::syncthreads_and((p) ? 1 : 0)
 
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }

@@ -88,6 +88,18 @@ void syncthreads() {
     while (bar_gen == gen) yield_to_main();
 }
 
+// __syncthreads_and: block-wide AND of a predicate (three rendezvous: deposit, read, re-arm)
+static int and_acc = 1;
+int syncthreads_and(int pred) {
+    if (!pred) and_acc = 0;
+    syncthreads();
+    const int r = and_acc;
+    syncthreads();
+    if (cur_t == 0) and_acc = 1;
+    syncthreads();
+    return r;
+}
+
 static void wave_barrier(Wave& wv) {
     const int gen = wv.gen;
     ++wv.count;
