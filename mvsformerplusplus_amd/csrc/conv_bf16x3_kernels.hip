@@ -416,9 +416,12 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     const float* sb = skip ? skip + (size_t)b * OD * OH * OW * COUT : nullptr;
     const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + lane;          // advanced class by class
 
+    // COUT == 8: the two x-parity classes of a (pd, ph) pair ride in one MFMA (rows 0-7: pw = 0, rows 8-15: pw = 1, tap set
+    // of pw = 1; weights packed accordingly, packing.pack_deconv_weights_bf16x3)
+    constexpr bool PAIR = COUT == 8;
     constexpr int NCLS = (SD == 2 ? 2 : 1) * 4;
-    for (int cls = 0; cls < NCLS; ++cls) {
-        const int pw = cls & 1, ph = (cls >> 1) & 1, pd = (SD == 2) ? (cls >> 2) : 0;
+    for (int cls = 0; cls < NCLS; cls += PAIR ? 2 : 1) {
+        const int pw = PAIR ? 1 : (cls & 1), ph = (cls >> 1) & 1, pd = (SD == 2) ? (cls >> 2) : 0;
         f32x4 acc[MREP][NREP];
 #pragma unroll
         for (int mb = 0; mb < MREP; ++mb)
@@ -445,6 +448,20 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             const int nbg = wave * NREP + nb;
             const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
             if (mz >= D || my >= H || mx >= W) continue;
+            if (PAIR) {
+                // lane groups 0/1: channels 0-3 / 4-7 of output voxel 2mx; groups 2/3: the same of voxel 2mx + 1
+                const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1), co = 4 * (g & 1);
+                const size_t off = (((size_t)oz * OH + oy) * OW + ox) * COUT + co;
+                const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+                float4 v = make_float4(fmaxf(acc[0][nb][0] + bb.x, 0.0f), fmaxf(acc[0][nb][1] + bb.y, 0.0f), fmaxf(acc[0][nb][2] + bb.z, 0.0f),
+                                       fmaxf(acc[0][nb][3] + bb.w, 0.0f));
+                if (sb) {
+                    const float4 sk = *reinterpret_cast<const float4*>(sb + off);
+                    v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
+                }
+                *reinterpret_cast<float4*>(yb + off) = v;
+                continue;
+            }
             const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + pw;
             const size_t off = (((size_t)oz * OH + oy) * OW + ox) * COUT;
 #pragma unroll
@@ -464,9 +481,6 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// host dispatch
-// ------------------------------------------------------------------------------------------------
 template <class Cfg>
 static int launch_conv_bf(const float* x, const void* wp, const float* bias, float* y, int B, int D, int H, int W, int relu, hipStream_t st) {
     const int OD = (D + 2 * Cfg::PD - Cfg::KD) / Cfg::SD + 1, OH = (H - 1) / Cfg::SH + 1, OW = (W - 1) / Cfg::SW + 1;

@@ -138,6 +138,25 @@ def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
     mrep = (cout + 15) // 16
     wf = w.reshape(opt, 8, cout, 27).float()                                       # [oc, e, co, tap]
     chunks = []
+    if cout == 8:
+        # Cout = 8 fills only half of the 16 MFMA rows: the two x-parity classes of a (pd, ph) pair share their input voxels
+        # (pw = 1 reads inputs mx+1 and mx with kw = 0 and 2, pw = 0 reads input mx with kw = 1), so rows 0-7 carry pw = 0
+        # (zero weights on the mx+1 tap) and rows 8-15 pw = 1: 2 tap units per pair instead of 1 + 2, all 16 rows useful,
+        # and one lane group pair stores the 64 contiguous bytes of the two output voxels 2mx, 2mx+1.
+        classes = deconv_class_taps(sd)
+        for c2 in range(len(classes) // 2):
+            taps1 = classes[2 * c2 + 1]                                            # pw = 1: (a_d, a_h, a_w) with a_w fastest, kw in (0, 2)
+            noct = len(taps1) * opt
+            nst = (noct + 3) // 4
+            full = torch.zeros(nst * 4, 16, 8, dtype=torch.float32)
+            for ti, t1 in enumerate(taps1):
+                kw = t1 % 3
+                full[ti * opt:(ti + 1) * opt, 8:16] = wf[:, :, :, t1].permute(0, 2, 1)           # [oc, co, e]
+                if kw == 2:                                                                       # input mx: pw = 0 uses kw = 1 of the same (kd, kh)
+                    full[ti * opt:(ti + 1) * opt, 0:8] = wf[:, :, :, t1 - 1].permute(0, 2, 1)
+            full = full.reshape(nst, 4, 1, 16, 8).permute(0, 2, 1, 3, 4)
+            chunks.append(_split_bf16(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1))
+        return torch.cat(chunks)
     for taps in deconv_class_taps(sd):
         noct = len(taps) * opt
         nst = (noct + 3) // 4
