@@ -1,0 +1,28 @@
+"""CPU: the bench line committed under profiles/ (produced by bench.py on an MI355X) carries every field of the driver's
+contract, with consistent arithmetic.  Guards the JSON schema without needing a GPU."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["r01_bench_1gpu.json", "r01_bench_1gpu_shipped.json"])
+def test_committed_bench_line(name):
+    r = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["unit"] == "ref-views/s" and r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["data"] == "synthetic" and r["dtype"] == "f32" and "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - r["n_gpus"] * r["config"]["global_batch"] / r["n_gpus"] * 1e3 / r["ms_per_step"]) <= 1e-6 * r["value"]
+    ro = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in ro, k
+    assert ro["bound"] in ("hbm", "mfma") and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    cb = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1
+    assert r["parity"]["refined_depth_rel_l1_vs_oracle"] <= r["parity"]["bar"] == 1e-3
