@@ -136,3 +136,26 @@ def test_attention_bf16p():
     """MVS_PREC_BF16P: bf16 softmax probabilities in p.v (optional fast mode of the transformer stage)."""
     P.case_attention_stress(DEV, n=4099, bf16p=True)
     P.case_stage_transformer_bf16p(DEV)
+
+
+def test_cascade_hip_graph_capture():
+    """The whole cascade (both regulariser mixes) is capturable in a HIP graph: no host synchronisation, no allocation outside the
+    caching allocator, every launch on the current stream; a replay reproduces the eager result bit for bit."""
+    import bench
+    from mvsformerplusplus_amd import synth
+    for shipped in (False, True):
+        head = bench.build_head(DEV, shipped=shipped)
+        feats, projs, dv = synth.make_cascade_inputs(128, 192, 3, seed=3, device=DEV)
+        with torch.no_grad():
+            eager = head(feats, projs, dv)["refined_depth"].clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                head(feats, projs, dv)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                captured = head(feats, projs, dv)
+            graph.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(captured["refined_depth"], eager)
