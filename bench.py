@@ -248,22 +248,30 @@ def main():
     if world > 1:
         try:
             head.set_view_group(dist.group.WORLD)
+            # every rank must see rank 0's reference view: same features, cameras and depth range (each rank generated its own)
             f0 = {k: v.clone() for k, v in feats.items()}
-            for k in f0:
-                dist.broadcast(f0[k], 0)
+            p0 = {k: v.clone() for k, v in projs.items()}
+            d0 = dv.clone()
+            for t in list(f0.values()) + list(p0.values()) + [d0]:
+                dist.broadcast(t, 0)
             with torch.no_grad():
                 for _ in range(2):
-                    head(f0, projs, dv, tmp=TMP)
+                    o_sh = head(f0, p0, d0, tmp=TMP)
                 sync_all()
                 t0 = time.perf_counter()
                 n_lat = max(3, a.steps // 4)
                 for _ in range(n_lat):
-                    head(f0, projs, dv, tmp=TMP)
+                    o_sh = head(f0, p0, d0, tmp=TMP)
                 sync_all()
                 lat = (time.perf_counter() - t0) / n_lat
+                # all ranks hold the same result; rank 0 also checks it against its own unsharded pass
+                head.set_view_group(None)
+                o_un = head(f0, p0, d0, tmp=TMP)
+                agree = float(((o_sh["refined_depth"] - o_un["refined_depth"]).abs() / o_un["refined_depth"].abs()).mean())
             tl = torch.tensor([lat], dtype=torch.float64, device=device)
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             result["view_sharded"] = {"ms_per_ref_view": float(tl.item()) * 1e3, "ref_views_per_s": 1.0 / float(tl.item()),
+                                      "refined_depth_rel_l1_vs_unsharded": agree,
                                       "note": "ONE reference view at a time, %d source views sharded over %d ranks, "
                                               "all-reduce(sum) of [8*D*H*W + H*W] fp32 per stage" % (a.views - 1, world)}
             head.set_view_group(None)
