@@ -109,11 +109,18 @@ def main():
             print("bench.py --gpus %d must be launched with torch.distributed.run (see docstring)" % a.gpus, file=sys.stderr)
             sys.exit(2)
     import torch.distributed as dist
+    # test hooks (scripts/gpu_round.sh runs the N = 2 flow on a one-GPU box with them): all ranks on one device, gloo instead of RCCL
+    if os.environ.get("MVS_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("MVS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from mvsformerplusplus_amd import profiling, synth
     head = build_head(device, shipped=a.cost_reg == "shipped")

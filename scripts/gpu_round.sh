@@ -27,6 +27,17 @@ import json
 r = json.loads(open('gpurun_out/bench_shipped.json').read().strip().splitlines()[-1])
 print('shipped', {k: r[k] for k in ('value', 'ms_per_step') if k in r}, 'parity', r.get('parity'))
 PY
+echo "== N = 2 flow of bench.py on this one-GPU box (both ranks on the device, gloo): code path check, not a measurement =="
+MVS_BENCH_ONE_DEVICE=1 MVS_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+  --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 1 --no-profile > $OUT/bench_n2.json 2> $OUT/bench_n2.err
+python - <<'PY'
+import json
+try:
+    r = json.loads(open('gpurun_out/bench_n2.json').read().strip().splitlines()[-1])
+    print('n2', {k: r[k] for k in ('value', 'n_gpus', 'ms_per_step')}, r.get('view_sharded'))
+except Exception as e:
+    print('bench_n2.json unreadable', e)
+PY
 echo "== rocprofv3 kernel trace (same bench command, 5 steps) =="
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof.log 2>&1
