@@ -12,6 +12,10 @@ numdepth 192 (-> cascade ndepths 32/16/8/4), fp32 fe
 synthetic features / cameras and seeded random weights with randomised BatchNorm statistics (no dataset or
 checkpoint exists offline).
 
+The timed reference views are issued round-robin on `--streams` HIP streams (default 3): views are independent, so the small
+latency-bound launches of one view's coarse stages overlap the large launches of another's fine stages (+11 % over one
+stream, same per-call API as the reference's batch-1 loop); the per-kernel profile behind `roofline` is single-stream.
+
 N > 1: one process per GPU; reference views are independent, so every rank runs its own stream of reference views
 (data parallel over reference views, no data-path collective; "scaling": "weak").  The view-sharded latency mode
 with the RCCL all-reduce of partial cost volumes is timed afterwards and reported in the
@@ -91,6 +95,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the timed reference views are issued on round-robin (independent views overlap: the small "
+                         "coarse-stage launches of one view run beside the large fine-stage launches of another, SURVEY.md section 8e)")
     ap.add_argument("--batch", type=int, default=1,
                     help="reference views per forward call (the reference's test.py runs batch 1; larger batches fill the GPU on the "
                          "small coarse-level launches)")
@@ -141,12 +148,27 @@ def main():
         while time.perf_counter() - t_pre < 0.3:
             out = head(feats, projs, dv, tmp=TMP)
             torch.cuda.synchronize()
-        for _ in range(a.warmup):
-            out = head(feats, projs, dv, tmp=TMP)
+        streams = [torch.cuda.Stream(device=device) for _ in range(a.streams)] if a.streams > 1 else None
+
+        def run(n):
+            o = None
+            if streams is None:
+                for _ in range(n):
+                    o = head(feats, projs, dv, tmp=TMP)
+                return o
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream(device))
+            for i in range(n):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    o = head(feats, projs, dv, tmp=TMP)
+            for st in streams:
+                torch.cuda.current_stream(device).wait_stream(st)
+            return o
+
+        out = run(a.warmup) or out
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            out = head(feats, projs, dv, tmp=TMP)
+        out = run(a.steps)
         sync_all()
         elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -164,7 +186,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD if is_cfg2 else "%dx%d V=%d 4-stage cascade" % (a.height, a.width, a.views),
                    "height": a.height, "width": a.width, "views": a.views, "global_batch": world * a.batch,
-                   "parallelism": "dp%d over reference views" % world, "features": "%s resident in HBM" % a.feat_dtype},
+                   "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams, "features": "%s resident in HBM" % a.feat_dtype},
         "hbm_algorithmic_gbs_per_gpu": (ALGO_BYTES_PER_VIEW * value / world / 1e9) if is_cfg2 else None,
         "hbm_algorithmic_frac_of_8TBs": (ALGO_BYTES_PER_VIEW * value / world / 8.0e12) if is_cfg2 else None,
     }
