@@ -12,7 +12,7 @@ constexpr int HW = 1152 * 1536, W = 1536, NL = 32, ROUNDS = 64;   // loads per t
 struct __attribute__((packed, aligned(4))) F2 { float x, y; };
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
 
-enum { DWORD, DWORD_HALFMASK, DWORD_1LANE, X2_ALIGNED, X2_OVERLAP_EVEN, X2_OVERLAP_ODD, X2_STRIDE2_UNALIGNED, X4_ALIGNED, X4_OVERLAP, X2_ROWPAIR, LDS_B32, LDS_B64_OVERLAP };
+enum { DWORD_SPARSE8, DWORD_SPARSE_JIT, DWORD, DWORD_HALFMASK, DWORD_1LANE, X2_ALIGNED, X2_OVERLAP_EVEN, X2_OVERLAP_ODD, X2_STRIDE2_UNALIGNED, X4_ALIGNED, X4_OVERLAP, X2_ROWPAIR, LDS_B32, LDS_B64_OVERLAP };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ f, float* __restrict__ out, int shift) {
@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ f, float* __r
     for (int i = 0; i < NL; ++i) {
         const float* s = f + (size_t)(i & 7) * HW + (i >> 3) * 4 + it * shift;     // 8 planes x 4 small shifts (16-byte aligned)
         if (MODE == DWORD) acc[i] += s[p];
+        if (MODE == DWORD_SPARSE8) acc[i] += s[(lane & 7) == 0 ? p : wave0];                      // 8 lanes read their own element, 56 share one
+        if (MODE == DWORD_SPARSE_JIT) acc[i] += s[p + ((lane * 5 + i) & 3)];                       // lane-consecutive with 0..3 elements of jitter
         if (MODE == DWORD_HALFMASK) { if (lane & 1) acc[i] += s[p]; }
         if (MODE == DWORD_1LANE) { if (lane == 0) acc[i] += s[p]; }
         if (MODE == X2_ALIGNED) { const float2 v = *reinterpret_cast<const float2*>(s + wave0 + lane * 2); acc[i] += v.x + v.y; }
@@ -74,6 +76,8 @@ int main() {
     const int reps = 20;
     struct { const char* name; float ms; int bytes; } r[] = {
         {"dword, lane-consecutive            ", run<DWORD>(blocks, f, out, reps), 4},
+        {"dword, 8 own + 56 on one address   ", run<DWORD_SPARSE8>(blocks, f, out, reps), 4},
+        {"dword, consecutive + 0..3 jitter   ", run<DWORD_SPARSE_JIT>(blocks, f, out, reps), 4},
         {"dword, odd lanes only (exec mask)  ", run<DWORD_HALFMASK>(blocks, f, out, reps), 4},
         {"dword, lane 0 only (exec mask)     ", run<DWORD_1LANE>(blocks, f, out, reps), 4},
         {"dwordx2, 8B-aligned, contiguous    ", run<X2_ALIGNED>(blocks, f, out, reps), 8},
