@@ -56,7 +56,7 @@ class StageNet(nn.Module):
             self.cost_reg = CostRegNet(self.in_channels, self.in_channels)
         self.view_group = None            # torch.distributed group for view sharding (None = single GPU)
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
-        self.keep_correlation = None      # None = heuristic (ndepth >= 8); True / False force the pass-2 variant
+        self.keep_correlation = False     # True: round-1 pass 2 (stream correlation volumes kept by pass 1); A/B measurements only
         # contraction of every MFMA convolution of the stage: "bf16x3" (3-term split bf16, ~2^-16 relative) or "fp32"
         self.conv_precision = args.get("conv_precision", DEFAULT_PRECISION)
         self._vis_cache = _PackedCache()
@@ -100,7 +100,7 @@ class StageNet(nn.Module):
         prec = precision_code(self.conv_precision)
         # pass 2 either re-gathers (fine stages: few planes, many pixels) or streams the correlation volumes pass 1 kept
         # (coarse stages: 2*(V-1)*32 B per voxel is cheaper than 4*C taps per voxel and view again); measured crossover D >= 8
-        keep_ip = self.keep_correlation if self.keep_correlation is not None else (hyp.shape[1] >= 8 and W >= 2)
+        keep_ip = bool(self.keep_correlation)
         if self.view_group is None:
             if keep_ip:
                 entropy, ip = ops.warp_corr_entropy(feats, code, hom, hyp, G, keep_ip=True)

@@ -17,6 +17,8 @@
 // (+ G*D*HW*4 volume write in pass 2); both kernels are gather/L1-bound, not MFMA work.
 #include "mvs_common.h"
 
+#include <stdlib.h>
+
 namespace mvs {
 
 // ------------------------------------------------------------------------------------------------
@@ -515,6 +517,20 @@ static int check_corr_args(const char* who, const void* feat, const float* hom, 
     return MVS_OK;
 }
 
+// LDS-staged form of the two gather passes (gather_lds_kernels.hip)
+bool gl_supported(int C, int G, int D, int H, int W);
+int gl_launch_entropy(const void* feat, int dtype, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H, int W,
+                      int vb, int ve, hipStream_t st);
+int gl_launch_aggregate(const void* feat, int dtype, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
+                        int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
+
+// MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels (A/B measurements); anything else = LDS-staged where supported
+static bool use_lds_gather(int C, int G, int D, int H, int W) {
+    const char* e = getenv("MVS_GATHER_IMPL");
+    if (e && e[0] == 'd') return false;
+    return gl_supported(C, G, D, H, W);
+}
+
 }  // namespace mvs
 
 using namespace mvs;
@@ -554,6 +570,8 @@ extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const 
     if (!entropy) { set_error("mvs_warp_corr_entropy_fwd: null output"); return MVS_ERR_ARG; }
     if (ip_out && (G != 8 || W < 2)) { set_error("mvs_warp_corr_entropy_fwd: ip_out needs G == 8 and W >= 2"); return MVS_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
+    if (!ip_out && use_lds_gather(C, G, D, H, W))
+        return gl_launch_entropy(features, dtype, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, homography, hyp, entropy, ip_out, B, V, C, G, D, H, W, view_begin, view_end, st);
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, homography, hyp, entropy, ip_out, B, V, C, G, D, H, W, view_begin, view_end, st);
@@ -569,6 +587,8 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, cons
     if (!vis || !volume_cl) { set_error("mvs_warp_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
     if (!normalise && !vis_sum) { set_error("mvs_warp_corr_aggregate_fwd: partial mode needs vis_sum"); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    if (use_lds_gather(C, G, D, H, W))
+        return gl_launch_aggregate(features, dtype, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F32, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_BF16, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);

@@ -139,7 +139,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.schedule_inverse_range(pd, ph, D, head.depth_interals_ratio[s], H, W))
         hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
-        keep_ip = net.keep_correlation if net.keep_correlation is not None else D >= 8
+        keep_ip = bool(net.keep_correlation)
         ip_bytes = B * (V - 1) * D * HW * 32 if keep_ip else 0
         res_e = _timed(launches, "warp_corr_entropy_kernel", s, corr_flops,
                        B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)) + ip_bytes,

@@ -190,6 +190,7 @@ static inline int hipemu_any(int pred) {
 }
 #define __any(p) hipemu_any((p) ? 1 : 0)
 #define MVS_OPAQUE_REG "r"      // x86 register class for the kernels' opaque-value asm
+#define MVS_OPAQUE_SREG "r"
 
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
@@ -199,3 +200,4 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))

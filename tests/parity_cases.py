@@ -174,12 +174,12 @@ def case_stage_pieces(device):
     assert (cpu(vol).permute(0, 4, 1, 2, 3) - ref["volume_mean"]).abs().max() <= 2e-5
     # pass-2 variants agree: streaming the correlation volumes kept by pass 1 == gathering again
     ent2, ip = ops.warp_corr_entropy(f, code, hom, dev(hyp, device), 8, keep_ip=True)
-    assert torch.equal(cpu(ent2), cpu(ent))
+    assert (cpu(ent2) - cpu(ent)).abs().max() <= 1e-5      # direct-gather kernel vs LDS-staged kernel
     vol2, _ = ops.weighted_aggregate(ip, vis)
-    assert (cpu(vol2) - cpu(vol)).abs().max() <= 1e-6
+    assert (cpu(vol2) - cpu(vol)).abs().max() <= 1e-5
     pa, sa = ops.weighted_aggregate(ip, vis, normalise=False, view_begin=1, view_end=2)
     pb, sb = ops.weighted_aggregate(ip, vis, normalise=False, view_begin=2, view_end=3)
-    assert (cpu(ops.volume_normalise_(pa + pb, sa + sb)) - cpu(vol)).abs().max() <= 1e-6
+    assert (cpu(ops.volume_normalise_(pa + pb, sa + sb)) - cpu(vol)).abs().max() <= 1e-5
     # partial (view-sharded) form: two halves summed and normalised == the fused single pass
     v1, s1 = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, normalise=False, view_begin=1, view_end=2)
     v2, s2 = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, normalise=False, view_begin=2, view_end=3)
@@ -274,6 +274,50 @@ def case_generic_shapes(device):
         pass
     else:
         raise AssertionError("G must divide C (cost_volume.py:87)")
+
+
+def case_gather_variants(device, quick=False):
+    """LDS-staged gather passes against the oracle over every channel-octet count (C = 8..64), depth-chunk geometry
+    (D = 4, 8, 16, 32, 48: 1 / 2 / 4 work-items per pixel, looping for D > 16), ragged tiles (W not a multiple of the tile
+    width), bf16 features, out-of-frame taps, and the block-uniform fallback for windows larger than the LDS capacity
+    (per-pixel hypotheses that jump across the whole range make the tap bounding box cover > 1024 source positions)."""
+    g = torch.Generator().manual_seed(11)
+    cases = [(8, 4, 12, 24, False, torch.float32), (16, 8, 10, 40, False, torch.float32), (32, 16, 9, 24, False, torch.float32),
+             (64, 32, 8, 16, False, torch.float32), (8, 48, 6, 24, False, torch.float32), (16, 6, 36, 48, True, torch.float32),
+             (8, 4, 36, 64, True, torch.bfloat16)]
+    if quick:
+        cases = cases[:2] + cases[5:6]
+    for C, D, H, W, wild, dt in cases:
+        B, V, G = 1, 3, 8
+        cams = synth.make_cameras(V, H * 8, W * 8, baseline=60.0, rot_deg=2.0, seed=C + D, batch=B)
+        cams[:, :, 1, :2, :] /= 8
+        feats = torch.randn(B, V, C, H, W, generator=g).to(dt)
+        if wild:      # every pixel draws its own hypotheses from the whole range: taps of one tile scatter over the image
+            hyp = 430.0 + 500.0 * torch.rand(B, D, H, W, generator=g)
+        else:
+            hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.03 * torch.rand(B, D, H, W, generator=g))).contiguous()
+        ref_p = O.compose_proj(cams[:, 0])
+        f, code = ops._feat(dev(feats, device))
+        hom = ops.compose_homography(dev(cams, device))
+        ent = cpu(ops.warp_corr_entropy(f, code, hom, dev(hyp, device), G))
+        vis = torch.rand(B, V - 1, H, W, generator=g)
+        vol, _ = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), dev(vis, device), G)
+        vsum, acc = 0.0, 0.0
+        ff = feats.float()
+        for v in range(1, V):
+            warped, _ = O.homo_warping_3D_with_mask(ff[:, v], O.compose_proj(cams[:, v]), ref_p, hyp)
+            ip = O.group_correlation(ff[:, 0], warped, G)
+            assert (ent[:, v - 1] - O.entropy_of_similarity(ip)[:, 0]).abs().max() <= 5e-5, (C, D, "entropy")
+            acc = acc + ip * vis[:, v - 1][:, None, None]
+            vsum = vsum + vis[:, v - 1]
+        expect = acc / (vsum[:, None, None] + 1e-6)
+        scale = max(1.0, float(expect.abs().max()))
+        assert (cpu(vol).permute(0, 4, 1, 2, 3) - expect).abs().max() <= 5e-5 * scale, (C, D, "volume")
+        # partial (view-sharded) form == fused form
+        v1, s1 = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), dev(vis, device), G, normalise=False, view_begin=1, view_end=2)
+        v2, s2 = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), dev(vis, device), G, normalise=False, view_begin=2, view_end=3)
+        both = ops.volume_normalise_(v1 + v2, s1 + s2)
+        assert (cpu(both) - cpu(vol)).abs().max() <= 2e-6 * scale, (C, D, "partial sums")
 
 
 # ---------------------------------------------------------------- a16 cascade
