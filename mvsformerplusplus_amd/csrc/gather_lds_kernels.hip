@@ -36,18 +36,6 @@ constexpr unsigned GL_NONE = 0xffffffffu;
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// tile geometry for D hypotheses: `ns` work-items share a pixel (one per chunk of GL_DCH planes, looping when D > 4*ns)
-struct GlGeo { int nch, ns, tp, tw, niter; };
-__host__ __device__ inline GlGeo gl_geometry(int D) {
-    GlGeo g;
-    g.nch = (D + GL_DCH - 1) / GL_DCH;
-    g.ns = g.nch >= 4 ? 4 : (g.nch >= 2 ? 2 : 1);
-    g.tp = 256 / g.ns;
-    g.tw = g.tp / GL_TH;
-    g.niter = (g.nch + g.ns - 1) / g.ns;
-    return g;
-}
-
 // Bilinear tap set as ONE 2x2 block of in-bounds source pixels: (xb, yb) = top-left corner clamped to
 // [0, W-2] x [0, H-2], with the four bilinear weights routed to whichever block slot each valid tap landed in and zero
 // for taps outside the image (ATen grid_sampler_2d, zeros padding).  pk = (yb << 16) | xb, GL_NONE when no tap is
@@ -58,7 +46,8 @@ struct GTap {
     float w00, w01, w10, w11;
 };
 
-__device__ __forceinline__ GTap make_gtap(const Homography& hm, float qx, float qy, float qz, float depth, int H, int W) {
+__device__ __forceinline__ GTap make_gtap(const Homography& hm, float qx, float qy, float qz, float depth, int H, int W, float cx,
+                                          float cy) {
     const float px = qx * depth + hm.t[0];                     // warping.py:90-92
     const float py = qy * depth + hm.t[1];
     const float pz = qz * depth + hm.t[2];
@@ -67,7 +56,8 @@ __device__ __forceinline__ GTap make_gtap(const Homography& hm, float qx, float 
     r = fmaf(fmaf(-zz, r, 1.0f), r, r);                        // one Newton step: <= 1 ulp
     const float ix = px * r, iy = py * r;
     GTap tp;
-    const bool sane = (ix > -1.0f) && (ix < (float)W) && (iy > -1.0f) && (iy < (float)H);    // false for NaN / inf
+    // -1 < ix < W and -1 < iy < H (at least one tap column and row inside the image); false for NaN / inf
+    const bool sane = (fabsf(ix - cx) < cx + 1.0f) && (fabsf(iy - cy) < cy + 1.0f);
     if (!sane) {
         tp.pk = GL_NONE; tp.w00 = 0.0f; tp.w01 = 0.0f; tp.w10 = 0.0f; tp.w11 = 0.0f;
         return tp;
@@ -76,12 +66,16 @@ __device__ __forceinline__ GTap make_gtap(const Homography& hm, float qx, float 
     const int x0 = (int)fx0, y0 = (int)fy0;                    // in [-1, W-1] x [-1, H-1]
     const float wx1 = ix - fx0, wy1 = iy - fy0;
     const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
-    const int xb = x0 < 0 ? 0 : (x0 > W - 2 ? W - 2 : x0);
-    const int yb = y0 < 0 ? 0 : (y0 > H - 2 ? H - 2 : y0);
-    const float wa = x0 < 0 ? wx1 : (x0 > W - 2 ? 0.0f : wx0);       // weight of column xb
-    const float wb = x0 < 0 ? 0.0f : (x0 > W - 2 ? wx0 : wx1);       // weight of column xb + 1
-    const float wt = y0 < 0 ? wy1 : (y0 > H - 2 ? 0.0f : wy0);       // weight of row yb
-    const float wd = y0 < 0 ? 0.0f : (y0 > H - 2 ? wy0 : wy1);       // weight of row yb + 1
+    int xb = x0, yb = y0;
+    float wa = wx0, wb = wx1, wt = wy0, wd = wy1;             // weights of column xb, xb + 1, row yb, yb + 1
+    if ((unsigned)x0 > (unsigned)(W - 2) || (unsigned)y0 > (unsigned)(H - 2)) {   // rare: the 2x2 block touches the image border
+        xb = x0 < 0 ? 0 : (x0 > W - 2 ? W - 2 : x0);
+        yb = y0 < 0 ? 0 : (y0 > H - 2 ? H - 2 : y0);
+        wa = x0 < 0 ? wx1 : (x0 > W - 2 ? 0.0f : wx0);
+        wb = x0 < 0 ? 0.0f : (x0 > W - 2 ? wx0 : wx1);
+        wt = y0 < 0 ? wy1 : (y0 > H - 2 ? 0.0f : wy0);
+        wd = y0 < 0 ? 0.0f : (y0 > H - 2 ? wy0 : wy1);
+    }
     tp.pk = ((unsigned)yb << 16) | (unsigned)xb;
     tp.w00 = wa * wt; tp.w01 = wb * wt; tp.w10 = wa * wd; tp.w11 = wb * wd;
     return tp;
@@ -89,6 +83,26 @@ __device__ __forceinline__ GTap make_gtap(const Homography& hm, float qx, float 
 
 __device__ __forceinline__ u16x2 gl_as_vec(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned gl_as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+// Wave-wide packed-u16 min / max with DPP (no LDS round trips): quad_perm, row_half_mirror, row_mirror leave every lane
+// of a 16-lane row with the row's result, row_bcast:15 / :31 fold the four rows; the full result lands in lane 63.
+template <bool MAX>
+__device__ __forceinline__ u16x2 gl_wave_reduce(u16x2 v) {
+#define GL_DPP_STEP(CTRL, ROWMASK)                                                                                             \
+    {                                                                                                                          \
+        const int cur = (int)gl_as_u32(v);                                                                                     \
+        const u16x2 o = gl_as_vec((unsigned)__builtin_amdgcn_update_dpp(cur, cur, CTRL, ROWMASK, 0xf, false));                 \
+        v = MAX ? __builtin_elementwise_max(v, o) : __builtin_elementwise_min(v, o);                                           \
+    }
+    GL_DPP_STEP(0xB1, 0xf)       // quad_perm:[1,0,3,2]
+    GL_DPP_STEP(0x4E, 0xf)       // quad_perm:[2,3,0,1]
+    GL_DPP_STEP(0x141, 0xf)      // row_half_mirror
+    GL_DPP_STEP(0x140, 0xf)      // row_mirror
+    GL_DPP_STEP(0x142, 0xa)      // row_bcast:15 -> rows 1, 3
+    GL_DPP_STEP(0x143, 0xc)      // row_bcast:31 -> rows 2, 3
+#undef GL_DPP_STEP
+    return v;
+}
 
 // One unit = one source view x the GL_DCH depth planes of every work-item of the block.
 //   KEEP_GROUPS = false: out[dd]              += wscale * sum_c ref[c] * warped[c, d]                 (pass 1)
@@ -118,21 +132,19 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
     const float qz = hm.r[6] * fx + hm.r[7] * fy + hm.r[8];
     GTap tp[GL_DCH];
     u16x2 mn = {0xffff, 0xffff}, mx = {0, 0};
+    const float cx = 0.5f * (float)(W - 1), cy = 0.5f * (float)(H - 1);
 #pragma unroll
     for (int dd = 0; dd < GL_DCH; ++dd) {
-        tp[dd] = make_gtap(hm, qx, qy, qz, depth[dd], H, W);
+        tp[dd] = make_gtap(hm, qx, qy, qz, depth[dd], H, W, cx, cy);
         if (active && tp[dd].pk != GL_NONE) {
             mn = __builtin_elementwise_min(mn, gl_as_vec(tp[dd].pk));
             mx = __builtin_elementwise_max(mx, gl_as_vec(tp[dd].pk));
         }
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        mn = __builtin_elementwise_min(mn, gl_as_vec(__shfl_xor(gl_as_u32(mn), m)));
-        mx = __builtin_elementwise_max(mx, gl_as_vec(__shfl_xor(gl_as_u32(mx), m)));
-    }
+    mn = gl_wave_reduce<false>(mn);                               // lane 63 holds the wave's result
+    mx = gl_wave_reduce<true>(mx);
     unsigned* rd = red + (unit & 1) * 8;
-    if (lane == 0) { rd[wave] = gl_as_u32(mn); rd[4 + wave] = gl_as_u32(mx); }
+    if (lane == 63) { rd[wave] = gl_as_u32(mn); rd[4 + wave] = gl_as_u32(mx); }
     __syncthreads();      // (A) bounding box complete; every thread has left the previous unit's gather
     mn = __builtin_elementwise_min(__builtin_elementwise_min(gl_as_vec(rd[0]), gl_as_vec(rd[1])),
                                    __builtin_elementwise_min(gl_as_vec(rd[2]), gl_as_vec(rd[3])));
@@ -151,7 +163,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             const unsigned pk = tp[dd].pk;
             pos[dd] = pk == GL_NONE ? 0u : ((pk >> 16) - (unsigned)ymin) * (unsigned)ww + ((pk & 0xffffu) - (unsigned)wx0);
         }
-        const float inv_ww = 1.0f / (float)ww;
+        const float inv_ww = __builtin_amdgcn_rcpf((float)ww) * 1.000001f;   // row = floor((i + 0.5) / ww): exact for i < 2^16
         const unsigned gbase = (unsigned)ymin * (unsigned)W + (unsigned)wx0;
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) {
@@ -164,7 +176,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;    // (ymin+row)*W + wx0 + (i - row*ww)
                 float v[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = to_f32(so[(size_t)c * HW + g]);
+                for (int c = 0; c < 8; ++c) v[c] = to_f32(so[(unsigned)c * HW + g]);
                 win[i] = f32x4{v[0], v[1], v[2], v[3]};
                 win[GL_CAP + i] = f32x4{v[4], v[5], v[6], v[7]};
             }
@@ -174,7 +186,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 asm volatile("" : "+" MVS_OPAQUE_REG(rofs));
                 float rf[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) rf[c] = to_f32(ref[(size_t)c * HW + rofs]) * wscale;
+                for (int c = 0; c < 8; ++c) rf[c] = to_f32(ref[(unsigned)c * HW + rofs]) * wscale;
 #pragma unroll
                 for (int dd = 0; dd < GL_DCH; ++dd) {
                     if (dd == 2) __builtin_amdgcn_sched_barrier(0);
@@ -237,15 +249,19 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
     }
 }
 
+// softmax over depth and its entropy (cost_volume.py:91-92) with the hardware exp2 / log2 (1 ulp each; the exponent's
+// argument is <= 0, so the scaling by log2(e) costs ~|x| * 6e-8 relative)
 __device__ __forceinline__ void gl_softmax_entropy_store(const float* sim, int stride, int D, float* dst) {
+    const float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     float m = -INFINITY;
     for (int d = 0; d < D; ++d) m = fmaxf(m, sim[d * stride]);
     float den = 0.0f;
-    for (int d = 0; d < D; ++d) den += expf(sim[d * stride] - m);
+    for (int d = 0; d < D; ++d) den += __builtin_amdgcn_exp2f((sim[d * stride] - m) * LOG2E);
+    const float rden = 1.0f / den;
     float ent = 0.0f;
     for (int d = 0; d < D; ++d) {
-        const float pr = expf(sim[d * stride] - m) / den;
-        ent += -pr * logf(pr + 1e-7f);                          // cost_volume.py:92
+        const float pr = __builtin_amdgcn_exp2f((sim[d * stride] - m) * LOG2E) * rden;
+        ent -= pr * (__builtin_amdgcn_logf(pr + 1e-7f) * LN2);  // cost_volume.py:92
     }
     *dst = ent;
 }
@@ -259,68 +275,112 @@ __device__ __forceinline__ Homography gl_load_homography(const float* p) {
     return hm;
 }
 
-// dynamic LDS: [ window: 2 * GL_CAP f32x4 ][ red: 16 u32 ][ sim: D * tp floats (pass 1 only) ]
+// dynamic LDS: [ window: 2 * GL_CAP f32x4 ][ red: 16 u32 ][ sim: D * TP floats (pass 1 only) ]
 constexpr size_t GL_WIN_BYTES = (size_t)2 * GL_CAP * 16;
 constexpr size_t GL_RED_BYTES = 64;
 
+// Work decomposition shared by both passes (compile-time: no run-time divisions in the prologue).  NS work-items share a
+// pixel, one per chunk of GL_DCH planes ("slot"); a block = TP = 256 / NS pixels = a tile of TW x 4.  Chunk groups of NS
+// chunks beyond the first are iterations (`it`) of a loop (pass 1) or blocks along grid.y (pass 2).
+template <int NS>
+struct GlTile {
+    static constexpr int TP = 256 / NS, TW = TP / GL_TH;
+    int slot, pi, x, y;
+    bool valid;
+    unsigned pc;
+    float fx, fy;
+    __device__ __forceinline__ GlTile(int blk, int ntx, int H, int W) {
+        const int tid = (int)threadIdx.x;
+        const int ty = blk / ntx, tx = blk - ty * ntx;
+        slot = tid / TP;
+        pi = tid % TP;
+        x = tx * TW + pi % TW;
+        y = ty * GL_TH + pi / TW;
+        valid = x < W && y < H;
+        pc = valid ? (unsigned)y * (unsigned)W + (unsigned)x : (unsigned)H * (unsigned)W - 1u;
+        fx = (float)(valid ? x : W - 1);
+        fy = (float)(valid ? y : H - 1);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // pass 1: entropy of the depth-softmax of the group-summed correlation          cost_volume.py:79-92
-// grid = (tiles, views in launch, B)
+// grid = (tiles, ceil(views in launch / vpb), B); a block walks `vpb` consecutive source views of its tile
 // ------------------------------------------------------------------------------------------------
-template <int DT, int NOCT>
+template <int DT, int NOCT, int NS>
 __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                          const float* __restrict__ hyp, float* __restrict__ entropy, int V, int D, int H,
-                                                         int W, int view_begin, int ntx, int nblk) {
+                                                         int W, int view_begin, int view_end, int vpb, int ntx, int nblk) {
     typedef typename FeatT<DT>::type T;
     HIP_DYNAMIC_SHARED(float, smem)
     f32x4* win = reinterpret_cast<f32x4*>(smem);
     unsigned* red = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem) + GL_WIN_BYTES);
     float* sim = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + GL_WIN_BYTES + GL_RED_BYTES);
     constexpr int C = 8 * NOCT;
-    const GlGeo geo = gl_geometry(D);
+    constexpr int TP = GlTile<NS>::TP;
     const unsigned HW = (unsigned)H * (unsigned)W;
-    const int tid = (int)threadIdx.x;
-    const int v = view_begin + (int)blockIdx.y, b = (int)blockIdx.z;
-    const int blk = (int)xcd_remap(blockIdx.x, (unsigned)nblk);
-    const int ty = blk / ntx, tx = blk - ty * ntx;
-    const int slot = tid / geo.tp, pi = tid - slot * geo.tp;
-    const int py = pi / geo.tw, px = pi - py * geo.tw;
-    const int x = tx * geo.tw + px, y = ty * GL_TH + py;
-    const bool valid = x < W && y < H;
-    const unsigned pc = valid ? (unsigned)y * (unsigned)W + (unsigned)x : HW - 1;
-    const float fx = (float)(valid ? x : W - 1), fy = (float)(valid ? y : H - 1);
-    const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
-    const T* feat = reinterpret_cast<const T*>(feat_);
-    const T* ref = feat + (size_t)(b * V) * C * HW;
-    const T* src = feat + (size_t)(b * V + v) * C * HW;
-    const float* hp = hyp + (size_t)b * D * HW + pc;
+    const int b = (int)blockIdx.z;
+    const GlTile<NS> t((int)xcd_remap(blockIdx.x, (unsigned)nblk), ntx, H, W);
+    const int nch = (D + GL_DCH - 1) / GL_DCH, niter = (nch + NS - 1) / NS;
+    const T* feat = reinterpret_cast<const T*>(feat_) + (size_t)(b * V) * C * HW;
+    const T* ref = feat;
+    const float* hp = hyp + (size_t)b * D * HW;
     const float inv_cpg = 1.0f / (float)NOCT;
-    for (int it = 0; it < geo.niter; ++it) {
-        const int chunk = it * geo.ns + slot;
-        const bool active = valid && chunk < geo.nch;
-        const int d0 = (chunk < geo.nch ? chunk : geo.nch - 1) * GL_DCH;
-        float depth[GL_DCH];
-#pragma unroll
-        for (int dd = 0; dd < GL_DCH; ++dd) depth[dd] = hp[(size_t)(d0 + dd < D ? d0 + dd : D - 1) * HW];
+    const int v0 = view_begin + (int)blockIdx.y * vpb, v1 = v0 + vpb < view_end ? v0 + vpb : view_end;
+    int unit = 0;
+    for (int v = v0; v < v1; ++v) {
+        const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
+        const T* src = feat + (size_t)v * C * HW;
         float s[GL_DCH];
+        for (int it = 0; it < niter; ++it, ++unit) {
+            const int chunk = it * NS + t.slot;
+            const bool active = t.valid && chunk < nch;
+            const int d0 = (chunk < nch ? chunk : nch - 1) * GL_DCH;
+            float depth[GL_DCH];
 #pragma unroll
-        for (int dd = 0; dd < GL_DCH; ++dd) s[dd] = 0.0f;
-        gl_unit<T, NOCT, false>(src, ref, hm, fx, fy, depth, active, H, W, HW, pc, win, red, it, inv_cpg, s);   // sum_g mean_c = (1/cpg) sum_c
-        if (chunk < geo.nch) {
+            for (int dd = 0; dd < GL_DCH; ++dd) depth[dd] = hp[(unsigned)(d0 + dd < D ? d0 + dd : D - 1) * HW + t.pc];
 #pragma unroll
-            for (int dd = 0; dd < GL_DCH; ++dd)
-                if (d0 + dd < D) sim[(d0 + dd) * geo.tp + pi] = s[dd];
+            for (int dd = 0; dd < GL_DCH; ++dd) s[dd] = 0.0f;
+            gl_unit<T, NOCT, false>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, s);   // sum_g mean_c = (1/cpg) sum_c
+            if (NS > 1 || niter > 1) {
+                if (chunk < nch) {
+#pragma unroll
+                    for (int dd = 0; dd < GL_DCH; ++dd)
+                        if (d0 + dd < D) sim[(d0 + dd) * TP + t.pi] = s[dd];
+                }
+            }
+        }
+        float* dst = entropy + (size_t)(b * (V - 1) + (v - 1)) * HW + t.pc;
+        if (NS == 1 && niter == 1) {
+            // every work-item owns all D <= 4 planes of its pixel: softmax-entropy straight from registers
+            const float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+            float m = s[0];
+#pragma unroll
+            for (int dd = 1; dd < GL_DCH; ++dd) m = dd < D ? fmaxf(m, s[dd]) : m;
+            float e[GL_DCH], den = 0.0f;
+#pragma unroll
+            for (int dd = 0; dd < GL_DCH; ++dd) { e[dd] = dd < D ? __builtin_amdgcn_exp2f((s[dd] - m) * LOG2E) : 0.0f; den += e[dd]; }
+            const float rden = 1.0f / den;
+            float ent = 0.0f;
+#pragma unroll
+            for (int dd = 0; dd < GL_DCH; ++dd) {
+                const float pr = e[dd] * rden;
+                if (dd < D) ent -= pr * (__builtin_amdgcn_logf(pr + 1e-7f) * LN2);                  // cost_volume.py:92
+            }
+            if (t.valid) *dst = ent;
+        } else {
+            __syncthreads();
+            // the next view's first sim store comes after its unit's barrier (A): no second barrier needed here
+            if (t.slot == 0 && t.valid) gl_softmax_entropy_store(sim + t.pi, TP, D, dst);
         }
     }
-    __syncthreads();
-    if (slot == 0 && valid) gl_softmax_entropy_store(sim + pi, geo.tp, D, entropy + (size_t)(b * (V - 1) + (v - 1)) * HW + pc);
 }
 
 // ------------------------------------------------------------------------------------------------
 // pass 2: visibility-weighted aggregation over the source views of the launch    cost_volume.py:97-101
-// grid = (tiles, 1, B); output channel-last [D,HW,8].
+// grid = (tiles, chunk groups, B); output channel-last [D,HW,8].
 // ------------------------------------------------------------------------------------------------
-template <int DT, int NOCT>
+template <int DT, int NOCT, int NS>
 __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                            const float* __restrict__ hyp, const float* __restrict__ vis,
                                                            float* __restrict__ vol, float* __restrict__ vis_sum, int normalise, int V,
@@ -330,55 +390,45 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     f32x4* win = reinterpret_cast<f32x4*>(smem);
     unsigned* red = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem) + GL_WIN_BYTES);
     constexpr int C = 8 * NOCT;
-    const GlGeo geo = gl_geometry(D);
     const unsigned HW = (unsigned)H * (unsigned)W;
-    const int tid = (int)threadIdx.x;
-    const int b = (int)blockIdx.z;
-    const int blk = (int)xcd_remap(blockIdx.x, (unsigned)nblk);
-    const int ty = blk / ntx, tx = blk - ty * ntx;
-    const int slot = tid / geo.tp, pi = tid - slot * geo.tp;
-    const int py = pi / geo.tw, px = pi - py * geo.tw;
-    const int x = tx * geo.tw + px, y = ty * GL_TH + py;
-    const bool valid = x < W && y < H;
-    const unsigned pc = valid ? (unsigned)y * (unsigned)W + (unsigned)x : HW - 1;
-    const float fx = (float)(valid ? x : W - 1), fy = (float)(valid ? y : H - 1);
-    const T* feat = reinterpret_cast<const T*>(feat_);
-    const T* ref = feat + (size_t)(b * V) * C * HW;
-    const float* hp = hyp + (size_t)b * D * HW + pc;
-    const float* vp = vis + (size_t)(b * (V - 1)) * HW + pc;
+    const int b = (int)blockIdx.z, it = (int)blockIdx.y;
+    const GlTile<NS> t((int)xcd_remap(blockIdx.x, (unsigned)nblk), ntx, H, W);
+    const int nch = (D + GL_DCH - 1) / GL_DCH;
+    const T* feat = reinterpret_cast<const T*>(feat_) + (size_t)(b * V) * C * HW;
+    const T* ref = feat;
+    const float* hp = hyp + (size_t)b * D * HW;
+    const float* vp = vis + (size_t)(b * (V - 1)) * HW + t.pc;
     float vsum = 0.0f;
-    for (int v = view_begin; v < view_end; ++v) vsum += vp[(size_t)(v - 1) * HW];                 // cost_volume.py:98
-    if (vis_sum != nullptr && slot == 0 && valid) vis_sum[(size_t)b * HW + pc] = vsum;
-    const float denom = vsum + 1e-6f;                                                             // cost_volume.py:101
+    for (int v = view_begin; v < view_end; ++v) vsum += vp[(unsigned)(v - 1) * HW];               // cost_volume.py:98
+    if (vis_sum != nullptr && it == 0 && t.slot == 0 && t.valid) vis_sum[(size_t)b * HW + t.pc] = vsum;
+    const float rdenom = normalise ? 1.0f / (vsum + 1e-6f) : 1.0f;                                // cost_volume.py:101
     const float inv_cpg = 1.0f / (float)NOCT;
+    const int chunk = it * NS + t.slot;
+    const bool active = t.valid && chunk < nch;
+    const int d0 = (chunk < nch ? chunk : nch - 1) * GL_DCH;
+    float depth[GL_DCH];
+#pragma unroll
+    for (int dd = 0; dd < GL_DCH; ++dd) depth[dd] = hp[(unsigned)(d0 + dd < D ? d0 + dd : D - 1) * HW + t.pc];
+    float acc[8 * GL_DCH];
+#pragma unroll
+    for (int i = 0; i < 8 * GL_DCH; ++i) acc[i] = 0.0f;
     int unit = 0;
-    for (int it = 0; it < geo.niter; ++it) {
-        const int chunk = it * geo.ns + slot;
-        const bool active = valid && chunk < geo.nch;
-        const int d0 = (chunk < geo.nch ? chunk : geo.nch - 1) * GL_DCH;
-        float depth[GL_DCH];
+    for (int v = view_begin; v < view_end; ++v, ++unit) {
+        const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
+        const float w = vp[(unsigned)(v - 1) * HW];                                               // cost_volume.py:97
+        gl_unit<T, NOCT, true>(feat + (size_t)v * C * HW, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg * w, acc);
+    }
+    if (active) {
+        float* vb = vol + (size_t)b * D * HW * 8;
 #pragma unroll
-        for (int dd = 0; dd < GL_DCH; ++dd) depth[dd] = hp[(size_t)(d0 + dd < D ? d0 + dd : D - 1) * HW];
-        float acc[8 * GL_DCH];
+        for (int dd = 0; dd < GL_DCH; ++dd) {
+            if (d0 + dd >= D) continue;
+            float r[8];
 #pragma unroll
-        for (int i = 0; i < 8 * GL_DCH; ++i) acc[i] = 0.0f;
-        for (int v = view_begin; v < view_end; ++v, ++unit) {
-            const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
-            const float w = vp[(size_t)(v - 1) * HW];                                             // cost_volume.py:97
-            gl_unit<T, NOCT, true>(feat + (size_t)(b * V + v) * C * HW, ref, hm, fx, fy, depth, active, H, W, HW, pc, win, red, unit,
-                                   inv_cpg * w, acc);
-        }
-        if (active) {
-#pragma unroll
-            for (int dd = 0; dd < GL_DCH; ++dd) {
-                if (d0 + dd >= D) continue;
-                float r[8];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) r[g] = normalise ? acc[g * GL_DCH + dd] / denom : acc[g * GL_DCH + dd];
-                f32x4* o = reinterpret_cast<f32x4*>(vol + ((size_t)(b * D + d0 + dd) * HW + pc) * 8);
-                o[0] = f32x4{r[0], r[1], r[2], r[3]};
-                o[1] = f32x4{r[4], r[5], r[6], r[7]};
-            }
+            for (int g = 0; g < 8; ++g) r[g] = acc[g * GL_DCH + dd] * rdenom;
+            f32x4* o = reinterpret_cast<f32x4*>(vb + ((size_t)(unsigned)(d0 + dd) * HW + t.pc) * 8);
+            o[0] = f32x4{r[0], r[1], r[2], r[3]};
+            o[1] = f32x4{r[4], r[5], r[6], r[7]};
         }
     }
 }
@@ -386,53 +436,68 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch (called from the C entry points in warp_kernels.hip)
 // ------------------------------------------------------------------------------------------------
+static int gl_slots(int D) {
+    const int nch = (D + GL_DCH - 1) / GL_DCH;
+    return nch >= 8 ? 8 : (nch >= 4 ? 4 : (nch >= 2 ? 2 : 1));
+}
+
 bool gl_supported(int C, int G, int D, int H, int W) {
     if (G != 8 || !(C == 8 || C == 16 || C == 32 || C == 64)) return false;
     if (W % GL_XALIGN != 0 || W < GL_XALIGN || H < 2 || W > 65535 || H > 65535) return false;
-    const GlGeo geo = gl_geometry(D);
-    return (size_t)D * geo.tp * sizeof(float) <= 64 * 1024;
+    if ((long long)D * H * W > 0x7fffffffLL) return false;                    // 32-bit voxel offsets inside one batch item
+    return (size_t)D * (256 / gl_slots(D)) * sizeof(float) <= 64 * 1024;
 }
 
-template <int DT, int NOCT>
+template <int DT, int NOCT, int NS>
 static int gl_launch_entropy_t(const void* feat, const float* hom, const float* hyp, float* ent, int B, int V, int D, int H, int W, int vb,
                                int ve, hipStream_t st) {
-    const GlGeo geo = gl_geometry(D);
-    const int ntx = (int)ceil_div(W, geo.tw), nty = (int)ceil_div(H, GL_TH);
+    constexpr int TP = 256 / NS, TW = TP / GL_TH;
+    const int ntx = (int)ceil_div(W, TW), nty = (int)ceil_div(H, GL_TH);
     const int nblk = ntx * nty;
-    const size_t lds = GL_WIN_BYTES + GL_RED_BYTES + (size_t)D * geo.tp * sizeof(float);
+    // plenty of tiles: one block walks all views of its tile (prologue, hypotheses and reference features amortised);
+    // few tiles (coarse stages): one block per (tile, view) so that the chip fills
+    const int vpb = (long long)nblk * B >= 4096 ? ve - vb : 1;
+    const size_t lds = GL_WIN_BYTES + GL_RED_BYTES + (size_t)D * TP * sizeof(float);
     if (lds > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_entropy_kernel<DT, NOCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gl_entropy_kernel<DT, NOCT>), dim3(nblk, ve - vb, B), dim3(256), lds, st, feat, hom, hyp, ent, V, D, H, W, vb, ntx, nblk);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_entropy_kernel<DT, NOCT, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gl_entropy_kernel<DT, NOCT, NS>), dim3(nblk, ceil_div(ve - vb, vpb), B), dim3(256), lds, st, feat, hom, hyp, ent, V, D, H,
+                       W, vb, ve, vpb, ntx, nblk);
     return check_launch("gl_entropy_kernel");
 }
 
-template <int DT, int NOCT>
+template <int DT, int NOCT, int NS>
 static int gl_launch_aggregate_t(const void* feat, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
                                  int normalise, int B, int V, int D, int H, int W, int vb, int ve, hipStream_t st) {
-    const GlGeo geo = gl_geometry(D);
-    const int ntx = (int)ceil_div(W, geo.tw), nty = (int)ceil_div(H, GL_TH);
+    constexpr int TP = 256 / NS, TW = TP / GL_TH;
+    const int ntx = (int)ceil_div(W, TW), nty = (int)ceil_div(H, GL_TH);
     const int nblk = ntx * nty;
+    const int nch = (D + GL_DCH - 1) / GL_DCH, niter = (nch + NS - 1) / NS;
     const size_t lds = GL_WIN_BYTES + GL_RED_BYTES;
-    hipLaunchKernelGGL((gl_aggregate_kernel<DT, NOCT>), dim3(nblk, 1, B), dim3(256), lds, st, feat, hom, hyp, vis, vol, vis_sum, normalise, V,
-                       D, H, W, vb, ve, ntx, nblk);
+    hipLaunchKernelGGL((gl_aggregate_kernel<DT, NOCT, NS>), dim3(nblk, niter, B), dim3(256), lds, st, feat, hom, hyp, vis, vol, vis_sum,
+                       normalise, V, D, H, W, vb, ve, ntx, nblk);
     return check_launch("gl_aggregate_kernel");
 }
 
+#define GL_DISPATCH_NS(FN, DTV, NOCTV, ...)                                                    \
+    switch (gl_slots(D)) {                                                                     \
+        case 1: return FN<DTV, NOCTV, 1>(__VA_ARGS__);                                         \
+        case 2: return FN<DTV, NOCTV, 2>(__VA_ARGS__);                                         \
+        case 4: return FN<DTV, NOCTV, 4>(__VA_ARGS__);                                         \
+        default: return FN<DTV, NOCTV, 8>(__VA_ARGS__);                                        \
+    }
+#define GL_DISPATCH_C(FN, DTV, ...)                                                            \
+    switch (C) {                                                                               \
+        case 8: GL_DISPATCH_NS(FN, DTV, 1, __VA_ARGS__)                                        \
+        case 16: GL_DISPATCH_NS(FN, DTV, 2, __VA_ARGS__)                                       \
+        case 32: GL_DISPATCH_NS(FN, DTV, 4, __VA_ARGS__)                                       \
+        default: GL_DISPATCH_NS(FN, DTV, 8, __VA_ARGS__)                                       \
+    }
 #define GL_DISPATCH(FN, ...)                                                                   \
     do {                                                                                       \
-        switch (dtype * 4 + (C == 8 ? 0 : C == 16 ? 1 : C == 32 ? 2 : 3)) {                    \
-            case 0: return FN<MVS_DTYPE_F32, 1>(__VA_ARGS__);                                  \
-            case 1: return FN<MVS_DTYPE_F32, 2>(__VA_ARGS__);                                  \
-            case 2: return FN<MVS_DTYPE_F32, 4>(__VA_ARGS__);                                  \
-            case 3: return FN<MVS_DTYPE_F32, 8>(__VA_ARGS__);                                  \
-            case 4: return FN<MVS_DTYPE_BF16, 1>(__VA_ARGS__);                                 \
-            case 5: return FN<MVS_DTYPE_BF16, 2>(__VA_ARGS__);                                 \
-            case 6: return FN<MVS_DTYPE_BF16, 4>(__VA_ARGS__);                                 \
-            case 7: return FN<MVS_DTYPE_BF16, 8>(__VA_ARGS__);                                 \
-            case 8: return FN<MVS_DTYPE_F16, 1>(__VA_ARGS__);                                  \
-            case 9: return FN<MVS_DTYPE_F16, 2>(__VA_ARGS__);                                  \
-            case 10: return FN<MVS_DTYPE_F16, 4>(__VA_ARGS__);                                 \
-            default: return FN<MVS_DTYPE_F16, 8>(__VA_ARGS__);                                 \
+        switch (dtype) {                                                                       \
+            case MVS_DTYPE_F32: GL_DISPATCH_C(FN, MVS_DTYPE_F32, __VA_ARGS__)                  \
+            case MVS_DTYPE_BF16: GL_DISPATCH_C(FN, MVS_DTYPE_BF16, __VA_ARGS__)                \
+            default: GL_DISPATCH_C(FN, MVS_DTYPE_F16, __VA_ARGS__)                             \
         }                                                                                      \
     } while (0)
 

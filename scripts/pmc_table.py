@@ -13,7 +13,8 @@ for f in sorted(glob.glob(root + "/p*/p*_counter_collection.csv")):
         per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in per.items():
         for c, vals in cs.items():
-            agg.setdefault(k, collections.OrderedDict())[c] = sum(vals) / len(vals)
+            # one row per launch group: launches are kept in order, so same-shape launches (reps) can be told apart by the caller
+            agg.setdefault(k, collections.OrderedDict())[c] = vals
 cols = []
 for k in agg:
     for c in agg[k]:
@@ -21,4 +22,6 @@ for k in agg:
 for k in agg:
     print(k)
     for c in cols:
-        if c in agg[k]: print("    %-34s %16.0f" % (c, agg[k][c]))
+        if c in agg[k]:
+            v = agg[k][c]
+            print("    %-34s n=%-3d mean %14.0f   per-launch: %s" % (c, len(v), sum(v) / len(v), " ".join("%.3g" % x for x in v[:16])))

@@ -172,16 +172,30 @@ static inline int hipemu_readfirstlane(int v) {
 }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
-// DPP: only wave_shr:1 (0x138) is used by the kernels - lane l receives src of lane l-1, lane 0 keeps `old`
-static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
-    if (ctrl != 0x138) { fprintf(stderr, "hipemu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+// DPP (gfx9 controls used by the kernels): quad_perm 0x00-0xFF, row_shr:n 0x111-0x11F, wave_shr:1 0x138, row_mirror 0x140,
+// row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.  A lane whose row / bank is masked off, or whose source
+// lane does not exist, keeps `old` (bound_ctrl:0 would give 0 for a missing source).
+static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     int all[64];
     hipemu::wave_gather(&src, all, sizeof(int));
     const int l = hipemu::lane_id();
-    return l > 0 ? all[l - 1] : old;
+    const int row = l >> 4, in_row = l & 15;
+    if (!((row_mask >> row) & 1) || !((bank_mask >> (in_row >> 2)) & 1)) return old;
+    int from = -1;
+    if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; from = in_row >= n ? l - n : -1; }
+    else if (ctrl == 0x138) from = l > 0 ? l - 1 : -1;
+    else if (ctrl == 0x140) from = (l & ~15) | (15 - in_row);
+    else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+    else if (ctrl == 0x142) from = row > 0 ? 16 * row - 1 : -1;
+    else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
+    else { fprintf(stderr, "hipemu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+    if (from < 0) return bound_ctrl ? 0 : old;
+    return all[from];
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_logf(x) log2f(x)
 static inline int hipemu_any(int pred) {
     int all[64];
     hipemu::wave_gather(&pred, all, sizeof(int));
