@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 3
+#define MVS_ABI_VERSION 4
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -69,14 +69,8 @@ int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* homography /*
  * -> entropy [B,V-1,H,W].  No [C,D,H,W] or [G,D,H,W] intermediate is materialised.
  * Only source views in [view_begin, view_end) (1-based view indices) are processed.              */
 int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homography /*[B,V-1,12]*/,
-                              const float* hyp, float* entropy, float* ip_out, int B, int V, int C, int G, int D, int H, int W,
+                              const float* hyp, float* entropy, int B, int V, int C, int G, int D, int H, int W,
                               int view_begin, int view_end, void* stream);
-/* ip_out (optional, NULL = off; needs G == 8): the per-view group correlation in_prod_vol, channel-last
- * [B,V-1,D,H,W,8] fp32 (cost_volume.py:79-87).  When it is kept, pass 2 is the streaming
- * mvs_weighted_aggregate_fwd instead of the re-gathering mvs_warp_corr_aggregate_fwd: cheaper wherever
- * 2*(V-1)*32 bytes per voxel cost less than gathering 4*C taps per voxel and view again (coarse stages). */
-int mvs_weighted_aggregate_fwd(const float* ip, const float* vis, float* volume_cl, float* vis_sum, int normalise,
-                               int B, int V, int D, int H, int W, int view_begin, int view_end, void* stream);
 
 /* ---- a5: visibility CNN, cost_volume.py:36,93 + module.py:168-197 ------------------------------
  * entropy [N,H,W] -> vis [N,H,W] = sigmoid(conv1x1(CBR(16->8)(CBR(16->16)(CBR(1->16)(entropy))))).

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
@@ -32,8 +32,7 @@ SIGNATURES = {
     "mvs_compose_homography": (_i, [_vp, _i, _i, _vp, _vp]),
     "mvs_homography_from_proj": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mvs_homo_warp_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
-    "mvs_weighted_aggregate_fwd": (_i, [_vp, _vp, _vp, _vp, _i] + [_i] * 7 + [_vp]),
+    "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mvs_vis_workspace_bytes": (_sz, [_i, _i, _i]),
     "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _i, _vp]),
     "mvs_vis_conv1_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

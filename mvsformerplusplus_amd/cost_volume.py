@@ -56,7 +56,6 @@ class StageNet(nn.Module):
             self.cost_reg = CostRegNet(self.in_channels, self.in_channels)
         self.view_group = None            # torch.distributed group for view sharding (None = single GPU)
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
-        self.keep_correlation = False     # True: round-1 pass 2 (stream correlation volumes kept by pass 1); A/B measurements only
         # contraction of every MFMA convolution of the stage: "bf16x3" (3-term split bf16, ~2^-16 relative) or "fp32"
         self.conv_precision = args.get("conv_precision", DEFAULT_PRECISION)
         self._vis_cache = _PackedCache()
@@ -98,19 +97,12 @@ class StageNet(nn.Module):
         vis_params = self._vis_params(feats.device)
 
         prec = precision_code(self.conv_precision)
-        # pass 2 either re-gathers (fine stages: few planes, many pixels) or streams the correlation volumes pass 1 kept
-        # (coarse stages: 2*(V-1)*32 B per voxel is cheaper than 4*C taps per voxel and view again); measured crossover D >= 8
-        keep_ip = bool(self.keep_correlation)
+        # pass 1 (entropy per view) -> visibility CNN -> pass 2 gathers again and writes the cost volume once: the per-view
+        # correlation volumes are never kept (round 1 kept them for D >= 8: 2 x 32 B per voxel and view of HBM traffic)
         if self.view_group is None:
-            if keep_ip:
-                entropy, ip = ops.warp_corr_entropy(feats, code, hom, hyp, G, keep_ip=True)
-                vis = ops.vis_weight(entropy, vis_params, prec)
-                volume, _ = ops.weighted_aggregate(ip, vis, normalise=True)
-                del ip
-            else:
-                entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
-                vis = ops.vis_weight(entropy, vis_params, prec)
-                volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
+            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
+            vis = ops.vis_weight(entropy, vis_params, prec)
+            volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
         else:
             volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
 

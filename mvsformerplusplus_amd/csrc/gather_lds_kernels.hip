@@ -122,7 +122,7 @@ __device__ __forceinline__ u16x2 gl_wave_reduce(u16x2 v) {
 template <typename T, int NOCT, bool KEEP_GROUPS>
 __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __restrict__ ref, const Homography& hm, float fx, float fy,
                                         const float* depth, bool active, int H, int W, unsigned HW, unsigned pc, f32x4* win,
-                                        unsigned* red, int unit, float wscale, float* out) {
+                                        unsigned* red, int unit, float wscale, const float* rf_in, float* out) {
     typedef typename PairOf<T>::type P2;
     constexpr int GPO = 8 / NOCT;          // groups per octet
     constexpr int CPG = NOCT;              // channels per group
@@ -171,6 +171,17 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             unsigned oofs = (unsigned)o * 8u * HW;
             asm volatile("" : "+" MVS_OPAQUE_SREG(oofs));
             const T* so = src + oofs;
+            // reference features of this octet: issued ahead of the staging loop so that they land while it runs (C = 8: the
+            // caller loaded them once per block)
+            float rf[8];
+            if (NOCT > 1) {
+                const T* ro = ref + oofs + pc;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rf[c] = to_f32(ro[(unsigned)c * HW]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rf[c] = rf_in[c];
+            }
             for (int i = tid; i < n; i += 256) {
                 const int row = (int)(((float)i + 0.5f) * inv_ww);
                 const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;    // (ymin+row)*W + wx0 + (i - row*ww)
@@ -182,11 +193,8 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             }
             __syncthreads();                                    // (B) window of octet o is in LDS
             if (active) {
-                unsigned rofs = (unsigned)o * 8u * HW + pc;
-                asm volatile("" : "+" MVS_OPAQUE_REG(rofs));
-                float rf[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) rf[c] = to_f32(ref[(unsigned)c * HW + rofs]) * wscale;
+                for (int c = 0; c < 8; ++c) rf[c] *= wscale;
 #pragma unroll
                 for (int dd = 0; dd < GL_DCH; ++dd) {
                     if (dd == 2) __builtin_amdgcn_sched_barrier(0);
@@ -326,6 +334,9 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
     const T* ref = feat;
     const float* hp = hyp + (size_t)b * D * HW;
     const float inv_cpg = 1.0f / (float)NOCT;
+    float rf0[8];                                               // C = 8: the pixel's reference features, once per block
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rf0[c] = NOCT == 1 ? to_f32(ref[(unsigned)c * HW + t.pc]) : 0.0f;
     const int v0 = view_begin + (int)blockIdx.y * vpb, v1 = v0 + vpb < view_end ? v0 + vpb : view_end;
     int unit = 0;
     for (int v = v0; v < v1; ++v) {
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
             for (int dd = 0; dd < GL_DCH; ++dd) depth[dd] = hp[(unsigned)(d0 + dd < D ? d0 + dd : D - 1) * HW + t.pc];
 #pragma unroll
             for (int dd = 0; dd < GL_DCH; ++dd) s[dd] = 0.0f;
-            gl_unit<T, NOCT, false>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, s);   // sum_g mean_c = (1/cpg) sum_c
+            gl_unit<T, NOCT, false>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, s);   // sum_g mean_c = (1/cpg) sum_c
             if (NS > 1 || niter > 1) {
                 if (chunk < nch) {
 #pragma unroll
@@ -403,6 +414,9 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     if (vis_sum != nullptr && it == 0 && t.slot == 0 && t.valid) vis_sum[(size_t)b * HW + t.pc] = vsum;
     const float rdenom = normalise ? 1.0f / (vsum + 1e-6f) : 1.0f;                                // cost_volume.py:101
     const float inv_cpg = 1.0f / (float)NOCT;
+    float rf0[8];                                               // C = 8: the pixel's reference features, once per block
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rf0[c] = NOCT == 1 ? to_f32(ref[(unsigned)c * HW + t.pc]) : 0.0f;
     const int chunk = it * NS + t.slot;
     const bool active = t.valid && chunk < nch;
     const int d0 = (chunk < nch ? chunk : nch - 1) * GL_DCH;
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     for (int v = view_begin; v < view_end; ++v, ++unit) {
         const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
         const float w = vp[(unsigned)(v - 1) * HW];                                               // cost_volume.py:97
-        gl_unit<T, NOCT, true>(feat + (size_t)v * C * HW, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg * w, acc);
+        gl_unit<T, NOCT, true>(feat + (size_t)v * C * HW, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg * w, rf0, acc);
     }
     if (active) {
         float* vb = vol + (size_t)b * D * HW * 8;

@@ -202,8 +202,7 @@ __device__ __forceinline__ void softmax_entropy_store(const float* sim, int stri
 template <int DT, int CT, int GT>
 __global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                                 const float* __restrict__ hyp, float* __restrict__ entropy,
-                                                                float* __restrict__ ip_out, int V, int C_, int G_, int D, int H, int W,
-                                                                int view_begin, int nblk) {
+                                                                int V, int C_, int G_, int D, int H, int W, int view_begin, int nblk) {
     typedef typename FeatT<DT>::type T;
     HIP_DYNAMIC_SHARED(float, sim)
     const int HW = H * W;
@@ -239,26 +238,9 @@ __global__ __launch_bounds__(256) void warp_corr_entropy_kernel(const void* __re
                 tp[dd] = make_pair_taps(hm, qx, qy, qz, hp[(size_t)d * HW], H, W, half_w, half_h);
             }
             float s[DCH];
-            if (ip_out != nullptr) {
-                // keep the per-group correlation: pass 2 of this stage will stream it instead of gathering again
-                float ip[DCH * 8];
-                correlate_chunk<T, 8, false>(src, ref, tp, (unsigned)HW, (unsigned)pc, cpg, ip);
 #pragma unroll
-                for (int dd = 0; dd < DCH; ++dd) {
-                    s[dd] = 0.0f;
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) s[dd] += ip[dd * 8 + g];
-                    if (valid && d0 + dd < D) {
-                        float4* o = reinterpret_cast<float4*>(ip_out + (((size_t)(b * (V - 1) + (v - 1)) * D + d0 + dd) * HW + p) * 8);
-                        o[0] = make_float4(ip[dd * 8], ip[dd * 8 + 1], ip[dd * 8 + 2], ip[dd * 8 + 3]);
-                        o[1] = make_float4(ip[dd * 8 + 4], ip[dd * 8 + 5], ip[dd * 8 + 6], ip[dd * 8 + 7]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int dd = 0; dd < DCH; ++dd) s[dd] = 0.0f;
-                correlate_chunk<T, (GT > 0 ? GT : 8), true>(src, ref, tp, (unsigned)HW, (unsigned)pc, cpg, s);
-            }
+            for (int dd = 0; dd < DCH; ++dd) s[dd] = 0.0f;
+            correlate_chunk<T, (GT > 0 ? GT : 8), true>(src, ref, tp, (unsigned)HW, (unsigned)pc, cpg, s);
 #pragma unroll
             for (int dd = 0; dd < DCH; ++dd)
                 if (d0 + dd < D) sim[(d0 + dd) * cm.ppb + pl] = s[dd];
@@ -391,35 +373,6 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_kernel(const void* __
     }
 }
 
-// pass 2, streaming form: volume = sum_v ip_v * vis_v (/ (sum_v vis_v + 1e-6)) from the correlation volumes pass 1 stored
-// (ip [B,V-1,D,HW,8]).  Pure HBM streaming: (n_views + 1) * 32 bytes per voxel.      cost_volume.py:97-101
-__global__ __launch_bounds__(256) void weighted_aggregate_kernel(const float* __restrict__ ip, const float* __restrict__ vis,
-                                                                 float* __restrict__ vol, float* __restrict__ vis_sum, int normalise, int V,
-                                                                 int D, int HW, int view_begin, int view_end) {
-    const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    const int d = (int)blockIdx.y, b = (int)blockIdx.z;
-    if (p >= HW) return;
-    float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
-    float vsum = 0.0f;
-    for (int v = view_begin; v < view_end; ++v) {
-        const float w = vis[(size_t)(b * (V - 1) + (v - 1)) * HW + p];
-        const float4* q = reinterpret_cast<const float4*>(ip + (((size_t)(b * (V - 1) + (v - 1)) * D + d) * HW + p) * 8);
-        const float4 x0 = q[0], x1 = q[1];
-        a0.x += x0.x * w; a0.y += x0.y * w; a0.z += x0.z * w; a0.w += x0.w * w;
-        a1.x += x1.x * w; a1.y += x1.y * w; a1.z += x1.z * w; a1.w += x1.w * w;
-        vsum += w;
-    }
-    if (vis_sum != nullptr && d == 0) vis_sum[(size_t)b * HW + p] = vsum;
-    if (normalise) {
-        const float den = vsum + 1e-6f;
-        a0.x = a0.x / den; a0.y = a0.y / den; a0.z = a0.z / den; a0.w = a0.w / den;
-        a1.x = a1.x / den; a1.y = a1.y / den; a1.z = a1.z / den; a1.w = a1.w / den;
-    }
-    float4* o = reinterpret_cast<float4*>(vol + ((size_t)(b * D + d) * HW + p) * 8);
-    o[0] = a0;
-    o[1] = a1;
-}
-
 __global__ void volume_normalise_kernel(float* __restrict__ vol, const float* __restrict__ vis_sum, int D, int HW, int G, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t vox = i / G;
@@ -474,7 +427,7 @@ __global__ __launch_bounds__(256) void homo_warp_kernel(const void* __restrict__
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
 template <int DT, int CT, int GT>
-static int launch_entropy(const void* feat, const float* hom, const float* hyp, float* ent, float* ip_out, int B, int V, int C, int G,
+static int launch_entropy(const void* feat, const float* hom, const float* hyp, float* ent, int B, int V, int C, int G,
                           int D, int H, int W, int vb, int ve, hipStream_t st) {
     const int HW = H * W;
     const int ppb = CT > 0 ? chunk_map(D).ppb : 64;
@@ -483,8 +436,8 @@ static int launch_entropy(const void* feat, const float* hom, const float* hyp, 
     if (lds > 160 * 1024) { set_error("warp_corr_entropy: D=%d needs %zu B of LDS (> 160 KiB)", D, lds); return MVS_ERR_UNSUPPORTED; }
     if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_corr_entropy_kernel<DT, CT, GT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((warp_corr_entropy_kernel<DT, CT, GT>), dim3(nblk, ve - vb, B), dim3(256), lds, st, feat, hom, hyp, ent, ip_out,
-                       V, C, G, D, H, W, vb, nblk);
+    hipLaunchKernelGGL((warp_corr_entropy_kernel<DT, CT, GT>), dim3(nblk, ve - vb, B), dim3(256), lds, st, feat, hom, hyp, ent, V, C, G, D,
+                       H, W, vb, nblk);
     return check_launch("warp_corr_entropy_kernel");
 }
 
@@ -563,19 +516,17 @@ extern "C" int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* ho
 }
 
 extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homography, const float* hyp, float* entropy,
-                                         float* ip_out, int B, int V, int C, int G, int D, int H, int W, int view_begin, int view_end,
-                                         void* stream) {
+                                         int B, int V, int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream) {
     int rc = check_corr_args("mvs_warp_corr_entropy_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, view_begin, view_end);
     if (rc != MVS_OK) return rc;
     if (!entropy) { set_error("mvs_warp_corr_entropy_fwd: null output"); return MVS_ERR_ARG; }
-    if (ip_out && (G != 8 || W < 2)) { set_error("mvs_warp_corr_entropy_fwd: ip_out needs G == 8 and W >= 2"); return MVS_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (!ip_out && use_lds_gather(C, G, D, H, W))
+    if (use_lds_gather(C, G, D, H, W))
         return gl_launch_entropy(features, dtype, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
-        case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, homography, hyp, entropy, ip_out, B, V, C, G, D, H, W, view_begin, view_end, st);
-        case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, homography, hyp, entropy, ip_out, B, V, C, G, D, H, W, view_begin, view_end, st);
-        default: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F16, features, homography, hyp, entropy, ip_out, B, V, C, G, D, H, W, view_begin, view_end, st);
+        case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
+        case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
+        default: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
     }
 }
 
@@ -594,15 +545,6 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, cons
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_BF16, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
         default: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F16, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
     }
-}
-
-extern "C" int mvs_weighted_aggregate_fwd(const float* ip, const float* vis, float* volume_cl, float* vis_sum, int normalise, int B, int V,
-                                          int D, int H, int W, int view_begin, int view_end, void* stream) {
-    if (!ip || !vis || !volume_cl || B < 1 || V < 2 || D < 1 || H < 1 || W < 1 || view_begin < 1 || view_end > V || view_begin >= view_end) { set_error("mvs_weighted_aggregate_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (!normalise && !vis_sum) { set_error("mvs_weighted_aggregate_fwd: partial mode needs vis_sum"); return MVS_ERR_ARG; }
-    hipLaunchKernelGGL(weighted_aggregate_kernel, dim3(ceil_div((long long)H * W, 256), D, B), dim3(256), 0, (hipStream_t)stream, ip, vis, volume_cl,
-                       vis_sum, normalise, V, D, H * W, view_begin, view_end);
-    return check_launch("weighted_aggregate_kernel");
 }
 
 extern "C" int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, void* stream) {

@@ -58,33 +58,21 @@ def homo_warp(src_fea: torch.Tensor, homography: torch.Tensor, depth_values: tor
 
 # ---- a2-a6 --------------------------------------------------------------------------------------
 def warp_corr_entropy(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, G: int,
-                      view_begin: int = 1, view_end: Optional[int] = None, keep_ip: bool = False):
-    """features [B,V,C,H,W] contiguous; -> entropy [B,V-1,H,W] (only views in [view_begin, view_end) are written).
-    keep_ip=True additionally returns the per-view correlation volumes [B,V-1,D,H,W,8] for `weighted_aggregate`."""
+                      view_begin: int = 1, view_end: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """features [B,V,C,H,W] contiguous; -> entropy [B,V-1,H,W] (only views in [view_begin, view_end) are written; pass a
+    preallocated `out` to skip the zero fill when every view is written)."""
     B, V, Cc, H, W = features.shape
     D = hyp.shape[1]
     view_end = V if view_end is None else view_end
-    ent = torch.zeros(B, V - 1, H, W, dtype=torch.float32, device=features.device)
-    ip = torch.empty(B, V - 1, D, H, W, 8, dtype=torch.float32, device=features.device) if keep_ip else None
-    check(lib().mvs_warp_corr_entropy_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(ent), ptr(ip), B, V, Cc, G, D, H, W,
-                                          view_begin, view_end, stream_of(features)), "mvs_warp_corr_entropy_fwd")
-    return (ent, ip) if keep_ip else ent
-
-
-def weighted_aggregate(ip: torch.Tensor, vis: torch.Tensor, normalise: bool = True, view_begin: int = 1,
-                       view_end: Optional[int] = None, out=None):
-    """Streaming pass 2 on stored correlation volumes: -> (volume_cl [B,D,H,W,8], vis_sum or None)."""
-    B, Vm1, D, H, W, G = ip.shape
-    V = Vm1 + 1
-    view_end = V if view_end is None else view_end
     if out is not None:
-        vol, vsum = out
+        ent = out
+    elif view_begin == 1 and view_end == V:
+        ent = torch.empty(B, V - 1, H, W, dtype=torch.float32, device=features.device)
     else:
-        vol = torch.empty(B, D, H, W, G, dtype=torch.float32, device=ip.device)
-        vsum = None if normalise else torch.empty(B, H, W, dtype=torch.float32, device=ip.device)
-    check(lib().mvs_weighted_aggregate_fwd(ptr(ip), ptr(vis), ptr(vol), ptr(vsum), 1 if normalise else 0, B, V, D, H, W,
-                                           view_begin, view_end, stream_of(ip)), "mvs_weighted_aggregate_fwd")
-    return vol, vsum
+        ent = torch.zeros(B, V - 1, H, W, dtype=torch.float32, device=features.device)
+    check(lib().mvs_warp_corr_entropy_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(ent), B, V, Cc, G, D, H, W,
+                                          view_begin, view_end, stream_of(features)), "mvs_warp_corr_entropy_fwd")
+    return ent
 
 
 def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor], precision: int = 0) -> torch.Tensor:

@@ -139,12 +139,9 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.schedule_inverse_range(pd, ph, D, head.depth_interals_ratio[s], H, W))
         hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
-        keep_ip = bool(net.keep_correlation)
-        ip_bytes = B * (V - 1) * D * HW * 32 if keep_ip else 0
-        res_e = _timed(launches, "warp_corr_entropy_kernel", s, corr_flops,
-                       B * (V * C * HW * esz + (V - 1) * (D * HW * 4 + HW * 4)) + ip_bytes,
-                       lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8, keep_ip=keep_ip))
-        ent, ip = res_e if keep_ip else (res_e, None)
+        # every feature map once, the hypotheses once, the entropy maps out
+        ent = _timed(launches, "gather_entropy", s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
+                     lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
         vp = net._vis_params(feats.device)
         prec = _lib.PRECISIONS[net.conv_precision]
         N = B * (V - 1)
@@ -163,14 +160,9 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                         lambda: ops.conv3d_bn_relu(t2, vp[4], vp[5], 8, 1, (1, 1, 1), True, prec))
             vis = _timed(launches, "vis_out", s, 2.0 * N * HW * 8, 4.0 * N * HW * 9,
                          lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
-        if keep_ip:
-            vol = _timed(launches, "weighted_aggregate_kernel", s, 2.0 * B * (V - 1) * D * HW * 8,
-                         ip_bytes + B * ((V - 1) * HW * 4 + 8 * D * HW * 4), lambda: ops.weighted_aggregate(ip, vis)[0])
-            del ip
-        else:
-            vol = _timed(launches, "warp_corr_aggregate_kernel", s, corr_flops,
-                         B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
-                         lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
+        vol = _timed(launches, "gather_aggregate", s, corr_flops,
+                     B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
+                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
         if getattr(net.cost_reg, "kind", None) == "transformer":
             pos = None
             if head.use_pe3d:
