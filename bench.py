@@ -2,24 +2,28 @@
 """Headline benchmark of the MI355X depth hot path (BASELINE.json: "ref-views/sec at 1152x1536 N=5 D=192 4-stage;
 achieved HBM GB/s vs peak").
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3          # 20 steps x 32 reference views
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
-One "step" = one reference view through the whole 4-stage cascade (features in HBM -> refined depth + confidence):
-hypothesis scheduling, fused warp + group-wise correlation + visibility weighting for the 4 source views, the
-3D-conv regulariser and the depth head of every stage.  Workload = BASELINE.json configs[1]: 1152x1536, V=5,
-numdepth 192 (-> cascade ndepths 32/16/8/4), fp32 features, all-"Normal" regularisers,
-synthetic features / cameras and seeded random weights with randomised BatchNorm statistics (no dataset or
-checkpoint exists offline).
+One "step" = one batch of `--views-per-step` (default 32) reference views, each pushed through the whole 4-stage cascade with
+batch 1 per forward call like the reference's test.py loop (features in HBM -> refined depth + confidence): hypothesis
+scheduling, fused warp + group-wise correlation + visibility weighting for the 4 source views, the 3D-conv regulariser and the
+depth head of every stage.  Consecutive reference views rotate over `--input-sets` (default 4) distinct synthetic input sets
+(4 x 531 MB of fp32 features > the 256 MiB Infinity Cache), so the default 20 steps time 640 reference views / > 1.5 s and no view
+finds its inputs cache-resident by construction.  `value` = reference views per second over the timed steps.
+Workload = BASELINE.json configs[1]: 1152x1536, V=5, numdepth 192 (-> cascade ndepths 32/16/8/4),
+fp32 features, all-"Normal" regularisers, synthetic features / cameras and seeded random weights with randomised BatchNorm
+statistics (no dataset or checkpoint exists offline).
 
-The timed reference views are issued round-robin on `--streams` HIP streams (default 3): views are independent, so the small
-latency-bound launches of one view's coarse stages overlap the large launches of another's fine stages (+11 % over one
-stream, same per-call API as the reference's batch-1 loop); the per-kernel profile behind `roofline` is single-stream.
+The reference views of a step are issued round-robin on `--streams` HIP streams (default 3): views are independent, so the small
+latency-bound launches of one view's coarse stages overlap the large launches of another's fine stages; the single-stream
+figure (one view at a time, the reference's loop) is reported in `latency`, the per-kernel profile behind `roofline` is
+single-stream too.
 
 N > 1: one process per GPU; reference views are independent, so every rank runs its own stream of reference views
 (data parallel over reference views, no data-path collective; "scaling": "weak").  The view-sharded latency mode
-with the RCCL all-reduce of partial cost volumes is timed afterwards and reported in the
-extra `view_sharded` object.
+(source views over ranks, partial cost volumes combined per stage over RCCL) is timed afterwards on
+BASELINE configs[2]'s shape (V = 10) and reported in the extra `view_sharded` object.
 
 Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, HIP-event timing on the launch stream) and
 `cpu_baseline` (the oracle - a CPU restatement of the reference path - timed on this host's cores, N=1 only).
@@ -89,6 +93,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views-per-step", type=int, default=32,
+                    help="reference views in one step (= one batch of synthetic input); 20 steps x 32 views keep the timed region > 2 s")
+    ap.add_argument("--input-sets", type=int, default=4,
+                    help="distinct synthetic input sets the reference views rotate over (4 x 531 MB of features > the 256 MiB Infinity "
+                         "Cache: no step finds its inputs cache-resident by construction)")
     ap.add_argument("--height", type=int, default=1152)
     ap.add_argument("--width", type=int, default=1536)
     ap.add_argument("--views", type=int, default=5)
@@ -96,11 +105,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the timed reference views are issued on round-robin (independent views overlap: the small "
-                         "coarse-stage launches of one view run beside the large fine-stage launches of another, SURVEY.md section 8e)")
-    ap.add_argument("--batch", type=int, default=1,
-                    help="reference views per forward call (the reference's test.py runs batch 1; larger batches fill the GPU on the "
-                         "small coarse-level launches)")
+                    help="HIP streams the reference views of a step are issued on round-robin (independent views overlap: the small "
+                         "coarse-stage launches of one view run beside the large fine-stage launches of another, SURVEY.md section 8e); "
+                         "the single-stream latency is reported beside it")
     ap.add_argument("--feat-dtype", choices=["fp32", "bf16", "fp16"], default="fp32",
                     help="dtype of the feature maps handed to the path (the reference's FPN emits bf16 under test.py:250's autocast and "
                          "StageNet upcasts per view, cost_volume.py:67); the headline keeps fp32")
@@ -132,7 +139,10 @@ def main():
     from mvsformerplusplus_amd import profiling, synth
     head = build_head(device, shipped=a.cost_reg == "shipped")
     fdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.feat_dtype]
-    feats, projs, dv = synth.make_cascade_inputs(a.height, a.width, a.views, seed=rank, device=device, feat_dtype=fdt, batch=a.batch)
+    nsets = max(1, a.input_sets)
+    sets = [synth.make_cascade_inputs(a.height, a.width, a.views, seed=100 * rank + i, device=device, feat_dtype=fdt) for i in range(nsets)]
+    feats, projs, dv = sets[0]
+    R = max(1, a.views_per_step)
     torch.cuda.synchronize()
 
     def sync_all():
@@ -150,33 +160,49 @@ def main():
             torch.cuda.synchronize()
         streams = [torch.cuda.Stream(device=device) for _ in range(a.streams)] if a.streams > 1 else None
 
-        def run(n):
+        def run(n_steps, first=0):
+            """n_steps steps; step k = the R reference views k*R .. k*R+R-1, view j on input set j % nsets and stream j % nstreams."""
             o = None
-            if streams is None:
-                for _ in range(n):
-                    o = head(feats, projs, dv, tmp=TMP)
-                return o
-            for st in streams:
-                st.wait_stream(torch.cuda.current_stream(device))
-            for i in range(n):
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    o = head(feats, projs, dv, tmp=TMP)
-            for st in streams:
-                torch.cuda.current_stream(device).wait_stream(st)
+            if streams is not None:
+                for st in streams:
+                    st.wait_stream(torch.cuda.current_stream(device))
+            for j in range(first * R, (first + n_steps) * R):
+                f, p, d = sets[j % nsets]
+                if streams is None:
+                    o = head(f, p, d, tmp=TMP)
+                else:
+                    with torch.cuda.stream(streams[j % len(streams)]):
+                        o = head(f, p, d, tmp=TMP)
+            if streams is not None:
+                for st in streams:
+                    torch.cuda.current_stream(device).wait_stream(st)
             return o
 
-        out = run(a.warmup) or out
+        run(a.warmup)
         sync_all()
         t0 = time.perf_counter()
-        out = run(a.steps)
+        run(a.steps, first=a.warmup)
         sync_all()
         elapsed = time.perf_counter() - t0
+
+        # single-stream latency: one reference view at a time on the current stream, the reference's own loop shape (test.py:238-252)
+        n_lat = 4 * nsets
+        for j in range(nsets):
+            head(*sets[j], tmp=TMP)
+        torch.cuda.synchronize()
+        tl0 = time.perf_counter()
+        for j in range(n_lat):
+            head(*sets[j % nsets], tmp=TMP)
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - tl0) / n_lat * 1e3
+        out = head(feats, projs, dv, tmp=TMP)
+        torch.cuda.synchronize()
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
-    value = world * a.steps * a.batch / elapsed
+    value = world * a.steps * R / elapsed
     is_cfg2 = (a.height, a.width, a.views) == (1152, 1536, 5)
 
     result = {
@@ -185,31 +211,40 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD if is_cfg2 else "%dx%d V=%d 4-stage cascade" % (a.height, a.width, a.views),
-                   "height": a.height, "width": a.width, "views": a.views, "global_batch": world * a.batch,
+                   "height": a.height, "width": a.width, "views": a.views, "global_batch": world * R,
+                   "step": "one batch of %d reference views (batch 1 per forward call, like test.py), rotating over %d input sets" % (R, nsets),
+                   "ref_views_per_step_per_gpu": R, "input_sets": nsets, "timed_seconds": elapsed,
                    "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams, "features": "%s resident in HBM" % a.feat_dtype},
-        "hbm_algorithmic_gbs_per_gpu": (ALGO_BYTES_PER_VIEW * value / world / 1e9) if is_cfg2 else None,
-        "hbm_algorithmic_frac_of_8TBs": (ALGO_BYTES_PER_VIEW * value / world / 8.0e12) if is_cfg2 else None,
+        "ms_per_ref_view": ms_per_step / R,
+        "latency": {"single_stream_ms_per_ref_view": latency_ms, "single_stream_ref_views_per_s": 1e3 / latency_ms,
+                    "note": "one reference view at a time on one stream (the reference's loop, test.py:238-252), same rotating inputs"},
     }
+    if is_cfg2:
+        gbs = ALGO_BYTES_PER_VIEW * value / world / 1e9
+        result["whole_path"] = {"algorithmic_bytes_per_ref_view": ALGO_BYTES_PER_VIEW, "achieved_gbs_per_gpu": gbs, "peak_gbs": 8000.0,
+                                "frac": gbs / 8000.0, "frac_single_stream": ALGO_BYTES_PER_VIEW / (latency_ms * 1e-3) / 8.0e12,
+                                "note": "SURVEY.md section 8d layer-wise byte model (5.03 GB per reference view at cfg2) x ref-views/s / 8 TB/s"}
 
     result["config"]["cost_reg_type"] = SHIPPED["cost_reg_type"] if a.cost_reg == "shipped" else ["Normal"] * 4
     result["config"]["conv_precision"] = ("%s MFMA contraction, fp32 activations and accumulation" % head.fusions[0].conv_precision)
 
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
     if not a.no_profile:
-        reps = 3
+        reps = 4
         allruns = []
-        for _ in range(reps):
-            _, launches = profiling.profile_cascade(head, feats, projs, dv, TMP)
+        for r in range(reps):
+            _, launches = profiling.profile_cascade(head, *sets[r % nsets], TMP)
             allruns.append(launches)
         agg = profiling.summarize([l for run in allruns for l in run])
         # the dominant SINGLE kernel symbol (bundles of several launches timed as a unit are not candidates)
         dom_name, dom = max(((k, v) for k, v in agg.items() if not k.startswith("[bundle]")), key=lambda kv: kv[1]["ms"])
-        mfma = dom_name.startswith("conv3d") or dom_name.startswith("deconv3d")
+        mfma = dom_name.startswith("conv3d") or dom_name.startswith("deconv3d") or dom_name.startswith("vis_cnn")
         per_launch = dom["flops" if mfma else "bytes"] / dom["calls"]
         achieved = (dom["tflops"] if mfma else dom["gbs"])
         prec = head.fusions[0].conv_precision
         if not mfma:
-            peak, note = profiling.PEAK_HBM_GBS, "gather kernel: algorithmic HBM bytes; rocprofv3 shows it TD (L1 data-return) bound, DESIGN.md"
+            peak, note = profiling.PEAK_HBM_GBS, ("algorithmic HBM bytes per launch (SURVEY.md section 8d: every feature map once + hypotheses once + "
+                                                  "outputs once) / HIP-event launch time on the launch stream")
         elif prec == "bf16x3":
             # every algorithmic product is three bf16 MFMA products: peak for algorithmic FLOPs = dense bf16 peak / 3
             peak, note = 2500.0 / 3.0, "3-term split-bf16 contraction on v_mfma_f32_16x16x32_bf16: dense bf16 peak 2500 TFLOP/s / 3 passes"
@@ -223,34 +258,16 @@ def main():
                               "unit": "TFLOP/s" if mfma else "GB/s", "frac": achieved / peak, "traffic": traffic,
                               "avg_launch_ms": dom["avg_ms"], "algorithmic_per_launch": per_launch,
                               "share_of_step": dom["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-9),
-                              "launches_per_step": dom["calls"] / reps, "note": note}
-        result["kernels"] = {k: {"calls_per_step": v["calls"] / reps, "ms_per_step": v["ms"] / reps, "gbs": v["gbs"], "tflops": v["tflops"]}
+                              "launches_per_ref_view": dom["calls"] / reps, "note": note}
+        result["kernels"] = {k: {"calls_per_ref_view": v["calls"] / reps, "ms_per_ref_view": v["ms"] / reps, "gbs": v["gbs"], "tflops": v["tflops"]}
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         if a.profile_table and rank == 0:
             tot = sum(v["ms"] for v in agg.values()) / reps
-            print("%-34s %6s %9s %9s %9s" % ("kernel", "calls", "ms/step", "GB/s", "TFLOP/s"), file=sys.stderr)
+            print("%-40s %6s %9s %9s %9s" % ("kernel", "calls", "ms/view", "GB/s", "TFLOP/s"), file=sys.stderr)
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-                print("%-34s %6.0f %9.3f %9.0f %9.1f" % (k, v["calls"] / reps, v["ms"] / reps, v["gbs"], v["tflops"]), file=sys.stderr)
-            print("sum of kernel times %.3f ms/step; wall %.3f ms/step" % (tot, ms_per_step), file=sys.stderr)
-
-    # ---- batched throughput (N = 1): 4 reference views per forward call fill the GPU on the small coarse-level launches ----
-    if world == 1 and a.batch == 1 and is_cfg2 and a.cost_reg == "normal" and not a.no_profile:
-        try:
-            f4, p4, d4 = synth.make_cascade_inputs(a.height, a.width, a.views, seed=1, device=device, feat_dtype=fdt, batch=4)
-            with torch.no_grad():
-                for _ in range(2):
-                    head(f4, p4, d4, tmp=TMP)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    head(f4, p4, d4, tmp=TMP)
-                torch.cuda.synchronize()
-                tb = (time.perf_counter() - t0) / 5
-            result["batched"] = {"batch": 4, "value": 4.0 / tb, "unit": "ref-views/s", "ms_per_ref_view": tb * 1e3 / 4,
-                                 "note": "same workload, 4 reference views per forward call (the headline keeps the reference's batch 1, test.py)"}
-            del f4, p4, d4
-        except Exception as e:
-            result["batched"] = {"error": repr(e)}
+                print("%-40s %6.0f %9.3f %9.0f %9.1f" % (k, v["calls"] / reps, v["ms"] / reps, v["gbs"], v["tflops"]), file=sys.stderr)
+            print("sum of kernel times %.3f ms/ref view; wall %.3f ms/ref view (%d streams), %.3f single stream" %
+                  (tot, ms_per_step / R, a.streams, latency_ms), file=sys.stderr)
 
     # ---- shipped mix with bf16 attention probabilities (optional fast mode of the transformer stage), N = 1 ----
     if world == 1 and a.cost_reg == "shipped" and not a.no_profile:
@@ -266,44 +283,17 @@ def main():
                 torch.cuda.synchronize()
                 tb = (time.perf_counter() - t0) / 5
             d1, d2 = out["refined_depth"], o2["refined_depth"]
-            result["attention_bf16p"] = {"value": a.batch / tb, "unit": "ref-views/s", "ms_per_step": tb * 1e3,
+            result["attention_bf16p"] = {"value": 1.0 / tb, "unit": "ref-views/s", "ms_per_ref_view": tb * 1e3,
                                          "refined_depth_rel_l1_vs_default": float(((d2 - d1).abs() / d1.abs()).mean()),
                                          "note": "attention_precision='bf16p': softmax probabilities enter p.v as one bf16 term"}
             head.fusions[0].cost_reg.attention_precision = "bf16x3"
         except Exception as e:
             result["attention_bf16p"] = {"error": repr(e)}
 
-    # ---- view-sharded latency mode (N > 1): source views over ranks + RCCL all-reduce per stage ----
+    # ---- view-sharded latency mode (N > 1): source views over ranks + RCCL collectives per stage ----
     if world > 1:
         try:
-            head.set_view_group(dist.group.WORLD)
-            # every rank must see rank 0's reference view: same features, cameras and depth range (each rank generated its own)
-            f0 = {k: v.clone() for k, v in feats.items()}
-            p0 = {k: v.clone() for k, v in projs.items()}
-            d0 = dv.clone()
-            for t in list(f0.values()) + list(p0.values()) + [d0]:
-                dist.broadcast(t, 0)
-            with torch.no_grad():
-                for _ in range(2):
-                    o_sh = head(f0, p0, d0, tmp=TMP)
-                sync_all()
-                t0 = time.perf_counter()
-                n_lat = max(3, a.steps // 4)
-                for _ in range(n_lat):
-                    o_sh = head(f0, p0, d0, tmp=TMP)
-                sync_all()
-                lat = (time.perf_counter() - t0) / n_lat
-                # all ranks hold the same result; rank 0 also checks it against its own unsharded pass
-                head.set_view_group(None)
-                o_un = head(f0, p0, d0, tmp=TMP)
-                agree = float(((o_sh["refined_depth"] - o_un["refined_depth"]).abs() / o_un["refined_depth"].abs()).mean())
-            tl = torch.tensor([lat], dtype=torch.float64, device=device)
-            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-            result["view_sharded"] = {"ms_per_ref_view": float(tl.item()) * 1e3, "ref_views_per_s": 1.0 / float(tl.item()),
-                                      "refined_depth_rel_l1_vs_unsharded": agree,
-                                      "note": "ONE reference view at a time, %d source views sharded over %d ranks, "
-                                              "all-reduce(sum) of [8*D*H*W + H*W] fp32 per stage" % (a.views - 1, world)}
-            head.set_view_group(None)
+            result["view_sharded"] = view_sharded_leg(head, a, device, world, rank, sync_all, fdt)
         except Exception as e:  # the headline number above is already measured; report the failure instead of dying
             result["view_sharded"] = {"error": repr(e)}
 
@@ -321,6 +311,44 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def view_sharded_leg(head, a, device, world, rank, sync_all, fdt):
+    """Latency mode of SURVEY.md section 8e on BASELINE configs[2]'s shape (V = 10: nine source views over the ranks): ONE
+    reference view at a time, source views sharded over the ranks, partial cost volumes combined per stage."""
+    import torch.distributed as dist
+    from mvsformerplusplus_amd import synth
+    V = max(a.views, 10)
+    f0, p0, d0 = synth.make_cascade_inputs(a.height, a.width, V, seed=7, device=device, feat_dtype=fdt)   # same seed on every rank
+    head.set_view_group(dist.group.WORLD)
+    with torch.no_grad():
+        for _ in range(2):
+            o_sh = head(f0, p0, d0, tmp=TMP)
+        sync_all()
+        t0 = time.perf_counter()
+        n_lat = max(3, a.steps // 4)
+        for _ in range(n_lat):
+            o_sh = head(f0, p0, d0, tmp=TMP)
+        sync_all()
+        lat = (time.perf_counter() - t0) / n_lat
+        head.set_view_group(None)
+        o_un = head(f0, p0, d0, tmp=TMP)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_lat):
+            o_un = head(f0, p0, d0, tmp=TMP)
+        torch.cuda.synchronize()
+        lat_un = (time.perf_counter() - t0) / n_lat
+        agree = float(((o_sh["refined_depth"] - o_un["refined_depth"]).abs() / o_un["refined_depth"].abs()).mean())
+    tl = torch.tensor([lat], dtype=torch.float64, device=device)
+    dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+    shapes = [(f0["stage%d" % (s + 1)].shape[-2:], ARGS["ndepths"][s]) for s in range(4)]
+    coll = [int((8 * D + 1) * int(hw[0]) * int(hw[1]) * 4) for hw, D in shapes]
+    return {"ms_per_ref_view": float(tl.item()) * 1e3, "ref_views_per_s": 1.0 / float(tl.item()),
+            "unsharded_ms_per_ref_view_one_gpu": lat_un * 1e3, "speedup_vs_one_gpu": lat_un / float(tl.item()),
+            "views": V, "ranks": world, "refined_depth_rel_l1_vs_unsharded": agree,
+            "collective_bytes_per_stage": coll, "mode": getattr(head.fusions[0], "shard_mode", "allreduce"),
+            "note": "ONE reference view at a time, %d source views sharded over %d ranks (SURVEY.md section 8e)" % (V - 1, world)}
 
 
 if __name__ == "__main__":

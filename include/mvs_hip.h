@@ -77,7 +77,7 @@ int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homo
  * Packed parameters are produced by the Python side (mvsformerplusplus_amd/packing.py):
  *   w1 [9][16] + b1[16] (BN folded), w2/w3 = MFMA-packed 3x3 weights (layout below), b2[16], b3[8]
  *   (padded to 16), w4[8], b4[1].  workspace >= mvs_vis_workspace_bytes(N,H,W).                  */
-size_t mvs_vis_workspace_bytes(int N, int H, int W);
+size_t mvs_vis_workspace_bytes(int N, int H, int W, int precision);
 int mvs_vis_weight_fwd(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2,
                        const void* w3, const float* b3, const float* w4, const float* b4, float* vis,
                        void* workspace, size_t workspace_bytes, int N, int H, int W, int precision, void* stream);

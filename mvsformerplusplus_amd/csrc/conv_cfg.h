@@ -80,6 +80,8 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
                            int kd, int sd, int sh, int sw, int relu, hipStream_t st);
 int vis_weight_fused_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
                             const float* w4, const float* b4, float* vis, float* scratch16, int N, int H, int W, hipStream_t st);
+int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                             const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st);
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,
                              int D, int H, int W, int sd, hipStream_t st);
 

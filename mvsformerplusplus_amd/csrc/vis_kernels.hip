@@ -1,0 +1,206 @@
+// Visibility CNN (reference cost_volume.py:36,93 + ConvBnReLU module.py:168-197) as ONE
+// row-streaming launch:  entropy [N,H,W] -> sigmoid(conv1x1(CBR(16->8)(CBR(16->16)(CBR(1->16)(entropy))))) [N,H,W].
+//
+// Round 1 ran two launches with a 16-channel fp32 intermediate in HBM (641 + 650 MB per reference view at cfg2 for an
+// operator whose algorithmic traffic is 8 bytes per pixel) and re-fetched the packed weights per tile.  Here a workgroup
+// owns a vertical strip of 60 output columns x SH output rows and walks down it one row per iteration; the three layers
+// run skewed by two rows each, so every iteration only reads rows produced by EARLIER iterations - one barrier per row:
+//     iteration i:  A  layer-1 row i      (VALU, 1 -> 16, from a 3x3 entropy window held in registers)
+//                   B  layer-2 row i-2    (MFMA 16 -> 16 from layer-1 rows i-3 .. i-1)
+//                   C  layer-3 row i-4    (MFMA 16 -> 8, then 1x1 + sigmoid in the epilogue, from layer-2 rows i-5 .. i-3)
+// Layer-1 / layer-2 activations live in two 4-row LDS rings as split bf16 (hi | lo), never in HBM; all packed weights of
+// both MFMA layers sit in registers for the whole strip (80 VGPRs) and the 1 -> 16 weights in SGPRs.  Contraction =
+// the 3-term split-bf16 product of the MFMA convolutions (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, ~2^-16 relative).
+//
+// LDS layout per layer: [octet o of 8 channels][ring row r][column c][hi x8 | lo x8 | 16 B pad]: 48 B per position make
+// the 16 ds_read_b128 lanes of a group (8 columns of octet 0 + 8 of octet 1) hit 16 different 16-byte bank slots and keep
+// the 8-byte epilogue stores 2-way at worst.  Column c of the layer-1 ring is image column x0 - 2 + c, of the layer-2 ring
+// x0 - 1 + c (c = 0..63); an MFMA tile is 16 consecutive columns of one row, wave w owns tile w.
+// Zero padding follows the reference exactly: every layer's OUTPUT is forced to zero outside the image (the next
+// Conv2d pads its input with zeros there), which is not the same as convolving zero-padded entropy.
+#include "mvs_common.h"
+
+namespace mvs {
+
+typedef __bf16 vs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vs_bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int VS_TW = 60;                 // output columns per strip
+constexpr int VS_P = 64;                  // columns per ring row
+constexpr int VS_POSB = 48;               // bytes per (position, octet)
+constexpr int VS_RING = 4;                // ring rows
+constexpr int VS_PLANE = ((VS_RING * VS_P + 2) * VS_POSB + 255) / 256 * 256;     // one octet plane; multiple of 256 B
+constexpr int VS_LAYER = 2 * VS_PLANE;
+constexpr int VS_LDS = 2 * VS_LAYER;
+
+#ifndef MVS_OPAQUE_VEC
+#define MVS_OPAQUE_VEC "v"
+#endif
+
+__device__ __forceinline__ void vs_split4(const float* v, vs_bf16x4& hi, vs_bf16x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(v[j] - (float)h);
+    }
+}
+
+// one MFMA layer row: 5 contraction steps of 32 k-values (two taps x 16 channels), three split-bf16 terms on three
+// independent accumulators.  rowbase = ring row of tap row kh = 0 (may be negative: masked to the ring size).
+__device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, int rowbase, const vs_bf16x8* wh, const vs_bf16x8* wl) {
+    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int tapA = 2 * t, tapB = 2 * t + 1 < 9 ? 2 * t + 1 : 8;          // tap 9 does not exist: zero weights, any finite data
+        const int offA = (((rowbase + tapA / 3) & (VS_RING - 1)) * VS_P + tapA % 3) * VS_POSB;      // wave-uniform
+        const int offB = (((rowbase + tapB / 3) & (VS_RING - 1)) * VS_P + tapB % 3) * VS_POSB;
+        const char* p = lds_layer + laneoff + (tapsel ? offB : offA);
+        const vs_bf16x8 bh = *reinterpret_cast<const vs_bf16x8*>(p);
+        const vs_bf16x8 bl = *reinterpret_cast<const vs_bf16x8*>(p + 16);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t], bh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], bl, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], bh, a2, 0, 0, 0);
+    }
+    return a0 + a1 + a2;
+}
+
+// grid = (strips, row segments, N)
+__global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ ent, const float* __restrict__ w1 /*[9][16]*/,
+                                                      const float* __restrict__ b1, const void* __restrict__ wp2, const float* __restrict__ b2,
+                                                      const void* __restrict__ wp3, const float* __restrict__ b3, const float* __restrict__ w4,
+                                                      const float* __restrict__ b4, float* __restrict__ vis, int H, int W, int SH) {
+    HIP_DYNAMIC_SHARED(float4, lds4)
+    char* lds1 = reinterpret_cast<char*>(lds4);
+    char* lds2 = lds1 + VS_LAYER;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int x0 = (int)blockIdx.x * VS_TW, r0 = (int)blockIdx.y * SH;
+    const int r1 = r0 + SH < H ? r0 + SH : H;
+    const float* e = ent + (size_t)blockIdx.z * H * W;
+    float* vo = vis + (size_t)blockIdx.z * H * W;
+
+    // ---- register-resident parameters ----
+    vs_bf16x8 w2h[5], w2l[5], w3h[5], w3l[5];
+    {
+        const vs_bf16x8* q2 = reinterpret_cast<const vs_bf16x8*>(wp2) + lane;
+        const vs_bf16x8* q3 = reinterpret_cast<const vs_bf16x8*>(wp3) + lane;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            w2h[t] = q2[(t * 2) * 64]; w2l[t] = q2[(t * 2 + 1) * 64];
+            w3h[t] = q3[(t * 2) * 64]; w3l[t] = q3[(t * 2 + 1) * 64];
+            // opaque: the compiler must keep them in registers instead of re-loading the invariant memory every row
+#ifndef MVS_NO_OPAQUE_VEC
+            asm volatile("" : "+" MVS_OPAQUE_VEC(w2h[t]), "+" MVS_OPAQUE_VEC(w2l[t]), "+" MVS_OPAQUE_VEC(w3h[t]), "+" MVS_OPAQUE_VEC(w3l[t]));
+#endif
+        }
+    }
+    float w1s[9][4], b1s[4];                                      // layer 1: channels 4*wave .. 4*wave+3 (wave-uniform -> SGPRs)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w1s[t][r] = w1[t * 16 + 4 * wave + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b1s[r] = b1[4 * wave + r];
+    float b2v[4], b3v[4], w4v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        b2v[r] = b2[4 * g + r];
+        b3v[r] = g < 2 ? b3[4 * g + r] : 0.0f;
+        w4v[r] = g < 2 ? w4[4 * g + r] : 0.0f;
+    }
+    const float bias4 = b4[0];
+
+    // ---- stage A state: 3x3 entropy window of layer-1 column `lane` (image column xa) ----
+    const int xa = x0 - 2 + lane;
+    const int i0 = r0 - 2, i1 = r1 + 4;                            // iterations i0 .. i1-1 (layer-1 rows i0 .. r1+1 are needed)
+    auto ent_at = [&](int rr, int xx) -> float { return (rr >= 0 && rr < H && xx >= 0 && xx < W) ? e[(size_t)rr * W + xx] : 0.0f; };
+    float er[3][3], nx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        er[1][k] = ent_at(i0 - 1, xa - 1 + k);                     // becomes row 0 after the first shift
+        er[2][k] = ent_at(i0, xa - 1 + k);
+        nx[k] = ent_at(i0 + 1, xa - 1 + k);
+        er[0][k] = 0.0f;
+    }
+    const int colmaskA = xa >= 0 && xa < W;
+    // per-lane LDS offsets
+    const int wrA = (wave >> 1) * VS_PLANE + lane * VS_POSB + (wave & 1) * 8;                     // stage A store (octet wave>>1, quad wave&1)
+    const int laneoff = (g & 1) * VS_PLANE + (16 * wave + li) * VS_POSB;                          // MFMA B-operand reads
+    const int wrB = (g >> 1) * VS_PLANE + (16 * wave + li) * VS_POSB + (g & 1) * 8;               // stage B store
+    const int tapsel = g >> 1;
+    const int c2 = 16 * wave + li;                                 // layer-2 / layer-3 column of this lane
+    const int xb = x0 - 1 + c2, xc = x0 + c2;
+
+    for (int i = i0; i < i1; ++i) {
+        // ---- A: layer-1 row i ----
+        if (i <= r1 + 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { er[0][k] = er[1][k]; er[1][k] = er[2][k]; er[2][k] = nx[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nx[k] = ent_at(i + 2, xa - 1 + k);                        // prefetch for the next iteration
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = b1s[r];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = fmaf(er[kh][kw], w1s[kh * 3 + kw][r], a[r]);
+            const bool in = colmaskA && i >= 0 && i < H;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = in ? fmaxf(a[r], 0.0f) : 0.0f;
+            vs_bf16x4 hi, lo;
+            vs_split4(a, hi, lo);
+            char* p = lds1 + wrA + (i & (VS_RING - 1)) * (VS_P * VS_POSB);
+            *reinterpret_cast<vs_bf16x4*>(p) = hi;
+            *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
+        }
+        // ---- B: layer-2 row i-2 from layer-1 rows i-3 .. i-1 ----
+        const int yb = i - 2;
+        if (yb >= r0 - 1 && yb <= r1) {
+            const f32x4 acc = vs_layer_row(lds1, laneoff, tapsel, i - 3, w2h, w2l);
+            const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc[r] + b2v[r], 0.0f) : 0.0f;
+            vs_bf16x4 hi, lo;
+            vs_split4(v, hi, lo);
+            char* p = lds2 + wrB + (yb & (VS_RING - 1)) * (VS_P * VS_POSB);
+            *reinterpret_cast<vs_bf16x4*>(p) = hi;
+            *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
+        }
+        // ---- C: layer-3 row i-4 from layer-2 rows i-5 .. i-3, then 1x1 + sigmoid ----
+        const int yc = i - 4;
+        if (yc >= r0) {
+            const f32x4 acc = vs_layer_row(lds2, laneoff, tapsel, i - 5, w3h, w3l);
+            float part = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += fmaxf(acc[r] + b3v[r], 0.0f) * w4v[r];           // rows 8..15 of the tile: zero weights
+            part += __shfl_xor(part, 16);
+            if (g == 0 && c2 < VS_TW && xc < W && yc < r1) {
+                const float z = part + bias4;
+                vo[(size_t)yc * W + xc] = 1.0f / (1.0f + __builtin_amdgcn_exp2f(-z * 1.4426950408889634f));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                             const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st) {
+    const int strips = (int)ceil_div(W, VS_TW);
+    // segment height: enough blocks to fill the chip (>= ~1024), warm-up overhead 6 rows per segment
+    long long per_row = (long long)strips * N;
+    int SH = (int)((per_row * H + 1023) / 1024);
+    SH = SH < 8 ? 8 : (SH > 64 ? 64 : SH);
+    const int segs = (int)ceil_div(H, SH);
+    if (VS_LDS > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS);
+    hipLaunchKernelGGL(vis_cnn_kernel, dim3(strips, segs, N), dim3(256), VS_LDS, st, entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, H, W, SH);
+    return check_launch("vis_cnn_kernel");
+}
+
+}  // namespace mvs

@@ -205,6 +205,7 @@ static inline int hipemu_any(int pred) {
 #define __any(p) hipemu_any((p) ? 1 : 0)
 #define MVS_OPAQUE_REG "r"      // x86 register class for the kernels' opaque-value asm
 #define MVS_OPAQUE_SREG "r"
+#define MVS_NO_OPAQUE_VEC 1    // 128-bit bf16 vectors have no x86 asm register class; the laundering is a GPU register-allocation hint only
 
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()

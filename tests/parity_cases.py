@@ -268,6 +268,26 @@ def case_generic_shapes(device):
         raise AssertionError("G must divide C (cost_volume.py:87)")
 
 
+def case_vis_cnn(device):
+    """Row-streaming visibility CNN against the oracle on sizes that exercise several 60-column strips, several row segments,
+    ragged right / bottom edges and images smaller than one strip."""
+    g = torch.Generator().manual_seed(21)
+    st = StageNet(dict(ARGS), 8, 2)
+    st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 9), strict=True)
+    st = st.eval()
+    sd = {k: v.detach().clone() for k, v in st.state_dict().items()}
+    st = st.to(device)
+    for (N, H, W) in ((3, 37, 130), (2, 70, 61), (1, 9, 24), (2, 64, 120)):
+        ent = torch.rand(1, N, H, W, generator=g) * 2.0
+        ref = torch.stack([O.vis_weight(ent[:, n:n + 1], sd) for n in range(N)], 1)[:, :, 0]      # [1, N, H, W]
+        for prec, tol in (("bf16x3", 1e-4), ("fp32", 2e-5)):
+            st.conv_precision = prec
+            vis = ops.vis_weight(dev(ent, device), st._vis_params(torch.device(device) if isinstance(device, str) else device), _lib.PRECISIONS[prec])
+            assert vis.shape == ent.shape
+            err = float((cpu(vis) - ref).abs().max())
+            assert err <= tol, (N, H, W, prec, err)
+
+
 def case_gather_variants(device, quick=False):
     """LDS-staged gather passes against the oracle over every channel-octet count (C = 8..64), depth-chunk geometry
     (D = 4, 8, 16, 32, 48: 1 / 2 / 4 work-items per pixel, looping for D > 16), ragged tiles (W not a multiple of the tile

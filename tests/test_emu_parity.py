@@ -53,6 +53,10 @@ def test_generic_shapes(emu):
     P.case_generic_shapes(emu)
 
 
+def test_vis_cnn(emu):
+    P.case_vis_cnn(emu)
+
+
 def test_gather_variants(emu):
     P.case_gather_variants(emu)
 

@@ -68,6 +68,10 @@ def test_generic_shapes():
     P.case_generic_shapes(DEV)
 
 
+def test_vis_cnn():
+    P.case_vis_cnn(DEV)
+
+
 def test_gather_variants():
     P.case_gather_variants(DEV)
 
