@@ -31,7 +31,10 @@ constexpr int VS_POSB = 48;               // bytes per (position, octet)
 constexpr int VS_RING = 4;                // ring rows
 constexpr int VS_PLANE = ((VS_RING * VS_P + 2) * VS_POSB + 255) / 256 * 256;     // one octet plane; multiple of 256 B
 constexpr int VS_LAYER = 2 * VS_PLANE;
-constexpr int VS_LDS = 2 * VS_LAYER;
+constexpr int VS_SH_MAX = 64;             // output rows per block (segment height) at most
+constexpr int VS_EP = VS_P + 2;           // entropy tile pitch: image columns x0 - 3 .. x0 + 62
+constexpr int VS_ENT_BYTES = (VS_SH_MAX + 6) * VS_EP * 4;
+constexpr int VS_LDS = 2 * VS_LAYER + VS_ENT_BYTES;
 
 #ifndef MVS_OPAQUE_VEC
 #define MVS_OPAQUE_VEC "v"
@@ -46,23 +49,73 @@ __device__ __forceinline__ void vs_split4(const float* v, vs_bf16x4& hi, vs_bf16
     }
 }
 
-// one MFMA layer row: 5 contraction steps of 32 k-values (two taps x 16 channels), three split-bf16 terms on three
-// independent accumulators.  rowbase = ring row of tap row kh = 0 (may be negative: masked to the ring size).
+// B-operand address of contraction step t: lane group g>>1 picks the first or second tap of the step (two taps x 16
+// channels = 32 k-values); rowbase = ring row of tap row kh = 0 (may be negative: masked to the ring size).
+__device__ __forceinline__ const char* vs_step_ptr(const char* lds_layer, int laneoff, int tapsel, int rowbase, int t) {
+    const int tapA = 2 * t, tapB = 2 * t + 1 < 9 ? 2 * t + 1 : 8;              // tap 9 does not exist: zero weights, any finite data
+    const int offA = (((rowbase + tapA / 3) & (VS_RING - 1)) * VS_P + tapA % 3) * VS_POSB;         // wave-uniform
+    const int offB = (((rowbase + tapB / 3) & (VS_RING - 1)) * VS_P + tapB % 3) * VS_POSB;
+    return lds_layer + laneoff + (tapsel ? offB : offA);
+}
+
+struct VsOperand { vs_bf16x8 h, l; };
+__device__ __forceinline__ VsOperand vs_load(const char* p) {
+    VsOperand o;
+    o.h = *reinterpret_cast<const vs_bf16x8*>(p);
+    o.l = *reinterpret_cast<const vs_bf16x8*>(p + 16);
+    return o;
+}
+
+// three split-bf16 terms of one step on three independent accumulators
+__device__ __forceinline__ void vs_mfma3(f32x4* a, const vs_bf16x8& wh, const vs_bf16x8& wl, const VsOperand& b) {
+    a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, b.h, a[0], 0, 0, 0);
+    a[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b.l, a[1], 0, 0, 0);
+    a[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b.h, a[2], 0, 0, 0);
+}
+
+// one MFMA layer row: 5 contraction steps, the operand reads of step t+1 issued before the MFMAs of step t
 __device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, int rowbase, const vs_bf16x8* wh, const vs_bf16x8* wl) {
-    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0;
+    f32x4 a[3] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    VsOperand cur = vs_load(vs_step_ptr(lds_layer, laneoff, tapsel, rowbase, 0));
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
-        const int tapA = 2 * t, tapB = 2 * t + 1 < 9 ? 2 * t + 1 : 8;          // tap 9 does not exist: zero weights, any finite data
-        const int offA = (((rowbase + tapA / 3) & (VS_RING - 1)) * VS_P + tapA % 3) * VS_POSB;      // wave-uniform
-        const int offB = (((rowbase + tapB / 3) & (VS_RING - 1)) * VS_P + tapB % 3) * VS_POSB;
-        const char* p = lds_layer + laneoff + (tapsel ? offB : offA);
-        const vs_bf16x8 bh = *reinterpret_cast<const vs_bf16x8*>(p);
-        const vs_bf16x8 bl = *reinterpret_cast<const vs_bf16x8*>(p + 16);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t], bh, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], bl, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], bh, a2, 0, 0, 0);
+        VsOperand nxt = cur;
+        if (t < 4) nxt = vs_load(vs_step_ptr(lds_layer, laneoff, tapsel, rowbase, t + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        vs_mfma3(a, wh[t], wl[t], cur);
+        cur = nxt;
     }
-    return a0 + a1 + a2;
+    return a[0] + a[1] + a[2];
+}
+
+// both MFMA layers of one iteration interleaved (layer 2 reads ring 1, layer 3 reads ring 2: independent): four operand
+// reads in flight under six MFMAs
+__device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* lds2, int laneoff, int tapsel, int rb2, int rb3,
+                                                  const vs_bf16x8* w2h, const vs_bf16x8* w2l, const vs_bf16x8* w3h, const vs_bf16x8* w3l,
+                                                  f32x4& out2, f32x4& out3) {
+    // one accumulator per layer: the two layers' MFMAs alternate, so a chain's next link is issued two MFMAs (32 cycles) later
+    f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, c = a;
+    VsOperand cb = vs_load(vs_step_ptr(lds1, laneoff, tapsel, rb2, 0));
+    VsOperand cc = vs_load(vs_step_ptr(lds2, laneoff, tapsel, rb3, 0));
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        VsOperand nb = cb, nc = cc;
+        if (t < 4) {
+            nb = vs_load(vs_step_ptr(lds1, laneoff, tapsel, rb2, t + 1));
+            nc = vs_load(vs_step_ptr(lds2, laneoff, tapsel, rb3, t + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[t], cb.h, a, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3l[t], cc.h, c, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t], cb.l, a, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[t], cc.l, c, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t], cb.h, a, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[t], cc.h, c, 0, 0, 0);
+        cb = nb;
+        cc = nc;
+    }
+    out2 = a;
+    out3 = c;
 }
 
 // grid = (strips, row segments, N)
@@ -112,18 +165,20 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     }
     const float bias4 = b4[0];
 
-    // ---- stage A state: 3x3 entropy window of layer-1 column `lane` (image column xa) ----
-    const int xa = x0 - 2 + lane;
+    // ---- stage A input: the strip's entropy rows r0-3 .. r1+2 staged once in LDS (zero outside the image = conv1's padding);
+    //      no global load is left inside the row loop ----
+    const int xa = x0 - 2 + lane;                                  // image column of layer-1 column `lane`
     const int i0 = r0 - 2, i1 = r1 + 4;                            // iterations i0 .. i1-1 (layer-1 rows i0 .. r1+1 are needed)
-    auto ent_at = [&](int rr, int xx) -> float { return (rr >= 0 && rr < H && xx >= 0 && xx < W) ? e[(size_t)rr * W + xx] : 0.0f; };
-    float er[3][3], nx[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        er[1][k] = ent_at(i0 - 1, xa - 1 + k);                     // becomes row 0 after the first shift
-        er[2][k] = ent_at(i0, xa - 1 + k);
-        nx[k] = ent_at(i0 + 1, xa - 1 + k);
-        er[0][k] = 0.0f;
+    float* ent_s = reinterpret_cast<float*>(lds1 + 2 * VS_LAYER);
+    {
+        const int nrow = r1 - r0 + 6;
+        for (int idx = tid; idx < nrow * VS_EP; idx += 256) {
+            const int rr = idx / VS_EP, cc = idx - rr * VS_EP;
+            const int yy = r0 - 3 + rr, xx = x0 - 3 + cc;
+            ent_s[idx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? e[(size_t)yy * W + xx] : 0.0f;
+        }
     }
+    __syncthreads();
     const int colmaskA = xa >= 0 && xa < W;
     // per-lane LDS offsets
     const int wrA = (wave >> 1) * VS_PLANE + lane * VS_POSB + (wave & 1) * 8;                     // stage A store (octet wave>>1, quad wave&1)
@@ -136,19 +191,23 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     for (int i = i0; i < i1; ++i) {
         // ---- A: layer-1 row i ----
         if (i <= r1 + 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { er[0][k] = er[1][k]; er[1][k] = er[2][k]; er[2][k] = nx[k]; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) nx[k] = ent_at(i + 2, xa - 1 + k);                        // prefetch for the next iteration
-            float a[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = b1s[r];
+            float er[3][3];                                        // entropy rows i-1 .. i+1, columns xa-1 .. xa+1
+            const float* ep = ent_s + (i - 1 - (r0 - 3)) * VS_EP + lane;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
+                for (int kw = 0; kw < 3; ++kw) er[kh][kw] = ep[kh * VS_EP + kw];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 a01 = {b1s[0], b1s[1]}, a23 = {b1s[2], b1s[3]};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[r] = fmaf(er[kh][kw], w1s[kh * 3 + kw][r], a[r]);
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const f32x2 ev = {er[kh][kw], er[kh][kw]};
+                    a01 = __builtin_elementwise_fma(ev, (f32x2){w1s[kh * 3 + kw][0], w1s[kh * 3 + kw][1]}, a01);
+                    a23 = __builtin_elementwise_fma(ev, (f32x2){w1s[kh * 3 + kw][2], w1s[kh * 3 + kw][3]}, a23);
+                }
+            float a[4] = {a01[0], a01[1], a23[0], a23[1]};
             const bool in = colmaskA && i >= 0 && i < H;
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = in ? fmaxf(a[r], 0.0f) : 0.0f;
@@ -158,31 +217,32 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             *reinterpret_cast<vs_bf16x4*>(p) = hi;
             *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
         }
-        // ---- B: layer-2 row i-2 from layer-1 rows i-3 .. i-1 ----
-        const int yb = i - 2;
-        if (yb >= r0 - 1 && yb <= r1) {
-            const f32x4 acc = vs_layer_row(lds1, laneoff, tapsel, i - 3, w2h, w2l);
+        // ---- B: layer-2 row i-2 from layer-1 rows i-3 .. i-1;  C: layer-3 row i-4 from layer-2 rows i-5 .. i-3 ----
+        const int yb = i - 2, yc = i - 4;
+        const bool doB = yb >= r0 - 1 && yb <= r1, doC = yc >= r0;
+        f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc3 = acc2;
+        if (doB && doC) vs_two_layer_rows(lds1, lds2, laneoff, tapsel, i - 3, i - 5, w2h, w2l, w3h, w3l, acc2, acc3);
+        else if (doB) acc2 = vs_layer_row(lds1, laneoff, tapsel, i - 3, w2h, w2l);
+        else if (doC) acc3 = vs_layer_row(lds2, laneoff, tapsel, i - 5, w3h, w3l);
+        if (doB) {
             const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc[r] + b2v[r], 0.0f) : 0.0f;
+            for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc2[r] + b2v[r], 0.0f) : 0.0f;
             vs_bf16x4 hi, lo;
             vs_split4(v, hi, lo);
             char* p = lds2 + wrB + (yb & (VS_RING - 1)) * (VS_P * VS_POSB);
             *reinterpret_cast<vs_bf16x4*>(p) = hi;
             *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
         }
-        // ---- C: layer-3 row i-4 from layer-2 rows i-5 .. i-3, then 1x1 + sigmoid ----
-        const int yc = i - 4;
-        if (yc >= r0) {
-            const f32x4 acc = vs_layer_row(lds2, laneoff, tapsel, i - 5, w3h, w3l);
+        if (doC) {                                                  // 1x1 + sigmoid
             float part = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part += fmaxf(acc[r] + b3v[r], 0.0f) * w4v[r];           // rows 8..15 of the tile: zero weights
+            for (int r = 0; r < 4; ++r) part += fmaxf(acc3[r] + b3v[r], 0.0f) * w4v[r];          // rows 8..15 of the tile: zero weights
             part += __shfl_xor(part, 16);
             if (g == 0 && c2 < VS_TW && xc < W && yc < r1) {
                 const float z = part + bias4;
-                vo[(size_t)yc * W + xc] = 1.0f / (1.0f + __builtin_amdgcn_exp2f(-z * 1.4426950408889634f));
+                vo[(size_t)yc * W + xc] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z * 1.4426950408889634f));
             }
         }
         __syncthreads();
@@ -195,7 +255,7 @@ int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float*
     // segment height: enough blocks to fill the chip (>= ~1024), warm-up overhead 6 rows per segment
     long long per_row = (long long)strips * N;
     int SH = (int)((per_row * H + 1023) / 1024);
-    SH = SH < 8 ? 8 : (SH > 64 ? 64 : SH);
+    SH = SH < 8 ? 8 : (SH > VS_SH_MAX ? VS_SH_MAX : SH);
     const int segs = (int)ceil_div(H, SH);
     if (VS_LDS > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS);

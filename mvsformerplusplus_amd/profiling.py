@@ -156,9 +156,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         N = B * (V - 1)
         vis_flops = 2.0 * N * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8)
         if net.conv_precision == "bf16x3":
-            # two fused launches inside one C call (vis_front_bf16x3_kernel, vis_back_bf16x3_kernel): timed as a bundle
-            vis = _timed(launches, "[bundle] vis_front+vis_back_bf16x3", s, vis_flops, 4.0 * N * HW * (1 + 16 + 16 + 1),
-                         lambda: ops.vis_weight(ent, vp, prec))
+            # one row-streaming launch; algorithmic traffic = entropy in + visibility out
+            vis = _timed(launches, "vis_cnn_kernel", s, vis_flops, 4.0 * N * HW * 2, lambda: ops.vis_weight(ent, vp, prec))
         else:
             # fp32 mode: the four launches of mvs_vis_weight_fwd one by one
             t1 = _timed(launches, "vis_conv1", s, 2.0 * N * HW * 9 * 16, 4.0 * N * HW * 17, lambda: ops.vis_conv1(ent, vp[0], vp[1]))
