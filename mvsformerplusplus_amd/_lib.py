@@ -81,7 +81,7 @@ def bind(path: str) -> C.CDLL:
         fn.argtypes = args
     if lib.mvs_abi_version() != ABI_VERSION:
         raise MvsHipError("libmvs_hip ABI version mismatch: %d" % lib.mvs_abi_version())
-    return lib
+    return _GuardedLib(lib)
 
 
 _LIB: Optional[C.CDLL] = None
@@ -104,6 +104,9 @@ def check(rc: int, what: str = "") -> None:
         raise MvsHipError("%s failed (code %d): %s" % (what or "libmvs_hip call", rc, msg.decode() if msg else "?"))
 
 
+_CALL_DEVICE: list = []       # devices of the tensors handed to ptr() since the last device_call()
+
+
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     """Raw address of a dense tensor (None -> NULL)."""
     if t is None:
@@ -112,11 +115,40 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
         raise MvsHipError("internal: non-contiguous tensor handed to the C ABI")
     if _REQUIRE_DEVICE and not t.is_cuda:
         raise MvsHipError("libmvs_hip needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+    if t.is_cuda:
+        _CALL_DEVICE.append(t.device)
     return t.data_ptr()
 
 
+class _GuardedLib:
+    """Every C-ABI call runs with the tensors' device made current (HIP resolves the null stream and launches on the CURRENT
+    device, not on the device that owns the pointers), and refuses tensors spread over several devices - what torch's own ops
+    do with their device guard.  Arguments are evaluated (ptr() records the devices) before the call is made."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if not name.startswith("mvs_") or name in ("mvs_abi_version", "mvs_last_error") or name.endswith("_bytes") or name.endswith("_floats"):
+            return fn
+
+        def call(*args):
+            devs = set(_CALL_DEVICE)
+            del _CALL_DEVICE[:]
+            if len(devs) > 1:
+                raise MvsHipError("%s: tensors on different devices %s" % (name, sorted(str(d) for d in devs)))
+            if devs:
+                dev = devs.pop()
+                if torch.cuda.current_device() != dev.index:
+                    with torch.cuda.device(dev):
+                        return fn(*args)
+            return fn(*args)
+        return call
+
+
 def stream_of(t: torch.Tensor) -> Optional[int]:
-    """The caller's current HIP stream (work is enqueued there, like any torch op)."""
+    """The caller's current HIP stream ON THE TENSOR'S DEVICE (work is enqueued there, like any torch op)."""
     if t.is_cuda:
         return torch.cuda.current_stream(t.device).cuda_stream
     return None

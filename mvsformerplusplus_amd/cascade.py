@@ -36,10 +36,13 @@ class CascadeDepthHead(nn.Module):
         self.use_pe3d = args.get("use_pe3d", False)
         self.fusions = nn.ModuleList([StageNet(args, self.ndepths[i], i) for i in range(len(self.ndepths))])
 
-    def set_view_group(self, group) -> None:
-        """Shard source views over the ranks of `group` (RCCL all-reduce of partial cost volumes per stage)."""
+    def set_view_group(self, group, shard_mode: str = "auto") -> None:
+        """Shard source views over the ranks of `group`.  shard_mode: "allreduce" = one all-reduce of the
+        partial cost volume per stage, regulariser replicated; "slab" = exchange of halo-extended row slabs, each rank regularises
+        1 / world of the volume; "auto" = slab wherever a rank's slab is at least one halo (40 rows) tall."""
         for f in self.fusions:
             f.view_group = group
+            f.shard_mode = shard_mode
 
     def forward(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
                 tmp: Sequence[float] = (5.0, 5.0, 5.0, 1.0)) -> Dict[str, torch.Tensor]:

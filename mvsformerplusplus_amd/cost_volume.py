@@ -55,6 +55,11 @@ class StageNet(nn.Module):
         else:
             self.cost_reg = CostRegNet(self.in_channels, self.in_channels)
         self.view_group = None            # torch.distributed group for view sharding (None = single GPU)
+        # "auto": all-reduce of the partial volumes on coarse stages, H-slab exchange + 1/R of the regulariser where a slab is
+        # at least one halo tall; "allreduce" / "slab" force one form
+        self.shard_mode = "auto"
+        self.last_collective_bytes = 0
+        self._buffers_cache = {}
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
         # contraction of every MFMA convolution of the stage: "bf16x3" (3-term split bf16, ~2^-16 relative) or "fp32"
         self.conv_precision = args.get("conv_precision", DEFAULT_PRECISION)
@@ -95,49 +100,180 @@ class StageNet(nn.Module):
             raise ValueError("depth_values must be [B,D,H,W] inside the cascade")
         hom = ops.compose_homography(proj_matrices)
         vis_params = self._vis_params(feats.device)
-
         prec = precision_code(self.conv_precision)
-        # pass 1 (entropy per view) -> visibility CNN -> pass 2 gathers again and writes the cost volume once: the per-view
-        # correlation volumes are never kept (round 1 kept them for D >= 8: 2 x 32 B per voxel and view of HBM traffic)
-        if self.view_group is None:
+        if self.view_group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(self.view_group)
+            slab = self._slab_plan(H, world) if self.shard_mode in ("auto", "slab") else None
+            if slab is not None and not isinstance(self.cost_reg, PureTransformerCostReg):
+                return self._forward_slab(feats, code, hom, hyp, depth_values, G, vis_params, float(tmp), slab)
+            volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
+        else:
+            # pass 1 (entropy per view) -> visibility CNN -> pass 2 gathers again and writes the cost volume once: the per-view
+            # correlation volumes are never kept (round 1 kept them for D >= 8: 2 x 32 B per voxel and view of HBM traffic)
             entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
             vis = ops.vis_weight(entropy, vis_params, prec)
             volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
-        else:
-            volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
+        return self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d)
 
-        D = hyp.shape[1]
+    def _head_mode(self, D):
         conf_n = 0
         if self.depth_type == "ce":
             mode = _lib.HEAD_CE_TRAIN if self.training else _lib.HEAD_CE_EVAL
         else:
             mode = _lib.HEAD_REG
             conf_n = 4 if D >= 32 else (3 if D == 16 else (2 if D == 8 else 0))                    # cost_volume.py:121-128
+        return mode, conf_n
+
+    def _regularise_and_regress(self, volume, hyp, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
+        """cost_volume.py:103-131 on a normalised channel-last volume [B,D,H,W,8] (H may be a row slab of the stage)."""
+        D = hyp.shape[1]
+        mode, conf_n = self._head_mode(D)
         if isinstance(self.cost_reg, PureTransformerCostReg):
             prob_volume_pre = self.cost_reg.logits_cl(volume, position3d)
-            depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, float(tmp), mode, conf_n, self.return_prob_volumes)
+            depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
         else:
-            ws, bs, prob_w, prob_b = self.cost_reg.packed_all(feats.device, self.conv_precision)
-            feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, prec)
+            ws, bs, prob_w, prob_b = self.cost_reg.packed_all(volume.device, self.conv_precision)
+            feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, precision_code(self.conv_precision))
             depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(
-                feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, float(tmp), mode, conf_n, self.return_prob_volumes)
+                feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, tmp, mode, conf_n, self.return_prob_volumes)
         return {"depth": depth, "prob_volume": prob_volume, "photometric_confidence": conf,
                 "depth_values": depth_values, "prob_volume_pre": prob_volume_pre}
 
-    # ---- source views sharded over ranks, one all-reduce(sum) of [G*D*HW + HW] floats ----
-    def _sharded_volume(self, feats, code, hom, hyp, G, vis_params):
+    # ---- SURVEY.md section 8e: source views sharded over the ranks of `view_group` ---------------------------------------
+    def _buffer(self, name, shape, device, zero=False):
+        """Persistent scratch per (name, shape): the sharded path allocates nothing in steady state."""
+        key = (name, tuple(shape), device)
+        buf = self._buffers_cache.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=torch.float32, device=device)
+            self._buffers_cache[key] = buf
+        if zero:
+            buf.zero_()
+        return buf
+
+    def _partial_volume(self, feats, code, hom, hyp, G, vis_params, flat):
+        """This rank's share of volume_sum / vis_sum (cost_volume.py:97-98) written into `flat` = [vol | vsum]."""
         import torch.distributed as dist
         B, V, C, H, W = feats.shape
         D = hyp.shape[1]
         world, rank = dist.get_world_size(self.view_group), dist.get_rank(self.view_group)
         vb, ve = shard_views(V - 1, world, rank)
-        flat = torch.zeros(B * D * H * W * G + B * H * W, dtype=torch.float32, device=feats.device)
-        vol = flat[: B * D * H * W * G].view(B, D, H, W, G)
-        vsum = flat[B * D * H * W * G:].view(B, H, W)
+        nvol = B * D * H * W * G
+        vol = flat[:nvol].view(B, D, H, W, G)
+        vsum = flat[nvol:].view(B, H, W)
         if ve > vb:
-            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, vb, ve)
-            vis = entropy.clone()
-            vis[:, vb - 1: ve - 1] = ops.vis_weight(entropy[:, vb - 1: ve - 1].contiguous(), vis_params, precision_code(self.conv_precision))
+            # entropy / visibility maps are indexed by absolute view; only this rank's views are written and read
+            entropy = self._buffer("entropy", (B, V - 1, H, W), feats.device)
+            ops.warp_corr_entropy(feats, code, hom, hyp, G, vb, ve, out=entropy)
+            vis = self._buffer("vis", (B, V - 1, H, W), feats.device)
+            own = entropy[:, vb - 1: ve - 1]
+            vis[:, vb - 1: ve - 1] = ops.vis_weight(own if own.is_contiguous() else own.contiguous(), vis_params, precision_code(self.conv_precision))
             ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=False, view_begin=vb, view_end=ve, out=(vol, vsum))
+        else:
+            flat.zero_()                                     # more ranks than source views: this rank contributes nothing
+        return vol, vsum
+
+    def _sharded_volume(self, feats, code, hom, hyp, G, vis_params):
+        """All-reduce mode: ONE all-reduce(sum) of [G*D*HW + HW] floats per stage, regulariser replicated on every rank."""
+        import torch.distributed as dist
+        B, V, C, H, W = feats.shape
+        D = hyp.shape[1]
+        flat = self._buffer("partial", (B * D * H * W * G + B * H * W,), feats.device)
+        vol, vsum = self._partial_volume(feats, code, hom, hyp, G, vis_params, flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.view_group)
+        self.last_collective_bytes = flat.numel() * 4
         return ops.volume_normalise_(vol, vsum)
+
+    # slab mode (SURVEY.md section 8e (i)) -----------------------------------------------------------------------------------
+    SLAB_HALO = 40      # rows: >= the U-Net + prob receptive radius (1+2+2+4+4+8+8+4+2+1 = 36) and a multiple of 8 (stride phase)
+
+    def _slab_plan(self, H, world):
+        """Row slabs [a, b) of equal height S (multiple of 8) per rank and their halo-extended ranges, or None when the slabs
+        would be thinner than the halo (the exchange + redundant halo work would not pay: coarse stages stay all-reduce)."""
+        S = -(-H // world)
+        S = -(-S // 8) * 8
+        if self.shard_mode != "slab" and S < self.SLAB_HALO:
+            return None
+        plan = []
+        for r in range(world):
+            a, b = min(r * S, H), min((r + 1) * S, H)
+            ea, eb = max(0, a - self.SLAB_HALO), min(H, b + self.SLAB_HALO)
+            plan.append((a, b, ea, eb))
+        return S, plan
+
+    def _forward_slab(self, feats, code, hom, hyp, depth_values, G, vis_params, tmp, slab):
+        """Partial volumes -> every rank receives the partials of ITS halo-extended row slab from all ranks, sums them,
+        regularises 1 / world of the volume (plus halo) and regresses its rows; an all-gather of the per-row outputs gives every
+        rank the whole stage result (bit-identical on all ranks: each row has one owner)."""
+        import torch.distributed as dist
+        B, V, C, H, W = feats.shape
+        D = hyp.shape[1]
+        dev = feats.device
+        world, rank = dist.get_world_size(self.view_group), dist.get_rank(self.view_group)
+        S, plan = slab
+        flat = self._buffer("partial", (B * D * H * W * G + B * H * W,), dev)
+        vol, vsum = self._partial_volume(feats, code, hom, hyp, G, vis_params, flat)
+        a, b, ea, eb = plan[rank]
+        rows = eb - ea
+        # ---- exchange: to rank j the rows [ea_j, eb_j) of this rank's partial (volume rows + vis_sum rows in one message) ----
+        ops_, sends, recvs = [], {}, {}
+        for j in range(world):
+            ja, jb, jea, jeb = plan[j]
+            if jb <= ja:
+                continue                                     # rank j owns no rows (more ranks than 8-row slabs)
+            n = B * D * (jeb - jea) * W * G + B * (jeb - jea) * W
+            if j == rank:
+                continue
+            sb = self._buffer("send%d" % j, (n,), dev)
+            sb[: n - B * (jeb - jea) * W].view(B, D, jeb - jea, W, G).copy_(vol[:, :, jea:jeb])
+            sb[n - B * (jeb - jea) * W:].view(B, jeb - jea, W).copy_(vsum[:, jea:jeb])
+            sends[j] = sb
+            ops_.append(dist.P2POp(dist.isend, sb, dist.get_global_rank(self.view_group, j), self.view_group))
+        nmine = B * D * rows * W * G + B * rows * W
+        if b > a:
+            for j in range(world):
+                if j == rank:
+                    continue
+                rb = self._buffer("recv%d" % j, (nmine,), dev)
+                recvs[j] = rb
+                ops_.append(dist.P2POp(dist.irecv, rb, dist.get_global_rank(self.view_group, j), self.view_group))
+        if ops_:
+            for w in dist.batch_isend_irecv(ops_):
+                w.wait()
+        self.last_collective_bytes = sum(t.numel() for t in sends.values()) * 4
+        out_rows = None
+        if b > a:
+            acc = self._buffer("slab", (nmine,), dev)
+            acc[: nmine - B * rows * W].view(B, D, rows, W, G).copy_(vol[:, :, ea:eb])
+            acc[nmine - B * rows * W:].view(B, rows, W).copy_(vsum[:, ea:eb])
+            for j in sorted(recvs):                          # fixed rank order: every rank sums in the same order
+                acc.add_(recvs[j])
+            svol = acc[: nmine - B * rows * W].view(B, D, rows, W, G)
+            ssum = acc[nmine - B * rows * W:].view(B, rows, W)
+            ops.volume_normalise_(svol, ssum)
+            shyp = hyp[:, :, ea:eb].contiguous()
+            st = self._regularise_and_regress(svol, shyp, None, tmp)
+            lo, hi = a - ea, b - ea
+            out_rows = {k: st[k][..., lo:hi, :] for k in ("depth", "photometric_confidence", "prob_volume", "prob_volume_pre") if st[k] is not None}
+        # ---- all-gather of the owners' rows: [channels, S, W] per rank, channels = depth, conf (+ 2 D probability planes) ----
+        nch = 2 + (2 * D if self.return_prob_volumes else 0)
+        mine = self._buffer("gather_in", (B, nch, S, W), dev, zero=True)
+        if out_rows is not None:
+            h = b - a
+            mine[:, 0, :h] = out_rows["depth"]
+            mine[:, 1, :h] = out_rows["photometric_confidence"]
+            if self.return_prob_volumes:
+                mine[:, 2: 2 + D, :h] = out_rows["prob_volume"]
+                mine[:, 2 + D: 2 + 2 * D, :h] = out_rows["prob_volume_pre"]
+        allb = self._buffer("gather_out", (world, B, nch, S, W), dev)
+        if dev.type == "cuda" and hasattr(dist, "all_gather_into_tensor"):
+            dist.all_gather_into_tensor(allb.view(-1), mine.view(-1), group=self.view_group)
+        else:
+            dist.all_gather(list(allb.unbind(0)), mine, group=self.view_group)
+        self.last_collective_bytes += allb.numel() * 4
+        full = allb.permute(1, 2, 0, 3, 4).reshape(B, nch, world * S, W)[:, :, :H]
+        res = {"depth": full[:, 0].contiguous(), "photometric_confidence": full[:, 1].contiguous(), "depth_values": depth_values,
+               "prob_volume": full[:, 2: 2 + D].contiguous() if self.return_prob_volumes else None,
+               "prob_volume_pre": full[:, 2 + D: 2 + 2 * D].contiguous() if self.return_prob_volumes else None}
+        return res

@@ -28,7 +28,7 @@ def _bn_dict(bn: nn.Module) -> Dict[str, torch.Tensor]:
         raise NotImplementedError("train-mode BatchNorm (batch statistics) is not implemented in the HIP path yet "
                                   "(SURVEY.md section 8f #2); call .eval() on the BatchNorm layers")
     return {"weight": bn.weight.detach().cpu(), "bias": bn.bias.detach().cpu(),
-            "running_mean": bn.running_mean.detach().cpu(), "running_var": bn.running_var.detach().cpu()}
+            "running_mean": bn.running_mean.detach().cpu(), "running_var": bn.running_var.detach().cpu(), "eps": float(bn.eps)}
 
 
 DEFAULT_PRECISION = "bf16x3"      # contraction of the MFMA convolutions: "bf16x3" (3-term split bf16) or "fp32" (exact)
@@ -47,15 +47,27 @@ class _PackedCache:
     def __init__(self):
         self._entries = {}
 
+    @staticmethod
+    def _version(t):
+        try:
+            return t._version
+        except RuntimeError:            # tensors created under torch.inference_mode() have no version counter
+            return -1
+
     def get(self, module: nn.Module, builder, tag=None):
         ts = list(module.parameters()) + list(module.buffers())
-        bn_modes = tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
-        key = (ts[0].device, sum(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]), bn_modes)
+        bn_modes = tuple((m.training, m.eps) for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+        # identity AND in-place version of EVERY tensor: replacing one parameter (new storage) or writing into one both miss
+        key = (ts[0].device, tuple((t.data_ptr(), self._version(t)) for t in ts), bn_modes)
         hit = self._entries.get(tag)
         if hit is None or hit[0] != key:
             hit = (key, builder(ts[0].device))
             self._entries[tag] = hit
         return hit[1]
+
+    def refresh(self):
+        """Drop every packed copy (call after mutating parameters in a way the version counters cannot see)."""
+        self._entries.clear()
 
 
 def _no_grad_path(*tensors):

@@ -22,7 +22,7 @@ BN_EPS = 1e-5
 
 def fold_bn(weight: torch.Tensor, bn: Dict[str, torch.Tensor], out_dim: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Fold eval-mode BatchNorm into the preceding bias-free conv.  ``out_dim`` = axis of ``weight`` that is Cout."""
-    scale = bn["weight"].double() / torch.sqrt(bn["running_var"].double() + BN_EPS)
+    scale = bn["weight"].double() / torch.sqrt(bn["running_var"].double() + float(bn.get("eps", BN_EPS)))
     shift = bn["bias"].double() - bn["running_mean"].double() * scale
     shape = [1] * weight.dim()
     shape[out_dim] = -1

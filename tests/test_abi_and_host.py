@@ -161,3 +161,69 @@ def test_seeded_weights_are_stable():
     assert abs(float(sd["a.conv.weight"].flatten()[0]) - (-0.31287533044815063)) < 1e-7 or True
     again = synth.seeded_state_dict({"a.bn.running_var": (4,), "a.conv.weight": (2, 3, 3, 3)}, 5)
     assert torch.equal(sd["a.conv.weight"], again["a.conv.weight"]) and torch.equal(sd["a.bn.running_var"], again["a.bn.running_var"])
+
+
+def test_device_guard_makes_the_tensor_device_current(monkeypatch):
+    """HIP launches on the CURRENT device's null stream, so a call on tensors of another device must switch to it
+    (torch's own ops do this with a device guard) and tensors spread over two devices must be refused."""
+    import contextlib
+    import torch
+
+    class FakeCdll:
+        def __init__(self):
+            self.seen = []
+
+        def mvs_fake_fwd(self, *args):
+            self.seen.append(("call", tuple(args)))
+            return 0
+
+        def mvs_vis_workspace_bytes(self, *args):
+            return 16
+
+    entered = []
+
+    @contextlib.contextmanager
+    def fake_device(dev):
+        entered.append(dev)
+        yield
+
+    fake = FakeCdll()
+    g = _lib._GuardedLib(fake)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", fake_device)
+    del _lib._CALL_DEVICE[:]
+    _lib._CALL_DEVICE.extend([torch.device("cuda", 1), torch.device("cuda", 1)])
+    assert g.mvs_fake_fwd(1, 2) == 0 and entered == [torch.device("cuda", 1)] and not _lib._CALL_DEVICE
+    _lib._CALL_DEVICE.extend([torch.device("cuda", 0)])
+    g.mvs_fake_fwd(3)
+    assert entered == [torch.device("cuda", 1)], "no switch needed when the tensors live on the current device"
+    _lib._CALL_DEVICE.extend([torch.device("cuda", 0), torch.device("cuda", 1)])
+    with pytest.raises(_lib.MvsHipError):
+        g.mvs_fake_fwd(4)
+    assert g.mvs_vis_workspace_bytes(1, 2, 3, 0) == 16          # size queries are not guarded
+
+
+def test_packed_cache_sees_replaced_and_rewritten_parameters():
+    """the packed-weight cache must miss when ANY parameter is replaced or written in place, and fold BN with the
+    layer's own eps."""
+    import torch
+    from mvsformerplusplus_amd import module as M, packing
+    layer = M.Conv3d(8, 16, stride=1, padding=1).eval()
+    builds = []
+
+    def build(dev):
+        builds.append(1)
+        return len(builds)
+    c = M._PackedCache()
+    assert c.get(layer, build) == 1 and c.get(layer, build) == 1
+    with torch.no_grad():
+        layer.bn.running_var.add_(0.5)                          # last buffers of the module: in-place write
+    assert c.get(layer, build) == 2
+    layer.bn.bias = torch.nn.Parameter(torch.zeros(16))         # replaced by a fresh tensor with version 0
+    assert c.get(layer, build) == 3
+    c.refresh()
+    assert c.get(layer, build) == 4
+    w = torch.ones(2, 1, 1, 1, 1)
+    bn = {"weight": torch.ones(2), "bias": torch.zeros(2), "running_mean": torch.zeros(2), "running_var": torch.ones(2), "eps": 3.0}
+    wf, _ = packing.fold_bn(w, bn, 0)
+    assert torch.allclose(wf.flatten(), torch.full((2,), 0.5))  # 1 / sqrt(1 + 3)

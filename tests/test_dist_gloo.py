@@ -1,6 +1,7 @@
-"""CPU, world_size 2, gloo: the view-sharded StageNet path (source views split over ranks, one all-reduce of
-[volume_sum || vis_sum] per stage) gives every rank the single-process result.
-The kernels run through the host emulator (tests/hipemu) because this container has no GPU."""
+"""CPU, gloo, world_size 2 and 4: the view-sharded latency mode gives every rank the single-process
+result - one StageNet in all-reduce mode, one StageNet in slab mode with a real interior halo cut, the whole 4-stage cascade,
+and an uneven 9-source-views-over-4-ranks split.  The kernels run through the host emulator (tests/hipemu) because this
+container has no GPU; the same Python code drives RCCL on the GPU node (backend "nccl")."""
 import os
 import socket
 import sys
@@ -22,25 +23,35 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, emu_path, V, q):
+def _setup(rank, world, port, emu_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from conftest import golden_weights, load_golden
     from mvsformerplusplus_amd import _lib
-    from mvsformerplusplus_amd.cost_volume import StageNet
     _lib._LIB = _lib.bind(emu_path)
     _lib._REQUIRE_DEVICE = False
+
+
+def _agree(t, world):
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t.contiguous())
+    return all(torch.equal(gathered[0], g) for g in gathered)
+
+
+def _stage_worker(rank, world, port, emu_path, V, q):
+    _setup(rank, world, port, emu_path)
+    from conftest import golden_weights, load_golden
+    from mvsformerplusplus_amd.cost_volume import StageNet
     fx = load_golden("f2_stage_s3.npz")
     args = {"base_ch": [8] * 4, "depth_type": ["ce"] * 4}
     net = StageNet(args, 4, 3)
     net.load_state_dict(golden_weights(fx), strict=True)
     net.eval()
     feats, proj = fx["features"], fx["proj"]
-    if V > feats.shape[1]:                      # more source views than ranks: repeat views with shifted cameras
+    if V > feats.shape[1]:                      # more source views than the fixture holds: repeat views with shifted cameras
         reps = (V + feats.shape[1] - 1) // feats.shape[1]
         feats = feats.repeat(1, reps, 1, 1, 1)[:, :V].contiguous()
         proj = proj.repeat(1, reps, 1, 1, 1)[:, :V].clone()
@@ -51,28 +62,99 @@ def _worker(rank, world, port, emu_path, V, q):
         net.view_group = dist.group.WORLD
         sharded = net(feats, proj, fx["hyp"], 1.0)
     err = float((single["depth"] - sharded["depth"]).abs().max() / single["depth"].abs().max())
-    gathered = [torch.zeros_like(sharded["depth"]) for _ in range(world)]
-    dist.all_gather(gathered, sharded["depth"])
-    same = all(torch.equal(gathered[0], g) for g in gathered)
-    q.put((rank, err, same))
+    q.put((rank, err, _agree(sharded["depth"], world)))
     dist.destroy_process_group()
+
+
+def _slab_worker(rank, world, port, emu_path, q):
+    """One fine-stage StageNet (C = 8, D = 4, CostRegNet3D) on a 208 x 16 map: slabs of 104 rows, halo-extended to [0,144) and
+    [64,208) - the regulariser really runs on cut volumes whose first / last 40 rows are discarded."""
+    _setup(rank, world, port, emu_path)
+    from mvsformerplusplus_amd import synth
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    H, W, V, D = 208, 16, 3, 4
+    net = StageNet({"base_ch": [8] * 4, "depth_type": ["ce"] * 4}, D, 3)
+    net.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(net.state_dict()), 3), strict=True)
+    net.eval()
+    g = torch.Generator().manual_seed(5)
+    cams = synth.make_cameras(V, H, W, baseline=30.0, seed=2)
+    feats = torch.randn(1, V, 8, H, W, generator=g)
+    hyp = (torch.linspace(800, 500, D)[None, :, None, None] * (1 + 0.02 * torch.rand(1, D, H, W, generator=g))).contiguous()
+    with torch.no_grad():
+        single = net(feats, cams, hyp, 1.0)
+        net.view_group = dist.group.WORLD
+        net.shard_mode = "auto"
+        assert net._slab_plan(H, world) is not None, "208 rows over 2 ranks must select the slab form"
+        sharded = net(feats, cams, hyp, 1.0)
+    errs = [float((single[k] - sharded[k]).abs().max() / single[k].abs().max()) for k in ("depth", "photometric_confidence", "prob_volume", "prob_volume_pre")]
+    q.put((rank, max(errs), _agree(sharded["depth"], world) and _agree(sharded["prob_volume"], world)))
+    dist.destroy_process_group()
+
+
+def _cascade_worker(rank, world, port, emu_path, V, mode, q):
+    _setup(rank, world, port, emu_path)
+    from conftest import golden_weights, load_golden
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    fx = load_golden("f4_cascade.npz")
+    args = {"base_ch": [8] * 4, "depth_type": ["ce"] * 4, "fusion_type": "cnn", "cost_reg_type": ["Normal"] * 4,
+            "ndepths": [32, 16, 8, 4], "depth_interals_ratio": [4.0, 2.67, 1.5, 1.0], "inverse_depth": True}
+    head = CascadeDepthHead(args)
+    for s in range(4):
+        head.fusions[s].load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
+    head.eval()
+    feats = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
+    projs = {"stage%d" % s: fx["proj%d" % s] for s in range(1, 5)}
+    if V > feats["stage1"].shape[1]:
+        for k in feats:
+            n = feats[k].shape[1]
+            reps = (V + n - 1) // n
+            feats[k] = feats[k].repeat(1, reps, 1, 1, 1)[:, :V].contiguous()
+            projs[k] = projs[k].repeat(1, reps, 1, 1, 1)[:, :V].clone()
+            for v in range(V):
+                projs[k][:, v, 0, 0, 3] += 2.0 * v
+    with torch.no_grad():
+        single = head(feats, projs, fx["depth_values"])
+        head.set_view_group(dist.group.WORLD, shard_mode=mode)
+        sharded = head(feats, projs, fx["depth_values"])
+    err = float(((single["refined_depth"] - sharded["refined_depth"]).abs() / single["refined_depth"].abs()).mean())
+    ok = _agree(sharded["refined_depth"], world) and _agree(sharded["photometric_confidence"], world)
+    q.put((rank, err, ok))
+    dist.destroy_process_group()
+
+
+def _run(target, world, *args):
+    import hipemu_build
+    emu = hipemu_build.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, emu) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
 
 
 @pytest.mark.parametrize("V", [3, 4, 2])
 def test_view_sharded_stage_matches_single_process(V):
-    import hipemu_build
-    emu = hipemu_build.build()
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, emu, V, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, err, same in res:
+    for rank, err, same in _run(_stage_worker, 2, V):
         assert err <= 1e-5, "rank %d: sharded depth differs from single-process depth by %g" % (rank, err)
         assert same, "ranks disagree after the all-reduce"
+
+
+def test_slab_mode_matches_single_process():
+    for rank, err, same in _run(_slab_worker, 2):
+        assert err <= 2e-5, "rank %d: slab-sharded outputs differ from single-process outputs by %g" % (rank, err)
+        assert same, "ranks disagree after the slab all-gather"
+
+
+@pytest.mark.parametrize("world,V,mode", [(2, 4, "auto"), (2, 4, "slab"), (4, 10, "auto")])
+def test_view_sharded_cascade_matches_single_process(world, V, mode):
+    """The whole 4-stage cascade: (2 ranks, 3 source views), the same with the slab exchange forced on every stage, and the
+    uneven BASELINE configs[2] split - 9 source views over 4 ranks (3 + 2 + 2 + 2)."""
+    for rank, err, same in _run(_cascade_worker, world, V, mode):
+        assert err <= 1e-4, "rank %d: sharded refined depth rel-L1 %g vs the single-process cascade" % (rank, err)
+        assert same, "ranks hold different results"
