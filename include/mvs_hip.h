@@ -113,6 +113,12 @@ int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const void* w_packed, const 
                                  float* y_cl, int B, int Cin, int Cout, int D, int H, int W, int sd, int precision,
                                  void* stream);
 
+/* the last U-Net layer with the 1x1x1 `prob` head in its epilogue (Cout = 8): x_cl [B,D,H,W,Cin] -> logits [B,D*sd,2H,2W]
+ * = prob(skip + relu(bn(deconv(x)))); MVS_PREC_BF16X3 only.  mvs_regnet_logits_fwd chains it after the other eight layers. */
+int mvs_deconv3d_prob_fwd(const float* x_cl, const void* w_packed, const float* bias, const float* skip_cl, const float* prob_w,
+                          const float* prob_b, float* logits, int B, int Cin, int D, int H, int W, int sd, int precision,
+                          void* stream);
+
 /* ---- a8/a9: whole regulariser U-Net (CostRegNet / CostRegNet3D), module.py:367-408 / 453-504 ----
  * volume_cl [B,D,H,W,8] -> feat_cl [B,D,H,W,8] = conv0 + relu(bn(deconv11(...))) (input of `prob`).
  * params: 9 packed weight pointers + 9 bias pointers in layer order conv1..conv6, conv7, conv9, conv11.*/
@@ -120,6 +126,12 @@ size_t mvs_regnet_workspace_bytes(int kind, int B, int D, int H, int W);
 int mvs_regnet_fwd(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias,
                    float* feat_cl, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int precision,
                    void* stream);
+/* the same U-Net with a 1x1x1 `prob` head (CostRegNet3D, module.py:486,502: prob_w [8], prob_b [1]) applied in the epilogue
+ * of the last ConvTranspose3d: volume_cl -> logits [B,D,H,W] = prob_volume_pre; the 8-channel full-resolution feature
+ * volume is never written (MVS_PREC_BF16X3 only).  Follow with mvs_softmax_regress_fwd.                              */
+int mvs_regnet_logits_fwd(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias,
+                          const float* prob_w, const float* prob_b, float* logits, void* workspace, size_t workspace_bytes,
+                          int B, int D, int H, int W, int precision, void* stream);
 
 /* ---- a8/a9 `prob` + a10 + a11: logits, softmax, depth regression, confidence --------------------
  * feat_cl [B,D,H,W,8]; prob_w: [8] (+ prob_b[1]) for the 1x1x1 head (CostRegNet3D, module.py:486)

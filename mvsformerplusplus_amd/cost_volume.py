@@ -58,6 +58,7 @@ class StageNet(nn.Module):
         # "auto": all-reduce of the partial volumes on coarse stages, H-slab exchange + 1/R of the regulariser where a slab is
         # at least one halo tall; "allreduce" / "slab" force one form
         self.shard_mode = "auto"
+        self.fuse_prob_head = True        # CostRegNet3D + bf16x3: `prob` applied in the last deconvolution's epilogue
         self.last_collective_bytes = 0
         self._buffers_cache = {}
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
@@ -134,9 +135,15 @@ class StageNet(nn.Module):
             depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
         else:
             ws, bs, prob_w, prob_b = self.cost_reg.packed_all(volume.device, self.conv_precision)
-            feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, precision_code(self.conv_precision))
-            depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(
-                feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+            if self.cost_reg.prob_ksize == 1 and self.conv_precision == "bf16x3" and self.fuse_prob_head:
+                # CostRegNet3D: the 1x1x1 head rides in the last deconvolution's epilogue (module.py:500-502): logits out, the
+                # 8-channel full-resolution features never reach HBM
+                prob_volume_pre = ops.regnet_logits(self.cost_reg.kind, volume, ws, bs, prob_w, prob_b, precision_code(self.conv_precision))
+                depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+            else:
+                feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, precision_code(self.conv_precision))
+                depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(
+                    feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, tmp, mode, conf_n, self.return_prob_volumes)
         return {"depth": depth, "prob_volume": prob_volume, "photometric_confidence": conf,
                 "depth_values": depth_values, "prob_volume_pre": prob_volume_pre}
 

@@ -368,8 +368,10 @@ __device__ __forceinline__ void bf_deconv_load_step(int st, int ntap, int pd, in
 
 template <class Cfg>
 __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
-                                                                   const float* __restrict__ skip, float* __restrict__ y, int D, int H, int W,
-                                                                   int tiles_x, int tiles_y, int ntiles) {
+                                                                   const float* __restrict__ skip, float* __restrict__ y,
+                                                                   const float* __restrict__ prob_w, const float* __restrict__ prob_b,
+                                                                   float* __restrict__ logits, int D, int H, int W, int tiles_x,
+                                                                   int tiles_y, int ntiles) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, TDM = Cfg::TDM, THM = Cfg::THM;
     constexpr int LH = Cfg::LH, LW = Cfg::LW, MREP = Cfg::MREP, NREP = Cfg::NREP;
     constexpr int OPT = BfDeconv<Cfg>::OPT, SB = BfDeconv<Cfg>::SB;
@@ -447,7 +449,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
         for (int nb = 0; nb < NREP; ++nb) {
             const int nbg = wave * NREP + nb;
             const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
-            if (mz >= D || my >= H || mx >= W) continue;
+            const bool inside = mz < D && my < H && mx < W;
+            if (!inside && !(PAIR && prob_w != nullptr)) continue;     // the fused head shuffles: every lane takes part, stores are guarded
             if (PAIR) {
                 // lane groups 0/1: channels 0-3 / 4-7 of output voxel 2mx; groups 2/3: the same of voxel 2mx + 1
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1), co = 4 * (g & 1);
@@ -455,11 +458,23 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 const float4 bb = *reinterpret_cast<const float4*>(bias + co);
                 float4 v = make_float4(fmaxf(acc[0][nb][0] + bb.x, 0.0f), fmaxf(acc[0][nb][1] + bb.y, 0.0f), fmaxf(acc[0][nb][2] + bb.z, 0.0f),
                                        fmaxf(acc[0][nb][3] + bb.w, 0.0f));
-                if (sb) {
+                if (sb && inside) {
                     const float4 sk = *reinterpret_cast<const float4*>(sb + off);
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
-                *reinterpret_cast<float4*>(yb + off) = v;
+                if (prob_w != nullptr) {
+                    // fused 1x1x1 `prob` head (module.py:486,502): logit = sum_c w[c] * feat[c] + b; the voxel's 8 channels sit in
+                    // two lane groups (g, g ^ 1): one cross-lane add.  The 8-channel feature volume never reaches HBM.
+                    const float4 pw4 = *reinterpret_cast<const float4*>(prob_w + co);
+                    float part = v.x * pw4.x;
+                    part += v.y * pw4.y;
+                    part += v.z * pw4.z;
+                    part += v.w * pw4.w;
+                    part += __shfl_xor(part, 16);
+                    if ((g & 1) == 0 && inside) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = part + prob_b[0];
+                } else {
+                    *reinterpret_cast<float4*>(yb + off) = v;
+                }
                 continue;
             }
             const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + pw;
@@ -493,12 +508,14 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
 }
 
 template <class Cfg>
-static int launch_deconv_bf(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int D, int H, int W, hipStream_t st) {
+static int launch_deconv_bf(const float* x, const void* wp, const float* bias, const float* skip, float* y, const float* prob_w,
+                            const float* prob_b, float* logits, int B, int D, int H, int W, hipStream_t st) {
     const int tx = (int)ceil_div(W, 16), ty = (int)ceil_div(H, Cfg::THM), tz = (int)ceil_div(D, Cfg::TDM);
     const int ntiles = tx * ty * tz;
     if (Cfg::LDS_BYTES > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((deconv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, skip, y, D, H, W, tx, ty, ntiles);
+    hipLaunchKernelGGL((deconv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, skip, y, prob_w, prob_b,
+                       logits, D, H, W, tx, ty, ntiles);
     return check_launch("deconv3d_mfma_bf16x3_kernel");
 }
 
@@ -514,9 +531,11 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
 }
 
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,
-                             int D, int H, int W, int sd, hipStream_t st) {
+                             int D, int H, int W, int sd, hipStream_t st, const float* prob_w, const float* prob_b, float* logits) {
+    if (prob_w != nullptr && Cout != 8) { set_error("deconv3d(bf16x3): the fused prob head needs Cout == 8"); return MVS_ERR_UNSUPPORTED; }
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
-    if (Cin == CI && Cout == CO && sd == SD) return launch_deconv_bf<DeconvCfg<CI, CO, SD, TDM, THM>>(x, wp, bias, skip, y, B, D, H, W, st);
+    if (Cin == CI && Cout == CO && sd == SD)                                                            \
+        return launch_deconv_bf<DeconvCfg<CI, CO, SD, TDM, THM>>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st);
     MVS_DECONV_TABLE(MVS_X)
 #undef MVS_X
     set_error("deconv3d(bf16x3): no kernel for Cin=%d Cout=%d stride=(%d,2,2)", Cin, Cout, sd);

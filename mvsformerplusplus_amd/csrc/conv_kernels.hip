@@ -348,8 +348,10 @@ int conv3d_dispatch(const float* x, const void* wp, const float* bias, float* y,
 }
 
 int deconv3d_dispatch(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout, int D,
-                      int H, int W, int sd, int prec, hipStream_t st) {
-    if (prec == MVS_PREC_BF16X3) return deconv3d_dispatch_bf16x3(x, wp, bias, skip, y, B, Cin, Cout, D, H, W, sd, st);
+                      int H, int W, int sd, int prec, hipStream_t st, const float* prob_w = nullptr, const float* prob_b = nullptr,
+                      float* logits = nullptr) {
+    if (prec == MVS_PREC_BF16X3) return deconv3d_dispatch_bf16x3(x, wp, bias, skip, y, B, Cin, Cout, D, H, W, sd, st, prob_w, prob_b, logits);
+    if (prob_w != nullptr) { set_error("deconv3d: the fused prob head exists for the bf16x3 contraction only"); return MVS_ERR_UNSUPPORTED; }
     if (prec != MVS_PREC_FP32) { set_error("deconv3d: unknown precision %d", prec); return MVS_ERR_ARG; }
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
     if (Cin == CI && Cout == CO && sd == SD)                                                            \
@@ -439,15 +441,23 @@ extern "C" size_t mvs_regnet_workspace_bytes(int kind, int B, int D, int H, int 
     return total * sizeof(float);
 }
 
-extern "C" int mvs_regnet_fwd(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias, float* feat_cl,
-                              void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int precision, void* stream) {
-    if (!volume_cl || !w_packed || !bias || !feat_cl || !workspace || B < 1) { set_error("mvs_regnet_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (kind != MVS_REG_COSTREGNET && kind != MVS_REG_COSTREGNET3D) { set_error("mvs_regnet_fwd: unknown regulariser kind %d", kind); return MVS_ERR_ARG; }
+extern "C" int mvs_deconv3d_prob_fwd(const float* x_cl, const void* w_packed, const float* bias, const float* skip_cl, const float* prob_w,
+                                     const float* prob_b, float* logits, int B, int Cin, int D, int H, int W, int sd, int precision,
+                                     void* stream) {
+    if (!x_cl || !w_packed || !bias || !prob_w || !prob_b || !logits || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_deconv3d_prob_fwd: bad arguments"); return MVS_ERR_ARG; }
+    return deconv3d_dispatch(x_cl, w_packed, bias, skip_cl, nullptr, B, Cin, 8, D, H, W, sd, precision, (hipStream_t)stream, prob_w, prob_b, logits);
+}
+
+static int regnet_run(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias, float* feat_cl,
+                      const float* prob_w, const float* prob_b, float* logits, void* workspace, size_t workspace_bytes, int B, int D, int H,
+                      int W, int precision, void* stream, const char* who) {
+    if (!volume_cl || !w_packed || !bias || !workspace || B < 1) { set_error("%s: bad arguments", who); return MVS_ERR_ARG; }
+    if (kind != MVS_REG_COSTREGNET && kind != MVS_REG_COSTREGNET3D) { set_error("%s: unknown regulariser kind %d", who, kind); return MVS_ERR_ARG; }
     if ((H % 8) || (W % 8) || (kind == MVS_REG_COSTREGNET && (D % 8))) {
-        set_error("mvs_regnet_fwd: spatial size %dx%dx%d must be divisible by 8 (U-Net skip adds, module.py:403-405)", D, H, W);
+        set_error("%s: spatial size %dx%dx%d must be divisible by 8 (U-Net skip adds, module.py:403-405)", who, D, H, W);
         return MVS_ERR_ARG;
     }
-    if (workspace_bytes < mvs_regnet_workspace_bytes(kind, B, D, H, W)) { set_error("mvs_regnet_fwd: workspace too small"); return MVS_ERR_WORKSPACE; }
+    if (workspace_bytes < mvs_regnet_workspace_bytes(kind, B, D, H, W)) { set_error("%s: workspace too small", who); return MVS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const int sd = (kind == MVS_REG_COSTREGNET) ? 2 : 1;
     int d1, h1, w1, d2, h2, w2, d3, h3, w3;
@@ -467,7 +477,24 @@ extern "C" int mvs_regnet_fwd(int kind, const float* volume_cl, const void* cons
     MVS_TRY(conv3d_dispatch(c5, w_packed[5], bias[5], c6, B, 64, 64, d3, h3, w3, 3, 1, 1, 1, 1, precision, st));           // conv6
     MVS_TRY(deconv3d_dispatch(c6, w_packed[6], bias[6], c4, c3, B, 64, 32, d3, h3, w3, sd, precision, st));                // conv4 + conv7 -> c3
     MVS_TRY(deconv3d_dispatch(c3, w_packed[7], bias[7], c2, c1, B, 32, 16, d2, h2, w2, sd, precision, st));                // conv2 + conv9 -> c1
-    MVS_TRY(deconv3d_dispatch(c1, w_packed[8], bias[8], volume_cl, feat_cl, B, 16, 8, d1, h1, w1, sd, precision, st));     // conv0 + conv11
+    MVS_TRY(deconv3d_dispatch(c1, w_packed[8], bias[8], volume_cl, feat_cl, B, 16, 8, d1, h1, w1, sd, precision, st, prob_w, prob_b,
+                              logits));                                                                                    // conv0 + conv11 (+ prob)
 #undef MVS_TRY
     return MVS_OK;
+}
+
+extern "C" int mvs_regnet_fwd(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias, float* feat_cl,
+                              void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int precision, void* stream) {
+    if (!feat_cl) { set_error("mvs_regnet_fwd: bad arguments"); return MVS_ERR_ARG; }
+    return regnet_run(kind, volume_cl, w_packed, bias, feat_cl, nullptr, nullptr, nullptr, workspace, workspace_bytes, B, D, H, W, precision, stream,
+                      "mvs_regnet_fwd");
+}
+
+extern "C" int mvs_regnet_logits_fwd(int kind, const float* volume_cl, const void* const* w_packed, const float* const* bias,
+                                     const float* prob_w, const float* prob_b, float* logits, void* workspace, size_t workspace_bytes, int B,
+                                     int D, int H, int W, int precision, void* stream) {
+    if (!prob_w || !prob_b || !logits) { set_error("mvs_regnet_logits_fwd: bad arguments"); return MVS_ERR_ARG; }
+    if (precision != MVS_PREC_BF16X3) { set_error("mvs_regnet_logits_fwd: the fused 1x1x1 head exists for MVS_PREC_BF16X3 only"); return MVS_ERR_UNSUPPORTED; }
+    return regnet_run(kind, volume_cl, w_packed, bias, nullptr, prob_w, prob_b, logits, workspace, workspace_bytes, B, D, H, W, precision, stream,
+                      "mvs_regnet_logits_fwd");
 }

@@ -153,6 +153,16 @@ def deconv3d_bn_relu_add(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch
     return y
 
 
+def deconv3d_prob(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, sd: int, skip_cl: torch.Tensor, prob_w: torch.Tensor,
+                  prob_b: torch.Tensor, precision: int) -> torch.Tensor:
+    """Last U-Net layer (Cout = 8) + skip + 1x1x1 `prob` in one launch -> logits [B, D*sd, 2H, 2W]."""
+    B, D, H, W, cin = x_cl.shape
+    logits = torch.empty(B, D * sd, 2 * H, 2 * W, dtype=torch.float32, device=x_cl.device)
+    check(lib().mvs_deconv3d_prob_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(skip_cl), ptr(prob_w), ptr(prob_b), ptr(logits), B, cin, D, H, W,
+                                      sd, precision, stream_of(x_cl)), "mvs_deconv3d_prob_fwd")
+    return logits
+
+
 def _ptr_array(ts: Sequence[torch.Tensor]):
     return (C.c_void_p * len(ts))(*[ptr(t) for t in ts])
 
@@ -169,6 +179,20 @@ def regnet(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.Tensor],
     check(lib().mvs_regnet_fwd(kind, ptr(volume_cl), C.cast(wa, C.c_void_p), C.cast(ba, C.c_void_p), ptr(out), ptr(ws), nbytes,
                                B, D, H, W, precision, stream_of(volume_cl)), "mvs_regnet_fwd")
     return out
+
+
+def regnet_logits(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.Tensor], bias: Sequence[torch.Tensor],
+                  prob_w: torch.Tensor, prob_b: torch.Tensor, precision: int) -> torch.Tensor:
+    """U-Net + fused 1x1x1 `prob` head: volume_cl [B,D,H,W,8] -> logits [B,D,H,W] (the feature volume stays on chip)."""
+    B, D, H, W, c = volume_cl.shape
+    assert c == 8 and len(w_packed) == 9 and len(bias) == 9
+    logits = torch.empty(B, D, H, W, dtype=torch.float32, device=volume_cl.device)
+    nbytes = lib().mvs_regnet_workspace_bytes(kind, B, D, H, W)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=volume_cl.device)
+    wa, ba = _ptr_array(w_packed), _ptr_array(bias)
+    check(lib().mvs_regnet_logits_fwd(kind, ptr(volume_cl), C.cast(wa, C.c_void_p), C.cast(ba, C.c_void_p), ptr(prob_w), ptr(prob_b),
+                                      ptr(logits), ptr(ws), nbytes, B, D, H, W, precision, stream_of(volume_cl)), "mvs_regnet_logits_fwd")
+    return logits
 
 
 # ---- a10/a11 ------------------------------------------------------------------------------------

@@ -59,9 +59,10 @@ def _timed(launches: List[Launch], kernel: str, stage: int, flops: float, nbytes
     return out
 
 
-def _regnet_layers(net, vol, stage, launches, precision):
-    """The nine U-Net launches of mvs_regnet_fwd, one C-ABI call each (same kernels, same order)."""
-    ws, bs, _, _ = net.packed_all(vol.device, precision)
+def _regnet_layers(net, vol, stage, launches, precision, fused_head=False):
+    """The nine U-Net launches of mvs_regnet_fwd, one C-ABI call each (same kernels, same order).  fused_head: the last layer
+    carries the 1x1x1 `prob` head (mvs_regnet_logits_fwd) and returns logits instead of features."""
+    ws, bs, prob_w, prob_b = net.packed_all(vol.device, precision)
     prec = _lib.PRECISIONS[precision]
     three_d = net.kind == _lib.REG_COSTREGNET3D
     s2 = (1, 2, 2) if three_d else (2, 2, 2)
@@ -89,6 +90,11 @@ def _regnet_layers(net, vol, stage, launches, precision):
     c6 = conv(c5, 5, 64, (1, 1, 1))
     x = deconv(c6, 6, 32, c4)
     x = deconv(x, 7, 16, c2)
+    if fused_head:
+        B, D, H, W, cin = x.shape
+        nout = B * D * sd * 4 * H * W
+        return _timed(launches, "deconv3d_mfma<%d,%d,s%d22>+prob" % (cin, 8, sd), stage, 2.0 * 27 * cin * 8 * (B * D * H * W) + 2.0 * 8 * nout,
+                      4.0 * (x.numel() + nout * 8 + nout), lambda: ops.deconv3d_prob(x, ws[8], bs[8], sd, vol, prob_w, prob_b, prec))
     return deconv(x, 8, 8, vol)
 
 
@@ -183,9 +189,16 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
             confs.append(r3[1])
             continue
+        ks = net.cost_reg.prob_ksize
+        if ks == 1 and net.conv_precision == "bf16x3" and net.fuse_prob_head:
+            logits = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, fused_head=True)
+            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * (3 * D * HW + 2 * HW),
+                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
+            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
+            confs.append(r3[1])
+            continue
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
-        ks = net.cost_reg.prob_ksize
         res = _timed(launches, "prob_regress_kernel<%d,%d>" % (D, ks), s, 2.0 * B * D * HW * 8 * (27 if ks == 3 else 1),
                      4.0 * B * (8 * D * HW + D * HW + 2 * D * HW + 2 * HW),
                      lambda: ops.prob_regress(feat_cl, prob_w, prob_b, ks, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))

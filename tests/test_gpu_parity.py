@@ -109,6 +109,17 @@ def test_baseline_cfgs_small_vs_oracle(name):
     P.case_baseline_cfg_small(DEV, name)
 
 
+@pytest.mark.parametrize("name", ["cfg4", "cfg5"])
+def test_baseline_cfgs_wide_range_vs_oracle(name):
+    """cfg4 / cfg5 on the literal 0.5 .. 10 hypothesis range, compared where the reference's own hypotheses stay finite."""
+    P.case_baseline_cfg_wide_range(DEV, name)
+
+
+def test_cfg2_fullsize_vs_oracle():
+    """BASELINE configs[1] at full size against the oracle (refined depth within 1e-3 relative L1, every stage too)."""
+    P.case_cfg2_fullsize_vs_oracle(DEV)
+
+
 @pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
 def test_baseline_cfgs_fullsize_properties(name):
     """The same configs at their full image size through size-independent properties."""
