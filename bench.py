@@ -71,7 +71,7 @@ def cpu_baseline(head, feats, projs, dv, max_threads=None, shipped=False):
     n = min(max_threads or 16, os.cpu_count() or 1)
     torch.set_num_threads(n)
     sds = [{k: v.detach().cpu() for k, v in st.state_dict().items()} for st in head.fusions]
-    f = {k: v.cpu() for k, v in feats.items()}
+    f = {k: v.float().cpu() for k, v in feats.items()}
     p = {k: v.cpu() for k, v in projs.items()}
     d = dv.cpu()
     times = []
@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--feat-dtype", choices=["fp32", "bf16", "fp16"], default="fp32",
                     help="dtype of the feature maps handed to the path (the reference's FPN emits bf16 under test.py:250's autocast and "
                          "StageNet upcasts per view, cost_volume.py:67); the headline keeps fp32")
+    ap.add_argument("--feat-layout", choices=["planar", "tiled"], default="planar",
+                    help="planar: [B,V,C,H,W] as the reference's FPN emits it (headline); tiled: the octet-tiled channel-last hand-off "
+                         "layout [B,V,C/8,H,W,8] (SURVEY.md section 8f #4) as a producer-side emitter would hand it over - packed once, "
+                         "outside the timed region")
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
                     help="normal: all-'Normal' regularisers (Track R headline); shipped: stage-1 transformer + PE3D as in the shipped config")
     a = ap.parse_args()
@@ -141,6 +145,9 @@ def main():
     fdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.feat_dtype]
     nsets = max(1, a.input_sets)
     sets = [synth.make_cascade_inputs(a.height, a.width, a.views, seed=100 * rank + i, device=device, feat_dtype=fdt) for i in range(nsets)]
+    if a.feat_layout == "tiled":
+        from mvsformerplusplus_amd import ops
+        sets = [({k: ops.pack_features(v) for k, v in f.items()}, p, d) for f, p, d in sets]
     feats, projs, dv = sets[0]
     R = max(1, a.views_per_step)
     torch.cuda.synchronize()
@@ -214,7 +221,8 @@ def main():
                    "height": a.height, "width": a.width, "views": a.views, "global_batch": world * R,
                    "step": "one batch of %d reference views (batch 1 per forward call, like test.py), rotating over %d input sets" % (R, nsets),
                    "ref_views_per_step_per_gpu": R, "input_sets": nsets, "timed_seconds": elapsed,
-                   "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams, "features": "%s resident in HBM" % a.feat_dtype},
+                   "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams,
+                   "features": "%s %s resident in HBM" % (a.feat_dtype, "octet-tiled [B,V,C/8,H,W,8]" if a.feat_layout == "tiled" else "planar [B,V,C,H,W]")},
         "ms_per_ref_view": ms_per_step / R,
         "latency": {"single_stream_ms_per_ref_view": latency_ms, "single_stream_ref_views_per_s": 1e3 / latency_ms,
                     "note": "one reference view at a time on one stream (the reference's loop, test.py:238-252), same rotating inputs"},
@@ -299,7 +307,8 @@ def main():
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) + a parity read-out ----
     if world == 1 and not a.no_cpu_baseline:
-        cb, ref = cpu_baseline(head, feats, projs, dv, shipped=a.cost_reg == "shipped")
+        planar = {k: (v.unpack() if hasattr(v, "unpack") else v) for k, v in feats.items()}
+        cb, ref = cpu_baseline(head, planar, projs, dv, shipped=a.cost_reg == "shipped")
         result["cpu_baseline"] = cb
         d, r = out["refined_depth"].cpu(), ref["refined_depth"]
         result["parity"] = {"refined_depth_rel_l1_vs_oracle": float(((d - r).abs() / r.abs()).mean()),

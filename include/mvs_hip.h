@@ -31,6 +31,12 @@ extern "C" {
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
+/* feature-map layouts accepted by the two gather passes:
+ *   MVS_LAYOUT_PLANAR       [B,V,C,H,W]          what the reference's FPN / FMT emit (models/module.py:257-270, models/FMT.py:195-197)
+ *   MVS_LAYOUT_OCTET_TILED  [B,V,C/8,H,W,8]      the hand-off layout: the 8 channels of an octet are one
+ *                                                contiguous 32-byte (fp32) / 16-byte (bf16, fp16) run; mvs_pack_features converts,
+ *                                                a producer that writes it directly skips that pass              */
+enum { MVS_LAYOUT_PLANAR = 0, MVS_LAYOUT_OCTET_TILED = 1 };
 /* depth / confidence head modes, cost_volume.py:108-128 */
 enum { MVS_HEAD_CE_EVAL = 0, MVS_HEAD_CE_TRAIN = 1, MVS_HEAD_REG = 2 };
 /* regulariser kinds, cost_volume.py:41-49 */
@@ -68,9 +74,14 @@ int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* homography /*
  * features [B,V,C,H,W] (dtype; view 0 = reference), hyp [B,D,H,W]
  * -> entropy [B,V-1,H,W].  No [C,D,H,W] or [G,D,H,W] intermediate is materialised.
  * Only source views in [view_begin, view_end) (1-based view indices) are processed.              */
-int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homography /*[B,V-1,12]*/,
+int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int layout, const float* homography /*[B,V-1,12]*/,
                               const float* hyp, float* entropy, int B, int V, int C, int G, int D, int H, int W,
                               int view_begin, int view_end, void* stream);
+
+/* ---- section 8f #4: feature hand-off -------------------------------------------------------------------
+ * features [N,C,H,W] (dtype) -> tiled [N,C/8,H,W,8] (out_dtype); C % 8 == 0.  fp32 / bf16 / fp16 in, any of them out except
+ * bf16 <-> fp16.  The cast to a 2-byte type rounds to nearest even, like the .to(bfloat16) the reference's autocast applies. */
+int mvs_pack_features(const void* features, int dtype, void* tiled, int out_dtype, int N, int C, int H, int W, void* stream);
 
 /* ---- a5: visibility CNN, cost_volume.py:36,93 + module.py:168-197 ------------------------------
  * entropy [N,H,W] -> vis [N,H,W] = sigmoid(conv1x1(CBR(16->8)(CBR(16->16)(CBR(1->16)(entropy))))).
@@ -92,7 +103,7 @@ int mvs_vis_out_fwd(const float* x_cl8, const float* w4, const float* b4, float*
  *   normalise = 1 : volume = sum_v ip_v*vis_v / (sum_v vis_v + 1e-6)              (single GPU)
  *   normalise = 0 : volume = partial sum over [view_begin, view_end), vis_sum [B,H,W] = partial
  *                   sum of vis (view-sharded multi-GPU: all-reduce both, then mvs_volume_normalise) */
-int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, const float* homography, const float* hyp,
+int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp,
                                 const float* vis, float* volume_cl, float* vis_sum, int normalise, int B, int V,
                                 int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream);
 int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, void* stream);

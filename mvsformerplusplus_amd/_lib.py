@@ -19,6 +19,7 @@ ABI_VERSION = 4
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
+LAYOUT_PLANAR, LAYOUT_OCTET_TILED = 0, 1
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
 PREC_FP32, PREC_BF16X3, PREC_BF16P = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
@@ -32,16 +33,17 @@ SIGNATURES = {
     "mvs_compose_homography": (_i, [_vp, _i, _i, _vp, _vp]),
     "mvs_homography_from_proj": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mvs_homo_warp_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "mvs_pack_features": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_vis_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _i, _vp]),
     "mvs_vis_conv1_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvs_vis_out_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i] + [_i] * 9 + [_vp]),
+    "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i] + [_i] * 9 + [_vp]),
     "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
-    "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 8 + [_vp]),
+    "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "mvs_regnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mvs_regnet_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "mvs_regnet_logits_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),

@@ -104,6 +104,31 @@ __device__ __forceinline__ u16x2 gl_wave_reduce(u16x2 v) {
     return v;
 }
 
+// Feature layouts (include/mvs_hip.h MVS_LAYOUT_*):
+//   TILED = false  planar NCHW [C][H*W]: channel c of position p at base[c * HW + p]            (what the reference's FPN emits)
+//   TILED = true   octet-tiled channel-last [C/8][H*W][8]: the 8 channels of an octet are one 32-byte (fp32) / 16-byte
+//                  (bf16, fp16) run - the hand-off layout of SURVEY.md section 8f #4: staging a window is a copy of whole
+//                  runs (one or two 16-byte loads per position instead of eight 4- / 2-byte loads)
+// `base` points at the octet (planar: channel 8*o of the view, tiled: tile plane o of the view).
+template <bool TILED, typename T>
+__device__ __forceinline__ void gl_load8(const T* __restrict__ base, unsigned HW, unsigned p, float* v) {
+    if (!TILED) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = to_f32(base[(unsigned)c * HW + p]);
+    } else if (sizeof(T) == 4) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(base) + (size_t)p * 2;
+        const f32x4 a = q[0], b = q[1];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        typedef T t8 __attribute__((ext_vector_type(8)));
+        const t8 a = *(reinterpret_cast<const t8*>(base) + p);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = to_f32((T)a[c]);
+    }
+}
+// offset (in elements of T) of octet o of a view: planar = 8 channel planes, tiled = one [HW][8] tile plane: the same number
+__device__ __forceinline__ unsigned gl_octet_offset(int o, unsigned HW) { return (unsigned)o * 8u * HW; }
+
 // One unit = one source view x the GL_DCH depth planes of every work-item of the block.
 //   KEEP_GROUPS = false: out[dd]              += wscale * sum_c ref[c] * warped[c, d]                 (pass 1)
 //   KEEP_GROUPS = true : out[g * GL_DCH + dd] += wscale * sum_{c in group g} ref[c] * warped[c, d]    (pass 2)
@@ -119,7 +144,7 @@ __device__ __forceinline__ u16x2 gl_wave_reduce(u16x2 v) {
 #ifndef MVS_OPAQUE_SREG
 #define MVS_OPAQUE_SREG "s"
 #endif
-template <typename T, int NOCT, bool KEEP_GROUPS>
+template <typename T, int NOCT, bool KEEP_GROUPS, bool TILED>
 __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __restrict__ ref, const Homography& hm, float fx, float fy,
                                         const float* depth, bool active, int H, int W, unsigned HW, unsigned pc, f32x4* win,
                                         unsigned* red, int unit, float wscale, const float* rf_in, float* out) {
@@ -168,16 +193,14 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) {
             if (o > 0) __syncthreads();                         // (C) the previous octet's taps have been read
-            unsigned oofs = (unsigned)o * 8u * HW;
+            unsigned oofs = gl_octet_offset(o, HW);
             asm volatile("" : "+" MVS_OPAQUE_SREG(oofs));
             const T* so = src + oofs;
             // reference features of this octet: issued ahead of the staging loop so that they land while it runs (C = 8: the
             // caller loaded them once per block)
             float rf[8];
             if (NOCT > 1) {
-                const T* ro = ref + oofs + pc;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rf[c] = to_f32(ro[(unsigned)c * HW]);
+                gl_load8<TILED, T>(ref + oofs, HW, pc, rf);
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rf[c] = rf_in[c];
@@ -186,8 +209,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 const int row = (int)(((float)i + 0.5f) * inv_ww);
                 const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;    // (ymin+row)*W + wx0 + (i - row*ww)
                 float v[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = to_f32(so[(unsigned)c * HW + g]);
+                gl_load8<TILED, T>(so, HW, g, v);
                 win[i] = f32x4{v[0], v[1], v[2], v[3]};
                 win[GL_CAP + i] = f32x4{v[4], v[5], v[6], v[7]};
             }
@@ -232,25 +254,60 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
         unsigned top[GL_DCH];
 #pragma unroll
         for (int dd = 0; dd < GL_DCH; ++dd) top[dd] = tp[dd].pk == GL_NONE ? 0u : (tp[dd].pk >> 16) * (unsigned)W + (tp[dd].pk & 0xffffu);
+        if (!TILED) {
 #pragma unroll 1
-        for (int c = 0; c < 8 * NOCT; ++c) {                    // rolled: one channel's pair loads in flight (rare path)
-            const unsigned plane = (unsigned)c * HW;
-            const float rfc = to_f32(ref[plane + pc]) * wscale;
-            const T* sp = src + plane;
-            const int g = c / CPG;
+            for (int c = 0; c < 8 * NOCT; ++c) {                // rolled: one channel's pair loads in flight (rare path)
+                const unsigned plane = (unsigned)c * HW;
+                const float rfc = to_f32(ref[plane + pc]) * wscale;
+                const T* sp = src + plane;
+                const int g = c / CPG;
 #pragma unroll
-            for (int dd = 0; dd < GL_DCH; ++dd) {
-                const P2 t = *reinterpret_cast<const P2*>(sp + top[dd]);
-                const P2 b = *reinterpret_cast<const P2*>(sp + top[dd] + (unsigned)W);
-                float wv = tp[dd].w00 * to_f32(t.x);
-                wv += tp[dd].w01 * to_f32(t.y);
-                wv += tp[dd].w10 * to_f32(b.x);
-                wv += tp[dd].w11 * to_f32(b.y);
-                if (KEEP_GROUPS) {
+                for (int dd = 0; dd < GL_DCH; ++dd) {
+                    const P2 t = *reinterpret_cast<const P2*>(sp + top[dd]);
+                    const P2 b = *reinterpret_cast<const P2*>(sp + top[dd] + (unsigned)W);
+                    float wv = tp[dd].w00 * to_f32(t.x);
+                    wv += tp[dd].w01 * to_f32(t.y);
+                    wv += tp[dd].w10 * to_f32(b.x);
+                    wv += tp[dd].w11 * to_f32(b.y);
+                    if (KEEP_GROUPS) {
 #pragma unroll
-                    for (int gg = 0; gg < 8; ++gg) out[gg * GL_DCH + dd] += (g == gg) ? rfc * wv : 0.0f;
-                } else {
-                    out[dd] += rfc * wv;
+                        for (int gg = 0; gg < 8; ++gg) out[gg * GL_DCH + dd] += (g == gg) ? rfc * wv : 0.0f;
+                    } else {
+                        out[dd] += rfc * wv;
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int o = 0; o < NOCT; ++o) {                    // rolled: one octet's four taps per plane in flight (rare path)
+                const unsigned oofs = gl_octet_offset(o, HW);
+                float rf[8];
+                gl_load8<true, T>(ref + oofs, HW, pc, rf);
+#pragma unroll 1
+                for (int dd = 0; dd < GL_DCH; ++dd) {
+                    float a[8], b[8], c[8], d[8];
+                    gl_load8<true, T>(src + oofs, HW, top[dd], a);
+                    gl_load8<true, T>(src + oofs, HW, top[dd] + 1u, b);
+                    gl_load8<true, T>(src + oofs, HW, top[dd] + (unsigned)W, c);
+                    gl_load8<true, T>(src + oofs, HW, top[dd] + (unsigned)W + 1u, d);
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float wv = tp[dd].w00 * a[ch];
+                        wv += tp[dd].w01 * b[ch];
+                        wv += tp[dd].w10 * c[ch];
+                        wv += tp[dd].w11 * d[ch];
+                        const float contrib = rf[ch] * wscale * wv;
+                        const int g = (o * 8 + ch) / CPG;
+                        if (KEEP_GROUPS) {
+#pragma unroll
+                            for (int gg = 0; gg < 8; ++gg)
+#pragma unroll
+                                for (int d2 = 0; d2 < GL_DCH; ++d2) out[gg * GL_DCH + d2] += (g == gg && d2 == dd) ? contrib : 0.0f;
+                        } else {
+#pragma unroll
+                            for (int d2 = 0; d2 < GL_DCH; ++d2) out[d2] += (d2 == dd) ? contrib : 0.0f;
+                        }
+                    }
                 }
             }
         }
@@ -315,7 +372,7 @@ struct GlTile {
 // pass 1: entropy of the depth-softmax of the group-summed correlation          cost_volume.py:79-92
 // grid = (tiles, ceil(views in launch / vpb), B); a block walks `vpb` consecutive source views of its tile
 // ------------------------------------------------------------------------------------------------
-template <int DT, int NOCT, int NS>
+template <int DT, int NOCT, int NS, bool TILED>
 __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                          const float* __restrict__ hyp, float* __restrict__ entropy, int V, int D, int H,
                                                          int W, int view_begin, int view_end, int vpb, int ntx, int nblk) {
@@ -335,8 +392,11 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
     const float* hp = hyp + (size_t)b * D * HW;
     const float inv_cpg = 1.0f / (float)NOCT;
     float rf0[8];                                               // C = 8: the pixel's reference features, once per block
+    if (NOCT == 1) gl_load8<TILED, T>(ref, HW, t.pc, rf0);
+    else {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) rf0[c] = NOCT == 1 ? to_f32(ref[(unsigned)c * HW + t.pc]) : 0.0f;
+        for (int c = 0; c < 8; ++c) rf0[c] = 0.0f;
+    }
     const int v0 = view_begin + (int)blockIdx.y * vpb, v1 = v0 + vpb < view_end ? v0 + vpb : view_end;
     int unit = 0;
     for (int v = v0; v < v1; ++v) {
@@ -352,7 +412,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
             for (int dd = 0; dd < GL_DCH; ++dd) depth[dd] = hp[(unsigned)(d0 + dd < D ? d0 + dd : D - 1) * HW + t.pc];
 #pragma unroll
             for (int dd = 0; dd < GL_DCH; ++dd) s[dd] = 0.0f;
-            gl_unit<T, NOCT, false>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, s);   // sum_g mean_c = (1/cpg) sum_c
+            gl_unit<T, NOCT, false, TILED>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, s);   // sum_g mean_c = (1/cpg) sum_c
             if (NS > 1 || niter > 1) {
                 if (chunk < nch) {
 #pragma unroll
@@ -391,7 +451,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
 // pass 2: visibility-weighted aggregation over the source views of the launch    cost_volume.py:97-101
 // grid = (tiles, chunk groups, B); output channel-last [D,HW,8].
 // ------------------------------------------------------------------------------------------------
-template <int DT, int NOCT, int NS>
+template <int DT, int NOCT, int NS, bool TILED>
 __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                            const float* __restrict__ hyp, const float* __restrict__ vis,
                                                            float* __restrict__ vol, float* __restrict__ vis_sum, int normalise, int V,
@@ -415,8 +475,11 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     const float rdenom = normalise ? 1.0f / (vsum + 1e-6f) : 1.0f;                                // cost_volume.py:101
     const float inv_cpg = 1.0f / (float)NOCT;
     float rf0[8];                                               // C = 8: the pixel's reference features, once per block
+    if (NOCT == 1) gl_load8<TILED, T>(ref, HW, t.pc, rf0);
+    else {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) rf0[c] = NOCT == 1 ? to_f32(ref[(unsigned)c * HW + t.pc]) : 0.0f;
+        for (int c = 0; c < 8; ++c) rf0[c] = 0.0f;
+    }
     const int chunk = it * NS + t.slot;
     const bool active = t.valid && chunk < nch;
     const int d0 = (chunk < nch ? chunk : nch - 1) * GL_DCH;
@@ -430,7 +493,7 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     for (int v = view_begin; v < view_end; ++v, ++unit) {
         const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
         const float w = vp[(unsigned)(v - 1) * HW];                                               // cost_volume.py:97
-        gl_unit<T, NOCT, true>(feat + (size_t)v * C * HW, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg * w, rf0, acc);
+        gl_unit<T, NOCT, true, TILED>(feat + (size_t)v * C * HW, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg * w, rf0, acc);
     }
     if (active) {
         float* vb = vol + (size_t)b * D * HW * 8;
@@ -462,7 +525,7 @@ bool gl_supported(int C, int G, int D, int H, int W) {
     return (size_t)D * (256 / gl_slots(D)) * sizeof(float) <= 64 * 1024;
 }
 
-template <int DT, int NOCT, int NS>
+template <int DT, int NOCT, int NS, bool TILED>
 static int gl_launch_entropy_t(const void* feat, const float* hom, const float* hyp, float* ent, int B, int V, int D, int H, int W, int vb,
                                int ve, hipStream_t st) {
     constexpr int TP = 256 / NS, TW = TP / GL_TH;
@@ -473,13 +536,13 @@ static int gl_launch_entropy_t(const void* feat, const float* hom, const float* 
     const int vpb = (long long)nblk * B >= 4096 ? ve - vb : 1;
     const size_t lds = GL_WIN_BYTES + GL_RED_BYTES + (size_t)D * TP * sizeof(float);
     if (lds > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_entropy_kernel<DT, NOCT, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gl_entropy_kernel<DT, NOCT, NS>), dim3(nblk, ceil_div(ve - vb, vpb), B), dim3(256), lds, st, feat, hom, hyp, ent, V, D, H,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_entropy_kernel<DT, NOCT, NS, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gl_entropy_kernel<DT, NOCT, NS, TILED>), dim3(nblk, ceil_div(ve - vb, vpb), B), dim3(256), lds, st, feat, hom, hyp, ent, V, D, H,
                        W, vb, ve, vpb, ntx, nblk);
     return check_launch("gl_entropy_kernel");
 }
 
-template <int DT, int NOCT, int NS>
+template <int DT, int NOCT, int NS, bool TILED>
 static int gl_launch_aggregate_t(const void* feat, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
                                  int normalise, int B, int V, int D, int H, int W, int vb, int ve, hipStream_t st) {
     constexpr int TP = 256 / NS, TW = TP / GL_TH;
@@ -487,17 +550,21 @@ static int gl_launch_aggregate_t(const void* feat, const float* hom, const float
     const int nblk = ntx * nty;
     const int nch = (D + GL_DCH - 1) / GL_DCH, niter = (nch + NS - 1) / NS;
     const size_t lds = GL_WIN_BYTES + GL_RED_BYTES;
-    hipLaunchKernelGGL((gl_aggregate_kernel<DT, NOCT, NS>), dim3(nblk, niter, B), dim3(256), lds, st, feat, hom, hyp, vis, vol, vis_sum,
+    hipLaunchKernelGGL((gl_aggregate_kernel<DT, NOCT, NS, TILED>), dim3(nblk, niter, B), dim3(256), lds, st, feat, hom, hyp, vis, vol, vis_sum,
                        normalise, V, D, H, W, vb, ve, ntx, nblk);
     return check_launch("gl_aggregate_kernel");
 }
 
 #define GL_DISPATCH_NS(FN, DTV, NOCTV, ...)                                                    \
-    switch (gl_slots(D)) {                                                                     \
-        case 1: return FN<DTV, NOCTV, 1>(__VA_ARGS__);                                         \
-        case 2: return FN<DTV, NOCTV, 2>(__VA_ARGS__);                                         \
-        case 4: return FN<DTV, NOCTV, 4>(__VA_ARGS__);                                         \
-        default: return FN<DTV, NOCTV, 8>(__VA_ARGS__);                                        \
+    switch (gl_slots(D) * 2 + (layout == MVS_LAYOUT_OCTET_TILED ? 1 : 0)) {                    \
+        case 2: return FN<DTV, NOCTV, 1, false>(__VA_ARGS__);                                  \
+        case 3: return FN<DTV, NOCTV, 1, true>(__VA_ARGS__);                                   \
+        case 4: return FN<DTV, NOCTV, 2, false>(__VA_ARGS__);                                  \
+        case 5: return FN<DTV, NOCTV, 2, true>(__VA_ARGS__);                                   \
+        case 8: return FN<DTV, NOCTV, 4, false>(__VA_ARGS__);                                  \
+        case 9: return FN<DTV, NOCTV, 4, true>(__VA_ARGS__);                                   \
+        case 16: return FN<DTV, NOCTV, 8, false>(__VA_ARGS__);                                 \
+        default: return FN<DTV, NOCTV, 8, true>(__VA_ARGS__);                                  \
     }
 #define GL_DISPATCH_C(FN, DTV, ...)                                                            \
     switch (C) {                                                                               \
@@ -515,14 +582,67 @@ static int gl_launch_aggregate_t(const void* feat, const float* hom, const float
         }                                                                                      \
     } while (0)
 
-int gl_launch_entropy(const void* feat, int dtype, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H, int W,
+int gl_launch_entropy(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H, int W,
                       int vb, int ve, hipStream_t st) {
     GL_DISPATCH(gl_launch_entropy_t, feat, hom, hyp, ent, B, V, D, H, W, vb, ve, st);
 }
 
-int gl_launch_aggregate(const void* feat, int dtype, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
+int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
                         int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st) {
     GL_DISPATCH(gl_launch_aggregate_t, feat, hom, hyp, vis, vol, vis_sum, normalise, B, V, D, H, W, vb, ve, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hand-off packer: planar [N, C, HW] of any feature dtype -> octet-tiled [N, C/8, HW, 8] of the
+// requested dtype.  A feature producer that emits the tiled layout directly skips this pass.
+// grid = (ceil(HW / 256), C / 8, N)
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void pack_features_kernel(const TI* __restrict__ in, TO* __restrict__ out, int C, unsigned HW) {
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= HW) return;
+    const size_t n = blockIdx.z, o = blockIdx.y;
+    const TI* src = in + (n * C + o * 8) * HW + p;
+    TO* dst = out + ((n * (C / 8) + o) * HW + p) * 8;
+    typedef TO to8 __attribute__((ext_vector_type(8)));
+    to8 v;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float f = to_f32(src[(size_t)c * HW]);
+        if (sizeof(TI) == 2 && sizeof(TO) == 2) v[c] = *reinterpret_cast<const TO*>(&src[(size_t)c * HW]);      // same 2-byte type: bit copy
+        else v[c] = from_f32<TO>(f);
+    }
+    *reinterpret_cast<to8*>(dst) = v;
+}
+
+template <typename TI, typename TO>
+static int pack_features_t(const void* in, void* out, int N, int C, int H, int W, hipStream_t st) {
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    hipLaunchKernelGGL((pack_features_kernel<TI, TO>), dim3(ceil_div(HW, 256), C / 8, N), dim3(256), 0, st, static_cast<const TI*>(in),
+                       static_cast<TO*>(out), C, HW);
+    return check_launch("pack_features_kernel");
+}
+
+int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W, hipStream_t st) {
+    if (out_dtype == MVS_DTYPE_F32) {
+        switch (in_dtype) {
+            case MVS_DTYPE_F32: return pack_features_t<float, float>(in, out, N, C, H, W, st);
+            case MVS_DTYPE_BF16: return pack_features_t<uint16_t, float>(in, out, N, C, H, W, st);
+            default: return pack_features_t<_Float16, float>(in, out, N, C, H, W, st);
+        }
+    }
+    if (out_dtype == MVS_DTYPE_BF16) {
+        switch (in_dtype) {
+            case MVS_DTYPE_F32: return pack_features_t<float, uint16_t>(in, out, N, C, H, W, st);
+            case MVS_DTYPE_BF16: return pack_features_t<uint16_t, uint16_t>(in, out, N, C, H, W, st);
+            default: set_error("mvs_pack_features: fp16 -> bf16 is not a hand-off the reference produces"); return MVS_ERR_UNSUPPORTED;
+        }
+    }
+    switch (in_dtype) {
+        case MVS_DTYPE_F32: return pack_features_t<float, _Float16>(in, out, N, C, H, W, st);
+        case MVS_DTYPE_F16: return pack_features_t<_Float16, _Float16>(in, out, N, C, H, W, st);
+        default: set_error("mvs_pack_features: bf16 -> fp16 is not a hand-off the reference produces"); return MVS_ERR_UNSUPPORTED;
+    }
 }
 
 }  // namespace mvs

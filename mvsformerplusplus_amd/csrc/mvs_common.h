@@ -40,6 +40,16 @@ __device__ __forceinline__ float to_f32(uint16_t bf16_bits) {
     return c.f;
 }
 
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
+template <> __device__ __forceinline__ uint16_t from_f32<uint16_t>(float v) {      // bf16 bits, round to nearest even (NaN kept quiet)
+    union { float f; uint32_t u; } c;
+    c.f = v;
+    if ((c.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((c.u >> 16) | 0x40u);
+    return (uint16_t)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+
 // 3x4 homography of one source view: p = R * [x, y, 1] * depth + t   (warping.py:80-92)
 struct Homography {
     float r[9];

@@ -472,10 +472,11 @@ static int check_corr_args(const char* who, const void* feat, const float* hom, 
 
 // LDS-staged form of the two gather passes (gather_lds_kernels.hip)
 bool gl_supported(int C, int G, int D, int H, int W);
-int gl_launch_entropy(const void* feat, int dtype, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H, int W,
-                      int vb, int ve, hipStream_t st);
-int gl_launch_aggregate(const void* feat, int dtype, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,
-                        int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
+int gl_launch_entropy(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H,
+                      int W, int vb, int ve, hipStream_t st);
+int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol,
+                        float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
+int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W, hipStream_t st);
 
 // MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels (A/B measurements); anything else = LDS-staged where supported
 static bool use_lds_gather(int C, int G, int D, int H, int W) {
@@ -515,14 +516,34 @@ extern "C" int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* ho
     return check_launch("homo_warp_kernel");
 }
 
-extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const float* homography, const float* hyp, float* entropy,
+extern "C" int mvs_pack_features(const void* features, int dtype, void* tiled, int out_dtype, int N, int C, int H, int W, void* stream) {
+    if (!features || !tiled || N < 1 || C < 8 || (C % 8) || H < 1 || W < 1 || dtype < 0 || dtype > 2 || out_dtype < 0 || out_dtype > 2) {
+        set_error("mvs_pack_features: bad arguments (C must be a multiple of 8)");
+        return MVS_ERR_ARG;
+    }
+    return pack_features_dispatch(features, dtype, tiled, out_dtype, N, C, H, W, (hipStream_t)stream);
+}
+
+static int check_layout(const char* who, int layout, int C, int G, int D, int H, int W) {
+    if (layout == MVS_LAYOUT_PLANAR) return MVS_OK;
+    if (layout != MVS_LAYOUT_OCTET_TILED) { set_error("%s: unknown feature layout %d", who, layout); return MVS_ERR_ARG; }
+    if (!gl_supported(C, G, D, H, W)) {
+        set_error("%s: the octet-tiled feature layout needs G == 8, C in {8,16,32,64} and W %% 8 == 0", who);
+        return MVS_ERR_UNSUPPORTED;
+    }
+    return MVS_OK;
+}
+
+extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, float* entropy,
                                          int B, int V, int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream) {
     int rc = check_corr_args("mvs_warp_corr_entropy_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, view_begin, view_end);
     if (rc != MVS_OK) return rc;
     if (!entropy) { set_error("mvs_warp_corr_entropy_fwd: null output"); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    if (use_lds_gather(C, G, D, H, W))
-        return gl_launch_entropy(features, dtype, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
+    rc = check_layout("mvs_warp_corr_entropy_fwd", layout, C, G, D, H, W);
+    if (rc != MVS_OK) return rc;
+    if (layout == MVS_LAYOUT_OCTET_TILED || use_lds_gather(C, G, D, H, W))
+        return gl_launch_entropy(features, dtype, layout, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
@@ -530,7 +551,7 @@ extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, const 
     }
 }
 
-extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, const float* homography, const float* hyp, const float* vis,
+extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, const float* vis,
                                            float* volume_cl, float* vis_sum, int normalise, int B, int V, int C, int G, int D, int H,
                                            int W, int view_begin, int view_end, void* stream) {
     int rc = check_corr_args("mvs_warp_corr_aggregate_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, view_begin, view_end);
@@ -538,8 +559,10 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, cons
     if (!vis || !volume_cl) { set_error("mvs_warp_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
     if (!normalise && !vis_sum) { set_error("mvs_warp_corr_aggregate_fwd: partial mode needs vis_sum"); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    if (use_lds_gather(C, G, D, H, W))
-        return gl_launch_aggregate(features, dtype, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, D, H, W, view_begin, view_end, st);
+    rc = check_layout("mvs_warp_corr_aggregate_fwd", layout, C, G, D, H, W);
+    if (rc != MVS_OK) return rc;
+    if (layout == MVS_LAYOUT_OCTET_TILED || use_lds_gather(C, G, D, H, W))
+        return gl_launch_aggregate(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F32, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_BF16, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);

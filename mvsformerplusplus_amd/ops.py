@@ -18,10 +18,67 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
-def _feat(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+class PackedFeatures:
+    """Feature maps of one stage in the hand-off layout: ``data`` [B,V,C/8,H,W,8], fp32 / bf16 / fp16.
+    Quacks like the [B,V,C,H,W] tensor the reference passes (``shape``, ``device``, ``dtype``) so StageNet.forward accepts either."""
+
+    def __init__(self, data: torch.Tensor):
+        assert data.dim() == 6 and data.shape[-1] == 8 and data.is_contiguous(), "PackedFeatures wants a dense [B,V,C/8,H,W,8] tensor"
+        self.data = data
+
+    @property
+    def shape(self):
+        B, V, O, H, W, _ = self.data.shape
+        return torch.Size((B, V, O * 8, H, W))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def requires_grad(self):
+        return False
+
+    def element_size(self):
+        return self.data.element_size()
+
+    def to(self, *a, **k):
+        return PackedFeatures(self.data.to(*a, **k).contiguous())
+
+    def unpack(self) -> torch.Tensor:
+        """Back to planar [B,V,C,H,W] (tests / debugging)."""
+        B, V, O, H, W, _ = self.data.shape
+        return self.data.permute(0, 1, 2, 5, 3, 4).reshape(B, V, O * 8, H, W).contiguous()
+
+
+def pack_features(features: torch.Tensor, dtype: Optional[torch.dtype] = None) -> PackedFeatures:
+    """[B,V,C,H,W] (fp32 / bf16 / fp16) -> PackedFeatures in `dtype` (default: keep).  One read + one write of the features;
+    a producer that emits the tiled layout itself has nothing to pack."""
+    f, code = _feat(features)
+    B, V, Cc, H, W = f.shape
+    dtype = f.dtype if dtype is None else dtype
+    out = torch.empty(B, V, Cc // 8, H, W, 8, dtype=dtype, device=f.device)
+    check(lib().mvs_pack_features(ptr(f), code, ptr(out), _lib.DTYPE_CODE[dtype], B * V, Cc, H, W, stream_of(f)), "mvs_pack_features")
+    return PackedFeatures(out)
+
+
+def _feat(t) -> Tuple[torch.Tensor, int]:
+    if isinstance(t, PackedFeatures):
+        return t, _lib.DTYPE_CODE[t.dtype]
     if t.dtype not in _lib.DTYPE_CODE:
         t = t.float()
     return t.contiguous(), _lib.DTYPE_CODE[t.dtype]
+
+
+def _feat_ptr(features):
+    """(tensor handed to the C ABI, layout code)"""
+    if isinstance(features, PackedFeatures):
+        return features.data, _lib.LAYOUT_OCTET_TILED
+    return features, _lib.LAYOUT_PLANAR
 
 
 # ---- a1 + warping.py:80 -------------------------------------------------------------------------
@@ -71,8 +128,9 @@ def warp_corr_entropy(features: torch.Tensor, code: int, homography: torch.Tenso
         ent = torch.empty(B, V - 1, H, W, dtype=torch.float32, device=features.device)
     else:
         ent = torch.zeros(B, V - 1, H, W, dtype=torch.float32, device=features.device)
-    check(lib().mvs_warp_corr_entropy_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(ent), B, V, Cc, G, D, H, W,
-                                          view_begin, view_end, stream_of(features)), "mvs_warp_corr_entropy_fwd")
+    ft, layout = _feat_ptr(features)
+    check(lib().mvs_warp_corr_entropy_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(ent), B, V, Cc, G, D, H, W,
+                                          view_begin, view_end, stream_of(ft)), "mvs_warp_corr_entropy_fwd")
     return ent
 
 
@@ -117,9 +175,10 @@ def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Ten
     else:
         vol = torch.empty(B, D, H, W, G, dtype=torch.float32, device=features.device)
         vsum = None if normalise else torch.empty(B, H, W, dtype=torch.float32, device=features.device)
-    check(lib().mvs_warp_corr_aggregate_fwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(vis), ptr(vol), ptr(vsum),
+    ft, layout = _feat_ptr(features)
+    check(lib().mvs_warp_corr_aggregate_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(vis), ptr(vol), ptr(vsum),
                                             1 if normalise else 0, B, V, Cc, G, D, H, W, view_begin, view_end,
-                                            stream_of(features)), "mvs_warp_corr_aggregate_fwd")
+                                            stream_of(ft)), "mvs_warp_corr_aggregate_fwd")
     return vol, vsum
 
 
