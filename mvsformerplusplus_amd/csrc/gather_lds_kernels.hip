@@ -205,6 +205,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rf[c] = rf_in[c];
             }
+#pragma unroll 1
             for (int i = tid; i < n; i += 256) {
                 const int row = (int)(((float)i + 0.5f) * inv_ww);
                 const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;    // (ymin+row)*W + wx0 + (i - row*ww)
@@ -254,60 +255,35 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
         unsigned top[GL_DCH];
 #pragma unroll
         for (int dd = 0; dd < GL_DCH; ++dd) top[dd] = tp[dd].pk == GL_NONE ? 0u : (tp[dd].pk >> 16) * (unsigned)W + (tp[dd].pk & 0xffffu);
-        if (!TILED) {
 #pragma unroll 1
-            for (int c = 0; c < 8 * NOCT; ++c) {                // rolled: one channel's pair loads in flight (rare path)
-                const unsigned plane = (unsigned)c * HW;
-                const float rfc = to_f32(ref[plane + pc]) * wscale;
-                const T* sp = src + plane;
-                const int g = c / CPG;
+        for (int c = 0; c < 8 * NOCT; ++c) {                    // rolled: one channel's taps in flight (rare path)
+            // element offset of channel c at position 0 and the stride between horizontally adjacent positions
+            const unsigned cbase = TILED ? (unsigned)(c >> 3) * 8u * HW + (unsigned)(c & 7) : (unsigned)c * HW;
+            const unsigned pstep = TILED ? 8u : 1u;
+            const float rfc = to_f32(ref[cbase + pc * pstep]) * wscale;
+            const T* sp = src + cbase;
+            const int g = c / CPG;
 #pragma unroll
-                for (int dd = 0; dd < GL_DCH; ++dd) {
+            for (int dd = 0; dd < GL_DCH; ++dd) {
+                float t0, t1, b0, b1;
+                if (TILED) {
+                    __builtin_amdgcn_sched_barrier(0);          // one plane's four taps in flight: the addresses are the register hog
+                    t0 = to_f32(sp[top[dd] * 8u]); t1 = to_f32(sp[(top[dd] + 1u) * 8u]);
+                    b0 = to_f32(sp[(top[dd] + (unsigned)W) * 8u]); b1 = to_f32(sp[(top[dd] + (unsigned)W + 1u) * 8u]);
+                } else {
                     const P2 t = *reinterpret_cast<const P2*>(sp + top[dd]);
                     const P2 b = *reinterpret_cast<const P2*>(sp + top[dd] + (unsigned)W);
-                    float wv = tp[dd].w00 * to_f32(t.x);
-                    wv += tp[dd].w01 * to_f32(t.y);
-                    wv += tp[dd].w10 * to_f32(b.x);
-                    wv += tp[dd].w11 * to_f32(b.y);
-                    if (KEEP_GROUPS) {
-#pragma unroll
-                        for (int gg = 0; gg < 8; ++gg) out[gg * GL_DCH + dd] += (g == gg) ? rfc * wv : 0.0f;
-                    } else {
-                        out[dd] += rfc * wv;
-                    }
+                    t0 = to_f32(t.x); t1 = to_f32(t.y); b0 = to_f32(b.x); b1 = to_f32(b.y);
                 }
-            }
-        } else {
-#pragma unroll 1
-            for (int o = 0; o < NOCT; ++o) {                    // rolled: one octet's four taps per plane in flight (rare path)
-                const unsigned oofs = gl_octet_offset(o, HW);
-                float rf[8];
-                gl_load8<true, T>(ref + oofs, HW, pc, rf);
-#pragma unroll 1
-                for (int dd = 0; dd < GL_DCH; ++dd) {
-                    float a[8], b[8], c[8], d[8];
-                    gl_load8<true, T>(src + oofs, HW, top[dd], a);
-                    gl_load8<true, T>(src + oofs, HW, top[dd] + 1u, b);
-                    gl_load8<true, T>(src + oofs, HW, top[dd] + (unsigned)W, c);
-                    gl_load8<true, T>(src + oofs, HW, top[dd] + (unsigned)W + 1u, d);
+                float wv = tp[dd].w00 * t0;
+                wv += tp[dd].w01 * t1;
+                wv += tp[dd].w10 * b0;
+                wv += tp[dd].w11 * b1;
+                if (KEEP_GROUPS) {
 #pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) {
-                        float wv = tp[dd].w00 * a[ch];
-                        wv += tp[dd].w01 * b[ch];
-                        wv += tp[dd].w10 * c[ch];
-                        wv += tp[dd].w11 * d[ch];
-                        const float contrib = rf[ch] * wscale * wv;
-                        const int g = (o * 8 + ch) / CPG;
-                        if (KEEP_GROUPS) {
-#pragma unroll
-                            for (int gg = 0; gg < 8; ++gg)
-#pragma unroll
-                                for (int d2 = 0; d2 < GL_DCH; ++d2) out[gg * GL_DCH + d2] += (g == gg && d2 == dd) ? contrib : 0.0f;
-                        } else {
-#pragma unroll
-                            for (int d2 = 0; d2 < GL_DCH; ++d2) out[d2] += (d2 == dd) ? contrib : 0.0f;
-                        }
-                    }
+                    for (int gg = 0; gg < 8; ++gg) out[gg * GL_DCH + dd] += (g == gg) ? rfc * wv : 0.0f;
+                } else {
+                    out[dd] += rfc * wv;
                 }
             }
         }
