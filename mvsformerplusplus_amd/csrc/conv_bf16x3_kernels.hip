@@ -422,7 +422,34 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     // of pw = 1; weights packed accordingly, packing.pack_deconv_weights_bf16x3)
     constexpr bool PAIR = COUT == 8;
     constexpr int NCLS = (SD == 2 ? 2 : 1) * 4;
+    // The skip tensor is the largest read of the layer (same size as the output) and it is only needed by the epilogue: all of its
+    // float4s are requested here, before the contraction, so that their HBM latency runs under the MFMA work instead of stalling
+    // every class's epilogue (PMC: these kernels sat 66-78 % of their wave cycles in s_waitcnt).
+    constexpr int NIT = PAIR ? NCLS / 2 : NCLS;
+    float4 skp[NIT][NREP][MREP];
+    if (sb) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cls = PAIR ? 2 * it : it;
+            const int pw = PAIR ? 1 : (cls & 1), ph = (cls >> 1) & 1, pd = (SD == 2) ? (cls >> 2) : 0;
+#pragma unroll
+            for (int nb = 0; nb < NREP; ++nb) {
+                const int nbg = wave * NREP + nb;
+                const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
+                const bool inside = mz < D && my < H && mx < W;
+                const int oz = mz * SD + pd, oy = 2 * my + ph, ox = PAIR ? 2 * mx + (g >> 1) : 2 * mx + pw;
+#pragma unroll
+                for (int mb = 0; mb < MREP; ++mb) {
+                    const int co = PAIR ? 4 * (g & 1) : 16 * mb + 4 * g;
+                    skp[it][nb][mb] = (inside && co < COUT) ? *reinterpret_cast<const float4*>(sb + (((size_t)oz * OH + oy) * OW + ox) * COUT + co)
+                                                            : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+        }
+    }
+#pragma unroll
     for (int cls = 0; cls < NCLS; cls += PAIR ? 2 : 1) {
+        const int it = PAIR ? cls / 2 : cls;
         const int pw = PAIR ? 1 : (cls & 1), ph = (cls >> 1) & 1, pd = (SD == 2) ? (cls >> 2) : 0;
         f32x4 acc[MREP][NREP];
 #pragma unroll
@@ -459,7 +486,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 float4 v = make_float4(fmaxf(acc[0][nb][0] + bb.x, 0.0f), fmaxf(acc[0][nb][1] + bb.y, 0.0f), fmaxf(acc[0][nb][2] + bb.z, 0.0f),
                                        fmaxf(acc[0][nb][3] + bb.w, 0.0f));
                 if (sb && inside) {
-                    const float4 sk = *reinterpret_cast<const float4*>(sb + off);
+                    const float4 sk = skp[it][nb][0];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 if (prob_w != nullptr) {
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 float4 v = make_float4(fmaxf(acc[mb][nb][0] + bb.x, 0.0f), fmaxf(acc[mb][nb][1] + bb.y, 0.0f),
                                        fmaxf(acc[mb][nb][2] + bb.z, 0.0f), fmaxf(acc[mb][nb][3] + bb.w, 0.0f));
                 if (sb) {
-                    const float4 sk = *reinterpret_cast<const float4*>(sb + off + co);
+                    const float4 sk = skp[it][nb][mb];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 *reinterpret_cast<float4*>(yb + off + co) = v;
