@@ -12,9 +12,10 @@
 // both MFMA layers sit in registers for the whole strip (80 VGPRs) and the 1 -> 16 weights in SGPRs.  Contraction =
 // the 3-term split-bf16 product of the MFMA convolutions (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, ~2^-16 relative).
 //
-// LDS layout per layer: [octet o of 8 channels][ring row r][column c][hi x8 | lo x8 | 16 B pad]: 48 B per position make
-// the 16 ds_read_b128 lanes of a group (8 columns of octet 0 + 8 of octet 1) hit 16 different 16-byte bank slots and keep
-// the 8-byte epilogue stores 2-way at worst.  Column c of the layer-1 ring is image column x0 - 2 + c, of the layer-2 ring
+// LDS layout per layer: [octet o of 8 channels][ring row r][column c][hi x8 | lo x8], 32 B per position, octet planes offset by
+// 16 B modulo the 256-byte bank row: the 16 ds_read_b128 lanes of a group (8 columns of octet 0 + 8 of octet 1) hit 16
+// different 16-byte bank slots (the 8-byte epilogue stores are 4-way, but there are 4 of them against 20 reads per row).
+// The ring slot of a row is row & 3; the row loop dispatches on i & 3 so that every slot offset is a compile-time constant.  Column c of the layer-1 ring is image column x0 - 2 + c, of the layer-2 ring
 // x0 - 1 + c (c = 0..63); an MFMA tile is 16 consecutive columns of one row, wave w owns tile w.
 // Zero padding follows the reference exactly: every layer's OUTPUT is forced to zero outside the image (the next
 // Conv2d pads its input with zeros there), which is not the same as convolving zero-padded entropy.
@@ -27,9 +28,11 @@ typedef __bf16 vs_bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int VS_TW = 60;                 // output columns per strip
 constexpr int VS_P = 64;                  // columns per ring row
-constexpr int VS_POSB = 48;               // bytes per (position, octet)
+constexpr int VS_POSB = 32;               // bytes per (position, octet): hi x8 | lo x8
 constexpr int VS_RING = 4;                // ring rows
-constexpr int VS_PLANE = ((VS_RING * VS_P + 2) * VS_POSB + 255) / 256 * 256;     // one octet plane; multiple of 256 B
+// one octet plane, sized = 16 (mod 256) bytes: the octet-1 lanes of a ds_read_b128 group then sit one 16-byte bank slot
+// away from the octet-0 lanes (which cover the even slots with their 32-byte position stride)
+constexpr int VS_PLANE = ((VS_RING * VS_P + 2) * VS_POSB + 255) / 256 * 256 + 16;
 constexpr int VS_LAYER = 2 * VS_PLANE;
 constexpr int VS_SH_MAX = 64;             // output rows per block (segment height) at most
 constexpr int VS_EP = VS_P + 2;           // entropy tile pitch: image columns x0 - 3 .. x0 + 62
@@ -49,13 +52,14 @@ __device__ __forceinline__ void vs_split4(const float* v, vs_bf16x4& hi, vs_bf16
     }
 }
 
-// B-operand address of contraction step t: lane group g>>1 picks the first or second tap of the step (two taps x 16
-// channels = 32 k-values); rowbase = ring row of tap row kh = 0 (may be negative: masked to the ring size).
-__device__ __forceinline__ const char* vs_step_ptr(const char* lds_layer, int laneoff, int tapsel, int rowbase, int t) {
+// B-operand offset of contraction step t: lane group g>>1 picks the first or second tap of the step (two taps x 16 channels =
+// 32 k-values).  SLOT0 = ring slot of tap row kh = 0 (compile-time: the row loop dispatches on i & 3).
+template <int SLOT0>
+__device__ __forceinline__ int vs_step_off(int laneoff, int tapsel, int t) {
     const int tapA = 2 * t, tapB = 2 * t + 1 < 9 ? 2 * t + 1 : 8;              // tap 9 does not exist: zero weights, any finite data
-    const int offA = (((rowbase + tapA / 3) & (VS_RING - 1)) * VS_P + tapA % 3) * VS_POSB;         // wave-uniform
-    const int offB = (((rowbase + tapB / 3) & (VS_RING - 1)) * VS_P + tapB % 3) * VS_POSB;
-    return lds_layer + laneoff + (tapsel ? offB : offA);
+    const int offA = (((SLOT0 + tapA / 3) & (VS_RING - 1)) * VS_P + tapA % 3) * VS_POSB;
+    const int offB = (((SLOT0 + tapB / 3) & (VS_RING - 1)) * VS_P + tapB % 3) * VS_POSB;
+    return laneoff + (tapsel ? offB : offA);
 }
 
 struct VsOperand { vs_bf16x8 h, l; };
@@ -66,43 +70,40 @@ __device__ __forceinline__ VsOperand vs_load(const char* p) {
     return o;
 }
 
-// three split-bf16 terms of one step on three independent accumulators
-__device__ __forceinline__ void vs_mfma3(f32x4* a, const vs_bf16x8& wh, const vs_bf16x8& wl, const VsOperand& b) {
-    a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, b.h, a[0], 0, 0, 0);
-    a[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b.l, a[1], 0, 0, 0);
-    a[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b.h, a[2], 0, 0, 0);
-}
-
-// one MFMA layer row: 5 contraction steps, the operand reads of step t+1 issued before the MFMAs of step t
-__device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, int rowbase, const vs_bf16x8* wh, const vs_bf16x8* wl) {
-    f32x4 a[3] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-    VsOperand cur = vs_load(vs_step_ptr(lds_layer, laneoff, tapsel, rowbase, 0));
+// one MFMA layer row: 5 contraction steps, three split-bf16 terms on three accumulators, the operand reads of step t+1 issued
+// before the MFMAs of step t
+template <int SLOT0>
+__device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, const vs_bf16x8* wh, const vs_bf16x8* wl) {
+    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0;
+    VsOperand cur = vs_load(lds_layer + vs_step_off<SLOT0>(laneoff, tapsel, 0));
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         VsOperand nxt = cur;
-        if (t < 4) nxt = vs_load(vs_step_ptr(lds_layer, laneoff, tapsel, rowbase, t + 1));
+        if (t < 4) nxt = vs_load(lds_layer + vs_step_off<SLOT0>(laneoff, tapsel, t + 1));
         __builtin_amdgcn_sched_barrier(0);
-        vs_mfma3(a, wh[t], wl[t], cur);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t], cur.h, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], cur.l, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], cur.h, a2, 0, 0, 0);
         cur = nxt;
     }
-    return a[0] + a[1] + a[2];
+    return a0 + a1 + a2;
 }
 
 // both MFMA layers of one iteration interleaved (layer 2 reads ring 1, layer 3 reads ring 2: independent): four operand
-// reads in flight under six MFMAs
-__device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* lds2, int laneoff, int tapsel, int rb2, int rb3,
-                                                  const vs_bf16x8* w2h, const vs_bf16x8* w2l, const vs_bf16x8* w3h, const vs_bf16x8* w3l,
-                                                  f32x4& out2, f32x4& out3) {
-    // one accumulator per layer: the two layers' MFMAs alternate, so a chain's next link is issued two MFMAs (32 cycles) later
+// reads in flight under six MFMAs; one accumulator per layer - the two chains alternate, so a chain's next link is issued two
+// MFMAs (32 cycles) after the previous one
+template <int SLOT2, int SLOT3>
+__device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* lds2, int laneoff, int tapsel, const vs_bf16x8* w2h,
+                                                  const vs_bf16x8* w2l, const vs_bf16x8* w3h, const vs_bf16x8* w3l, f32x4& out2, f32x4& out3) {
     f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, c = a;
-    VsOperand cb = vs_load(vs_step_ptr(lds1, laneoff, tapsel, rb2, 0));
-    VsOperand cc = vs_load(vs_step_ptr(lds2, laneoff, tapsel, rb3, 0));
+    VsOperand cb = vs_load(lds1 + vs_step_off<SLOT2>(laneoff, tapsel, 0));
+    VsOperand cc = vs_load(lds2 + vs_step_off<SLOT3>(laneoff, tapsel, 0));
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         VsOperand nb = cb, nc = cc;
         if (t < 4) {
-            nb = vs_load(vs_step_ptr(lds1, laneoff, tapsel, rb2, t + 1));
-            nc = vs_load(vs_step_ptr(lds2, laneoff, tapsel, rb3, t + 1));
+            nb = vs_load(lds1 + vs_step_off<SLOT2>(laneoff, tapsel, t + 1));
+            nc = vs_load(lds2 + vs_step_off<SLOT3>(laneoff, tapsel, t + 1));
         }
         __builtin_amdgcn_sched_barrier(0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[t], cb.h, a, 0, 0, 0);
@@ -117,6 +118,8 @@ __device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* 
     out2 = a;
     out3 = c;
 }
+
+template <int V> struct VsInt { static constexpr int value = V; };
 
 // grid = (strips, row segments, N)
 __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ ent, const float* __restrict__ w1 /*[9][16]*/,
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     const int c2 = 16 * wave + li;                                 // layer-2 / layer-3 column of this lane
     const int xb = x0 - 1 + c2, xc = x0 + c2;
 
-    for (int i = i0; i < i1; ++i) {
+    auto iteration = [&](auto phase, int i) {
+        constexpr int PH = decltype(phase)::value;                  // == i & 3: ring slot of row i + k is (PH + k) & 3
         // ---- A: layer-1 row i ----
         if (i <= r1 + 1) {
             float er[3][3];                                        // entropy rows i-1 .. i+1, columns xa-1 .. xa+1
@@ -213,17 +217,18 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r) a[r] = in ? fmaxf(a[r], 0.0f) : 0.0f;
             vs_bf16x4 hi, lo;
             vs_split4(a, hi, lo);
-            char* p = lds1 + wrA + (i & (VS_RING - 1)) * (VS_P * VS_POSB);
+            char* p = lds1 + wrA + PH * (VS_P * VS_POSB);
             *reinterpret_cast<vs_bf16x4*>(p) = hi;
             *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
         }
         // ---- B: layer-2 row i-2 from layer-1 rows i-3 .. i-1;  C: layer-3 row i-4 from layer-2 rows i-5 .. i-3 ----
         const int yb = i - 2, yc = i - 4;
         const bool doB = yb >= r0 - 1 && yb <= r1, doC = yc >= r0;
+        constexpr int S2 = (PH + 1) & 3, S3 = (PH + 3) & 3;          // slots of rows i-3 and i-5
         f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc3 = acc2;
-        if (doB && doC) vs_two_layer_rows(lds1, lds2, laneoff, tapsel, i - 3, i - 5, w2h, w2l, w3h, w3l, acc2, acc3);
-        else if (doB) acc2 = vs_layer_row(lds1, laneoff, tapsel, i - 3, w2h, w2l);
-        else if (doC) acc3 = vs_layer_row(lds2, laneoff, tapsel, i - 5, w3h, w3l);
+        if (doB && doC) vs_two_layer_rows<S2, S3>(lds1, lds2, laneoff, tapsel, w2h, w2l, w3h, w3l, acc2, acc3);
+        else if (doB) acc2 = vs_layer_row<S2>(lds1, laneoff, tapsel, w2h, w2l);
+        else if (doC) acc3 = vs_layer_row<S3>(lds2, laneoff, tapsel, w3h, w3l);
         if (doB) {
             const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
             float v[4];
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc2[r] + b2v[r], 0.0f) : 0.0f;
             vs_bf16x4 hi, lo;
             vs_split4(v, hi, lo);
-            char* p = lds2 + wrB + (yb & (VS_RING - 1)) * (VS_P * VS_POSB);
+            char* p = lds2 + wrB + ((PH + 2) & 3) * (VS_P * VS_POSB);          // row i-2
             *reinterpret_cast<vs_bf16x4*>(p) = hi;
             *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
         }
@@ -246,17 +251,31 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             }
         }
         __syncthreads();
+    };
+    for (int i = i0; i < i1; ++i) {
+        switch (i & 3) {
+            case 0: iteration(VsInt<0>(), i); break;
+            case 1: iteration(VsInt<1>(), i); break;
+            case 2: iteration(VsInt<2>(), i); break;
+            default: iteration(VsInt<3>(), i); break;
+        }
     }
 }
 
 int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                              const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st) {
     const int strips = (int)ceil_div(W, VS_TW);
-    // segment height: enough blocks to fill the chip (>= ~1024), warm-up overhead 6 rows per segment
-    long long per_row = (long long)strips * N;
-    int SH = (int)((per_row * H + 1023) / 1024);
-    SH = SH < 8 ? 8 : (SH > VS_SH_MAX ? VS_SH_MAX : SH);
-    const int segs = (int)ceil_div(H, SH);
+    // segment height: a block's run time is ~ (SH + 6) row iterations (6 warm-up rows) and the launch takes ceil(blocks / resident
+    // blocks) of those back to back - pick the segment count that minimises that product (3 blocks per CU fit: 52 KB LDS, 152 VGPRs)
+    const long long per_seg = (long long)strips * N, resident = 3 * 256;
+    int segs = (int)ceil_div(H, VS_SH_MAX), SH = (int)ceil_div(H, segs);
+    long long best = -1;
+    for (int sg = (int)ceil_div(H, VS_SH_MAX); sg <= (H + 7) / 8; ++sg) {
+        const int sh = (int)ceil_div(H, sg);
+        const long long rounds = (per_seg * ceil_div(H, sh) + resident - 1) / resident;
+        const long long cost = rounds * (sh + 6);
+        if (best < 0 || cost < best) { best = cost; segs = (int)ceil_div(H, sh); SH = sh; }
+    }
     if (VS_LDS > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS);
     hipLaunchKernelGGL(vis_cnn_kernel, dim3(strips, segs, N), dim3(256), VS_LDS, st, entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, H, W, SH);
