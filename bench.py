@@ -267,6 +267,14 @@ def main():
                               "avg_launch_ms": dom["avg_ms"], "algorithmic_per_launch": per_launch,
                               "share_of_step": dom["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-9),
                               "launches_per_ref_view": dom["calls"] / reps, "note": note}
+        # the two gather passes (the kernels VERDICT r1 named: 6 % of the HBM roofline then), per instantiation, by the SURVEY 8d byte count
+        result["gather_roofline"] = {k: {"achieved_gbs": v["gbs"], "frac_of_8TBs": v["gbs"] / profiling.PEAK_HBM_GBS, "avg_launch_ms": v["avg_ms"],
+                                         "algorithmic_bytes_per_launch": v["bytes"] / v["calls"]}
+                                     for k, v in agg.items() if k.startswith(("gl_", "warp_corr_"))}
+        gb = sum(v["bytes"] for k, v in agg.items() if k.startswith(("gl_", "warp_corr_")))
+        gt = sum(v["ms"] for k, v in agg.items() if k.startswith(("gl_", "warp_corr_")))
+        result["gather_roofline"]["all_passes"] = {"achieved_gbs": gb / max(gt, 1e-9) / 1e6, "frac_of_8TBs": gb / max(gt, 1e-9) / 1e6 / profiling.PEAK_HBM_GBS,
+                                                   "ms_per_ref_view": gt / reps}
         result["kernels"] = {k: {"calls_per_ref_view": v["calls"] / reps, "ms_per_ref_view": v["ms"] / reps, "gbs": v["gbs"], "tflops": v["tflops"]}
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         if a.profile_table and rank == 0:

@@ -37,12 +37,13 @@ class Launch:
         self.ms = 0.0
 
 
-def gather_kernel_name(which: str, code: int, C: int, D: int, W: int) -> str:
-    """Symbol rocprofv3 reports for the gather pass of a stage (template args: feature dtype, C / 8, work-items per pixel)."""
+def gather_kernel_name(which: str, code: int, C: int, D: int, W: int, tiled: bool = False) -> str:
+    """Symbol rocprofv3 reports for the gather pass of a stage (template args: feature dtype, C / 8, work-items per pixel,
+    octet-tiled layout)."""
     if C in (8, 16, 32, 64) and W % 8 == 0:
         nch = (D + 3) // 4
         ns = 8 if nch >= 8 else 4 if nch >= 4 else 2 if nch >= 2 else 1
-        return "gl_%s_kernel<%d, %d, %d>" % (which, code, C // 8, ns)
+        return "gl_%s_kernel<%d, %d, %d, %s>" % (which, code, C // 8, ns, "true" if tiled else "false")
     return "warp_corr_%s_kernel" % which
 
 
@@ -155,7 +156,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
         # every feature map once, the hypotheses once, the entropy maps out
-        ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
+        ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, isinstance(feats, ops.PackedFeatures)), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
                      lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
         vp = net._vis_params(feats.device)
         prec = _lib.PRECISIONS[net.conv_precision]
@@ -174,7 +175,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                         lambda: ops.conv3d_bn_relu(t2, vp[4], vp[5], 8, 1, (1, 1, 1), True, prec))
             vis = _timed(launches, "vis_out", s, 2.0 * N * HW * 8, 4.0 * N * HW * 9,
                          lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
-        vol = _timed(launches, gather_kernel_name("aggregate", code, C, D, W), s, corr_flops,
+        vol = _timed(launches, gather_kernel_name("aggregate", code, C, D, W, isinstance(feats, ops.PackedFeatures)), s, corr_flops,
                      B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
                      lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
         if getattr(net.cost_reg, "kind", None) == "transformer":
