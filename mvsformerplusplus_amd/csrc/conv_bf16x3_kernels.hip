@@ -53,48 +53,85 @@ template <class Cfg>
 struct BfConv {
     static constexpr int OPT = Cfg::CH / 8;                              // octets per tap and voxel in one pass
     static constexpr int NSTEP = (Cfg::NTAP * OPT + 3) / 4;
-    static constexpr int SB = Cfg::S * 4;                                // bytes per LDS voxel (CH*4 + 16)
-    static_assert(Cfg::CH % 8 == 0, "split-bf16 path stages whole octets");
+    // LDS image of a staged tile.  One octet per pass (CH = 8): [voxel][hi x8 | lo x8 | 16 B pad], 48 B per voxel (conflict-free
+    // for the stride-2 reads, brute-forced).  Two octets (CH = 16): one PLANE per octet, [voxel][hi x8 | lo x8] at 32 B per voxel,
+    // planes offset by 16 B modulo the 256-byte bank row - the 16 lanes of a ds_read_b128 group (8 voxels of octet 0 + 8 of octet 1)
+    // then hit 16 different bank slots.  (Round 1 interleaved both octets in an 80-byte voxel: every read 2-way conflicted, PMC
+    // SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles, and the tile was 25 % larger.)
+    static constexpr bool PLANES = OPT == 2;
+    static constexpr int SB = PLANES ? 32 : Cfg::S * 4;                  // bytes per voxel (within a plane)
+    static constexpr int PLANE = PLANES ? (Cfg::NVOX * 32 + 255) / 256 * 256 + 16 : 32;    // byte offset of octet 1
+    static constexpr size_t LDS_BYTES = PLANES ? (size_t)2 * PLANE : Cfg::LDS_BYTES;
+    static_assert(Cfg::CH % 8 == 0 && OPT <= 2, "split-bf16 path stages one or two octets per pass");
 };
 
+// LDS byte offset of channel octet o = tap * OPT + oc of a staged tile (compile-time for a compile-time o)
 template <class Cfg>
-__device__ __forceinline__ void bf_conv_load_step(int t, int g, const bf16x8* wq, const char* ldsb, const int* voxbase, bf16x8* ah,
-                                                  bf16x8* al, bf16x8* bh, bf16x8* bl) {
+__device__ __forceinline__ constexpr int bf_tap_offset(int o) {
     constexpr int OPT = BfConv<Cfg>::OPT;
-    const int o = 4 * t + g;
     int tap = o / OPT;
     const int oc = o - tap * OPT;
     tap = tap < Cfg::NTAP ? tap : Cfg::NTAP - 1;                          // padded octets carry zero weights
     const int kd = tap / 9, r9 = tap - kd * 9, kh = r9 / 3, kw = r9 - kh * 3;
-    const int tapoff = ((kd * Cfg::IH + kh) * Cfg::IW + kw) * BfConv<Cfg>::SB + oc * 32;
+    return ((kd * Cfg::IH + kh) * Cfg::IW + kw) * BfConv<Cfg>::SB + oc * BfConv<Cfg>::PLANE;
+}
+
+// Operands of contraction step T (compile-time).  Lane group g owns octet 4T + g: its tile offset is one of four
+// compile-time constants, picked with (at most) three selects - the round-1 form decoded tap / kd / kh / kw with run-time
+// divisions in every step (~35 VALU per step against 12 MFMAs; PMC: 6.4 VALU per MFMA on the 16 -> 16 layer).
+// The NREP rows of a wave are consecutive output rows of one output plane (static_assert below), so row nb is a compile-time
+// delta from the wave's first row and all NREP reads share one address register.
+template <class Cfg, int T>
+__device__ __forceinline__ void bf_conv_load_step(int g, const bf16x8* wq, const char* ldsb, int voxbase0, bf16x8* ah, bf16x8* al,
+                                                  bf16x8* bh, bf16x8* bl) {
+    static_assert(Cfg::TH % Cfg::NREP == 0, "a wave's rows must stay inside one output plane");
+    constexpr int ROWB = Cfg::SH * Cfg::IW * BfConv<Cfg>::SB;             // bytes between consecutive output rows in the tile
+    constexpr int c0 = bf_tap_offset<Cfg>(4 * T), c1 = bf_tap_offset<Cfg>(4 * T + 1), c2 = bf_tap_offset<Cfg>(4 * T + 2),
+                  c3 = bf_tap_offset<Cfg>(4 * T + 3);
+    int sel = c0;
+    sel = g == 1 ? c1 : sel;
+    sel = g == 2 ? c2 : sel;
+    sel = g == 3 ? c3 : sel;
+    const char* p = ldsb + voxbase0 + sel;
 #pragma unroll
     for (int mb = 0; mb < Cfg::MREP; ++mb) {
-        ah[mb] = wq[(size_t)((t * Cfg::MREP + mb) * 2) * 64];
-        al[mb] = wq[(size_t)((t * Cfg::MREP + mb) * 2 + 1) * 64];
+        ah[mb] = wq[(size_t)((T * Cfg::MREP + mb) * 2) * 64];
+        al[mb] = wq[(size_t)((T * Cfg::MREP + mb) * 2 + 1) * 64];
     }
 #pragma unroll
     for (int nb = 0; nb < Cfg::NREP; ++nb) {
-        bh[nb] = *reinterpret_cast<const bf16x8*>(ldsb + voxbase[nb] + tapoff);
-        bl[nb] = *reinterpret_cast<const bf16x8*>(ldsb + voxbase[nb] + tapoff + 16);
+        bh[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB);
+        bl[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB + 16);
     }
 }
 
-// software-pipelined contraction of one staged channel chunk (see conv_kernels.hip for the pipeline rationale)
+// software-pipelined contraction of one staged channel chunk, fully unrolled: step T+1's operands are requested before step
+// T's MFMAs (two named register sets; sched_barrier keeps the prefetch above the MFMAs it hides under)
+template <class Cfg, int T>
+struct BfConvSteps {
+    static __device__ __forceinline__ void run(int g, const bf16x8* wq, const char* ldsb, int voxbase0, f32x4 (*acc)[Cfg::NREP], bf16x8* ah0,
+                                               bf16x8* al0, bf16x8* bh0, bf16x8* bl0, bf16x8* ah1, bf16x8* al1, bf16x8* bh1, bf16x8* bl1) {
+        constexpr int NSTEP = BfConv<Cfg>::NSTEP;
+        if constexpr (T < NSTEP) {
+            // set (T & 1) holds step T; load step T + 1 into the other set, then contract step T
+            if constexpr (T + 1 < NSTEP) {
+                if constexpr ((T & 1) == 0) bf_conv_load_step<Cfg, T + 1>(g, wq, ldsb, voxbase0, ah1, al1, bh1, bl1);
+                else bf_conv_load_step<Cfg, T + 1>(g, wq, ldsb, voxbase0, ah0, al0, bh0, bl0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah0, al0, bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah1, al1, bh1, bl1, acc);
+            BfConvSteps<Cfg, T + 1>::run(g, wq, ldsb, voxbase0, acc, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1);
+        }
+    }
+};
+
 template <class Cfg>
 __device__ __forceinline__ void bf_conv_contract(const bf16x8* wq, const char* ldsb, const int* voxbase, int g, f32x4 (*acc)[Cfg::NREP]) {
-    constexpr int MREP = Cfg::MREP, NREP = Cfg::NREP, NSTEP = BfConv<Cfg>::NSTEP;
+    constexpr int MREP = Cfg::MREP, NREP = Cfg::NREP;
     bf16x8 ah0[MREP], al0[MREP], bh0[NREP], bl0[NREP], ah1[MREP], al1[MREP], bh1[NREP], bl1[NREP];
-    bf_conv_load_step<Cfg>(0, g, wq, ldsb, voxbase, ah0, al0, bh0, bl0);
-#pragma unroll 1
-    for (int t = 0; t + 1 < NSTEP; t += 2) {
-        bf_conv_load_step<Cfg>(t + 1, g, wq, ldsb, voxbase, ah1, al1, bh1, bl1);
-        __builtin_amdgcn_sched_barrier(0);
-        bf_mfma_step<MREP, NREP>(ah0, al0, bh0, bl0, acc);
-        bf_conv_load_step<Cfg>(t + 2 < NSTEP ? t + 2 : NSTEP - 1, g, wq, ldsb, voxbase, ah0, al0, bh0, bl0);
-        __builtin_amdgcn_sched_barrier(0);
-        bf_mfma_step<MREP, NREP>(ah1, al1, bh1, bl1, acc);
-    }
-    if (NSTEP & 1) bf_mfma_step<MREP, NREP>(ah0, al0, bh0, bl0, acc);
+    bf_conv_load_step<Cfg, 0>(g, wq, ldsb, voxbase[0], ah0, al0, bh0, bl0);
+    BfConvSteps<Cfg, 0>::run(g, wq, ldsb, voxbase[0], acc, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1);
 }
 
 template <class Cfg>
@@ -148,8 +185,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
             }
             bf16x8 hi, lo;
             split8(u, v, hi, lo);
-            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32) = hi;
-            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32 + 16) = lo;
+            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE) = hi;
+            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE + 16) = lo;
         }
         __syncthreads();
         bf_conv_contract<Cfg>(reinterpret_cast<const bf16x8*>(wp) + (size_t)pass * NSTEP * MREP * 2 * 64 + lane, ldsb, voxbase, g, acc);
@@ -172,162 +209,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
             *reinterpret_cast<float4*>(o + co) = v;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Visibility CNN fused into two launches (cost_volume.py:36,93):
-//   vis_front: entropy [N,H,W] -> ConvBnReLU(1,16) computed on the fly while the 18x18 input tile of ConvBnReLU(16,16)
-//              is staged (the 16-channel first activation never reaches HBM) -> [N,H,W,16]
-//   vis_back : ConvBnReLU(16,8) with Conv2d(8,1,1) + Sigmoid folded into the epilogue (the 8 output channels of a
-//              pixel live in two lane groups of the MFMA result: one wave shuffle) -> vis [N,H,W]
-// ------------------------------------------------------------------------------------------------
-typedef ConvCfg<16, 16, 1, 1, 1, 1, 1, 16, 16> VisCfgA;
-typedef ConvCfg<16, 8, 1, 1, 1, 1, 1, 16, 16> VisCfgB;
-
-__global__ __launch_bounds__(256) void vis_front_bf16x3_kernel(const float* __restrict__ ent, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                               const void* wp2, const float* __restrict__ bias2, float* __restrict__ y, int H, int W,
-                                                               int tiles_x, int ntiles_per_view) {
-    typedef VisCfgA Cfg;
-    constexpr int IH = Cfg::IH, IW = Cfg::IW, NREP = Cfg::NREP, SB = BfConv<Cfg>::SB, EW = IW + 2;
-    HIP_DYNAMIC_SHARED(float4, lds4)
-    char* ldsb = reinterpret_cast<char*>(lds4);
-    float* ent_s = reinterpret_cast<float*>(ldsb + Cfg::NVOX * SB);          // (IH+2) x (IW+2) entropy tile
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
-    int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles_per_view);
-    const int n = (int)blockIdx.y;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int oy0 = ty * 16, ox0 = tx * 16;
-    const float* e = ent + (size_t)n * H * W;
-    for (int i = tid; i < (IH + 2) * EW; i += 256) {
-        const int dy = i / EW, dx = i - dy * EW;
-        const int yy = oy0 - 2 + dy, xx = ox0 - 2 + dx;
-        ent_s[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? e[(size_t)yy * W + xx] : 0.0f;
-    }
-    __syncthreads();
-    // first layer (1 -> 16, 3x3, folded BN, ReLU) for the 18x18 tile, split into bf16 hi/lo, 8 channels per iteration.
-    // i & 1 == tid & 1: a work-item always produces the same 8 channels, so their 72 weights + 8 biases sit in registers
-    // (indexing w1 by a lane-dependent octet made every tap a vector load: TA 79 % busy in the PMC profile)
-    float w1r[9][8], b1r[8];
-    {
-        const int oc = tid & 1;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float4 a = *reinterpret_cast<const float4*>(w1 + t * 16 + oc * 8), c = *reinterpret_cast<const float4*>(w1 + t * 16 + oc * 8 + 4);
-            w1r[t][0] = a.x; w1r[t][1] = a.y; w1r[t][2] = a.z; w1r[t][3] = a.w; w1r[t][4] = c.x; w1r[t][5] = c.y; w1r[t][6] = c.z; w1r[t][7] = c.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b1r[j] = b1[oc * 8 + j];
-    }
-    for (int i = tid; i < Cfg::NVOX * 2; i += 256) {
-        const int vox = i >> 1, oc = i & 1;
-        const int dx = vox % IW, dy = vox / IW;
-        const int yy = oy0 - 1 + dy, xx = ox0 - 1 + dx;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {                        // outside the image the 16->16 conv sees zero padding
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float ev = ent_s[(dy + kh) * EW + dx + kw];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += ev * w1r[kh * 3 + kw][j];
-                }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] + b1r[j], 0.0f);
-        }
-        bf16x8 hi, lo;
-        split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
-        *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32) = hi;
-        *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32 + 16) = lo;
-    }
-    __syncthreads();
-    f32x4 acc[1][NREP];
-    int voxbase[NREP];
-#pragma unroll
-    for (int nb = 0; nb < NREP; ++nb) {
-        acc[0][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        voxbase[nb] = ((wave * NREP + nb) * IW + li) * SB;
-    }
-    bf_conv_contract<Cfg>(reinterpret_cast<const bf16x8*>(wp2) + lane, ldsb, voxbase, g, acc);
-    const float4 bb = *reinterpret_cast<const float4*>(bias2 + 4 * g);
-#pragma unroll
-    for (int nb = 0; nb < NREP; ++nb) {
-        const int oy = oy0 + wave * NREP + nb, ox = ox0 + li;
-        if (oy >= H || ox >= W) continue;
-        const float4 r = make_float4(fmaxf(acc[0][nb][0] + bb.x, 0.0f), fmaxf(acc[0][nb][1] + bb.y, 0.0f), fmaxf(acc[0][nb][2] + bb.z, 0.0f),
-                                     fmaxf(acc[0][nb][3] + bb.w, 0.0f));
-        *reinterpret_cast<float4*>(y + (((size_t)n * H + oy) * W + ox) * 16 + 4 * g) = r;
-    }
-}
-
-__global__ __launch_bounds__(256) void vis_back_bf16x3_kernel(const float* __restrict__ x, const void* wp3, const float* __restrict__ bias3,
-                                                              const float* __restrict__ w4, const float* __restrict__ b4, float* __restrict__ vis,
-                                                              int H, int W, int tiles_x, int ntiles_per_view) {
-    typedef VisCfgB Cfg;
-    constexpr int IH = Cfg::IH, IW = Cfg::IW, NREP = Cfg::NREP, SB = BfConv<Cfg>::SB;
-    HIP_DYNAMIC_SHARED(float4, lds4)
-    char* ldsb = reinterpret_cast<char*>(lds4);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
-    int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles_per_view);
-    const int n = (int)blockIdx.y;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int oy0 = ty * 16, ox0 = tx * 16;
-    const float* xb = x + (size_t)n * H * W * 16;
-    for (int i = tid; i < Cfg::NVOX * 2; i += 256) {
-        const int vox = i >> 1, oc = i & 1;
-        const int dx = vox % IW, dy = vox / IW;
-        const int yy = oy0 - 1 + dy, xx = ox0 - 1 + dx;
-        float4 u = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v = u;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const float4* src = reinterpret_cast<const float4*>(xb + ((size_t)yy * W + xx) * 16 + oc * 8);
-            u = src[0];
-            v = src[1];
-        }
-        bf16x8 hi, lo;
-        split8(u, v, hi, lo);
-        *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32) = hi;
-        *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32 + 16) = lo;
-    }
-    __syncthreads();
-    f32x4 acc[1][NREP];
-    int voxbase[NREP];
-#pragma unroll
-    for (int nb = 0; nb < NREP; ++nb) {
-        acc[0][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        voxbase[nb] = ((wave * NREP + nb) * IW + li) * SB;
-    }
-    bf_conv_contract<Cfg>(reinterpret_cast<const bf16x8*>(wp3) + lane, ldsb, voxbase, g, acc);
-    // epilogue: relu(acc + bias3) for channels 4g..4g+3 (g < 2), dot with the 1x1 weights, add the other lane group, sigmoid
-    const int cg = g < 2 ? g : 0;
-    const float4 bb = *reinterpret_cast<const float4*>(bias3 + 4 * cg);
-    const float4 ww = *reinterpret_cast<const float4*>(w4 + 4 * cg);
-    const float bias4 = b4[0];
-#pragma unroll
-    for (int nb = 0; nb < NREP; ++nb) {
-        float part = fmaxf(acc[0][nb][0] + bb.x, 0.0f) * ww.x;
-        part += fmaxf(acc[0][nb][1] + bb.y, 0.0f) * ww.y;
-        part += fmaxf(acc[0][nb][2] + bb.z, 0.0f) * ww.z;
-        part += fmaxf(acc[0][nb][3] + bb.w, 0.0f) * ww.w;
-        if (g >= 2) part = 0.0f;                                             // rows 8..15 of the 16-row MFMA are padding
-        part += __shfl_xor(part, 16);
-        const int oy = oy0 + wave * NREP + nb, ox = ox0 + li;
-        if (g == 0 && oy < H && ox < W) vis[((size_t)n * H + oy) * W + ox] = 1.0f / (1.0f + expf(-(part + bias4)));
-    }
-}
-
-int vis_weight_fused_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
-                            const float* w4, const float* b4, float* vis, float* scratch16, int N, int H, int W, hipStream_t st) {
-    const int tx = (int)ceil_div(W, 16), ty = (int)ceil_div(H, 16);
-    const size_t ldsA = VisCfgA::LDS_BYTES + (VisCfgA::IH + 2) * (VisCfgA::IW + 2) * sizeof(float);
-    hipLaunchKernelGGL(vis_front_bf16x3_kernel, dim3(tx * ty, N), dim3(256), ldsA, st, entropy, w1, b1, w2, b2, scratch16, H, W, tx, tx * ty);
-    int rc = check_launch("vis_front_bf16x3_kernel");
-    if (rc != MVS_OK) return rc;
-    hipLaunchKernelGGL(vis_back_bf16x3_kernel, dim3(tx * ty, N), dim3(256), VisCfgB::LDS_BYTES, st, scratch16, w3, b3, w4, b4, vis, H, W, tx, tx * ty);
-    return check_launch("vis_back_bf16x3_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -528,9 +409,10 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
     const int OD = (D + 2 * Cfg::PD - Cfg::KD) / Cfg::SD + 1, OH = (H - 1) / Cfg::SH + 1, OW = (W - 1) / Cfg::SW + 1;
     const int tx = (int)ceil_div(OW, 16), ty = (int)ceil_div(OH, Cfg::TH), tz = (int)ceil_div(OD, Cfg::TD);
     const int ntiles = tx * ty * tz;
-    if (Cfg::LDS_BYTES > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
+    constexpr size_t LDS = BfConv<Cfg>::LDS_BYTES;
+    if (LDS > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), LDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
     return check_launch("conv3d_mfma_bf16x3_kernel");
 }
 

@@ -404,12 +404,8 @@ extern "C" int mvs_vis_weight_fwd(const float* entropy, const float* w1, const f
     if (workspace_bytes < mvs_vis_workspace_bytes(N, H, W, precision)) { set_error("mvs_vis_weight_fwd: workspace too small (%zu < %zu)", workspace_bytes, mvs_vis_workspace_bytes(N, H, W, precision)); return MVS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const size_t HW = (size_t)H * W;
-    if (precision == MVS_PREC_BF16X3) {                  // one row-streaming launch, every intermediate in LDS (vis_kernels.hip)
-        const char* e = getenv("MVS_VIS_IMPL");          // MVS_VIS_IMPL=tiles: the round-1 two-launch form (A/B measurements; needs the fp32-size workspace)
-        if (e && e[0] == 't' && workspace_bytes >= (size_t)N * HW * 32 * sizeof(float))
-            return vis_weight_fused_bf16x3(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, static_cast<float*>(workspace), N, H, W, st);
+    if (precision == MVS_PREC_BF16X3)                    // one row-streaming launch, every intermediate in LDS (vis_kernels.hip)
         return vis_weight_stream_bf16x3(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
-    }
     float* t1 = static_cast<float*>(workspace);          // [N,H,W,16]
     float* t2 = t1 + (size_t)N * HW * 16;                // [N,H,W,16]
     hipLaunchKernelGGL(vis_conv1_kernel, dim3(ceil_div((long long)HW, 256), N), dim3(256), 0, st, entropy, w1, b1, t1, H, W);

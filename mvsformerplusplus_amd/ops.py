@@ -140,8 +140,7 @@ def vis_weight(entropy: torch.Tensor, params: Sequence[torch.Tensor], precision:
     H, W = e.shape[-2:]
     N = e.numel() // (H * W)
     vis = torch.empty_like(e)
-    tiles = precision == _lib.PREC_BF16X3 and os.environ.get("MVS_VIS_IMPL", "").startswith("t")    # A/B hook: round-1 two-launch form
-    nbytes = lib().mvs_vis_workspace_bytes(N, H, W, _lib.PREC_FP32 if tiles else precision)
+    nbytes = lib().mvs_vis_workspace_bytes(N, H, W, precision)
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=e.device)
     check(lib().mvs_vis_weight_fwd(ptr(e), *[ptr(p) for p in params], ptr(vis), ptr(ws), nbytes, N, H, W, precision, stream_of(e)),
           "mvs_vis_weight_fwd")
