@@ -54,13 +54,19 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RO
 cd $ROOT
 mkdir -p $OUT/profiles_$TAG
 python scripts/pmc_traffic.py $OUT/pmc_$TAG $OUT/profiles_$TAG/pmc_traffic.json $OUT/profiles_$TAG/${TAG}_pmc_fetch_write_raw.json
-find $OUT/prof_$TAG -name '*kernel_stats.csv' -exec cp {} $OUT/profiles_$TAG/${TAG}_kernel_stats_whole_process.csv \;
-python - $OUT/profiles_$TAG/${TAG}_kernel_stats_whole_process.csv $OUT/profiles_$TAG/${TAG}_kernel_stats.csv <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if not any(t in r["Name"] for t in ("at::native", "Cijk_", "__amd_", "elementwise"))]
-w = csv.DictWriter(open(sys.argv[2], "w"), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
-for r in keep[:12]: print(r["Name"][:70], r["Calls"], r["AverageNs"], r["Percentage"])
-PY
+DB=$(find $OUT/prof_$TAG -name '*.db' | head -1)
+if [ -n "$DB" ]; then
+  python scripts/rocpd_stats.py $DB > $OUT/profiles_$TAG/${TAG}_kernel_stats_whole_process.csv
+  python scripts/rocpd_stats.py $DB "mvs::" > $OUT/profiles_$TAG/${TAG}_kernel_stats.csv
+  head -14 $OUT/profiles_$TAG/${TAG}_kernel_stats.csv | cut -c1-150
+else
+  echo "no rocpd database under $OUT/prof_$TAG"; find $OUT/prof_$TAG | head
+fi
+cp $OUT/bench.json $OUT/profiles_$TAG/${TAG}_bench_1gpu.json
+cp $OUT/bench_shipped.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_shipped.json
+cp $OUT/bench_n2.json $OUT/profiles_$TAG/${TAG}_bench_n2_flow_check_one_gpu_gloo.json
+cp $OUT/bench_tiled_bf16.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_tiled_bf16.json
+grep -v "amdgpu.ids" $OUT/bench.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table.txt
+grep -v "amdgpu.ids" $OUT/bench_shipped.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_shipped.txt
 rm -rf $OUT/prof_$TAG $OUT/pmc_$TAG
 ls -la $OUT/profiles_$TAG

@@ -8,7 +8,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["r01_bench_1gpu.json", "r01_bench_1gpu_shipped.json"])
+@pytest.mark.parametrize("name", ["r01_bench_1gpu.json", "r01_bench_1gpu_shipped.json", "r02_bench_1gpu.json", "r02_bench_1gpu_shipped.json"])
 def test_committed_bench_line(name):
     r = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
