@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 4
+#define MVS_ABI_VERSION 5
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -116,6 +116,13 @@ int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, i
 int mvs_conv3d_bn_relu_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin,
                            int Cout, int D, int H, int W, int kd, int sd, int sh, int sw, int relu, int precision,
                            void* stream);
+
+/* ---- a10: CostRegNet's 3x3x3 `prob` head (Conv3d(8, 1, 3, padding 1, bias=False), module.py:391,407) on the MFMA path:
+ * x_cl [B,D,H,W,8] -> logits [B,D,H,W] planar.  w_packed = the [1,8,3,3,3] weight zero-padded to 16 output rows and packed like
+ * a Conv3d(8,16) (packing.pack_conv_weights_bf16x3); bias [16] (zeros for the reference's bias-free layer).  MVS_PREC_BF16X3 only;
+ * the exact-fp32 form of the same head is mvs_prob_regress_fwd(prob_ksize = 3).                                               */
+int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* bias, float* logits, int B, int D, int H,
+                          int W, int precision, void* stream);
 
 /* ---- a7: ConvTranspose3d(k3, padding 1, stride (sd,2,2), output_padding (sd-1,1,1)) + BN + ReLU,
  * then + skip (module.py:129-165, 402-405, 467-481, 498-501).

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
@@ -44,6 +44,7 @@ SIGNATURES = {
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
+    "mvs_conv3d_logits_fwd": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "mvs_regnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mvs_regnet_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "mvs_regnet_logits_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),

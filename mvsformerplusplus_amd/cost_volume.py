@@ -140,6 +140,11 @@ class StageNet(nn.Module):
                 # 8-channel full-resolution features never reach HBM
                 prob_volume_pre = ops.regnet_logits(self.cost_reg.kind, volume, ws, bs, prob_w, prob_b, precision_code(self.conv_precision))
                 depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+            elif self.cost_reg.prob_ksize == 3 and self.conv_precision == "bf16x3":
+                # CostRegNet: the 3x3x3 head (module.py:391,407) as an MFMA convolution with one real output row, logits out
+                feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, precision_code(self.conv_precision))
+                prob_volume_pre = ops.conv3d_logits(feat_cl, prob_w, prob_b, precision_code(self.conv_precision))
+                depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
             else:
                 feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, precision_code(self.conv_precision))
                 depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(

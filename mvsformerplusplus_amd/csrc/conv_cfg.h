@@ -50,34 +50,44 @@ struct DeconvCfg {
 // the coarsest U-Net level (few voxels) and uses 2x4x16 tiles to keep all CUs busy; strided: 2x4x16 outputs, 8-channel
 // chunks (57-71 KiB -> 2 blocks/CU), except the 8->16 (1,2,2) layer of stage 3/4 which is HBM-bound and runs faster with
 // 2x2x16 tiles (32 KiB -> 5 blocks/CU: more loads in flight; measured 0.238 -> 0.195 ms, the other layers lose);
-// 2-D (visibility CNN): 1x16x16 outputs.  Deconvs 16->8 and 32->16 at (1,2,2): 2x4 input rows (0.376 -> 0.340 ms).
+// 2-D (visibility CNN): 1x16x16 outputs.  8->16 stride 1 is CostRegNet's 3x3x3 `prob` head (one real output row of 16).  Deconvs 16->8 and 32->16 at (1,2,2): 2x4 input rows (0.376 -> 0.340 ms).
 // The (2,2,2) layers only run on the small stage-1/2 volumes (tens of blocks on 256 CUs): 2x2x16 tiles double the
 // number of blocks and halve each block's serial work (0.338 -> 0.257 ms for the six layers).
+#ifndef MVS_T816_TD
+#define MVS_T816_TD 4
+#define MVS_T816_TH 2
+#endif
 #define MVS_CONV_TABLE(X)            \
     X(16, 16, 3, 1, 1, 1, 4, 4, 16)  \
     X(32, 32, 3, 1, 1, 1, 4, 4, 16)  \
     X(64, 64, 3, 1, 1, 1, 2, 4, 16)  \
+    X(8, 16, 3, 1, 1, 1, 2, 4, 8)    \
     X(8, 16, 3, 2, 2, 2, 2, 2, 8)    \
     X(16, 32, 3, 2, 2, 2, 2, 2, 8)   \
     X(32, 64, 3, 2, 2, 2, 2, 2, 8)   \
-    X(8, 16, 3, 1, 2, 2, 2, 2, 8)    \
+    X(8, 16, 3, 1, 2, 2, MVS_T816_TD, MVS_T816_TH, 8)    \
     X(16, 32, 3, 1, 2, 2, 2, 4, 8)   \
     X(32, 64, 3, 1, 2, 2, 2, 4, 8)   \
     X(16, 16, 1, 1, 1, 1, 1, 16, 16) \
     X(16, 8, 1, 1, 1, 1, 1, 16, 16)
 
 // X(CIN, COUT, SD, TDM, THM)
+#ifndef MVS_D168_TDM
+#define MVS_D168_TDM 4
+#define MVS_D168_THM 2
+#endif
 #define MVS_DECONV_TABLE(X) \
     X(64, 32, 2, 2, 2)      \
     X(32, 16, 2, 2, 2)      \
     X(16, 8, 2, 2, 2)       \
     X(64, 32, 1, 2, 2)      \
     X(32, 16, 1, 2, 4)      \
-    X(16, 8, 1, 2, 4)
+    X(16, 8, 1, MVS_D168_TDM, MVS_D168_THM)
 
 // precision of the MFMA contraction (C ABI: MVS_PREC_*)
+// logits != NULL (persistent Cin = 8 kernels only): output channel 0 is written as a planar volume [B,OD,OH,OW] instead of y
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
-                           int kd, int sd, int sh, int sw, int relu, hipStream_t st);
+                           int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits = nullptr);
 int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                              const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st);
 // prob_w / prob_b / logits != NULL (Cout == 8 only): the 1x1x1 `prob` head is applied in the epilogue and the planar logits

@@ -202,7 +202,13 @@ class _RegNetBase(nn.Module):
             ws.append(w)
             bs.append(b)
         pw = self.prob.weight.detach().cpu().float()
-        if self.prob_ksize == 3:
+        if self.prob_ksize == 3 and precision == "bf16x3":
+            # the head as an MFMA convolution with one real output row of 16 (ops.conv3d_logits); prob_b = its (zero) bias
+            w16 = torch.zeros(16, 8, 3, 3, 3)
+            w16[0] = pw[0]
+            prob_w = packing.pack_conv_weights_bf16x3(w16, 8).to(dev)
+            prob_b = torch.zeros(16, dtype=torch.float32, device=dev)
+        elif self.prob_ksize == 3:
             prob_w = pw[0].permute(1, 2, 3, 0).reshape(27, 8).contiguous().to(dev)     # [tap][cin]
             prob_b = None
         else:
@@ -232,6 +238,8 @@ class _RegNetBase(nn.Module):
         feat = self.forward_cl(vol)
         _, _, prob_w, prob_b = self.packed_all(x.device)
         B, D, H, W, _ = feat.shape
+        if self.prob_ksize == 3 and self.conv_precision == "bf16x3":
+            return ops.conv3d_logits(feat, prob_w, prob_b, precision_code(self.conv_precision)).unsqueeze(1)
         dummy_hyp = torch.ones(B, D, H, W, dtype=torch.float32, device=x.device)
         _, _, _, pre = ops.prob_regress(feat, prob_w, prob_b, self.prob_ksize, dummy_hyp, 1.0, _lib.HEAD_CE_EVAL, 0, True)
         return pre.unsqueeze(1)

@@ -221,6 +221,16 @@ def deconv3d_prob(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor
     return logits
 
 
+def conv3d_logits(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, precision: int) -> torch.Tensor:
+    """CostRegNet's 3x3x3 `prob` head on the MFMA path: x_cl [B,D,H,W,8] -> logits [B,D,H,W]."""
+    B, D, H, W, c = x_cl.shape
+    assert c == 8
+    logits = torch.empty(B, D, H, W, dtype=torch.float32, device=x_cl.device)
+    check(lib().mvs_conv3d_logits_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(logits), B, D, H, W, precision, stream_of(x_cl)),
+          "mvs_conv3d_logits_fwd")
+    return logits
+
+
 def _ptr_array(ts: Sequence[torch.Tensor]):
     return (C.c_void_p * len(ts))(*[ptr(t) for t in ts])
 

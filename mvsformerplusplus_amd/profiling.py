@@ -200,6 +200,14 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             continue
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
+        if ks == 3 and net.conv_precision == "bf16x3":
+            logits = _timed(launches, "conv3d_mfma<8,1,k3,s111> prob head", s, 2.0 * B * D * HW * 8 * 27, 4.0 * B * (8 * D * HW + D * HW),
+                            lambda: ops.conv3d_logits(feat_cl, prob_w, prob_b, _lib.PRECISIONS[net.conv_precision]))
+            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * (3 * D * HW + 2 * HW),
+                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
+            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
+            confs.append(r3[1])
+            continue
         res = _timed(launches, "prob_regress_kernel<%d,%d>" % (D, ks), s, 2.0 * B * D * HW * 8 * (27 if ks == 3 else 1),
                      4.0 * B * (8 * D * HW + D * HW + 2 * D * HW + 2 * HW),
                      lambda: ops.prob_regress(feat_cl, prob_w, prob_b, ks, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
