@@ -108,6 +108,17 @@ int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, con
                                 int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream);
 int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, void* stream);
 
+/* ---- section 8f #2 (first slice): backward of mvs_warp_corr_aggregate_fwd(normalise = 1) ----------------------------
+ * The gradient the reference's autograd produces for cost_volume.py:74-101: the sampling grid is built under torch.no_grad()
+ * (warping.py:80) and the entropy from sim.detach() (cost_volume.py:90), so gradients reach the features and the visibility
+ * maps only.  features planar [B,V,C,H,W] (fp32 / bf16 / fp16), volume_cl = the forward's output, vis_sum [B,H,W] = sum_v vis_v,
+ * grad_volume_cl [B,D,H,W,G]; outputs: grad_features [B,V,C,H,W] fp32 (zeroed here, source views accumulated with atomics),
+ * grad_vis [B,V-1,H,W].  Any C, G with C % G == 0.                                                                          */
+int mvs_warp_corr_aggregate_bwd(const void* features, int dtype, const float* homography, const float* hyp, const float* vis,
+                                const float* vis_sum, const float* volume_cl, const float* grad_volume_cl,
+                                float* grad_features, float* grad_vis, int B, int V, int C, int G, int D, int H, int W,
+                                void* stream);
+
 /* ---- a7: Conv3d + folded BatchNorm3d + ReLU, module.py:89-126 ----------------------------------
  * x_cl [B,D,H,W,Cin] -> y_cl [B,OD,OH,OW,Cout]; kernel (kd,3,3), kd in {1,3}, padding (kd/2,1,1),
  * stride (sd,sh,sw) in {1,2}.  Implicit GEMM on MFMA; `precision` = MVS_PREC_* selects the contraction and the

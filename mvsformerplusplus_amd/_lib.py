@@ -45,6 +45,7 @@ SIGNATURES = {
     "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "mvs_conv3d_logits_fwd": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
+    "mvs_warp_corr_aggregate_bwd": (_i, [_vp, _i] + [_vp] * 8 + [_i] * 7 + [_vp]),
     "mvs_regnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mvs_regnet_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "mvs_regnet_logits_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),

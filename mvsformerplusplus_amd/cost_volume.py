@@ -86,8 +86,17 @@ class StageNet(nn.Module):
             return out
         return self._vis_cache.get(self.vis, build, prec)
 
+    def _wants_autograd(self, features) -> bool:
+        """Training mode (BatchNorm batch statistics) or a caller that differentiates w.r.t. the features."""
+        return self.training or (torch.is_grad_enabled() and torch.is_tensor(features) and features.requires_grad)
+
     def forward(self, features, proj_matrices, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
-        _no_grad_path(features, depth_values)
+        if self._wants_autograd(features):
+            # SURVEY.md section 8f #2, first slice: HIP gather forward + backward, PyTorch-ROCm autograd for the conv / BatchNorm
+            # layers (training.py says exactly what runs where)
+            from .training import stage_forward_train
+            assert features.shape[1] == proj_matrices.shape[1], "Different number of images and projection matrices"
+            return stage_forward_train(self, features, proj_matrices, depth_values, tmp)
         B, V, C, H, W = features.shape
         assert V == proj_matrices.shape[1], "Different number of images and projection matrices"   # cost_volume.py:56
         G = self.in_channels

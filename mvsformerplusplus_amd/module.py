@@ -175,8 +175,9 @@ class ConvBnReLU(nn.Module):
         self.bn = nn.BatchNorm2d(out_channels)
 
     def forward(self, x):
-        raise NotImplementedError("ConvBnReLU is evaluated inside the fused visibility kernel (StageNet.vis); "
-                                  "a standalone 2D conv is outside the hot path")
+        """Standalone / training form (PyTorch-ROCm autograd ops, training.py); at inference the layer is evaluated inside the fused
+        visibility kernel (StageNet.vis) and this method is not called."""
+        return torch.relu(self.bn(self.conv(x)))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -181,6 +181,19 @@ def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Ten
     return vol, vsum
 
 
+def warp_corr_aggregate_bwd(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, vis: torch.Tensor,
+                            vis_sum: torch.Tensor, volume_cl: torch.Tensor, grad_volume_cl: torch.Tensor, G: int):
+    """Backward of warp_corr_aggregate(normalise=True) -> (grad_features [B,V,C,H,W] fp32, grad_vis [B,V-1,H,W])."""
+    B, V, Cc, H, W = features.shape
+    D = hyp.shape[1]
+    gfeat = torch.empty(B, V, Cc, H, W, dtype=torch.float32, device=features.device)
+    gvis = torch.empty(B, V - 1, H, W, dtype=torch.float32, device=features.device)
+    check(lib().mvs_warp_corr_aggregate_bwd(ptr(features), code, ptr(homography), ptr(hyp), ptr(vis), ptr(vis_sum), ptr(volume_cl),
+                                            ptr(grad_volume_cl), ptr(gfeat), ptr(gvis), B, V, Cc, G, D, H, W, stream_of(features)),
+          "mvs_warp_corr_aggregate_bwd")
+    return gfeat, gvis
+
+
 def volume_normalise_(vol_cl: torch.Tensor, vis_sum: torch.Tensor) -> torch.Tensor:
     B, D, H, W, G = vol_cl.shape
     check(lib().mvs_volume_normalise(ptr(vol_cl), ptr(vis_sum), B, D, H, W, G, stream_of(vol_cl)), "mvs_volume_normalise")

@@ -56,13 +56,22 @@ def run():
               ("conv 16->16 s222 st2", "c", 16, 16, (1, 1, 1), 8, 72, 96), ("conv 8->16 s122 st3", "c", 8, 16, (1, 2, 2), 8, 576, 768),
               ("conv 8->16 s222 st2", "c", 8, 16, (2, 2, 2), 16, 288, 384), ("conv 8->16 s222 st1", "c", 8, 16, (2, 2, 2), 32, 144, 192),
               ("deconv 16->8 s122 st3", "d", 16, 8, 1, 8, 288, 384), ("deconv 16->8 s222 st2", "d", 16, 8, 2, 8, 144, 192),
-              ("deconv 16->8+prob st4", "p", 16, 8, 1, 4, 576, 768), ("deconv 16->8+prob st3", "p", 16, 8, 1, 8, 288, 384)]
+              ("deconv 16->8+prob st4", "p", 16, 8, 1, 4, 576, 768), ("deconv 16->8+prob st3", "p", 16, 8, 1, 8, 288, 384),
+              ("prob head 8->1 st2", "h", 8, 1, (1, 1, 1), 16, 288, 384), ("prob head 8->1 st1", "h", 8, 1, (1, 1, 1), 32, 144, 192),
+              ("conv 64->64 s111 st1", "c", 64, 64, (1, 1, 1), 4, 18, 24), ("conv 32->64 s222 st1", "c", 32, 64, (2, 2, 2), 8, 36, 48),
+              ("deconv 64->32 s222 st1", "d", 64, 32, 2, 4, 18, 24), ("conv 32->32 s111 st1", "c", 32, 32, (1, 1, 1), 8, 36, 48)]
     res = {}
     for k in VARIANTS:
         _lib._LIB = _lib.bind(os.path.join(OUT, "libmvs_abl%s.so" % _tag(k)))
         for name, kind, cin, cout, stride, D, H, W in layers:
             x = torch.randn(1, D, H, W, cin, generator=g).to(dev)
-            if kind == "c":
+            if kind == "h":
+                w16 = torch.zeros(16, 8, 3, 3, 3)
+                w16[0] = torch.randn(8, 3, 3, 3, generator=g) * 0.05
+                wp = packing.pack_conv_weights_bf16x3(w16, 8).to(dev)
+                bias = torch.zeros(16, device=dev)
+                f = lambda: ops.conv3d_logits(x, wp, bias, 1)
+            elif kind == "c":
                 w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05
                 wp = packing.pack_conv_weights_bf16x3(w, _ch_of(cin, cout, stride)).to(dev)
                 bias = torch.zeros(cout, device=dev)

@@ -215,6 +215,29 @@ def f6_train_mode():
         photometric_confidence=out["photometric_confidence"], **wman)
 
 
+def f12_train_backward():
+    """Full train mode (BatchNorm batch statistics, checkpointed regulariser) forward + backward of the reference StageNet:
+    gradients w.r.t. the features and every parameter, and the running statistics after the step (SURVEY.md section 8f #2)."""
+    for tag, stage_idx, C, D in (("s3", 3, 8, 4), ("s1", 1, 32, 16)):
+        torch.manual_seed(120 + stage_idx)
+        net = StageNet(dict(ARGS), D, stage_idx).train()
+        wman = seed_weights(net, 1200 + stage_idx)
+        parts = [stage_inputs(C, D, 16, 24, 3, 130 + stage_idx + 7 * b, down=2 ** (3 - stage_idx)) for b in range(2)]
+        feats = torch.cat([p[0] for p in parts]).requires_grad_(True)
+        cams = torch.cat([p[1] for p in parts])
+        hyp = torch.cat([p[2] for p in parts])
+        R = torch.randn(2, D, 16, 24, generator=torch.Generator().manual_seed(5 + stage_idx))
+        out = net(feats, cams, hyp, tmp=1.0)
+        loss = (out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
+        loss.backward()
+        grads = {"g." + k: v.grad for k, v in net.named_parameters()}
+        assert all(g is not None for g in grads.values())
+        stats = {"stat." + k: v for k, v in net.state_dict().items() if "running_" in k}
+        npz("f12_train_backward_%s.npz" % tag, features=feats, proj=cams, hyp=hyp, R=R, stage_idx=np.int32(stage_idx), loss=loss,
+            prob_volume_pre=out["prob_volume_pre"], depth=out["depth"], photometric_confidence=out["photometric_confidence"],
+            g_features=feats.grad, **grads, **stats, **wman)
+
+
 TRANSFORMER_CFG = {"base_channel": 8, "mid_channel": 64, "num_heads": 4, "down_rate": [2, 4, 4], "mlp_ratio": 4, "layer_num": 6,
                    "drop": 0.0, "attn_drop": 0.0, "position_encoding": True, "attention_type": "FLASH2",
                    "softmax_scale": "entropy_invariance", "train_avg_length": 12185, "use_pe_proj": True}   # config/mvsformer++.json:94-113
@@ -416,3 +439,4 @@ if __name__ == "__main__":
     f4_cascade()
     f5_small_fns()
     f6_train_mode()
+    f12_train_backward()

@@ -680,3 +680,107 @@ def case_fusion_golden(device):
         assert float(same.float().mean()) >= 0.99
         assert ((cpu(out["depth"]) - fx["d_depth"]).abs()[same]).max() <= 2e-3
         assert ((cpu(out["points"]) - fx["d_points"]).abs().amax(1, keepdim=True)[same]).max() <= 5e-3
+
+
+# ---------------------------------------------------------------- section 8f #2: backward of the aggregation, training path
+def case_aggregate_backward(device):
+    """mvs_warp_corr_aggregate_bwd against torch autograd through the oracle's warp + correlation + aggregation, for C = G
+    (one channel per group), C = 4 G, a border-heavy camera pair (zero-padding taps) and bf16 features."""
+    for C, G, D, H, W, V, dt in ((8, 8, 4, 12, 20, 3, torch.float32), (32, 8, 6, 10, 16, 4, torch.float32), (16, 8, 4, 12, 20, 3, torch.bfloat16)):
+        g = torch.Generator().manual_seed(C + D)
+        cams = synth.make_cameras(V, H, W, baseline=60.0, rot_deg=4.0, seed=C)
+        feats = torch.randn(1, V, C, H, W, generator=g).to(dt)
+        hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.05 * torch.rand(1, D, H, W, generator=g))).contiguous()
+        vis = torch.rand(1, V - 1, H, W, generator=g) * 0.9 + 0.05
+        gvol = torch.randn(1, G, D, H, W, generator=g)
+        # oracle + autograd (float32 math on the same, possibly bf16-rounded, feature values)
+        f32 = feats.float().requires_grad_(True)
+        visr = vis.clone().requires_grad_(True)
+        ref_proj = O.compose_proj(cams[:, 0])
+        vol_sum, vis_sum = 0.0, 0.0
+        for v in range(1, V):
+            warped, _ = O.homo_warping_3D_with_mask(f32[:, v], O.compose_proj(cams[:, v]), ref_proj, hyp)
+            ip = O.group_correlation(f32[:, 0], warped, G)
+            vol_sum = vol_sum + ip * visr[:, v - 1].unsqueeze(1).unsqueeze(1)
+            vis_sum = vis_sum + visr[:, v - 1]
+        vol = vol_sum / (vis_sum.unsqueeze(1).unsqueeze(1) + 1e-6)
+        (vol * gvol).sum().backward()
+        # HIP
+        fd, code = ops._feat(dev(feats, device))
+        hom = ops.compose_homography(dev(cams, device))
+        vol_cl, _ = ops.warp_corr_aggregate(fd, code, hom, dev(hyp, device), dev(vis, device), G)
+        assert (cpu(vol_cl).permute(0, 4, 1, 2, 3) - vol.detach()).abs().max() <= 3e-5
+        gfeat, gvis = ops.warp_corr_aggregate_bwd(fd, code, hom, dev(hyp, device), dev(vis, device), dev(vis.sum(1), device), vol_cl,
+                                                  dev(gvol.permute(0, 2, 3, 4, 1).contiguous(), device), G)
+        scale_f, scale_v = float(f32.grad.abs().max()), float(visr.grad.abs().max())
+        assert (cpu(gfeat) - f32.grad).abs().max() <= 2e-5 * scale_f + 1e-6, (C, G, "feature gradient")
+        assert (cpu(gvis) - visr.grad).abs().max() <= 2e-5 * scale_v + 1e-6, (C, G, "visibility gradient")
+        assert float(cpu(gfeat)[:, 1:].abs().sum()) > 0 and float(cpu(gfeat)[:, 0].abs().sum()) > 0
+
+
+def case_train_backward_golden(device, tag):
+    """Train-mode StageNet (BatchNorm batch statistics, checkpointed regulariser) forward + backward against gradients produced by
+    the reference itself (tests/golden/make_golden.py f12): features, every parameter, running statistics after the step."""
+    fx = load_golden("f12_train_backward_%s.npz" % tag)
+    D = fx["hyp"].shape[1]
+    net = StageNet(dict(ARGS), D, int(fx["stage_idx"]))
+    net.load_state_dict(golden_weights(fx), strict=True)
+    net = net.to(device).train()
+    feats = dev(fx["features"], device).requires_grad_(True)
+    out = net(feats, dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
+    loss = (out["prob_volume"] * dev(fx["R"], device)).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) <= 2e-4 * max(1.0, abs(float(fx["loss"])))
+    assert (cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max() <= 2e-3 * float(fx["prob_volume_pre"].abs().max())
+
+    def close(a, b, what, tol=5e-3):
+        # gradients pass through train-mode BatchNorm (division by batch std) and ~12 conv layers: compare in the max norm,
+        # relative to the largest entry of the reference's gradient
+        err = float((cpu(a) - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+        errs.append(err)
+        assert err <= tol, "%s: %g" % (what, err)
+    errs = []
+    close(feats.grad, fx["g_features"], "d loss / d features")
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        close(p.grad, fx["g." + name], "d loss / d " + name)
+    for k, v in net.state_dict().items():
+        if "running_" in k:
+            close(v, fx["stat." + k], k, 1e-3)
+    import os
+    if os.environ.get("MVS_TEST_VERBOSE"):
+        print("train-backward golden %s: worst relative max-norm error %.2e over %d tensors" % (tag, max(errs), len(errs)))
+
+
+def case_train_path_properties(device):
+    """Training-path behaviour that needs no golden: eval-mode autograd equals the HIP inference outputs, gradient flows to the
+    source AND reference features, and the transformer regulariser refuses to train."""
+    fx = load_golden("f2_stage_s3.npz")
+    net = make_stage(fx, fx["hyp"].shape[1], 3, device)          # eval mode: BatchNorm uses running statistics on both paths
+    feats, proj, hyp = dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device)
+    with torch.no_grad():
+        ref = net(feats, proj, hyp, 1.0)
+    fg = feats.clone().requires_grad_(True)
+    out = net(fg, proj, hyp, 1.0)                                # features require grad -> autograd path
+    assert out["prob_volume_pre"].requires_grad
+    assert (cpu(out["prob_volume_pre"]) - cpu(ref["prob_volume_pre"])).abs().max() <= 1e-3
+    assert rel_l1(cpu(out["depth"]), cpu(ref["depth"])) <= 2e-5
+    out["prob_volume_pre"].square().mean().backward()
+    assert float(fg.grad[:, 0].abs().sum()) > 0 and float(fg.grad[:, 1:].abs().sum()) > 0
+    # the 4-stage cascade trains end to end: every stage's parameters and every stage's features receive a gradient
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    fx = load_golden("f4_cascade.npz")
+    args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True)
+    head = CascadeDepthHead(args)
+    for s in range(4):
+        head.fusions[s].load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
+    head = head.to(device).train()
+    feats = {"stage%d" % s: dev(fx["features%d" % s], device).requires_grad_(True) for s in range(1, 5)}
+    projs = {"stage%d" % s: dev(fx["proj%d" % s], device) for s in range(1, 5)}
+    out = head(feats, projs, dev(fx["depth_values"], device))
+    loss = sum(out["stage%d" % s]["prob_volume_pre"].square().mean() for s in range(1, 5))
+    loss.backward()
+    for s in range(1, 5):
+        assert torch.isfinite(feats["stage%d" % s].grad).all() and float(feats["stage%d" % s].grad.abs().sum()) > 0, s
+    for name, p in head.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name

@@ -41,11 +41,19 @@ def test_no_cpu_fallback():
             net(torch.zeros(1, 2, 8, 8, 8), torch.zeros(1, 2, 2, 4, 4), torch.ones(1, 4, 8, 8), 1.0)
 
 
-def test_backward_is_refused_not_faked():
+def test_training_path_needs_the_hip_library_too():
+    """The autograd path (training.py) builds the cost volume with the HIP kernels: host tensors are refused, nothing is
+    silently computed by PyTorch instead; the transformer regulariser has no training path and says so."""
     net = StageNet({"base_ch": 8, "depth_type": "ce"}, 4, 3).eval()
     f = torch.zeros(1, 2, 8, 8, 8, requires_grad=True)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.MvsHipError):
         net(f, torch.zeros(1, 2, 2, 4, 4), torch.ones(1, 4, 8, 8), 1.0)
+    with pytest.raises(_lib.MvsHipError):
+        net.train()(f.detach(), torch.zeros(1, 2, 2, 4, 4), torch.ones(1, 4, 8, 8), 1.0)
+    tr = StageNet({"base_ch": 8, "depth_type": "ce", "cost_reg_type": ["PureTransformerCostReg"] * 4, "transformer_config": [dict(TRANSFORMER_CFG)]},
+                  32, 0).train()
+    with pytest.raises(NotImplementedError):
+        tr(torch.zeros(1, 2, 8, 8, 8), torch.zeros(1, 2, 2, 4, 4), torch.ones(1, 32, 8, 8), 1.0)
 
 
 def test_unsupported_configs_raise():

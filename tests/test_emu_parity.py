@@ -88,3 +88,16 @@ def test_fusion_golden(emu):
 def test_attention_bf16p(emu):
     P.case_attention_stress(emu, bf16p=True)
     P.case_stage_transformer_bf16p(emu)
+
+
+def test_aggregate_backward(emu):
+    P.case_aggregate_backward(emu)
+
+
+@pytest.mark.parametrize("tag", ["s3", "s1"])
+def test_train_backward_golden(emu, tag):
+    P.case_train_backward_golden(emu, tag)
+
+
+def test_train_path_properties(emu):
+    P.case_train_path_properties(emu)

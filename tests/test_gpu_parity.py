@@ -76,6 +76,19 @@ def test_gather_variants():
     P.case_gather_variants(DEV)
 
 
+def test_aggregate_backward():
+    P.case_aggregate_backward(DEV)
+
+
+@pytest.mark.parametrize("tag", ["s3", "s1"])
+def test_train_backward_golden(tag):
+    P.case_train_backward_golden(DEV, tag)
+
+
+def test_train_path_properties():
+    P.case_train_path_properties(DEV)
+
+
 def test_cascade_golden():
     P.case_cascade_golden(DEV)
 
