@@ -135,6 +135,29 @@ int mvs_conv3d_bn_relu_fwd(const float* x_cl, const void* w_packed, const float*
 int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* bias, float* logits, int B, int D, int H,
                           int W, int precision, void* stream);
 
+/* ---- section 8f #2: training-mode regulariser (batch-statistics BatchNorm, weight gradients) -------------------------------
+ * Channel-last fp32 [N voxels][C], C in {8,16,32,64}.  The forward convolutions and the DATA gradients of the training path are
+ * mvs_conv3d_bn_relu_fwd (relu = 0, zero bias) / mvs_deconv3d_linear_fwd with un-folded, re-packed weights (training.py).
+ *   mvs_bn_stats       sums[2C] (double) = per-channel [sum x | sum x^2]                       nn.BatchNorm3d, training=True
+ *   mvs_bn_finalize    mean / biased var / 1/sqrt(var+eps) from sums and the voxel count (after an optional SyncBN all-reduce)
+ *   mvs_bn_relu_apply  y = relu((z-mean)*invstd*gamma+beta) [+ skip]                            module.py:120-125, 402-405
+ *   mvs_bn_relu_bwd    phase 0: sums[2C] = [d beta | d gamma] of dy through the ReLU mask; phase 1: dz (count = voxels of all
+ *                      ranks, use_batch_stats = 0 for eval-mode BatchNorm inside a training graph)
+ *   mvs_conv3d_wgrad   dW[CB][CA][27] of Conv3d(k3, padding 1, stride) from input a_cl [B,D,H,W,CA] and output gradient
+ *                      g_cl [B,OD,OH,OW,CB] on the fp32 MFMA path; a transposed convolution's weight gradient is the same call
+ *                      with a = its output gradient and g = its input (result in ConvTranspose3d's [Cin][Cout][27] layout)    */
+int mvs_deconv3d_linear_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout,
+                            int D, int H, int W, int sd, int precision, void* stream);
+int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C, void* stream);
+int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, int C, void* stream);
+int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* skip_cl, float* y_cl, long long N, int C, int relu, void* stream);
+int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, double* sums, double count, float* dz_cl, long long N, int C, int relu,
+                    int use_batch_stats, int phase, void* stream);
+int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int sd,
+                     int sh, int sw, void* stream);
+
 /* ---- a7: ConvTranspose3d(k3, padding 1, stride (sd,2,2), output_padding (sd-1,1,1)) + BN + ReLU,
  * then + skip (module.py:129-165, 402-405, 467-481, 498-501).
  * x_cl [B,D,H,W,Cin] -> y_cl [B,D*sd,2H,2W,Cout]; skip_cl has y's shape (NULL = no skip).          */

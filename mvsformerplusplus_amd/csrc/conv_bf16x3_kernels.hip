@@ -507,10 +507,11 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                                                                    const float* __restrict__ skip, float* __restrict__ y,
                                                                    const float* __restrict__ prob_w, const float* __restrict__ prob_b,
                                                                    float* __restrict__ logits, int D, int H, int W, int tiles_x,
-                                                                   int tiles_y, int ntiles) {
+                                                                   int tiles_y, int ntiles, int relu) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, TDM = Cfg::TDM, THM = Cfg::THM;
     constexpr int LH = Cfg::LH, LW = Cfg::LW, MREP = Cfg::MREP, NREP = Cfg::NREP;
     constexpr int OPT = BfDeconv<Cfg>::OPT, SB = BfDeconv<Cfg>::SB;
+    const float lo_clamp = relu ? 0.0f : -INFINITY;                       // relu = 0: the linear transposed convolution (training path: BN follows)
     HIP_DYNAMIC_SHARED(float4, lds4)
     char* ldsb = reinterpret_cast<char*>(lds4);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -619,8 +620,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1), co = 4 * (g & 1);
                 const size_t off = (((size_t)oz * OH + oy) * OW + ox) * COUT + co;
                 const float4 bb = *reinterpret_cast<const float4*>(bias + co);
-                float4 v = make_float4(fmaxf(acc[0][nb][0] + bb.x, 0.0f), fmaxf(acc[0][nb][1] + bb.y, 0.0f), fmaxf(acc[0][nb][2] + bb.z, 0.0f),
-                                       fmaxf(acc[0][nb][3] + bb.w, 0.0f));
+                float4 v = make_float4(fmaxf(acc[0][nb][0] + bb.x, lo_clamp), fmaxf(acc[0][nb][1] + bb.y, lo_clamp), fmaxf(acc[0][nb][2] + bb.z, lo_clamp),
+                                       fmaxf(acc[0][nb][3] + bb.w, lo_clamp));
                 if (sb && inside) {
                     const float4 sk = skp[it][nb][0];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
@@ -647,8 +648,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 const int co = 16 * mb + 4 * g;
                 if (co >= COUT) continue;
                 const float4 bb = *reinterpret_cast<const float4*>(bias + co);
-                float4 v = make_float4(fmaxf(acc[mb][nb][0] + bb.x, 0.0f), fmaxf(acc[mb][nb][1] + bb.y, 0.0f),
-                                       fmaxf(acc[mb][nb][2] + bb.z, 0.0f), fmaxf(acc[mb][nb][3] + bb.w, 0.0f));
+                float4 v = make_float4(fmaxf(acc[mb][nb][0] + bb.x, lo_clamp), fmaxf(acc[mb][nb][1] + bb.y, lo_clamp),
+                                       fmaxf(acc[mb][nb][2] + bb.z, lo_clamp), fmaxf(acc[mb][nb][3] + bb.w, lo_clamp));
                 if (sb) {
                     const float4 sk = skp[it][nb][mb];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
@@ -743,8 +744,9 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                                                                            const float* __restrict__ skip, float* __restrict__ y,
                                                                            const float* __restrict__ prob_w, const float* __restrict__ prob_b,
                                                                            float* __restrict__ logits, int D, int H, int W, int tiles_x, int tiles_y,
-                                                                           int ntiles) {
+                                                                           int ntiles, int relu) {
     using P = BfDeconvP<Cfg>;
+    const float lo_clamp = relu ? 0.0f : -INFINITY;
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, TDM = Cfg::TDM, THM = Cfg::THM;
     constexpr int LH = Cfg::LH, LW = Cfg::LW, NREP = Cfg::NREP, NIT = P::NIT, OPT = P::OPT, SB = P::SB;
     HIP_DYNAMIC_SHARED(float4, lds4)
@@ -854,8 +856,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
             BfDeconvSteps<Cfg, IT, 0>::run(g, lane, ldsx, ldsw, voxbase[0], acc, a0, bh0, bl0, a1, bh1, bl1);
 #pragma unroll
             for (int nb = 0; nb < NREP; ++nb)
-                outv[IT][nb] = make_float4(fmaxf(acc[0][nb][0] + bb.x, 0.0f), fmaxf(acc[0][nb][1] + bb.y, 0.0f), fmaxf(acc[0][nb][2] + bb.z, 0.0f),
-                                           fmaxf(acc[0][nb][3] + bb.w, 0.0f));
+                outv[IT][nb] = make_float4(fmaxf(acc[0][nb][0] + bb.x, lo_clamp), fmaxf(acc[0][nb][1] + bb.y, lo_clamp), fmaxf(acc[0][nb][2] + bb.z, lo_clamp),
+                                           fmaxf(acc[0][nb][3] + bb.w, lo_clamp));
         };
         run_class(std::integral_constant<int, 0>{});
         run_class(std::integral_constant<int, 1>{});
@@ -929,7 +931,7 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
 
 template <class Cfg>
 static int launch_deconv_bf(const float* x, const void* wp, const float* bias, const float* skip, float* y, const float* prob_w,
-                            const float* prob_b, float* logits, int B, int D, int H, int W, hipStream_t st) {
+                            const float* prob_b, float* logits, int B, int D, int H, int W, hipStream_t st, int relu) {
     const int tx = (int)ceil_div(W, 16), ty = (int)ceil_div(H, Cfg::THM), tz = (int)ceil_div(D, Cfg::TDM);
     const int ntiles = tx * ty * tz;
     if constexpr (MVS_PERSIST && Cfg::CIN == 16 && Cfg::COUT == 8) {
@@ -949,13 +951,13 @@ static int launch_deconv_bf(const float* x, const void* wp, const float* bias, c
         }
         const int nblk = ntiles < resident ? ntiles : resident;
         hipLaunchKernelGGL((deconv3d_mfma_bf16x3_persist_kernel<Cfg>), dim3(nblk, B), dim3(256), LDS, st, x, wp, bias, skip, y, prob_w, prob_b, logits, D, H,
-                           W, tx, ty, ntiles);
+                           W, tx, ty, ntiles, relu);
         return check_launch("deconv3d_mfma_bf16x3_persist_kernel");
     }
     if (Cfg::LDS_BYTES > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     hipLaunchKernelGGL((deconv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, skip, y, prob_w, prob_b,
-                       logits, D, H, W, tx, ty, ntiles);
+                       logits, D, H, W, tx, ty, ntiles, relu);
     return check_launch("deconv3d_mfma_bf16x3_kernel");
 }
 
@@ -971,11 +973,11 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
 }
 
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,
-                             int D, int H, int W, int sd, hipStream_t st, const float* prob_w, const float* prob_b, float* logits) {
+                             int D, int H, int W, int sd, hipStream_t st, const float* prob_w, const float* prob_b, float* logits, int relu) {
     if (prob_w != nullptr && Cout != 8) { set_error("deconv3d(bf16x3): the fused prob head needs Cout == 8"); return MVS_ERR_UNSUPPORTED; }
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
     if (Cin == CI && Cout == CO && sd == SD)                                                            \
-        return launch_deconv_bf<DeconvCfg<CI, CO, SD, TDM, THM>>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st);
+        return launch_deconv_bf<DeconvCfg<CI, CO, SD, TDM, THM>>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);
     MVS_DECONV_TABLE(MVS_X)
 #undef MVS_X
     set_error("deconv3d(bf16x3): no kernel for Cin=%d Cout=%d stride=(%d,2,2)", Cin, Cout, sd);

@@ -98,6 +98,6 @@ int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float*
 // [B,OD,OH,OW] are written instead of y
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,
                              int D, int H, int W, int sd, hipStream_t st, const float* prob_w = nullptr, const float* prob_b = nullptr,
-                             float* logits = nullptr);
+                             float* logits = nullptr, int relu = 1);
 
 }  // namespace mvs

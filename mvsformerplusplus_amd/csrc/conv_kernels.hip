@@ -372,6 +372,13 @@ extern "C" int mvs_conv3d_bn_relu_fwd(const float* x_cl, const void* w_packed, c
     return conv3d_dispatch(x_cl, w_packed, bias, y_cl, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, precision, (hipStream_t)stream);
 }
 
+extern "C" int mvs_deconv3d_linear_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout, int D,
+                                       int H, int W, int sd, int precision, void* stream) {
+    if (!x_cl || !w_packed || !bias || !y_cl || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_deconv3d_linear_fwd: bad arguments"); return MVS_ERR_ARG; }
+    if (precision != MVS_PREC_BF16X3) { set_error("mvs_deconv3d_linear_fwd: only MVS_PREC_BF16X3"); return MVS_ERR_UNSUPPORTED; }
+    return deconv3d_dispatch_bf16x3(x_cl, w_packed, bias, nullptr, y_cl, B, Cin, Cout, D, H, W, sd, (hipStream_t)stream, nullptr, nullptr, nullptr, 0);
+}
+
 extern "C" int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* bias, float* logits, int B, int D, int H, int W,
                                      int precision, void* stream) {
     if (!x_cl || !w_packed || !bias || !logits || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_conv3d_logits_fwd: bad arguments"); return MVS_ERR_ARG; }

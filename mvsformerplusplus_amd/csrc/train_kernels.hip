@@ -1,0 +1,329 @@
+// Training-mode kernels of the 3-D U-Net regulariser: batch-statistics BatchNorm (forward and
+// backward) fused with ReLU and the skip add, and the weight gradient of the (transposed) convolutions on the fp32 MFMA path.
+// Reference behaviour: nn.BatchNorm3d in train mode + ReLU inside Conv3d / Deconv3d (module.py:89-165), the skip adds of
+// CostRegNet / CostRegNet3D (module.py:398-408, 494-504), autograd's convolution_backward for the weights.
+//
+// The forward convolutions and the data gradients reuse the inference kernels (conv_bf16x3_kernels.hip) with un-folded,
+// re-packed weights: the data gradient of a stride-1 convolution is the convolution with flipped, transposed taps; of a strided
+// convolution the transposed convolution with the same taps; of a transposed convolution the strided convolution (training.py).
+//
+// Everything is channel-last fp32 [N voxels][C], C in {8, 16, 32, 64}.
+#include "mvs_common.h"
+
+namespace mvs {
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics: per-channel sum and sum of squares in double (N reaches 10^7 voxels).
+// sums[0..C) = sum x, sums[C..2C) = sum x^2 (zeroed by the entry point, accumulated with one f64 atomic per block and value).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, size_t n4, int C) {
+    __shared__ double part[2 * 64];
+    const int tid = (int)threadIdx.x;
+    if (tid < 2 * C) part[tid] = 0.0;
+    __syncthreads();
+    const int q4 = C / 4;                                                  // float4s per voxel; gridDim.x * 256 is a multiple of it
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + tid;
+    const int c0 = (int)(i % (size_t)q4) * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    for (; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        atomicAdd(&part[c0 + k], s[k]);
+        atomicAdd(&part[C + c0 + k], ss[k]);
+    }
+    __syncthreads();
+    if (tid < 2 * C) atomicAdd(&sums[tid], part[tid]);
+}
+
+// mean / biased variance / 1 / sqrt(var + eps) from the sums (count = voxels summed, possibly over several ranks)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float* __restrict__ mean, float* __restrict__ var,
+                                   float* __restrict__ invstd, int C) {
+    const int c = (int)threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / count;
+    double v = sums[C + c] / count - m * m;
+    v = v > 0.0 ? v : 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+    invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+}
+
+// y = relu((z - mean) * invstd * gamma + beta) [+ skip]        (relu = 0: no clamp)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ skip, float* __restrict__ y, size_t n4, int C, int relu) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c0 = (int)(i % (size_t)(C / 4)) * 4;
+    const float4 v = reinterpret_cast<const float4*>(z)[i];
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    float out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sc = invstd[c0 + k] * gamma[c0 + k];
+        float t = (in[k] - mean[c0 + k]) * sc + beta[c0 + k];
+        if (relu) t = fmaxf(t, 0.0f);
+        out[k] = t;
+    }
+    if (skip != nullptr) {
+        const float4 s = reinterpret_cast<const float4*>(skip)[i];
+        out[0] += s.x; out[1] += s.y; out[2] += s.z; out[3] += s.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// backward, phase 1: g = dy * [bn(z) > 0] (relu) ; sums[0..C) = sum g (= d beta), sums[C..2C) = sum g * xhat (= d gamma)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, double* __restrict__ sums, size_t n4, int C, int relu) {
+    __shared__ double part[2 * 64];
+    const int tid = (int)threadIdx.x;
+    if (tid < 2 * C) part[tid] = 0.0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + tid;
+    const int c0 = (int)(i % (size_t)(C / 4)) * 4;
+    float mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; }
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+    for (; i < n4; i += stride) {
+        const float4 zv = reinterpret_cast<const float4*>(z)[i], gv = reinterpret_cast<const float4*>(dy)[i];
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (zz[k] - mu[k]) * is[k];
+            const float g = (!relu || xh * ga[k] + be[k] > 0.0f) ? gg[k] : 0.0f;
+            s[k] += g;
+            sx[k] += (double)g * xh;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        atomicAdd(&part[c0 + k], s[k]);
+        atomicAdd(&part[C + c0 + k], sx[k]);
+    }
+    __syncthreads();
+    if (tid < 2 * C) atomicAdd(&sums[tid], part[tid]);
+}
+
+// backward, phase 2: dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))   (batch statistics)
+//                    dz = gamma * invstd * g                                        (use_batch_stats = 0: running statistics)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const double* __restrict__ sums, double count,
+                                                           float* __restrict__ dz, size_t n4, int C, int relu, int use_batch_stats) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c0 = (int)(i % (size_t)(C / 4)) * 4;
+    const float4 zv = reinterpret_cast<const float4*>(z)[i], gv = reinterpret_cast<const float4*>(dy)[i];
+    const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    float out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float is = invstd[c0 + k], ga = gamma[c0 + k];
+        const float xh = (zz[k] - mean[c0 + k]) * is;
+        const float g = (!relu || xh * ga + beta[c0 + k] > 0.0f) ? gg[k] : 0.0f;
+        float t = g;
+        if (use_batch_stats) t -= (float)(sums[c0 + k] / count) + xh * (float)(sums[C + c0 + k] / count);
+        out[k] = t * ga * is;
+    }
+    reinterpret_cast<float4*>(dz)[i] = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of Conv3d(k3, padding 1, stride (SD,SH,SW)):
+//     dW[co][ci][tap] = sum over output voxels o of  g[o][co] * a[o * stride + tap - 1][ci]
+// as 27 GEMMs (one per tap) with M = co, N = ci, K = output voxels on v_mfma_f32_16x16x4_f32 (exact fp32 products).
+// A block owns one 16 x 16 (co, ci) block (blockIdx.y) and walks a run of output tiles; per tile it stages 16 channels of the
+// gradient tile and of the input halo tile in LDS; wave w accumulates taps w, w + 4, ... (7, 7, 7, 6) in registers over ALL its
+// tiles and adds them to dW once at the end (dW zeroed by the entry point).  The weight gradient of a transposed convolution
+// is the same sum with the roles of input and output exchanged (a = its output gradient, g = its input).
+// ------------------------------------------------------------------------------------------------
+template <int SD_, int SH_, int SW_, int TD_, int TH_>
+struct WgCfg {
+    static constexpr int SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, TW = 16;
+    static constexpr int ID = (TD - 1) * SD + 3, IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
+    static constexpr int NVOX = ID * IH * IW, NVO = TD * TH * TW;
+    static constexpr size_t LDS_BYTES = (size_t)(NVOX + NVO) * 16 * sizeof(float);
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ dw, int D,
+                                                           int H, int W, int OD, int OH, int OW, int CA, int CB, int tiles_x, int tiles_y,
+                                                           int tiles_per_batch, int ntiles) {
+    constexpr int SD = Cfg::SD, SH = Cfg::SH, SW = Cfg::SW, TD = Cfg::TD, TH = Cfg::TH, IH = Cfg::IH, IW = Cfg::IW;
+    HIP_DYNAMIC_SHARED(float4, lds4)
+    float* la = reinterpret_cast<float*>(lds4);                            // [NVOX][16] input halo tile
+    float* lg = la + Cfg::NVOX * 16;                                       // [NVO][16] output-gradient tile
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, grp = lane >> 4;
+    const int nbn = (CA + 15) / 16;
+    const int co0 = ((int)blockIdx.y / nbn) * 16, ci0 = ((int)blockIdx.y % nbn) * 16;
+    const int nblk = (int)gridDim.x, per = (ntiles + nblk - 1) / nblk;
+    const int t_begin = (int)blockIdx.x * per;
+    const int t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+    if (t_begin >= t_end) return;
+
+    constexpr int NT = 7;                                                  // taps per wave (wave 3: six)
+    f32x4 acc[NT];
+    int tapoff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        const int tap = wave + 4 * j < 27 ? wave + 4 * j : 26;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        tapoff[j] = ((kd * IH + kh) * IW + kw) * 16;
+    }
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int b = tile / tiles_per_batch;
+        int t = tile - b * tiles_per_batch;
+        const int tx = t % tiles_x;
+        t /= tiles_x;
+        const int ty = t % tiles_y, tz = t / tiles_y;
+        const int oz0 = tz * TD, oy0 = ty * TH, ox0 = tx * 16;
+        const int iz0 = oz0 * SD - 1, iy0 = oy0 * SH - 1, ix0 = ox0 * SW - 1;
+        const float* ab = a + (size_t)b * D * H * W * CA;
+        const float* gb = g + (size_t)b * OD * OH * OW * CB;
+        for (int e = tid; e < Cfg::NVOX * 4; e += 256) {
+            const int vox = e >> 2, q = e & 3;
+            const int dx = vox % IW;
+            const int t2 = vox / IW;
+            const int dy = t2 % IH, dz = t2 / IH;
+            const int zz = iz0 + dz, yy = iy0 + dy, xx = ix0 + dx, c = ci0 + 4 * q;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < CA)
+                v = *reinterpret_cast<const float4*>(ab + (((size_t)zz * H + yy) * W + xx) * CA + c);
+            *reinterpret_cast<float4*>(la + vox * 16 + 4 * q) = v;
+        }
+        for (int e = tid; e < Cfg::NVO * 4; e += 256) {
+            const int vox = e >> 2, q = e & 3;
+            const int ox = vox & 15, row = vox >> 4;
+            const int oz = oz0 + row / TH, oy = oy0 + row % TH, c = co0 + 4 * q;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (oz < OD && oy < OH && ox0 + ox < OW && c < CB)
+                v = *reinterpret_cast<const float4*>(gb + (((size_t)oz * OH + oy) * OW + ox0 + ox) * CB + c);
+            *reinterpret_cast<float4*>(lg + vox * 16 + 4 * q) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int k4 = 0; k4 < Cfg::NVO / 4; ++k4) {
+            // the four voxels of this k-group sit in one row of 16: x = 4 * (k4 % 4) + grp
+            const int row = k4 >> 2, ox = 4 * (k4 & 3) + grp;
+            const int oz = row / TH, oy = row % TH;
+            const float aop = lg[(row * 16 + ox) * 16 + li];              // A operand: [m = co][k = voxel]
+            const float* bp = la + (((oz * SD) * IH + oy * SH) * IW + ox * SW) * 16 + li;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (j == NT - 1 && wave == 3) continue;                    // tap 27 does not exist
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, bp[tapoff[j]], acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int tap = wave + 4 * j;
+        if (tap >= 27) continue;
+        const int ci = ci0 + li;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + 4 * grp + i;
+            if (co < CB && ci < CA) atomicAdd(dw + ((size_t)co * CA + ci) * 27 + tap, acc[j][i]);
+        }
+    }
+}
+
+template <class Cfg>
+static int launch_wgrad(const float* a, const float* g, float* dw, int B, int D, int H, int W, int OD, int OH, int OW, int CA, int CB, hipStream_t st) {
+    const int tx = (int)ceil_div(OW, 16), ty = (int)ceil_div(OH, Cfg::TH), tz = (int)ceil_div(OD, Cfg::TD);
+    const int per_batch = tx * ty * tz, ntiles = per_batch * B;
+    const int jobs = (int)ceil_div(CA, 16) * (int)ceil_div(CB, 16);
+    if (Cfg::LDS_BYTES > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    // one chip-load of persistent blocks (256 CUs x 2 resident): every block ends with 27 x 256 atomic adds into ITS (co, ci) block
+    // of dW, so the number of blocks per job is the depth of the same-address atomic chains (2048 blocks per job: 14 M atomics on
+    // 6912 addresses, 700 us per launch on the MI355X; 512 in total: measured below)
+    int nblk = 512 / jobs;
+    nblk = nblk < 1 ? 1 : nblk;
+    nblk = nblk > ntiles ? ntiles : nblk;
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<Cfg>), dim3(nblk, jobs), dim3(256), Cfg::LDS_BYTES, st, a, g, dw, D, H, W, OD, OH, OW, CA, CB, tx, ty,
+                       per_batch, ntiles);
+    return check_launch("conv3d_wgrad_kernel");
+}
+
+static unsigned ew_blocks(size_t n4, int C, unsigned cap) {
+    // a multiple of C / 4 threads in total (each work-item then stays on one channel quad): 256 * blocks always is
+    size_t b = (n4 + 255) / 256;
+    if (cap && b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+static bool bn_shape_ok(const char* who, size_t N, int C) {
+    if (N < 1 || (C != 8 && C != 16 && C != 32 && C != 64)) { set_error("%s: C must be 8, 16, 32 or 64 and N >= 1", who); return false; }
+    return true;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C, void* stream) {
+    if (!x_cl || !sums || !bn_shape_ok("mvs_bn_stats", (size_t)N, C)) { if (!x_cl || !sums) set_error("mvs_bn_stats: null pointer"); return MVS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), st) != hipSuccess) { set_error("mvs_bn_stats: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
+    const size_t n4 = (size_t)N * C / 4;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(ew_blocks(n4, C, 2048)), dim3(256), 0, st, x_cl, sums, n4, C);
+    return check_launch("bn_stats_kernel");
+}
+
+extern "C" int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, int C, void* stream) {
+    if (!sums || !mean || !var || !invstd || count < 1.0 || !bn_shape_ok("mvs_bn_finalize", 1, C)) { set_error("mvs_bn_finalize: bad arguments"); return MVS_ERR_ARG; }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, count, eps, mean, var, invstd, C);
+    return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* skip_cl,
+                                 float* y_cl, long long N, int C, int relu, void* stream) {
+    if (!z_cl || !mean || !invstd || !gamma || !beta || !y_cl || !bn_shape_ok("mvs_bn_relu_apply", (size_t)N, C)) { set_error("mvs_bn_relu_apply: bad arguments"); return MVS_ERR_ARG; }
+    const size_t n4 = (size_t)N * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4, C, 0)), dim3(256), 0, (hipStream_t)stream, z_cl, mean, invstd, gamma, beta, skip_cl, y_cl, n4, C, relu);
+    return check_launch("bn_apply_kernel");
+}
+
+extern "C" int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               double* sums, double count, float* dz_cl, long long N, int C, int relu, int use_batch_stats, int phase, void* stream) {
+    if (!dy_cl || !z_cl || !mean || !invstd || !gamma || !beta || !sums || !bn_shape_ok("mvs_bn_relu_bwd", (size_t)N, C)) { set_error("mvs_bn_relu_bwd: bad arguments"); return MVS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n4 = (size_t)N * C / 4;
+    if (phase == 0) {                                                      // reduce: sums = [d beta | d gamma] of THIS rank's voxels
+        if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), st) != hipSuccess) { set_error("mvs_bn_relu_bwd: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ew_blocks(n4, C, 2048)), dim3(256), 0, st, dy_cl, z_cl, mean, invstd, gamma, beta, sums, n4, C, relu);
+        return check_launch("bn_bwd_reduce_kernel");
+    }
+    if (!dz_cl || count < 1.0) { set_error("mvs_bn_relu_bwd: bad arguments"); return MVS_ERR_ARG; }
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4, C, 0)), dim3(256), 0, st, dy_cl, z_cl, mean, invstd, gamma, beta, sums, count, dz_cl, n4, C, relu,
+                       use_batch_stats);
+    return check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int sd, int sh, int sw,
+                                void* stream) {
+    if (!a_cl || !g_cl || !dw || B < 1 || D < 1 || H < 1 || W < 1 || CA < 4 || CB < 4 || (CA % 4) || (CB % 4)) {
+        set_error("mvs_conv3d_wgrad: bad arguments (channel counts must be multiples of 4)");
+        return MVS_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
+    if (hipMemsetAsync(dw, 0, (size_t)CA * CB * 27 * sizeof(float), st) != hipSuccess) { set_error("mvs_conv3d_wgrad: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
+    if (sd == 1 && sh == 1 && sw == 1) return launch_wgrad<WgCfg<1, 1, 1, 4, 4>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);
+    if (sd == 1 && sh == 2 && sw == 2) return launch_wgrad<WgCfg<1, 2, 2, 2, 2>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);
+    if (sd == 2 && sh == 2 && sw == 2) return launch_wgrad<WgCfg<2, 2, 2, 2, 2>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);
+    set_error("mvs_conv3d_wgrad: stride (%d,%d,%d) unsupported", sd, sh, sw);
+    return MVS_ERR_UNSUPPORTED;
+}

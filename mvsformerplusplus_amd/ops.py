@@ -234,6 +234,67 @@ def deconv3d_prob(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor
     return logits
 
 
+# ---- section 8f #2: training-mode regulariser ----------------------------------------------------
+def deconv3d_linear(x_cl: torch.Tensor, w_packed: torch.Tensor, zero_bias: torch.Tensor, cout: int, sd: int, precision: int) -> torch.Tensor:
+    """ConvTranspose3d(k3, padding 1, stride (sd,2,2), output_padding (sd-1,1,1)) without bias / BatchNorm / ReLU."""
+    B, D, H, W, cin = x_cl.shape
+    y = torch.empty(B, D * sd, 2 * H, 2 * W, cout, dtype=torch.float32, device=x_cl.device)
+    check(lib().mvs_deconv3d_linear_fwd(ptr(x_cl), ptr(w_packed), ptr(zero_bias), ptr(y), B, cin, cout, D, H, W, sd, precision, stream_of(x_cl)),
+          "mvs_deconv3d_linear_fwd")
+    return y
+
+
+def bn_stats(x_cl: torch.Tensor) -> torch.Tensor:
+    """-> float64 [2C]: per-channel [sum x | sum x^2] over all voxels of a channel-last tensor."""
+    Cc = x_cl.shape[-1]
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=x_cl.device)
+    check(lib().mvs_bn_stats(ptr(x_cl), ptr(sums), x_cl.numel() // Cc, Cc, stream_of(x_cl)), "mvs_bn_stats")
+    return sums
+
+
+def bn_finalize(sums: torch.Tensor, count: float, eps: float):
+    Cc = sums.numel() // 2
+    mean, var, invstd = (torch.empty(Cc, dtype=torch.float32, device=sums.device) for _ in range(3))
+    check(lib().mvs_bn_finalize(ptr(sums), float(count), float(eps), ptr(mean), ptr(var), ptr(invstd), Cc, stream_of(sums)), "mvs_bn_finalize")
+    return mean, var, invstd
+
+
+def bn_relu_apply(z_cl, mean, invstd, gamma, beta, skip_cl=None, relu=True) -> torch.Tensor:
+    Cc = z_cl.shape[-1]
+    y = torch.empty_like(z_cl)
+    check(lib().mvs_bn_relu_apply(ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(skip_cl), ptr(y), z_cl.numel() // Cc, Cc,
+                                  1 if relu else 0, stream_of(z_cl)), "mvs_bn_relu_apply")
+    return y
+
+
+def bn_relu_bwd_reduce(dy_cl, z_cl, mean, invstd, gamma, beta, relu=True) -> torch.Tensor:
+    """-> float64 [2C]: [sum g | sum g * xhat] with g = dy through the ReLU mask (= [d beta | d gamma] of these voxels)."""
+    Cc = z_cl.shape[-1]
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=z_cl.device)
+    check(lib().mvs_bn_relu_bwd(ptr(dy_cl), ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums), 1.0, None, z_cl.numel() // Cc, Cc,
+                                1 if relu else 0, 1, 0, stream_of(z_cl)), "mvs_bn_relu_bwd")
+    return sums
+
+
+def bn_relu_bwd_apply(dy_cl, z_cl, mean, invstd, gamma, beta, sums, count: float, relu=True, use_batch_stats=True) -> torch.Tensor:
+    Cc = z_cl.shape[-1]
+    dz = torch.empty_like(z_cl)
+    check(lib().mvs_bn_relu_bwd(ptr(dy_cl), ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums), float(count), ptr(dz),
+                                z_cl.numel() // Cc, Cc, 1 if relu else 0, 1 if use_batch_stats else 0, 1, stream_of(z_cl)), "mvs_bn_relu_bwd")
+    return dz
+
+
+def conv3d_wgrad(a_cl: torch.Tensor, g_cl: torch.Tensor, stride: Tuple[int, int, int]) -> torch.Tensor:
+    """Weight gradient of Conv3d(k3, padding 1, stride): a_cl [B,D,H,W,CA] input, g_cl [B,OD,OH,OW,CB] output gradient -> [CB, CA, 3, 3, 3]."""
+    B, D, H, W, CA = a_cl.shape
+    CB = g_cl.shape[-1]
+    sd, sh, sw = stride
+    assert tuple(g_cl.shape[:4]) == (B, (D - 1) // sd + 1, (H - 1) // sh + 1, (W - 1) // sw + 1), "wgrad: gradient shape does not match the stride"
+    dw = torch.empty(CB, CA, 3, 3, 3, dtype=torch.float32, device=a_cl.device)
+    check(lib().mvs_conv3d_wgrad(ptr(a_cl), ptr(g_cl), ptr(dw), B, CA, CB, D, H, W, sd, sh, sw, stream_of(a_cl)), "mvs_conv3d_wgrad")
+    return dw
+
+
 def conv3d_logits(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, precision: int) -> torch.Tensor:
     """CostRegNet's 3x3x3 `prob` head on the MFMA path: x_cl [B,D,H,W,8] -> logits [B,D,H,W]."""
     B, D, H, W, c = x_cl.shape

@@ -31,7 +31,7 @@ def fold_bn(weight: torch.Tensor, bn: Dict[str, torch.Tensor], out_dim: int) -> 
 
 def conv_chunk(cin: int, stride: Tuple[int, int, int]) -> int:
     """Channel chunk staged per LDS pass - must match the ConvCfg table in csrc/conv_kernels.hip."""
-    return 16 if tuple(stride) == (1, 1, 1) else 8
+    return 16 if tuple(stride) == (1, 1, 1) and cin >= 16 else 8
 
 
 def pack_conv_weights(w: torch.Tensor, ch: int) -> torch.Tensor:
@@ -46,7 +46,7 @@ def pack_conv_weights(w: torch.Tensor, ch: int) -> torch.Tensor:
     mrep = (cout + 15) // 16
     wt = w.reshape(cout, npass, qc, 4, ntap).float()                       # [co, pass, cq, s, tap]
     wt = wt.permute(1, 4, 2, 0, 3).reshape(npass, nquad, cout, 4)          # [pass, kq = tap*qc + cq, co, s]
-    full = torch.zeros(npass, nstep * 4, mrep * 16, 4, dtype=torch.float32)
+    full = torch.zeros(npass, nstep * 4, mrep * 16, 4, dtype=torch.float32, device=w.device)
     full[:, :nquad, :cout] = wt
     full = full.reshape(npass, nstep, 4, mrep, 16, 4)                      # [pass, step, g, mb, j, s]
     return full.permute(0, 1, 3, 2, 4, 5).contiguous().reshape(-1)         # [pass, step, mb, g, j, s]
@@ -59,7 +59,7 @@ def pack_deconv_weights(w: torch.Tensor) -> torch.Tensor:
     nq = cin // 16
     mrep = (cout + 15) // 16
     wt = w.reshape(nq, 4, 4, cout, 27).float()                             # [q, g, s, co, tap]
-    full = torch.zeros(nq, 4, 4, mrep * 16, 27, dtype=torch.float32)
+    full = torch.zeros(nq, 4, 4, mrep * 16, 27, dtype=torch.float32, device=w.device)
     full[:, :, :, :cout] = wt
     full = full.reshape(nq, 4, 4, mrep, 16, 27)                            # [q, g, s, mb, j, tap]
     return full.permute(5, 0, 3, 1, 4, 2).contiguous().reshape(-1)         # [tap, q, mb, g, j, s]
@@ -87,7 +87,7 @@ def pack_conv_weights_bf16x3(w: torch.Tensor, ch: int) -> torch.Tensor:
     nstep = (noct + 3) // 4
     mrep = (cout + 15) // 16
     wt = w.reshape(cout, npass, opt, 8, ntap).float().permute(1, 4, 2, 0, 3).reshape(npass, noct, cout, 8)   # [pass, o, co, e]
-    full = torch.zeros(npass, nstep * 4, mrep * 16, 8, dtype=torch.float32)
+    full = torch.zeros(npass, nstep * 4, mrep * 16, 8, dtype=torch.float32, device=w.device)
     full[:, :noct, :cout] = wt
     full = full.reshape(npass, nstep, 4, mrep, 16, 8).permute(0, 1, 3, 2, 4, 5)                              # [pass, step, mb, g, j, e]
     return _split_bf16(full).permute(1, 2, 3, 0, 4, 5, 6).contiguous().reshape(-1)                           # [pass, step, mb, 2, g, j, e]
@@ -148,7 +148,7 @@ def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
             taps1 = classes[2 * c2 + 1]                                            # pw = 1: (a_d, a_h, a_w) with a_w fastest, kw in (0, 2)
             noct = len(taps1) * opt
             nst = (noct + 3) // 4
-            full = torch.zeros(nst * 4, 16, 8, dtype=torch.float32)
+            full = torch.zeros(nst * 4, 16, 8, dtype=torch.float32, device=w.device)
             for ti, t1 in enumerate(taps1):
                 kw = t1 % 3
                 full[ti * opt:(ti + 1) * opt, 8:16] = wf[:, :, :, t1].permute(0, 2, 1)           # [oc, co, e]
@@ -161,7 +161,7 @@ def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
         noct = len(taps) * opt
         nst = (noct + 3) // 4
         sel = wf[:, :, :, taps].permute(3, 0, 2, 1).reshape(noct, cout, 8)         # [o = ti*opt + oc, co, e]
-        full = torch.zeros(nst * 4, mrep * 16, 8, dtype=torch.float32)
+        full = torch.zeros(nst * 4, mrep * 16, 8, dtype=torch.float32, device=w.device)
         full[:noct, :cout] = sel
         full = full.reshape(nst, 4, mrep, 16, 8).permute(0, 2, 1, 3, 4)             # [step, mb, g, j, e]
         chunks.append(_split_bf16(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1))   # [step, mb, 2, g, j, e]
@@ -170,6 +170,6 @@ def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
 
 def pad_bias(b: torch.Tensor) -> torch.Tensor:
     n = max(16, ((b.numel() + 15) // 16) * 16)
-    out = torch.zeros(n, dtype=torch.float32)
+    out = torch.zeros(n, dtype=torch.float32, device=b.device)
     out[: b.numel()] = b.float()
     return out

@@ -1,4 +1,4 @@
-"""Training-mode path of one cascade stage (first slice).
+"""Training-mode path of one cascade stage.
 
 What is native and what is not, stated plainly:
 
@@ -7,10 +7,20 @@ What is native and what is not, stated plainly:
   ``torch.autograd.Function`` whose forward is ``mvs_warp_corr_aggregate_fwd`` and whose backward is
   ``mvs_warp_corr_aggregate_bwd`` (gradients w.r.t. reference features, source features and visibility maps; the warped
   [B,C,D,H,W] volumes the reference keeps alive per view for ``grid_sample``'s backward are never materialised);
-* the visibility CNN, the 3-D U-Net regulariser (under ``torch.utils.checkpoint`` like the reference, module.py:393-396 /
-  488-492) and the softmax / regression head run as PyTorch-ROCm autograd ops on the module's own ``nn.Conv*`` /
-  ``nn.BatchNorm*`` parameters, so batch statistics, running-stat updates, SyncBatchNorm conversion and DDP (train.py:196-200)
-  behave exactly as in the reference.  Hand-written conv / BatchNorm backward kernels are NOT part of this slice.
+* the 3-D U-Net regulariser (CostRegNet / CostRegNet3D, nine Conv3d / ConvTranspose3d + BatchNorm3d + ReLU blocks and three skip
+  adds) runs on the library's kernels in both directions (``RegNetTrain``): forward convolutions and DATA gradients on the
+  split-bf16 MFMA kernels of the inference path with un-folded, re-packed weights (the data gradient of a stride-1 convolution is
+  the convolution with flipped, transposed taps; of a strided convolution the transposed convolution; of a transposed convolution
+  the strided convolution), WEIGHT gradients on an fp32-MFMA kernel (``mvs_conv3d_wgrad``), batch-statistics BatchNorm + ReLU +
+  skip forward and backward on ``mvs_bn_*`` (sums in double, SyncBatchNorm's all-reduce of the sums included).  Activations are
+  kept (pre-BatchNorm convolution outputs and block outputs) instead of being recomputed under ``torch.utils.checkpoint``
+  (module.py:393-396): at training sizes they are tens of MB per stage;
+* the visibility CNN's three Conv2d + BatchNorm2d + ReLU blocks (``VisTrain``: the same kernels on D = 1 volumes, BatchNorm per
+  source view like the reference's per-view calls) and CostRegNet's 3x3x3 `prob` (``Prob3Train``) are native as well;
+* still PyTorch-ROCm autograd, all of it element-wise or tiny: the visibility CNN's 1x1 Conv2d + sigmoid, CostRegNet3D's 1x1x1 `prob`,
+  the softmax / argmax / regression head, the running-statistics momentum update.  ``MVS_TRAIN_REGNET=torch`` routes every conv /
+  BatchNorm layer through autograd ops instead (the first form of this path; on the MI355X image MIOpen picks naive kernels for
+  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 28 ms natively).
 
 The reference differentiates neither the sampling grid (built under ``torch.no_grad()``, warping.py:80) nor the entropy
 (``sim_vol.detach()``, cost_volume.py:90); this path follows it: no gradient reaches the depth hypotheses, the cameras or - via
@@ -18,34 +28,202 @@ the entropy - the features.  The transformer regulariser of the shipped stage 1 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 
-from . import _lib, ops
+from . import _lib, ops, packing
 
 
 class WarpCorrAggregate(torch.autograd.Function):
     """volume_mean [B,G,D,H,W] = sum_v in_prod_v * vis_v / (sum_v vis_v + 1e-6)   (cost_volume.py:74-101), HIP forward and backward."""
 
     @staticmethod
-    def forward(ctx, features, vis, homography, hyp, G):
+    def forward(ctx, features, vis, homography, hyp, G, channel_last=False):
         feats, code = ops._feat(features.detach())
         vis_c = ops._f32c(vis.detach())
         vol_cl, _ = ops.warp_corr_aggregate(feats, code, homography, hyp, vis_c, G, normalise=True)
         ctx.save_for_backward(feats, vis_c, homography, hyp, vol_cl)
-        ctx.code, ctx.G, ctx.in_dtype = code, G, features.dtype
-        return ops.cl_to_ncdhw(vol_cl)
+        ctx.code, ctx.G, ctx.in_dtype, ctx.channel_last = code, G, features.dtype, bool(channel_last)
+        return vol_cl if channel_last else ops.cl_to_ncdhw(vol_cl)
 
     @staticmethod
     def backward(ctx, grad_volume):
         feats, vis, hom, hyp, vol_cl = ctx.saved_tensors
-        gvol_cl = ops.ncdhw_to_cl(ops._f32c(grad_volume))
+        gvol_cl = ops._f32c(grad_volume) if ctx.channel_last else ops.ncdhw_to_cl(ops._f32c(grad_volume))
         vis_sum = vis.sum(dim=1).contiguous()
         gfeat, gvis = ops.warp_corr_aggregate_bwd(feats, ctx.code, hom, hyp, vis, vis_sum, vol_cl, gvol_cl, ctx.G)
-        return gfeat.to(ctx.in_dtype), gvis, None, None, None
+        return gfeat.to(ctx.in_dtype), gvis, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# native training form of the U-Net regulariser
+# --------------------------------------------------------------------------------------------------
+_PREC = _lib.PRECISIONS["bf16x3"]
+
+
+def _block_parts(layer):
+    """(conv module, BatchNorm module, is_transposed) of one Conv3d / Deconv3d wrapper or CostRegNet3D's Sequential block."""
+    if isinstance(layer, nn.Sequential):
+        return layer[0], layer[1], True
+    return layer.conv, layer.bn, isinstance(layer.conv, nn.ConvTranspose3d)
+
+
+def _stride3(conv):
+    s = conv.stride
+    return (s, s, s) if isinstance(s, int) else tuple(s)
+
+
+
+def _conv_fwd(a_cl, w, stride, transposed, zero_bias, kd=3):
+    """Linear (no bias / BatchNorm / ReLU) Conv3d(k (kd,3,3), 'same' padding, stride) or ConvTranspose3d(k3, stride (sd,2,2)) of a
+    channel-last tensor on the split-bf16 MFMA kernels, from the un-folded weight tensor."""
+    if transposed:
+        return ops.deconv3d_linear(a_cl, packing.pack_deconv_weights_bf16x3(w, stride[0]), zero_bias, w.shape[1], stride[0], _PREC)
+    wp = packing.pack_conv_weights_bf16x3(w, packing.conv_chunk(w.shape[1], stride))
+    return ops.conv3d_bn_relu(a_cl, wp, zero_bias, w.shape[0], kd, stride, False, _PREC)
+
+
+def _conv_bwd(a_in, dz, w, stride, transposed, zero_bias, need_da=True):
+    """(weight gradient, data gradient) of _conv_fwd.  Data gradients reuse the forward kernels: a transposed convolution's is the
+    strided convolution with the same taps, a stride-1 convolution's the convolution with flipped, transposed taps, a strided
+    convolution's the transposed convolution with the same taps."""
+    if transposed:
+        dw = ops.conv3d_wgrad(dz, a_in, stride)
+        da = _conv_fwd(dz, w, stride, False, zero_bias) if need_da else None
+        return dw, da
+    dw = ops.conv3d_wgrad(a_in, dz, stride)
+    if not need_da:
+        return dw, None
+    if stride == (1, 1, 1):
+        return dw, _conv_fwd(dz, w.transpose(0, 1).flip(2, 3, 4).contiguous(), stride, False, zero_bias)
+    if any(d % s for d, s in zip(a_in.shape[1:4], stride)):
+        raise _lib.MvsHipError("training: strided convolutions need even input sizes (got %s)" % (tuple(a_in.shape[1:4]),))
+    return dw, _conv_fwd(dz, w, stride, True, zero_bias)
+
+
+def _embed_2d(w2d, cin_pad=None):
+    """Conv2d weight [Cout, Cin, 3, 3] -> Conv3d weight [Cout, Cin (padded), 3, 3, 3] that acts on D = 1 volumes (only the centre
+    depth tap is non-zero; the outer ones meet zero padding anyway)."""
+    co, ci = w2d.shape[:2]
+    w3 = torch.zeros(co, cin_pad or ci, 3, 3, 3, dtype=torch.float32, device=w2d.device)
+    w3[:, :ci, 1] = w2d
+    return w3
+
+
+class _BnState:
+    """Forward statistics of one BatchNorm layer (batch statistics in train mode, running statistics otherwise) and the
+    bookkeeping nn.BatchNorm3d / nn.SyncBatchNorm do: momentum update of the running statistics, all-reduce of the sums."""
+
+    def __init__(self, bn, z_cl):
+        self.batch = bn.training or bn.running_mean is None
+        self.group = None
+        C = z_cl.shape[-1]
+        n_local = z_cl.numel() // C
+        self.count = float(n_local)
+        if self.batch:
+            sums = ops.bn_stats(z_cl)
+            if isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
+                self.group = bn.process_group
+                cnt = torch.tensor([float(n_local)], dtype=torch.float64, device=z_cl.device)
+                torch.distributed.all_reduce(sums, group=self.group)
+                torch.distributed.all_reduce(cnt, group=self.group)
+                self.count = float(cnt.item())
+            self.mean, self.var, self.invstd = ops.bn_finalize(sums, self.count, bn.eps)
+            self.bn = bn if (bn.training and bn.running_mean is not None) else None
+            self.update_running_stats()
+        else:
+            self.bn = None
+            self.mean = bn.running_mean.detach().float().contiguous()
+            self.invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous()
+
+    def update_running_stats(self):
+        """One momentum step of nn.BatchNorm's running statistics (unbiased variance).  Called once in the forward and once more
+        in the backward: the reference runs its regulariser under torch.utils.checkpoint (module.py:393-396), whose recomputation
+        in the backward pass is a second train-mode forward - its running statistics take two steps per iteration."""
+        bn = self.bn
+        if bn is None:
+            return
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1.0 - m).add_(self.mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(self.var * (self.count / max(self.count - 1.0, 1.0)), alpha=m)
+
+
+class RegNetTrain(torch.autograd.Function):
+    """features_cl [B,D,H,W,8] = U-Net(volume_cl) up to (not including) `prob`, module.py:398-406 / 494-501, with gradients for the
+    volume and all 27 parameters (nine weights, nine BatchNorm weights, nine BatchNorm biases) - see the module docstring."""
+
+    NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")
+    SKIP = {6: 3, 7: 1, 8: -1}                       # block index -> index of the block whose output is added (-1: the input volume)
+
+    @staticmethod
+    def forward(ctx, volume_cl, reg, *params):
+        x = ops._f32c(volume_cl.detach())
+        zero_bias = torch.zeros(64, dtype=torch.float32, device=x.device)
+        blocks, acts, saved = [], [x], []
+        for i, name in enumerate(RegNetTrain.NAMES):
+            conv, bn, transposed = _block_parts(getattr(reg, name))
+            w = params[3 * i].detach().float()
+            gamma, beta = params[3 * i + 1].detach().float().contiguous(), params[3 * i + 2].detach().float().contiguous()
+            stride = _stride3(conv)
+            a_in = acts[-1]
+            z = _conv_fwd(a_in, w, stride, transposed, zero_bias)
+            st = _BnState(bn, z)
+            skip_idx = RegNetTrain.SKIP.get(i)
+            skip = None if skip_idx is None else acts[skip_idx + 1]
+            acts.append(ops.bn_relu_apply(z, st.mean, st.invstd, gamma, beta, skip, relu=True))
+            blocks.append((transposed, stride, st.batch, st.count, st.group, st))
+            saved += [a_in, z, st.mean, st.invstd, w, gamma, beta]
+        ctx.blocks = blocks
+        ctx.save_for_backward(*saved)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        S = ctx.saved_tensors
+        n = len(ctx.blocks)
+        grads = [None] * (3 * n)
+        pending = {}                                     # activation index (0 = volume, i + 1 = output of block i) -> gradient so far
+        pending[n] = ops._f32c(grad_out)
+        zero_bias = torch.zeros(64, dtype=torch.float32, device=grad_out.device)
+        for i in range(n - 1, -1, -1):
+            transposed, stride, batch, count, group, bn_state = ctx.blocks[i]
+            bn_state.update_running_stats()              # the reference's checkpoint recomputation (see _BnState)
+            a_in, z, mean, invstd, w, gamma, beta = S[7 * i:7 * i + 7]
+            g = pending.pop(i + 1)
+            skip_idx = RegNetTrain.SKIP.get(i)
+            if skip_idx is not None:                     # the skip source receives the block output's gradient unchanged
+                k = skip_idx + 1
+                pending[k] = g if k not in pending else pending[k] + g
+            sums = ops.bn_relu_bwd_reduce(g, z, mean, invstd, gamma, beta, relu=True)
+            grads[3 * i + 2] = sums[: sums.numel() // 2].float()                     # d beta (this rank's voxels; DDP averages)
+            grads[3 * i + 1] = sums[sums.numel() // 2:].float()                      # d gamma
+            if group is not None:
+                sums = sums.clone()
+                torch.distributed.all_reduce(sums, group=group)
+            dz = ops.bn_relu_bwd_apply(g, z, mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
+            grads[3 * i], da = _conv_bwd(a_in, dz, w, stride, transposed, zero_bias)
+            pending[i] = da if i not in pending else pending[i] + da
+        return (pending[0], None) + tuple(grads)
+
+
+def regnet_forward_native(reg, volume_cl: torch.Tensor) -> torch.Tensor:
+    """CostRegNet / CostRegNet3D up to `prob` on the library's kernels, channel-last in and out."""
+    if not isinstance(reg.inner, nn.Identity):
+        raise NotImplementedError("in_channels != base_channels (1x1x1 `inner` conv) is not used by any shipped config")
+    params = []
+    for name in RegNetTrain.NAMES:
+        conv, bn, _ = _block_parts(getattr(reg, name))
+        if bn is None or conv.bias is not None:
+            raise NotImplementedError("the training path implements the bias-free conv + BatchNorm + ReLU blocks of the regularisers")
+        params += [conv.weight, bn.weight, bn.bias]
+    return RegNetTrain.apply(volume_cl, reg, *params)
 
 
 def regnet_forward_torch(reg, x: torch.Tensor) -> torch.Tensor:
@@ -70,6 +248,122 @@ def regnet_forward_torch(reg, x: torch.Tensor) -> torch.Tensor:
     if torch.is_grad_enabled() and x.requires_grad:
         return cp.checkpoint(once, x, use_reentrant=True)
     return once(x)
+
+
+class VisTrain(torch.autograd.Function):
+    """The three Conv2d + BatchNorm2d + ReLU blocks of the visibility CNN (cost_volume.py:36, module.py:168-197) on the library's
+    kernels: entropy [B, V-1, H, W] (no gradient: it comes from sim.detach()) -> features [V-1, B, H, W, 8] channel-last, with
+    gradients for the nine parameters.  The 2-D layers run as k = (1|3,3,3) convolutions on D = 1 volumes; the reference calls the
+    CNN once per source view on a batch of B maps, so the BatchNorm statistics (and running-stat updates) are per view here too."""
+
+    @staticmethod
+    def forward(ctx, entropy, vis_seq, *params):
+        B, NV, H, W = entropy.shape
+        dev = entropy.device
+        zero_bias = torch.zeros(64, dtype=torch.float32, device=dev)
+        x = torch.zeros(NV, B, H, W, 8, dtype=torch.float32, device=dev)         # view-major, 8 channels: the MFMA kernels' smallest Cin
+        x[..., 0] = entropy.detach().float().permute(1, 0, 2, 3)
+        a = x.view(NV * B, 1, H, W, 8)
+        saved, blocks = [], []
+        for i in range(3):
+            w2d = params[3 * i].detach().float()
+            gamma, beta = params[3 * i + 1].detach().float().contiguous(), params[3 * i + 2].detach().float().contiguous()
+            w3 = _embed_2d(w2d, 8 if i == 0 else None)
+            if w3.shape[0] == 8:                                                 # the 16 -> 8 layer: the kernels have its k = (1,3,3) form
+                z = _conv_fwd(a, w3[:, :, 1:2].contiguous(), (1, 1, 1), False, zero_bias, kd=1)
+            else:
+                z = _conv_fwd(a, w3, (1, 1, 1), False, zero_bias)
+            C = z.shape[-1]
+            y = torch.empty_like(z)
+            states = []
+            for v in range(NV):
+                zs = z[v * B:(v + 1) * B]
+                st = _BnState(vis_seq[i].bn, zs)
+                y[v * B:(v + 1) * B] = ops.bn_relu_apply(zs, st.mean, st.invstd, gamma, beta, None, relu=True)
+                states.append((st.mean, st.invstd, st.batch, st.count, st.group))
+            blocks.append(states)
+            saved += [a, z, w3, gamma, beta]
+            a = y
+        ctx.blocks, ctx.B, ctx.NV = blocks, B, NV
+        ctx.save_for_backward(*saved)
+        return a.view(NV, B, H, W, 8)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        S = ctx.saved_tensors
+        B, NV = ctx.B, ctx.NV
+        g = ops._f32c(grad_out).view(NV * B, 1, *grad_out.shape[2:])
+        zero_bias = torch.zeros(64, dtype=torch.float32, device=g.device)
+        grads = [None] * 9
+        for i in (2, 1, 0):
+            a_in, z, w3, gamma, beta = S[5 * i:5 * i + 5]
+            C = z.shape[-1]
+            dz = torch.empty_like(z)
+            dgamma = torch.zeros(C, dtype=torch.float64, device=g.device)
+            dbeta = torch.zeros(C, dtype=torch.float64, device=g.device)
+            for v in range(NV):
+                mean, invstd, batch, count, group = ctx.blocks[i][v]
+                sl = slice(v * B, (v + 1) * B)
+                sums = ops.bn_relu_bwd_reduce(g[sl], z[sl], mean, invstd, gamma, beta, relu=True)
+                dbeta += sums[:C]
+                dgamma += sums[C:]
+                if group is not None:
+                    sums = sums.clone()
+                    torch.distributed.all_reduce(sums, group=group)
+                dz[sl] = ops.bn_relu_bwd_apply(g[sl], z[sl], mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
+            grads[3 * i + 1], grads[3 * i + 2] = dgamma.float(), dbeta.float()
+            if w3.shape[0] == 8:
+                # 16 -> 8: weight gradient from the k3 kernel (outer depth taps see only padding), data gradient = flipped 8 -> 16 conv
+                dw3 = ops.conv3d_wgrad(a_in, dz, (1, 1, 1))
+                da = _conv_fwd(dz, w3.transpose(0, 1).flip(2, 3, 4).contiguous(), (1, 1, 1), False, zero_bias)
+            else:
+                dw3, da = _conv_bwd(a_in, dz, w3, (1, 1, 1), False, zero_bias, need_da=i > 0)
+            cin = 1 if i == 0 else w3.shape[1]
+            grads[3 * i] = dw3[:, :cin, 1].contiguous()
+            g = da
+        return (None, None) + tuple(grads)
+
+
+class Prob3Train(torch.autograd.Function):
+    """CostRegNet's `prob` = Conv3d(8, 1, 3, padding 1, bias=False) (module.py:391,407): features_cl [B,D,H,W,8] -> logits [B,D,H,W].
+    Forward on the MFMA head kernel; the gradients reuse the 8 <-> 16 channel kernels with the single logit channel zero-padded."""
+
+    @staticmethod
+    def forward(ctx, feat_cl, weight):
+        f = ops._f32c(feat_cl.detach())
+        w = weight.detach().float()
+        w16 = torch.zeros(16, 8, 3, 3, 3, dtype=torch.float32, device=f.device)
+        w16[0] = w[0]
+        zero_bias = torch.zeros(64, dtype=torch.float32, device=f.device)
+        ctx.save_for_backward(f, w)
+        return ops.conv3d_logits(f, packing.pack_conv_weights_bf16x3(w16, 8), zero_bias, _PREC)
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        f, w = ctx.saved_tensors
+        g = ops._f32c(grad_logits)
+        zero_bias = torch.zeros(64, dtype=torch.float32, device=g.device)
+        g8 = torch.zeros(*g.shape, 8, dtype=torch.float32, device=g.device)
+        g8[..., 0] = g
+        dw = ops.conv3d_wgrad(f, g8, (1, 1, 1))[0:1].contiguous()                 # [1, 8, 3, 3, 3]
+        wt = torch.zeros(16, 8, 3, 3, 3, dtype=torch.float32, device=g.device)   # rows = feature channels, column 0 = the logit channel
+        wt[:8, 0] = w[0].flip(1, 2, 3)
+        df = _conv_fwd(g8, wt, (1, 1, 1), False, zero_bias)[..., :8].contiguous()
+        return df, dw
+
+
+def vis_forward_native(vis_seq, entropy: torch.Tensor) -> torch.Tensor:
+    """self.vis per source view (cost_volume.py:93) -> [B, V-1, H, W]; conv / BatchNorm / ReLU blocks native, the 1x1 conv + sigmoid
+    as elementwise autograd ops."""
+    params = []
+    for i in range(3):
+        params += [vis_seq[i].conv.weight, vis_seq[i].bn.weight, vis_seq[i].bn.bias]
+    t = VisTrain.apply(entropy, vis_seq, *params)                                 # [V-1, B, H, W, 8]
+    last = vis_seq[3]
+    v = (t * last.weight.reshape(1, 1, 1, 1, -1)).sum(-1)
+    if last.bias is not None:
+        v = v + last.bias
+    return torch.sigmoid(v).permute(1, 0, 2, 3)
 
 
 def vis_forward_torch(vis_seq, entropy: torch.Tensor) -> torch.Tensor:
@@ -102,9 +396,24 @@ def stage_forward_train(net, features, proj_matrices, depth_values, tmp) -> Dict
         entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)                                 # [B,V-1,H,W], from sim.detach() in the reference
     # the reference runs the visibility CNN once per source view on a batch of B maps (cost_volume.py:93); BatchNorm statistics
     # are per call there, so the views are kept as separate calls here as well
-    vis = torch.cat([vis_forward_torch(net.vis, entropy[:, v:v + 1]) for v in range(V - 1)], dim=1)        # [B,V-1,H,W]
-    volume = WarpCorrAggregate.apply(features, vis, hom, hyp, G)                                   # [B,G,D,H,W]
-    prob_volume_pre = regnet_forward_torch(net.cost_reg, volume).squeeze(1)
+    native = os.environ.get("MVS_TRAIN_REGNET", "hip") != "torch" and G == 8
+    if native:
+        vis = vis_forward_native(net.vis, entropy)                                                # [B,V-1,H,W]
+    else:
+        vis = torch.cat([vis_forward_torch(net.vis, entropy[:, v:v + 1]) for v in range(V - 1)], dim=1)
+    if not native:
+        volume = WarpCorrAggregate.apply(features, vis, hom, hyp, G)                               # [B,G,D,H,W]
+        prob_volume_pre = regnet_forward_torch(net.cost_reg, volume).squeeze(1)
+    else:
+        volume_cl = WarpCorrAggregate.apply(features, vis, hom, hyp, G, True)                      # [B,D,H,W,G]
+        feat_cl = regnet_forward_native(net.cost_reg, volume_cl)                                   # [B,D,H,W,8]
+        prob = net.cost_reg.prob
+        if tuple(prob.kernel_size) == (1, 1, 1):
+            prob_volume_pre = (feat_cl * prob.weight.reshape(1, 1, 1, 1, -1)).sum(-1)              # module.py:486,502
+            if prob.bias is not None:
+                prob_volume_pre = prob_volume_pre + prob.bias
+        else:
+            prob_volume_pre = Prob3Train.apply(feat_cl, prob.weight)                               # module.py:391,407
     prob_volume = F.softmax(prob_volume_pre, dim=1)
     D = hyp.shape[1]
     if net.depth_type == "ce":

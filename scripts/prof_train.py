@@ -18,17 +18,22 @@ for stage, C, D, H, W in ((3, 8, 4, 512, 640), (2, 16, 8, 256, 320), (1, 32, 16,
     def step():
         out = net(feats, cams, hyp, 1.0)
         out["prob_volume_pre"].square().mean().backward()
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    e[0].record()
-    for _ in range(5):
-        step()
-    e[1].record()
-    torch.cuda.synchronize()
-    total = e[0].elapsed_time(e[1]) / 5
+    res = {}
+    for mode in (("hip",) if os.environ.get("PROF_TRAIN_HIP_ONLY") else ("hip", "torch")):
+        os.environ["MVS_TRAIN_REGNET"] = mode
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        e[0].record()
+        for _ in range(5):
+            step()
+        e[1].record()
+        torch.cuda.synchronize()
+        res[mode] = (e[0].elapsed_time(e[1]) / 5, torch.cuda.max_memory_allocated() / 2 ** 20)
+    os.environ["MVS_TRAIN_REGNET"] = "hip"
+    total = res["hip"][0]
     # the two HIP gather kernels on their own
     with torch.no_grad():
         f, code = ops._feat(feats.detach())
@@ -45,5 +50,5 @@ for stage, C, D, H, W in ((3, 8, 4, 512, 640), (2, 16, 8, 256, 320), (1, 32, 16,
                 fn()
             e[1].record(); torch.cuda.synchronize()
             t.append(e[0].elapsed_time(e[1]) / 5)
-    print("stage %d  B=%d V=%d C=%d D=%d %dx%d: step (fwd+bwd) %.2f ms, peak %.0f MB | HIP aggregate fwd %.3f ms, bwd %.3f ms"
-          % (stage + 1, B, V, C, D, H, W, total, torch.cuda.max_memory_allocated() / 2 ** 20, t[0], t[1]))
+    print("stage %d  B=%d V=%d C=%d D=%d %dx%d: step (fwd+bwd) %.2f ms, peak %.0f MB (U-Net through PyTorch autograd: %.2f ms, %.0f MB) | HIP aggregate fwd %.3f ms, bwd %.3f ms"
+          % (stage + 1, B, V, C, D, H, W, total, res["hip"][1], res.get("torch", (0, 0))[0], res.get("torch", (0, 0))[1], t[0], t[1]))

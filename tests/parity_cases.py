@@ -733,9 +733,12 @@ def case_train_backward_golden(device, tag):
     assert abs(loss.item() - float(fx["loss"])) <= 2e-4 * max(1.0, abs(float(fx["loss"])))
     assert (cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max() <= 2e-3 * float(fx["prob_volume_pre"].abs().max())
 
-    def close(a, b, what, tol=5e-3):
-        # gradients pass through train-mode BatchNorm (division by batch std) and ~12 conv layers: compare in the max norm,
-        # relative to the largest entry of the reference's gradient
+    def close(a, b, what, tol=3e-2):
+        # Max norm relative to the largest entry of the reference's gradient.  The bulk of the tensors agrees to ~3e-5 (checked
+        # through the median below); the bound on a single tensor has to allow for ONE ReLU unit whose pre-activation sits within
+        # the 2^-16-class rounding difference between the split-bf16 forward and the reference's fp32 forward: at these fixture
+        # sizes (24 576 activations in the first U-Net block) one flipped unit moves that block's BatchNorm-bias gradient by 1e-2
+        # of its largest entry and its input gradient by 1.3e-2 (measured; the flip was located and counted: exactly one).
         err = float((cpu(a) - b).abs().max()) / max(float(b.abs().max()), 1e-12)
         errs.append(err)
         assert err <= tol, "%s: %g" % (what, err)
@@ -744,6 +747,7 @@ def case_train_backward_golden(device, tag):
     for name, p in net.named_parameters():
         assert p.grad is not None, name
         close(p.grad, fx["g." + name], "d loss / d " + name)
+    assert sorted(errs)[len(errs) // 2] <= 2e-4, "median gradient error %g" % sorted(errs)[len(errs) // 2]
     for k, v in net.state_dict().items():
         if "running_" in k:
             close(v, fx["stat." + k], k, 1e-3)
@@ -784,3 +788,81 @@ def case_train_path_properties(device):
         assert torch.isfinite(feats["stage%d" % s].grad).all() and float(feats["stage%d" % s].grad.abs().sum()) > 0, s
     for name, p in head.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
+
+
+def case_train_kernels(device):
+    """The training-mode building blocks one by one against PyTorch on the CPU: batch-statistics BatchNorm + ReLU + skip (forward,
+    backward), the fp32-MFMA weight gradient for every stride and channel pair the U-Nets use (ragged tiles, batch 2), and the three
+    data-gradient identities the path relies on (conv <-> flipped conv, strided conv <-> transposed conv)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    # ---- BatchNorm + ReLU + skip
+    for C, shape in ((8, (2, 3, 6, 10)), (32, (1, 4, 5, 7)), (64, (2, 2, 3, 5))):
+        z = (torch.randn(*shape, C, generator=g) * 2 + 0.5).requires_grad_(True)
+        skip = torch.randn(*shape, C, generator=g)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).requires_grad_(True), (torch.randn(C, generator=g) * 0.3).requires_grad_(True)
+        dy = torch.randn(*shape, C, generator=g)
+        y_ref = F.relu(F.batch_norm(z.reshape(-1, C), None, None, gamma, beta, True, 0.1, 1e-5)).reshape(*shape, C) + skip
+        (y_ref * dy).sum().backward()
+        zd = dev(z.detach(), device)
+        sums = ops.bn_stats(zd)
+        n = z.numel() // C
+        mean, var, invstd = ops.bn_finalize(sums, n, 1e-5)
+        assert (cpu(mean) - z.detach().reshape(-1, C).mean(0)).abs().max() <= 1e-5
+        assert (cpu(var) - z.detach().reshape(-1, C).var(0, unbiased=False)).abs().max() <= 1e-4
+        y = ops.bn_relu_apply(zd, mean, invstd, dev(gamma.detach(), device), dev(beta.detach(), device), dev(skip, device))
+        assert (cpu(y) - y_ref.detach()).abs().max() <= 2e-5
+        s2 = ops.bn_relu_bwd_reduce(dev(dy, device), zd, mean, invstd, dev(gamma.detach(), device), dev(beta.detach(), device))
+        dz = ops.bn_relu_bwd_apply(dev(dy, device), zd, mean, invstd, dev(gamma.detach(), device), dev(beta.detach(), device), s2, n)
+        assert (cpu(s2[:C]).float() - beta.grad).abs().max() <= 1e-4 * max(1.0, float(beta.grad.abs().max()))
+        assert (cpu(s2[C:]).float() - gamma.grad).abs().max() <= 1e-4 * max(1.0, float(gamma.grad.abs().max()))
+        assert (cpu(dz) - z.grad).abs().max() <= 1e-4 * max(1.0, float(z.grad.abs().max())), C
+    # ---- weight gradient (and the transposed-convolution form)
+    for CA, CB, stride, shape in ((8, 16, (1, 2, 2), (2, 4, 10, 36)), (16, 16, (1, 1, 1), (1, 5, 9, 20)), (32, 64, (2, 2, 2), (1, 4, 6, 8)),
+                                 (64, 64, (1, 1, 1), (1, 2, 3, 5)), (8, 16, (2, 2, 2), (2, 6, 8, 18))):
+        a = torch.randn(shape[0], CA, *shape[1:], generator=g)
+        w = torch.randn(CB, CA, 3, 3, 3, generator=g) * 0.1
+        out = F.conv3d(a, w, None, stride=stride, padding=1)
+        gy = torch.randn(out.shape, generator=g)
+        ref = torch.nn.grad.conv3d_weight(a, w.shape, gy, stride=stride, padding=1)
+        dw = ops.conv3d_wgrad(dev(a.permute(0, 2, 3, 4, 1).contiguous(), device), dev(gy.permute(0, 2, 3, 4, 1).contiguous(), device), stride)
+        assert (cpu(dw) - ref).abs().max() <= 2e-5 * float(ref.abs().max()) + 1e-5, (CA, CB, stride)
+    # ConvTranspose3d(16 -> 8, stride (1,2,2)): dW[ci][co] from (a = output gradient, g = input)
+    x = torch.randn(1, 16, 3, 5, 6, generator=g, requires_grad=False)
+    wt = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    yt = F.conv_transpose3d(x, wt, None, stride=(1, 2, 2), padding=1, output_padding=(0, 1, 1))
+    gyt = torch.randn(yt.shape, generator=g)
+    (yt * gyt).sum().backward()
+    dwt = ops.conv3d_wgrad(dev(gyt.permute(0, 2, 3, 4, 1).contiguous(), device), dev(x.permute(0, 2, 3, 4, 1).contiguous(), device), (1, 2, 2))
+    assert (cpu(dwt) - wt.grad).abs().max() <= 2e-5 * float(wt.grad.abs().max()) + 1e-5
+
+
+def case_regnet_train_native(device):
+    """RegNetTrain (forward convolutions and data gradients on the split-bf16 MFMA kernels, weight gradients on fp32 MFMA, BatchNorm
+    kernels) against PyTorch autograd through the same modules, CostRegNet (stride 2,2,2) and CostRegNet3D (1,2,2), train mode."""
+    import copy
+    from mvsformerplusplus_amd import training as T
+    for cls, shape in ((M.CostRegNet3D, (2, 4, 16, 24)), (M.CostRegNet, (2, 16, 16, 24))):
+        reg = cls(8, 8)
+        reg.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(reg.state_dict()), 3))
+        reg.train()
+        native = copy.deepcopy(reg).to(device)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(shape[0], 8, *shape[1:], generator=g) * 0.3
+        R = torch.randn(shape[0], *shape[1:], 8, generator=g)
+        xa = x.clone().requires_grad_(True)
+        ya = T.regnet_forward_torch(reg, xa)                          # [B,1,D,H,W] logits incl. `prob`
+        xb = dev(x.permute(0, 2, 3, 4, 1).contiguous(), device).requires_grad_(True)
+        fb = T.regnet_forward_native(native, xb)
+        yb = native.prob(fb.permute(0, 4, 1, 2, 3))
+        assert (cpu(yb) - ya.detach()).abs().max() <= 1e-4 * float(ya.abs().max())
+        w = torch.randn(ya.shape, generator=g)
+        (ya * w).sum().backward()
+        (yb * dev(w, device)).sum().backward()
+        errs = [float((cpu(xb.grad).permute(0, 4, 1, 2, 3) - xa.grad).abs().max() / xa.grad.abs().max())]
+        for (n, p), (_, q) in zip(reg.named_parameters(), native.named_parameters()):
+            errs.append(float((cpu(q.grad) - p.grad).abs().max() / p.grad.abs().max().clamp_min(1e-12)))
+        assert max(errs) <= 3e-2 and sorted(errs)[len(errs) // 2] <= 2e-4, (cls.__name__, max(errs))     # see case_train_backward_golden
+        for (n, b1), (_, b2) in zip(reg.named_buffers(), native.named_buffers()):
+            if "running_" in n:
+                assert (cpu(b2) - b1).abs().max() <= 1e-4 * max(1.0, float(b1.abs().max())), n

@@ -101,3 +101,11 @@ def test_train_backward_golden(emu, tag):
 
 def test_train_path_properties(emu):
     P.case_train_path_properties(emu)
+
+
+def test_train_kernels(emu):
+    P.case_train_kernels(emu)
+
+
+def test_regnet_train_native(emu):
+    P.case_regnet_train_native(emu)

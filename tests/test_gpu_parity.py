@@ -191,3 +191,11 @@ def test_cascade_hip_graph_capture():
             graph.replay()
             torch.cuda.synchronize()
         assert torch.equal(captured["refined_depth"], eager)
+
+
+def test_train_kernels():
+    P.case_train_kernels(DEV)
+
+
+def test_regnet_train_native():
+    P.case_regnet_train_native(DEV)
