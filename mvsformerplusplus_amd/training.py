@@ -121,6 +121,7 @@ class _BnState:
 
     def __init__(self, bn, z_cl):
         self.batch = bn.training or bn.running_mean is None
+        self.sync = False                                  # SyncBatchNorm: the sums are all-reduced over bn.process_group (None = WORLD)
         self.group = None
         C = z_cl.shape[-1]
         n_local = z_cl.numel() // C
@@ -128,7 +129,7 @@ class _BnState:
         if self.batch:
             sums = ops.bn_stats(z_cl)
             if isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
-                self.group = bn.process_group
+                self.sync, self.group = True, bn.process_group
                 cnt = torch.tensor([float(n_local)], dtype=torch.float64, device=z_cl.device)
                 torch.distributed.all_reduce(sums, group=self.group)
                 torch.distributed.all_reduce(cnt, group=self.group)
@@ -178,7 +179,7 @@ class RegNetTrain(torch.autograd.Function):
             skip_idx = RegNetTrain.SKIP.get(i)
             skip = None if skip_idx is None else acts[skip_idx + 1]
             acts.append(ops.bn_relu_apply(z, st.mean, st.invstd, gamma, beta, skip, relu=True))
-            blocks.append((transposed, stride, st.batch, st.count, st.group, st))
+            blocks.append((transposed, stride, st.batch, st.count, (st.sync, st.group), st))
             saved += [a_in, z, st.mean, st.invstd, w, gamma, beta]
         ctx.blocks = blocks
         ctx.save_for_backward(*saved)
@@ -204,9 +205,9 @@ class RegNetTrain(torch.autograd.Function):
             sums = ops.bn_relu_bwd_reduce(g, z, mean, invstd, gamma, beta, relu=True)
             grads[3 * i + 2] = sums[: sums.numel() // 2].float()                     # d beta (this rank's voxels; DDP averages)
             grads[3 * i + 1] = sums[sums.numel() // 2:].float()                      # d gamma
-            if group is not None:
+            if group[0]:
                 sums = sums.clone()
-                torch.distributed.all_reduce(sums, group=group)
+                torch.distributed.all_reduce(sums, group=group[1])
             dz = ops.bn_relu_bwd_apply(g, z, mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
             grads[3 * i], da = _conv_bwd(a_in, dz, w, stride, transposed, zero_bias)
             pending[i] = da if i not in pending else pending[i] + da
@@ -280,7 +281,7 @@ class VisTrain(torch.autograd.Function):
                 zs = z[v * B:(v + 1) * B]
                 st = _BnState(vis_seq[i].bn, zs)
                 y[v * B:(v + 1) * B] = ops.bn_relu_apply(zs, st.mean, st.invstd, gamma, beta, None, relu=True)
-                states.append((st.mean, st.invstd, st.batch, st.count, st.group))
+                states.append((st.mean, st.invstd, st.batch, st.count, (st.sync, st.group)))
             blocks.append(states)
             saved += [a, z, w3, gamma, beta]
             a = y
@@ -307,9 +308,9 @@ class VisTrain(torch.autograd.Function):
                 sums = ops.bn_relu_bwd_reduce(g[sl], z[sl], mean, invstd, gamma, beta, relu=True)
                 dbeta += sums[:C]
                 dgamma += sums[C:]
-                if group is not None:
+                if group[0]:
                     sums = sums.clone()
-                    torch.distributed.all_reduce(sums, group=group)
+                    torch.distributed.all_reduce(sums, group=group[1])
                 dz[sl] = ops.bn_relu_bwd_apply(g[sl], z[sl], mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
             grads[3 * i + 1], grads[3 * i + 2] = dgamma.float(), dbeta.float()
             if w3.shape[0] == 8:

@@ -158,3 +158,50 @@ def test_view_sharded_cascade_matches_single_process(world, V, mode):
     for rank, err, same in _run(_cascade_worker, world, V, mode):
         assert err <= 1e-4, "rank %d: sharded refined depth rel-L1 %g vs the single-process cascade" % (rank, err)
         assert same, "ranks hold different results"
+
+
+def _syncbn_worker(rank, world, port, emu_path, q):
+    """Training path under SyncBatchNorm: each rank holds one sample of a batch of two; the BatchNorm statistics (forward and
+    backward sums) are all-reduced inside the native kernels' host code, so every rank's feature gradient equals the matching
+    sample's gradient of a single-process batch-of-two step, and the parameter gradients summed over the ranks equal its."""
+    _setup(rank, world, port, emu_path)
+    from conftest import golden_weights, load_golden
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    fx = load_golden("f12_train_backward_s3.npz")
+    args = {"base_ch": [8] * 4, "depth_type": ["ce"] * 4}
+
+    def make():
+        net = StageNet(args, 4, 3)
+        net.load_state_dict(golden_weights(fx), strict=True)
+        return net.train()
+
+    def loss_of(out, R):
+        return (out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).sum()
+
+    full = make()
+    f_all = fx["features"].clone().requires_grad_(True)
+    loss_of(full(f_all, fx["proj"], fx["hyp"], 1.0), fx["R"]).backward()
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(make())
+    sl = slice(rank, rank + 1)
+    f_loc = fx["features"][sl].clone().requires_grad_(True)
+    loss_of(net(f_loc, fx["proj"][sl], fx["hyp"][sl], 1.0), fx["R"][sl]).backward()
+    err = float((f_loc.grad - f_all.grad[sl]).abs().max() / f_all.grad.abs().max())
+    if os.environ.get("MVS_TEST_VERBOSE") and rank == 0:
+        print("features", err)
+    worst = 0.0
+    for (n, p), (_, pf) in zip(net.named_parameters(), full.named_parameters()):
+        g = p.grad.clone()
+        dist.all_reduce(g)
+        e = float((g - pf.grad).abs().max() / pf.grad.abs().max().clamp_min(1e-12))
+        if os.environ.get("MVS_TEST_VERBOSE") and rank == 0:
+            print("%-36s %.2e" % (n, e))
+        worst = max(worst, e)
+    stats = max(float((b - bf).abs().max()) for (n, b), (_, bf) in zip(net.named_buffers(), full.named_buffers()) if "running_" in n)
+    q.put((rank, max(err, worst), stats <= 1e-4))
+    dist.destroy_process_group()
+
+
+def test_training_path_syncbn_matches_single_process():
+    for rank, err, stats_ok in _run(_syncbn_worker, 2):
+        assert err <= 2e-3, "rank %d: SyncBatchNorm training gradients differ from the single-process batch by %g" % (rank, err)
+        assert stats_ok, "running statistics differ"
