@@ -143,7 +143,7 @@ int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* 
  *   mvs_bn_relu_apply  y = relu((z-mean)*invstd*gamma+beta) [+ skip]                            module.py:120-125, 402-405
  *   mvs_bn_relu_bwd    phase 0: sums[2C] = [d beta | d gamma] of dy through the ReLU mask; phase 1: dz (count = voxels of all
  *                      ranks, use_batch_stats = 0 for eval-mode BatchNorm inside a training graph)
- *   mvs_conv3d_wgrad   dW[CB][CA][27] of Conv3d(k3, padding 1, stride) from input a_cl [B,D,H,W,CA] and output gradient
+ *   mvs_conv3d_wgrad   dW[CB][CA][kd*9] of Conv3d(k (kd,3,3), kd = 1 | 3, 'same' padding, stride) from input a_cl [B,D,H,W,CA] and output gradient
  *                      g_cl [B,OD,OH,OW,CB] on the fp32 MFMA path; a transposed convolution's weight gradient is the same call
  *                      with a = its output gradient and g = its input (result in ConvTranspose3d's [Cin][Cout][27] layout)    */
 int mvs_deconv3d_linear_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout,
@@ -155,8 +155,8 @@ int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd,
 int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, double* sums, double count, float* dz_cl, long long N, int C, int relu,
                     int use_batch_stats, int phase, void* stream);
-int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int sd,
-                     int sh, int sw, void* stream);
+int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int kd,
+                     int sd, int sh, int sw, void* stream);
 
 /* ---- a7: ConvTranspose3d(k3, padding 1, stride (sd,2,2), output_padding (sd-1,1,1)) + BN + ReLU,
  * then + skip (module.py:129-165, 402-405, 467-481, 498-501).

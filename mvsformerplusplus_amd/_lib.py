@@ -50,7 +50,7 @@ SIGNATURES = {
     "mvs_bn_finalize": (_i, [_vp, C.c_double, C.c_float, _vp, _vp, _vp, _i, _vp]),
     "mvs_bn_relu_apply": (_i, [_vp] * 7 + [C.c_longlong, _i, _i, _vp]),
     "mvs_bn_relu_bwd": (_i, [_vp] * 7 + [C.c_double, _vp, C.c_longlong, _i, _i, _i, _i, _vp]),
-    "mvs_conv3d_wgrad": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),
+    "mvs_conv3d_wgrad": (_i, [_vp] * 3 + [_i] * 10 + [_vp]),
     "mvs_warp_corr_aggregate_bwd": (_i, [_vp, _i] + [_vp] * 8 + [_i] * 7 + [_vp]),
     "mvs_regnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mvs_regnet_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),

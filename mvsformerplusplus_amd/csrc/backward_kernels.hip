@@ -20,15 +20,19 @@
 
 namespace mvs {
 
-// One work-item per (reference pixel, source view, chunk of BW_DCH depth planes): the chunk's tap sets live in registers, every
-// channel is gathered for all planes of the chunk back to back (as in the forward passes), the reference-feature gradient of a
-// channel is accumulated over the chunk before ONE atomic add, and the four taps of every (channel, plane) are scattered with
-// atomics (global_atomic_add_f32).  Measured on the MI355X at 2 x 512 x 640, V = 5, C = 8, D = 4: 5.5 ms against 0.11 ms for the
-// forward - 335 M float atomics at 61 G/s; the kernel is bound by the L2 atomic units (a one-work-item-per-pixel form with 16 x
-// less parallelism took the same 5.2 ms).  The remedy is accumulating each tile's scatter in an LDS window - the forward passes'
-// window machinery - and flushing one atomic per window element (~9 x fewer); not built: the step this kernel sits in spends
-// 400 ms in the 3-D convolutions' autograd.
+// A block = a 16 x 16 tile of reference pixels x one source view x one chunk of BW_DCH depth planes; one work-item per pixel.
+// The chunk's tap sets live in registers, every channel is gathered for all planes of the chunk back to back (as in the forward
+// passes), the reference-feature gradient of a channel is accumulated over the chunk before ONE atomic add.
+//
+// Source-feature gradients: all taps of the tile fall into a small window of the source image (its bounding box is reduced with
+// LDS atomics).  Four channels at a time, the scatter is accumulated in an LDS image of that window (ds_add_f32) and flushed with
+// one global atomic per non-zero window element - ~8 x fewer global atomics than four per (pixel, plane, channel), which is
+// what bounded the first form of this kernel (335 M global_atomic_add_f32 at 61 G/s = 5.5 ms at 2 x 512 x 640, V = 5, C = 8, D = 4,
+// against 0.11 ms for the forward; with the LDS image: 3.7 ms, 2.6 / 2.0 / 1.9 ms at the three coarser stages).  A tile whose
+// window exceeds the LDS image (steep geometry) scatters straight to global.
 constexpr int BW_DCH = 4;
+constexpr int BW_TILE = 16;
+constexpr int BW_CAP = 2048;                  // window positions of the LDS image: 2048 x 4 channels x 4 B = 32 KiB
 
 template <typename T>
 __global__ __launch_bounds__(256) void warp_corr_aggregate_bwd_kernel(const T* __restrict__ feat, const float* __restrict__ hom,
@@ -36,14 +40,18 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_bwd_kernel(const T* _
                                                                       const float* __restrict__ vis_sum, const float* __restrict__ vol,
                                                                       const float* __restrict__ gvol, float* __restrict__ gfeat,
                                                                       float* __restrict__ gvis, int V, int C, int G, int D, int H, int W,
-                                                                      int nchunk) {
+                                                                      int nchunk, int tiles_x) {
+    __shared__ float accw[BW_CAP * 4];
+    __shared__ int box[4];
     const int HW = H * W;
-    const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int tid = (int)threadIdx.x;
+    const int tx = (int)blockIdx.x % tiles_x, ty = (int)blockIdx.x / tiles_x;
+    const int x = tx * BW_TILE + (tid & 15), y = ty * BW_TILE + (tid >> 4);
+    const bool inside = x < W && y < H;
+    const int p = inside ? y * W + x : 0;
     const int b = (int)blockIdx.z;
     const int v = 1 + (int)blockIdx.y / nchunk, d0 = ((int)blockIdx.y % nchunk) * BW_DCH;
-    if (p >= HW) return;
     const int nd = D - d0 < BW_DCH ? D - d0 : BW_DCH;
-    const int y = p / W, x = p - y * W;
     const int cpg = C / G;
     const float inv_cpg = 1.0f / (float)cpg;
     const float inv_den = 1.0f / (vis_sum[(size_t)b * HW + p] + 1e-6f);
@@ -65,30 +73,67 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_bwd_kernel(const T* _
     const T* src = ref + (size_t)v * C * HW;
     float* gsrc = gref + (size_t)v * C * HW;
     const float visv = vis[((size_t)b * (V - 1) + (v - 1)) * HW + p];
+    if (tid == 0) { box[0] = 0x7fffffff; box[1] = 0x7fffffff; box[2] = -1; box[3] = -1; }
+    __syncthreads();
     Taps tp[BW_DCH];
 #pragma unroll
     for (int dd = 0; dd < BW_DCH; ++dd) {
         const int d = d0 + (dd < nd ? dd : 0);
         tp[dd] = make_taps(hm, qx, qy, qz, hyp[((size_t)b * D + d) * HW + p], H, W, half_w, half_h, nullptr);
-    }
-    float gv = 0.0f;
-    for (int g = 0; g < G; ++g) {
-        float go[BW_DCH], gs[BW_DCH], sim[BW_DCH];
+        if (!inside || dd >= nd) {
 #pragma unroll
-        for (int dd = 0; dd < BW_DCH; ++dd) {
-            go[dd] = dd < nd ? gvol[(((size_t)b * D + d0 + dd) * HW + p) * G + g] : 0.0f;
-            gs[dd] = go[dd] * visv * inv_den * inv_cpg;
-            sim[dd] = 0.0f;
+            for (int k = 0; k < 4; ++k) tp[dd].w[k] = 0.0f;               // this work-item contributes nothing
         }
-        for (int cc = 0; cc < cpg; ++cc) {
-            const int c = g * cpg + cc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tp[dd].w[k] != 0.0f) {
+                const int py = tp[dd].off[k] / W, px = tp[dd].off[k] - py * W;
+                atomicMin(&box[0], px); atomicMin(&box[1], py); atomicMax(&box[2], px); atomicMax(&box[3], py);
+            }
+    }
+    __syncthreads();
+    const int xmin = box[0], ymin = box[1], ww = box[2] - xmin + 1, wh = box[3] - ymin + 1;
+    const bool any_tap = box[2] >= 0;
+    const bool use_lds = any_tap && ww * wh <= BW_CAP;
+    // window index of every tap (LDS path)
+    int lpos[BW_DCH][4];
+#pragma unroll
+    for (int dd = 0; dd < BW_DCH; ++dd)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int py = tp[dd].off[k] / W, px = tp[dd].off[k] - py * W;
+            lpos[dd][k] = tp[dd].w[k] != 0.0f ? ((py - ymin) * ww + (px - xmin)) * 4 : 0;
+        }
+    float gv = 0.0f;
+    float go[BW_DCH], gs[BW_DCH], sim[BW_DCH];
+    int cur_g = -1;
+    for (int c4 = 0; c4 < C; c4 += 4) {
+        if (use_lds) {
+            for (int i = tid; i < ww * wh * 4; i += 256) accw[i] = 0.0f;
+            __syncthreads();
+        }
+        for (int j = 0; j < 4 && c4 + j < C; ++j) {
+            const int c = c4 + j, g = c / cpg;
+            if (g != cur_g) {
+                if (cur_g >= 0) {
+#pragma unroll
+                    for (int dd = 0; dd < BW_DCH; ++dd)
+                        if (dd < nd) gv += go[dd] * (sim[dd] * inv_cpg - vol[(((size_t)b * D + d0 + dd) * HW + p) * G + cur_g]);
+                }
+                cur_g = g;
+#pragma unroll
+                for (int dd = 0; dd < BW_DCH; ++dd) {
+                    go[dd] = (inside && dd < nd) ? gvol[(((size_t)b * D + d0 + dd) * HW + p) * G + g] : 0.0f;
+                    gs[dd] = go[dd] * visv * inv_den * inv_cpg;
+                    sim[dd] = 0.0f;
+                }
+            }
             const T* sp = src + (size_t)c * HW;
             float* gp = gsrc + (size_t)c * HW;
             const float rc = to_f32(ref[(size_t)c * HW + p]);
             float gr = 0.0f;
 #pragma unroll
             for (int dd = 0; dd < BW_DCH; ++dd) {
-                if (dd >= nd) continue;
                 float wv = tp[dd].w[0] * to_f32(sp[tp[dd].off[0]]);
                 wv += tp[dd].w[1] * to_f32(sp[tp[dd].off[1]]);
                 wv += tp[dd].w[2] * to_f32(sp[tp[dd].off[2]]);
@@ -99,18 +144,37 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_bwd_kernel(const T* _
                 if (gw != 0.0f) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (tp[dd].w[k] != 0.0f) atomicAdd(gp + tp[dd].off[k], gw * tp[dd].w[k]);
+                        if (tp[dd].w[k] != 0.0f) {
+                            if (use_lds) atomicAdd(&accw[lpos[dd][k] + j], gw * tp[dd].w[k]);
+                            else atomicAdd(gp + tp[dd].off[k], gw * tp[dd].w[k]);
+                        }
                 }
             }
-            atomicAdd(gref + (size_t)c * HW + p, gr);
+            if (inside && gr != 0.0f) atomicAdd(gref + (size_t)c * HW + p, gr);
         }
+        if (use_lds) {
+            __syncthreads();
+            for (int i = tid; i < ww * wh * 4; i += 256) {
+                const float val = accw[i];
+                if (val != 0.0f) {
+                    const int pos = i >> 2, j = i & 3;
+                    const int wy = pos / ww, wx = pos - wy * ww;
+                    atomicAdd(gsrc + (size_t)(c4 + j) * HW + (size_t)(ymin + wy) * W + xmin + wx, val);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (cur_g >= 0) {
 #pragma unroll
         for (int dd = 0; dd < BW_DCH; ++dd)
-            if (dd < nd) gv += go[dd] * (sim[dd] * inv_cpg - vol[(((size_t)b * D + d0 + dd) * HW + p) * G + g]);
+            if (dd < nd) gv += go[dd] * (sim[dd] * inv_cpg - vol[(((size_t)b * D + d0 + dd) * HW + p) * G + cur_g]);
     }
-    float* gvp = gvis + ((size_t)b * (V - 1) + (v - 1)) * HW + p;
-    if (nchunk == 1) *gvp = gv * inv_den;
-    else atomicAdd(gvp, gv * inv_den);
+    if (inside) {
+        float* gvp = gvis + ((size_t)b * (V - 1) + (v - 1)) * HW + p;
+        if (nchunk == 1) *gvp = gv * inv_den;
+        else atomicAdd(gvp, gv * inv_den);
+    }
 }
 
 template <typename T>
@@ -121,8 +185,9 @@ static int launch_bwd(const void* feat, const float* hom, const float* hyp, cons
         set_error("mvs_warp_corr_aggregate_bwd: hipMemsetAsync failed");
         return MVS_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((warp_corr_aggregate_bwd_kernel<T>), dim3(ceil_div((long long)H * W, 256), (V - 1) * nchunk, B), dim3(256), 0, st,
-                       reinterpret_cast<const T*>(feat), hom, hyp, vis, vis_sum, vol, gvol, gfeat, gvis, V, C, G, D, H, W, nchunk);
+    const int tiles_x = (int)ceil_div(W, BW_TILE), tiles_y = (int)ceil_div(H, BW_TILE);
+    hipLaunchKernelGGL((warp_corr_aggregate_bwd_kernel<T>), dim3(tiles_x * tiles_y, (V - 1) * nchunk, B), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(feat), hom, hyp, vis, vis_sum, vol, gvol, gfeat, gvis, V, C, G, D, H, W, nchunk, tiles_x);
     return check_launch("warp_corr_aggregate_bwd_kernel");
 }
 

@@ -145,10 +145,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // tiles and adds them to dW once at the end (dW zeroed by the entry point).  The weight gradient of a transposed convolution
 // is the same sum with the roles of input and output exchanged (a = its output gradient, g = its input).
 // ------------------------------------------------------------------------------------------------
-template <int SD_, int SH_, int SW_, int TD_, int TH_>
+template <int SD_, int SH_, int SW_, int TD_, int TH_, int KD_ = 3>
 struct WgCfg {
-    static constexpr int SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, TW = 16;
-    static constexpr int ID = (TD - 1) * SD + 3, IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
+    static constexpr int SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, TW = 16, KD = KD_;
+    static constexpr int NTAP = KD * 9, NT = (NTAP + 3) / 4;               // taps in all, taps per wave (the last waves may own one less)
+    static constexpr int ID = (TD - 1) * SD + KD, IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
     static constexpr int NVOX = ID * IH * IW, NVO = TD * TH * TW;
     static constexpr size_t LDS_BYTES = (size_t)(NVOX + NVO) * 16 * sizeof(float);
 };
@@ -170,13 +171,13 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     const int t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
     if (t_begin >= t_end) return;
 
-    constexpr int NT = 7;                                                  // taps per wave (wave 3: six)
+    constexpr int NT = Cfg::NT, NTAP = Cfg::NTAP;                          // k3: 7 taps per wave (wave 3: six); k = (1,3,3): 3, 2, 2, 2
     f32x4 acc[NT];
     int tapoff[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        const int tap = wave + 4 * j < 27 ? wave + 4 * j : 26;
+        const int tap = wave + 4 * j < NTAP ? wave + 4 * j : NTAP - 1;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         tapoff[j] = ((kd * IH + kh) * IW + kw) * 16;
     }
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
         t /= tiles_x;
         const int ty = t % tiles_y, tz = t / tiles_y;
         const int oz0 = tz * TD, oy0 = ty * TH, ox0 = tx * 16;
-        const int iz0 = oz0 * SD - 1, iy0 = oy0 * SH - 1, ix0 = ox0 * SW - 1;
+        const int iz0 = oz0 * SD - Cfg::KD / 2, iy0 = oy0 * SH - 1, ix0 = ox0 * SW - 1;
         const float* ab = a + (size_t)b * D * H * W * CA;
         const float* gb = g + (size_t)b * OD * OH * OW * CB;
         for (int e = tid; e < Cfg::NVOX * 4; e += 256) {
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
             const float* bp = la + (((oz * SD) * IH + oy * SH) * IW + ox * SW) * 16 + li;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (j == NT - 1 && wave == 3) continue;                    // tap 27 does not exist
+                if (j == NT - 1 && wave + 4 * j >= NTAP) continue;         // the last round of taps is not full
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, bp[tapoff[j]], acc[j], 0, 0, 0);
             }
         }
@@ -229,12 +230,12 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int tap = wave + 4 * j;
-        if (tap >= 27) continue;
+        if (tap >= NTAP) continue;
         const int ci = ci0 + li;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = co0 + 4 * grp + i;
-            if (co < CB && ci < CA) atomicAdd(dw + ((size_t)co * CA + ci) * 27 + tap, acc[j][i]);
+            if (co < CB && ci < CA) atomicAdd(dw + ((size_t)co * CA + ci) * NTAP + tap, acc[j][i]);
         }
     }
 }
@@ -312,15 +313,19 @@ extern "C" int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const floa
     return check_launch("bn_bwd_apply_kernel");
 }
 
-extern "C" int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int sd, int sh, int sw,
-                                void* stream) {
+extern "C" int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int kd, int sd, int sh,
+                                int sw, void* stream) {
     if (!a_cl || !g_cl || !dw || B < 1 || D < 1 || H < 1 || W < 1 || CA < 4 || CB < 4 || (CA % 4) || (CB % 4)) {
         set_error("mvs_conv3d_wgrad: bad arguments (channel counts must be multiples of 4)");
         return MVS_ERR_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
     const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
-    if (hipMemsetAsync(dw, 0, (size_t)CA * CB * 27 * sizeof(float), st) != hipSuccess) { set_error("mvs_conv3d_wgrad: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
+    if (kd != 1 && kd != 3) { set_error("mvs_conv3d_wgrad: kernel depth %d (1 or 3)", kd); return MVS_ERR_UNSUPPORTED; }
+    if (hipMemsetAsync(dw, 0, (size_t)CA * CB * kd * 9 * sizeof(float), st) != hipSuccess) { set_error("mvs_conv3d_wgrad: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
+    // k = (1,3,3), stride 1: the 2-D layers of the visibility CNN (maps as D = 1 volumes); 1 x 16 x 16 output tiles
+    if (kd == 1 && sd == 1 && sh == 1 && sw == 1) return launch_wgrad<WgCfg<1, 1, 1, 1, 16, 1>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);
+    if (kd == 1) { set_error("mvs_conv3d_wgrad: k = (1,3,3) is built for stride 1"); return MVS_ERR_UNSUPPORTED; }
     if (sd == 1 && sh == 1 && sw == 1) return launch_wgrad<WgCfg<1, 1, 1, 4, 4>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);
     if (sd == 1 && sh == 2 && sw == 2) return launch_wgrad<WgCfg<1, 2, 2, 2, 2>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);
     if (sd == 2 && sh == 2 && sw == 2) return launch_wgrad<WgCfg<2, 2, 2, 2, 2>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);

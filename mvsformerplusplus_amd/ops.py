@@ -284,14 +284,15 @@ def bn_relu_bwd_apply(dy_cl, z_cl, mean, invstd, gamma, beta, sums, count: float
     return dz
 
 
-def conv3d_wgrad(a_cl: torch.Tensor, g_cl: torch.Tensor, stride: Tuple[int, int, int]) -> torch.Tensor:
-    """Weight gradient of Conv3d(k3, padding 1, stride): a_cl [B,D,H,W,CA] input, g_cl [B,OD,OH,OW,CB] output gradient -> [CB, CA, 3, 3, 3]."""
+def conv3d_wgrad(a_cl: torch.Tensor, g_cl: torch.Tensor, stride: Tuple[int, int, int], kd: int = 3) -> torch.Tensor:
+    """Weight gradient of Conv3d(k (kd,3,3), 'same' padding, stride): a_cl [B,D,H,W,CA] input, g_cl [B,OD,OH,OW,CB] output gradient
+    -> [CB, CA, kd, 3, 3]."""
     B, D, H, W, CA = a_cl.shape
     CB = g_cl.shape[-1]
     sd, sh, sw = stride
     assert tuple(g_cl.shape[:4]) == (B, (D - 1) // sd + 1, (H - 1) // sh + 1, (W - 1) // sw + 1), "wgrad: gradient shape does not match the stride"
-    dw = torch.empty(CB, CA, 3, 3, 3, dtype=torch.float32, device=a_cl.device)
-    check(lib().mvs_conv3d_wgrad(ptr(a_cl), ptr(g_cl), ptr(dw), B, CA, CB, D, H, W, sd, sh, sw, stream_of(a_cl)), "mvs_conv3d_wgrad")
+    dw = torch.empty(CB, CA, kd, 3, 3, dtype=torch.float32, device=a_cl.device)
+    check(lib().mvs_conv3d_wgrad(ptr(a_cl), ptr(g_cl), ptr(dw), B, CA, CB, D, H, W, kd, sd, sh, sw, stream_of(a_cl)), "mvs_conv3d_wgrad")
     return dw
 
 

@@ -20,7 +20,7 @@ What is native and what is not, stated plainly:
 * still PyTorch-ROCm autograd, all of it element-wise or tiny: the visibility CNN's 1x1 Conv2d + sigmoid, CostRegNet3D's 1x1x1 `prob`,
   the softmax / argmax / regression head, the running-statistics momentum update.  ``MVS_TRAIN_REGNET=torch`` routes every conv /
   BatchNorm layer through autograd ops instead (the first form of this path; on the MI355X image MIOpen picks naive kernels for
-  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 28 ms natively).
+  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 17 ms natively).
 
 The reference differentiates neither the sampling grid (built under ``torch.no_grad()``, warping.py:80) nor the entropy
 (``sim_vol.detach()``, cost_volume.py:90); this path follows it: no gradient reaches the depth hypotheses, the cameras or - via
@@ -313,15 +313,12 @@ class VisTrain(torch.autograd.Function):
                     torch.distributed.all_reduce(sums, group=group[1])
                 dz[sl] = ops.bn_relu_bwd_apply(g[sl], z[sl], mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
             grads[3 * i + 1], grads[3 * i + 2] = dgamma.float(), dbeta.float()
-            if w3.shape[0] == 8:
-                # 16 -> 8: weight gradient from the k3 kernel (outer depth taps see only padding), data gradient = flipped 8 -> 16 conv
-                dw3 = ops.conv3d_wgrad(a_in, dz, (1, 1, 1))
-                da = _conv_fwd(dz, w3.transpose(0, 1).flip(2, 3, 4).contiguous(), (1, 1, 1), False, zero_bias)
-            else:
-                dw3, da = _conv_bwd(a_in, dz, w3, (1, 1, 1), False, zero_bias, need_da=i > 0)
+            # weight gradient on the k = (1,3,3) form of the kernel (the maps are D = 1 volumes); data gradient = the convolution with
+            # flipped, transposed taps (nothing to propagate below the first layer: the entropy carries no gradient)
+            dw2 = ops.conv3d_wgrad(a_in, dz, (1, 1, 1), kd=1)
             cin = 1 if i == 0 else w3.shape[1]
-            grads[3 * i] = dw3[:, :cin, 1].contiguous()
-            g = da
+            grads[3 * i] = dw2[:, :cin, 0].contiguous()
+            g = _conv_fwd(dz, w3.transpose(0, 1).flip(2, 3, 4).contiguous(), (1, 1, 1), False, zero_bias) if i > 0 else None
         return (None, None) + tuple(grads)
 
 

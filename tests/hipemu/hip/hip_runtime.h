@@ -222,4 +222,6 @@ static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; *p = v < o ? v : o; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; *p = v > o ? v : o; return o; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

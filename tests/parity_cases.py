@@ -686,9 +686,13 @@ def case_fusion_golden(device):
 def case_aggregate_backward(device):
     """mvs_warp_corr_aggregate_bwd against torch autograd through the oracle's warp + correlation + aggregation, for C = G
     (one channel per group), C = 4 G, a border-heavy camera pair (zero-padding taps) and bf16 features."""
-    for C, G, D, H, W, V, dt in ((8, 8, 4, 12, 20, 3, torch.float32), (32, 8, 6, 10, 16, 4, torch.float32), (16, 8, 4, 12, 20, 3, torch.bfloat16)):
+    # last case: the source view sees the scene at 4 x the reference's magnification, so the taps of a 16 x 16 tile spread over
+    # ~48 x 64 source pixels - more than the LDS window image holds (the tile scatters straight to global memory)
+    for C, G, D, H, W, V, dt, zoom in ((8, 8, 4, 12, 20, 3, torch.float32, 1.0), (32, 8, 6, 10, 16, 4, torch.float32, 1.0),
+                                      (16, 8, 4, 12, 20, 3, torch.bfloat16, 1.0), (8, 8, 4, 48, 96, 3, torch.float32, 4.0)):
         g = torch.Generator().manual_seed(C + D)
         cams = synth.make_cameras(V, H, W, baseline=60.0, rot_deg=4.0, seed=C)
+        cams[:, 1:, 1, :2, :] *= zoom
         feats = torch.randn(1, V, C, H, W, generator=g).to(dt)
         hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.05 * torch.rand(1, D, H, W, generator=g))).contiguous()
         vis = torch.rand(1, V - 1, H, W, generator=g) * 0.9 + 0.05
@@ -709,12 +713,15 @@ def case_aggregate_backward(device):
         fd, code = ops._feat(dev(feats, device))
         hom = ops.compose_homography(dev(cams, device))
         vol_cl, _ = ops.warp_corr_aggregate(fd, code, hom, dev(hyp, device), dev(vis, device), G)
-        assert (cpu(vol_cl).permute(0, 4, 1, 2, 3) - vol.detach()).abs().max() <= 3e-5
+        # tap positions agree with the oracle's to ~1e-4 px; on white-noise features at 4 x magnification (coordinates up to 400 px)
+        # that is worth 5e-4 of the value range, on the other cases 3e-5
+        tol = 3e-5 if zoom == 1.0 else 1e-3
+        assert (cpu(vol_cl).permute(0, 4, 1, 2, 3) - vol.detach()).abs().max() <= tol
         gfeat, gvis = ops.warp_corr_aggregate_bwd(fd, code, hom, dev(hyp, device), dev(vis, device), dev(vis.sum(1), device), vol_cl,
                                                   dev(gvol.permute(0, 2, 3, 4, 1).contiguous(), device), G)
         scale_f, scale_v = float(f32.grad.abs().max()), float(visr.grad.abs().max())
-        assert (cpu(gfeat) - f32.grad).abs().max() <= 2e-5 * scale_f + 1e-6, (C, G, "feature gradient")
-        assert (cpu(gvis) - visr.grad).abs().max() <= 2e-5 * scale_v + 1e-6, (C, G, "visibility gradient")
+        assert (cpu(gfeat) - f32.grad).abs().max() <= (tol / 1.5) * scale_f + 1e-6, (C, G, "feature gradient")
+        assert (cpu(gvis) - visr.grad).abs().max() <= (tol / 1.5) * scale_v + 1e-6, (C, G, "visibility gradient", float((cpu(gvis) - visr.grad).abs().max()), scale_v)
         assert float(cpu(gfeat)[:, 1:].abs().sum()) > 0 and float(cpu(gfeat)[:, 0].abs().sum()) > 0
 
 
@@ -827,6 +834,14 @@ def case_train_kernels(device):
         ref = torch.nn.grad.conv3d_weight(a, w.shape, gy, stride=stride, padding=1)
         dw = ops.conv3d_wgrad(dev(a.permute(0, 2, 3, 4, 1).contiguous(), device), dev(gy.permute(0, 2, 3, 4, 1).contiguous(), device), stride)
         assert (cpu(dw) - ref).abs().max() <= 2e-5 * float(ref.abs().max()) + 1e-5, (CA, CB, stride)
+    # k = (1,3,3): the 2-D layers of the visibility CNN on D = 1 volumes
+    a2 = torch.randn(3, 16, 21, 37, generator=g)
+    w2 = torch.randn(8, 16, 3, 3, generator=g) * 0.1
+    gy2 = torch.randn(3, 8, 21, 37, generator=g)
+    ref2 = torch.nn.grad.conv2d_weight(a2, w2.shape, gy2, padding=1)
+    dw2 = ops.conv3d_wgrad(dev(a2.permute(0, 2, 3, 1).contiguous().unsqueeze(1), device), dev(gy2.permute(0, 2, 3, 1).contiguous().unsqueeze(1), device),
+                           (1, 1, 1), kd=1)
+    assert (cpu(dw2)[:, :, 0] - ref2).abs().max() <= 2e-5 * float(ref2.abs().max()) + 1e-5
     # ConvTranspose3d(16 -> 8, stride (1,2,2)): dW[ci][co] from (a = output gradient, g = input)
     x = torch.randn(1, 16, 3, 5, 6, generator=g, requires_grad=False)
     wt = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.1).requires_grad_(True)
