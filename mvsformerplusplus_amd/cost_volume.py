@@ -96,7 +96,7 @@ class StageNet(nn.Module):
             # layers (training.py says exactly what runs where)
             from .training import stage_forward_train
             assert features.shape[1] == proj_matrices.shape[1], "Different number of images and projection matrices"
-            return stage_forward_train(self, features, proj_matrices, depth_values, tmp)
+            return stage_forward_train(self, features, proj_matrices, depth_values, tmp, position3d)
         B, V, C, H, W = features.shape
         assert V == proj_matrices.shape[1], "Different number of images and projection matrices"   # cost_volume.py:56
         G = self.in_channels

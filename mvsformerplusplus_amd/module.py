@@ -374,6 +374,7 @@ class PureTransformerCostReg(nn.Module):
         if in_channels != 8 or base_channel != 8 or mid_channel != 64 or mid_channel // num_heads != 16:
             raise NotImplementedError("HIP transformer regulariser is built for 8 -> 64 channels, heads of 16 (shipped transformer_config)")
         self.num_heads = num_heads
+        self.drop, self.attn_drop = float(drop), float(attn_drop)       # only read by the training path (training.py): must be 0
         self.softmax_scale = kwargs.get("softmax_scale", None)
         self.train_avg_length = kwargs.get("train_avg_length", None)
         if self.softmax_scale not in (None, "entropy_invariance"):

@@ -24,7 +24,9 @@ What is native and what is not, stated plainly:
 
 The reference differentiates neither the sampling grid (built under ``torch.no_grad()``, warping.py:80) nor the entropy
 (``sim_vol.detach()``, cost_volume.py:90); this path follows it: no gradient reaches the depth hypotheses, the cameras or - via
-the entropy - the features.  The transformer regulariser of the shipped stage 1 has no training path here and raises.
+the entropy - the features.  The transformer regulariser of the shipped stage 1 trains through PyTorch autograd ops
+(``transformer_forward_torch``: token GEMMs, scaled-dot-product attention, LayerNorms on the module's own parameters) between the
+native cost volume and head; a hand-written attention backward is not built.
 """
 from __future__ import annotations
 
@@ -373,12 +375,54 @@ def vis_forward_torch(vis_seq, entropy: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(vis_seq[3](t))
 
 
-def stage_forward_train(net, features, proj_matrices, depth_values, tmp) -> Dict[str, torch.Tensor]:
+def _position_encoding_3d(position3d: torch.Tensor, C: int, rescale: float = 4.0) -> torch.Tensor:
+    """PositionEncoding3D (position_encoding.py:166-189): per axis C channels, sin on the even and cos on the odd ones of
+    position * rescale * 10000^(-2i/C) -> [B, 3C, D, H, W].  No gradient: the positions come from the hypotheses."""
+    import math
+    B, _, D, H, W = position3d.shape
+    freq = torch.exp(torch.arange(0, C, 2, device=position3d.device, dtype=torch.float32) * (-math.log(10000.0) / C)).view(1, 1, -1, 1)
+    ang = position3d.reshape(B, 3, 1, D * H * W).float() * rescale * freq                           # [B, 3, C/2, N]
+    pe = torch.stack([torch.sin(ang), torch.cos(ang)], dim=3)                                      # [B, 3, C/2, 2, N]: interleaved
+    return pe.reshape(B, 3 * C, D, H, W)
+
+
+def _layer_norm_channels(x: torch.Tensor, ln) -> torch.Tensor:
+    """LayerNorm3D (module.py:586-599): normalise an NCDHW tensor over its channel axis."""
+    mu = x.mean(1, keepdim=True)
+    xc = x - mu
+    return ln.weight.view(1, -1, 1, 1, 1) * (xc * torch.rsqrt(xc.pow(2).mean(1, keepdim=True) + ln.eps)) + ln.bias.view(1, -1, 1, 1, 1)
+
+
+def transformer_forward_torch(reg, x: torch.Tensor, position3d) -> torch.Tensor:
+    """PureTransformerCostReg.forward (module.py:629-646, blocks :569-581, attention dino/layers/attention.py:76-101,141-170) as
+    PyTorch autograd ops on the module's own parameters - the training form of the shipped stage 1 (the inference form is the
+    HIP path of csrc/transformer_kernels.hip; a hand-written attention backward is not built)."""
+    import math
+    if reg.training and (reg.drop or reg.attn_drop):
+        raise NotImplementedError("dropout inside the transformer regulariser (drop / attn_drop != 0) is not used by the shipped config")
+    if position3d is not None:
+        x = x + reg.pe_proj(_position_encoding_3d(position3d, x.shape[1]))
+    x = _layer_norm_channels(reg.down[0](x), reg.down[1])
+    B, C, d, h, w = x.shape
+    heads = reg.num_heads
+    t = x.permute(0, 3, 4, 2, 1).reshape(B, h * w * d, C)                                          # tokens ordered (h w d), module.py:573
+    N = t.shape[1]
+    scale = (C // heads) ** -0.5
+    if reg.softmax_scale == "entropy_invariance":
+        scale *= math.log(N, reg.train_avg_length)
+    for blk in reg.attention_layers:
+        q, k, v = blk.attn.qkv(t).reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(q, k, v, scale=scale).transpose(1, 2).reshape(B, N, C)
+        t = blk.norm1(t + blk.gamma1 * blk.attn.proj(a))
+        t = blk.norm2(t + blk.gamma2 * blk.ffn.linear2(F.gelu(blk.ffn.linear1(t))))
+    x = t.reshape(B, h, w, d, C).permute(0, 4, 3, 1, 2)
+    return reg.prob(_layer_norm_channels(reg.up[0](x), reg.up[1]))
+
+
+def stage_forward_train(net, features, proj_matrices, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
     """StageNet.forward with autograd (cost_volume.py:51-133).  See the module docstring for what runs where."""
     from .module import PureTransformerCostReg
-    if isinstance(net.cost_reg, PureTransformerCostReg):
-        raise NotImplementedError("training through the transformer regulariser is not implemented (SURVEY.md section 8f #2 covers the "
-                                  "'Normal' regularisers in this slice)")
+    transformer = isinstance(net.cost_reg, PureTransformerCostReg)
     if isinstance(features, ops.PackedFeatures):
         raise NotImplementedError("the training path takes planar [B,V,C,H,W] features")
     if net.view_group is not None:
@@ -399,7 +443,10 @@ def stage_forward_train(net, features, proj_matrices, depth_values, tmp) -> Dict
         vis = vis_forward_native(net.vis, entropy)                                                # [B,V-1,H,W]
     else:
         vis = torch.cat([vis_forward_torch(net.vis, entropy[:, v:v + 1]) for v in range(V - 1)], dim=1)
-    if not native:
+    if transformer:
+        volume = WarpCorrAggregate.apply(features, vis, hom, hyp, G)                               # [B,G,D,H,W]
+        prob_volume_pre = transformer_forward_torch(net.cost_reg, volume, position3d).squeeze(1)
+    elif not native:
         volume = WarpCorrAggregate.apply(features, vis, hom, hyp, G)                               # [B,G,D,H,W]
         prob_volume_pre = regnet_forward_torch(net.cost_reg, volume).squeeze(1)
     else:

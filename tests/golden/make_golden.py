@@ -282,6 +282,30 @@ def f8_stage_transformer():
         cfg=np.array(json.dumps(TRANSFORMER_CFG)), **wman)
 
 
+def f13_train_backward_transformer():
+    """The shipped stage 1 (transformer regulariser + Frustoconical PE) in train mode: loss, logits and the gradients of the features
+    and of every parameter (SURVEY.md section 8f #2)."""
+    from models.position_encoding import get_position_3d
+    args = json.loads(json.dumps(SHIPPED_ARGS))
+    torch.manual_seed(13)
+    net = StageNet(args, 32, 0).train()
+    wman = seed_weights(net, 1300)
+    feats, cams, hyp = stage_inputs(64, 32, 16, 24, 3, 138, down=8)
+    feats = feats.half().float().requires_grad_(True)
+    dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None]
+    with torch.no_grad():
+        pos = get_position_3d(1, 16, 24, cams[:, 0, 1, :3, :3], hyp, depth_min=dv.min(), depth_max=dv.max(), height_min=None,
+                              height_max=None, width_min=None, width_max=None, normalize=True)[0]
+    R = torch.randn(1, 32, 16, 24, generator=torch.Generator().manual_seed(14))
+    out = net(feats, cams, hyp, tmp=1.0, position3d=pos)
+    loss = (out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
+    loss.backward()
+    grads = {"g." + k: v.grad for k, v in net.named_parameters()}
+    assert all(g is not None for g in grads.values())
+    npz("f13_train_backward_transformer.npz", features=feats.detach().half(), proj=cams, hyp=hyp, position3d=pos, R=R, loss=loss,
+        prob_volume_pre=out["prob_volume_pre"], g_features=feats.grad, cfg=np.array(json.dumps(TRANSFORMER_CFG)), **grads, **wman)
+
+
 @torch.no_grad()
 def f9_cascade_shipped():
     """The f4 cascade inputs through the SHIPPED regulariser mix (stage-1 transformer + PE3D), driver logic of
@@ -440,3 +464,4 @@ if __name__ == "__main__":
     f5_small_fns()
     f6_train_mode()
     f12_train_backward()
+    f13_train_backward_transformer()

@@ -795,6 +795,20 @@ def case_train_path_properties(device):
         assert torch.isfinite(feats["stage%d" % s].grad).all() and float(feats["stage%d" % s].grad.abs().sum()) > 0, s
     for name, p in head.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    # ... and so does the shipped mix (stage-1 transformer + Frustoconical PE through PyTorch autograd, the rest native)
+    f9 = load_golden("f9_cascade_shipped.npz")
+    sargs = dict(args, use_pe3d=True, cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(f9)])
+    shead = CascadeDepthHead(sargs)
+    for s in range(4):
+        shead.fusions[s].load_state_dict(golden_weights(f9, "w%d." % (s + 1)), strict=True)
+    shead = shead.to(device).train()
+    for t in feats.values():
+        t.grad = None
+    out = shead(feats, projs, dev(fx["depth_values"], device))
+    sum(out["stage%d" % s]["prob_volume_pre"].square().mean() for s in range(1, 5)).backward()
+    for name, p in shead.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert float(feats["stage1"].grad.abs().sum()) > 0
 
 
 def case_train_kernels(device):
@@ -881,3 +895,25 @@ def case_regnet_train_native(device):
         for (n, b1), (_, b2) in zip(reg.named_buffers(), native.named_buffers()):
             if "running_" in n:
                 assert (cpu(b2) - b1).abs().max() <= 1e-4 * max(1.0, float(b1.abs().max())), n
+
+
+def case_train_backward_transformer_golden(device):
+    """Train-mode forward + backward of the SHIPPED stage 1 (transformer regulariser + Frustoconical PE) against the reference's own
+    loss and gradients (f13): native cost volume / visibility CNN / gather backward, PyTorch autograd through the transformer."""
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    fx = load_golden("f13_train_backward_transformer.npz")
+    args = dict(ARGS, cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(fx)])
+    net = StageNet(args, 32, 0)
+    net.load_state_dict(golden_weights(fx), strict=True)
+    net = net.to(device).train()
+    feats = dev(fx["features"].float(), device).requires_grad_(True)
+    out = net(feats, dev(fx["proj"], device), dev(fx["hyp"], device), 1.0, position3d=dev(fx["position3d"], device))
+    loss = (out["prob_volume"] * dev(fx["R"], device)).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) <= 2e-4 * max(1.0, abs(float(fx["loss"])))
+    errs = [float((cpu(feats.grad) - fx["g_features"]).abs().max() / fx["g_features"].abs().max())]
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        ref = torch.as_tensor(fx["g." + name], dtype=torch.float32)            # 0-dim parameters (gamma1 / gamma2) come back as scalars
+        errs.append(float((cpu(p.grad) - ref).abs().max() / ref.abs().max().clamp_min(1e-12)))
+    assert max(errs) <= 3e-2 and sorted(errs)[len(errs) // 2] <= 5e-4, (max(errs), sorted(errs)[len(errs) // 2])

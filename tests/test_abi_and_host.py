@@ -43,7 +43,7 @@ def test_no_cpu_fallback():
 
 def test_training_path_needs_the_hip_library_too():
     """The autograd path (training.py) builds the cost volume with the HIP kernels: host tensors are refused, nothing is
-    silently computed by PyTorch instead; the transformer regulariser has no training path and says so."""
+    silently computed by PyTorch instead - with the transformer regulariser as well (its cost volume is the HIP one)."""
     net = StageNet({"base_ch": 8, "depth_type": "ce"}, 4, 3).eval()
     f = torch.zeros(1, 2, 8, 8, 8, requires_grad=True)
     with pytest.raises(_lib.MvsHipError):
@@ -52,7 +52,7 @@ def test_training_path_needs_the_hip_library_too():
         net.train()(f.detach(), torch.zeros(1, 2, 2, 4, 4), torch.ones(1, 4, 8, 8), 1.0)
     tr = StageNet({"base_ch": 8, "depth_type": "ce", "cost_reg_type": ["PureTransformerCostReg"] * 4, "transformer_config": [dict(TRANSFORMER_CFG)]},
                   32, 0).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.MvsHipError):
         tr(torch.zeros(1, 2, 8, 8, 8), torch.zeros(1, 2, 2, 4, 4), torch.ones(1, 32, 8, 8), 1.0)
 
 

@@ -109,3 +109,7 @@ def test_train_kernels(emu):
 
 def test_regnet_train_native(emu):
     P.case_regnet_train_native(emu)
+
+
+def test_train_backward_transformer_golden(emu):
+    P.case_train_backward_transformer_golden(emu)

@@ -199,3 +199,7 @@ def test_train_kernels():
 
 def test_regnet_train_native():
     P.case_regnet_train_native(DEV)
+
+
+def test_train_backward_transformer_golden():
+    P.case_train_backward_transformer_golden(DEV)
