@@ -45,3 +45,62 @@ def test_patch_model_on_the_reference_network(emu):
     r = float(((out["refined_depth"] - ref["refined_depth"]).abs() / ref["refined_depth"].abs()).mean())
     assert r <= 2e-4, r
     assert (out["photometric_confidence"] - ref["photometric_confidence"]).abs().max() <= 5e-3
+
+
+def test_patch_model_trains_like_the_reference_network(emu):
+    """train.py's use: the reference's whole network in .train() mode with its stages swapped by patch_model.  The stage-1 loss
+    (before any argmax-dependent hypothesis scheduling) must give the same gradients for the stage's own parameters AND for the
+    reference's feature extractor upstream of it; the later stages must produce finite gradients for everything."""
+    sys.path.insert(0, REF)
+    try:
+        from models.networks.DINOv2_mvsformer_model import DINOv2MVSNet
+    finally:
+        sys.path.remove(REF)
+    from mvsformerplusplus_amd import patch_model, synth
+    args = json.load(open(os.path.join(REF, "config", "mvsformer++.json")))["arch"]["args"]
+    torch.manual_seed(0)
+    model = DINOv2MVSNet(args).train()
+    synth.randomize_bn_(model, seed=3)
+    patched = patch_model(copy.deepcopy(model))
+    assert all(f.training for f in patched.fusions)
+    H, W, V = 64, 128, 3
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.rand(1, V, 3, H, W, generator=g)
+    cams = synth.make_cameras(V, H, W, baseline=30.0, rot_deg=1.0, seed=2)
+    projs = synth.stage_proj_matrices(cams, 4)
+    dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None]
+    grads = []
+    for m in (model, patched):
+        torch.manual_seed(5)                                          # any stochastic layer of the backbone draws the same numbers
+        out = m(imgs, projs, dv)
+        pre = out["stage1"]["prob_volume_pre"]
+        R = torch.randn(pre.shape, generator=torch.Generator().manual_seed(9))
+        loss = (torch.softmax(pre, 1) * R).sum() + sum(out["stage%d" % s]["prob_volume_pre"].square().mean() for s in (2, 3, 4)) * 0.0
+        loss.backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    ref_g, hip_g = grads
+    assert set(ref_g) == set(hip_g)
+    # parameters whose gradient is analytically zero (a bias in front of a normalisation, a constant added to every logit under
+    # the softmax) hold rounding noise in both models: they are compared on an absolute floor, not relative to themselves
+    top = max(float(gr.abs().max()) for gr in ref_g.values())
+    worst, n_cmp = 0.0, 0
+    for n, gr in ref_g.items():
+        if float(gr.abs().max()) <= 1e-6 * top:
+            assert float(hip_g[n].abs().max()) <= 1e-5 * top, n
+            continue
+        worst = max(worst, float((hip_g[n] - gr).abs().max() / gr.abs().max()))
+        n_cmp += 1
+    if os.environ.get("MVS_TEST_VERBOSE"):
+        errs = sorted(((float((hip_g[n] - gr).abs().max() / gr.abs().max()), n) for n, gr in ref_g.items() if float(gr.abs().max()) > 1e-6 * top), reverse=True)
+        for e, n in errs[:12] + errs[-3:]:
+            print("%.3e  %s" % (e, n))
+    assert n_cmp > 250 and worst <= 2e-3, (n_cmp, worst)             # measured: 7e-5 worst over 284 tensors
+    assert any(n.startswith("fusions.0.cost_reg.attention_layers") for n in ref_g) and any(not n.startswith("fusions.") for n in ref_g)
+    # all four stages in the loss (stages 2-4: the native U-Net training path): every parameter that receives a gradient gets a finite one
+    patched.zero_grad()
+    out = patched(imgs, projs, dv)
+    sum(out["stage%d" % s]["prob_volume_pre"].square().mean() for s in (1, 2, 3, 4)).backward()
+    got = {n: p.grad for n, p in patched.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    for s in (1, 2, 3):
+        assert float(got["fusions.%d.cost_reg.conv1.conv.weight" % s].abs().max()) > 0
