@@ -28,7 +28,7 @@ namespace mvs {
 // LDS atomics).  Four channels at a time, the scatter is accumulated in an LDS image of that window (ds_add_f32) and flushed with
 // one global atomic per non-zero window element - ~8 x fewer global atomics than four per (pixel, plane, channel), which is
 // what bounded the first form of this kernel (335 M global_atomic_add_f32 at 61 G/s = 5.5 ms at 2 x 512 x 640, V = 5, C = 8, D = 4,
-// against 0.11 ms for the forward; with the LDS image: 3.7 ms, 2.6 / 2.0 / 1.9 ms at the three coarser stages).  A tile whose
+// against 0.11 ms for the forward; with the LDS image 3.7 ms, with the forward passes' 2 x 2-block tap sets 1.8 ms).  A tile whose
 // window exceeds the LDS image (steep geometry) scatters straight to global.
 constexpr int BW_DCH = 4;
 constexpr int BW_TILE = 16;
@@ -75,41 +75,40 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_bwd_kernel(const T* _
     const float visv = vis[((size_t)b * (V - 1) + (v - 1)) * HW + p];
     if (tid == 0) { box[0] = 0x7fffffff; box[1] = 0x7fffffff; box[2] = -1; box[3] = -1; }
     __syncthreads();
-    Taps tp[BW_DCH];
+    // tap sets as in the forward passes: one 2 x 2 block of in-bounds source pixels per plane, weights routed to its four slots
+    GTap tp[BW_DCH];
+    const float cx = 0.5f * (float)(W - 1), cy = 0.5f * (float)(H - 1);
 #pragma unroll
     for (int dd = 0; dd < BW_DCH; ++dd) {
         const int d = d0 + (dd < nd ? dd : 0);
-        tp[dd] = make_taps(hm, qx, qy, qz, hyp[((size_t)b * D + d) * HW + p], H, W, half_w, half_h, nullptr);
-        if (!inside || dd >= nd) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tp[dd].w[k] = 0.0f;               // this work-item contributes nothing
+        tp[dd] = make_gtap(hm, qx, qy, qz, hyp[((size_t)b * D + d) * HW + p], H, W, cx, cy);
+        if (!inside || dd >= nd) tp[dd].pk = GL_NONE;                     // this work-item contributes nothing
+        if (tp[dd].pk != GL_NONE) {
+            const int xb = (int)(tp[dd].pk & 0xffffu), yb = (int)(tp[dd].pk >> 16);
+            atomicMin(&box[0], xb); atomicMin(&box[1], yb); atomicMax(&box[2], xb + 1); atomicMax(&box[3], yb + 1);
+        } else {
+            tp[dd].w00 = 0.0f; tp[dd].w01 = 0.0f; tp[dd].w10 = 0.0f; tp[dd].w11 = 0.0f;
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (tp[dd].w[k] != 0.0f) {
-                const int py = tp[dd].off[k] / W, px = tp[dd].off[k] - py * W;
-                atomicMin(&box[0], px); atomicMin(&box[1], py); atomicMax(&box[2], px); atomicMax(&box[3], py);
-            }
     }
     __syncthreads();
     const int xmin = box[0], ymin = box[1], ww = box[2] - xmin + 1, wh = box[3] - ymin + 1;
-    const bool any_tap = box[2] >= 0;
-    const bool use_lds = any_tap && ww * wh <= BW_CAP;
-    // window index of every tap (LDS path)
-    int lpos[BW_DCH][4];
+    const bool use_lds = box[2] >= 0 && ww * wh <= BW_CAP;
+    int goff[BW_DCH], lpos[BW_DCH];                                        // top-left slot: element offset in the source map / in the LDS image
 #pragma unroll
-    for (int dd = 0; dd < BW_DCH; ++dd)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int py = tp[dd].off[k] / W, px = tp[dd].off[k] - py * W;
-            lpos[dd][k] = tp[dd].w[k] != 0.0f ? ((py - ymin) * ww + (px - xmin)) * 4 : 0;
-        }
+    for (int dd = 0; dd < BW_DCH; ++dd) {
+        const int xb = tp[dd].pk == GL_NONE ? 0 : (int)(tp[dd].pk & 0xffffu), yb = tp[dd].pk == GL_NONE ? 0 : (int)(tp[dd].pk >> 16);
+        goff[dd] = yb * W + xb;
+        lpos[dd] = tp[dd].pk == GL_NONE ? 0 : (yb - ymin) * ww + (xb - xmin);
+    }
     float gv = 0.0f;
     float go[BW_DCH], gs[BW_DCH], sim[BW_DCH];
     int cur_g = -1;
     for (int c4 = 0; c4 < C; c4 += 4) {
         if (use_lds) {
-            for (int i = tid; i < ww * wh * 4; i += 256) accw[i] = 0.0f;
+            for (int i = tid; i < ww * wh; i += 256) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accw[j * BW_CAP + i] = 0.0f;
+            }
             __syncthreads();
         }
         for (int j = 0; j < 4 && c4 + j < C; ++j) {
@@ -130,23 +129,26 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_bwd_kernel(const T* _
             }
             const T* sp = src + (size_t)c * HW;
             float* gp = gsrc + (size_t)c * HW;
+            float* lp = accw + j * BW_CAP;                                  // one LDS plane per channel: neighbouring positions, neighbouring banks
             const float rc = to_f32(ref[(size_t)c * HW + p]);
             float gr = 0.0f;
 #pragma unroll
             for (int dd = 0; dd < BW_DCH; ++dd) {
-                float wv = tp[dd].w[0] * to_f32(sp[tp[dd].off[0]]);
-                wv += tp[dd].w[1] * to_f32(sp[tp[dd].off[1]]);
-                wv += tp[dd].w[2] * to_f32(sp[tp[dd].off[2]]);
-                wv += tp[dd].w[3] * to_f32(sp[tp[dd].off[3]]);
+                const T* q = sp + goff[dd];
+                float wv = tp[dd].w00 * to_f32(q[0]);
+                wv += tp[dd].w01 * to_f32(q[1]);
+                wv += tp[dd].w10 * to_f32(q[W]);
+                wv += tp[dd].w11 * to_f32(q[W + 1]);
                 sim[dd] += rc * wv;
                 gr += gs[dd] * wv;
                 const float gw = gs[dd] * rc;
                 if (gw != 0.0f) {
+                    const float w4[4] = {tp[dd].w00, tp[dd].w01, tp[dd].w10, tp[dd].w11};
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (tp[dd].w[k] != 0.0f) {
-                            if (use_lds) atomicAdd(&accw[lpos[dd][k] + j], gw * tp[dd].w[k]);
-                            else atomicAdd(gp + tp[dd].off[k], gw * tp[dd].w[k]);
+                        if (w4[k] != 0.0f) {
+                            if (use_lds) atomicAdd(lp + lpos[dd] + (k >> 1) * ww + (k & 1), gw * w4[k]);
+                            else atomicAdd(gp + goff[dd] + (k >> 1) * W + (k & 1), gw * w4[k]);
                         }
                 }
             }
@@ -154,12 +156,13 @@ __global__ __launch_bounds__(256) void warp_corr_aggregate_bwd_kernel(const T* _
         }
         if (use_lds) {
             __syncthreads();
-            for (int i = tid; i < ww * wh * 4; i += 256) {
-                const float val = accw[i];
-                if (val != 0.0f) {
-                    const int pos = i >> 2, j = i & 3;
-                    const int wy = pos / ww, wx = pos - wy * ww;
-                    atomicAdd(gsrc + (size_t)(c4 + j) * HW + (size_t)(ymin + wy) * W + xmin + wx, val);
+            for (int i = tid; i < ww * wh; i += 256) {
+                const int wy = i / ww, wx = i - wy * ww;
+                float* dst = gsrc + (size_t)c4 * HW + (size_t)(ymin + wy) * W + xmin + wx;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float val = accw[j * BW_CAP + i];
+                    if (val != 0.0f) atomicAdd(dst + (size_t)j * HW, val);
                 }
             }
             __syncthreads();

@@ -32,54 +32,8 @@ constexpr int GL_CAP = MVS_GL_CAP;   // window capacity in source positions: LDS
 constexpr int GL_XALIGN = 8;       // window x origin / width granularity in pixels (32 B of fp32, 16 B of bf16)
 constexpr int GL_DCH = 4;          // depth planes per work-item
 constexpr int GL_TH = 4;           // tile height in pixels
-constexpr unsigned GL_NONE = 0xffffffffu;
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-// Bilinear tap set as ONE 2x2 block of in-bounds source pixels: (xb, yb) = top-left corner clamped to
-// [0, W-2] x [0, H-2], with the four bilinear weights routed to whichever block slot each valid tap landed in and zero
-// for taps outside the image (ATen grid_sampler_2d, zeros padding).  pk = (yb << 16) | xb, GL_NONE when no tap is
-// inside the image.  The sample position is the projected pixel itself: the reference's normalise (warping.py:94-95)
-// and grid_sample's un-normalise cancel up to fp32 rounding (validated against the reference).
-struct GTap {
-    unsigned pk;
-    float w00, w01, w10, w11;
-};
-
-__device__ __forceinline__ GTap make_gtap(const Homography& hm, float qx, float qy, float qz, float depth, int H, int W, float cx,
-                                          float cy) {
-    const float px = qx * depth + hm.t[0];                     // warping.py:90-92
-    const float py = qy * depth + hm.t[1];
-    const float pz = qz * depth + hm.t[2];
-    const float zz = pz + 1e-6f;                               // warping.py:93
-    float r = __builtin_amdgcn_rcpf(zz);
-    r = fmaf(fmaf(-zz, r, 1.0f), r, r);                        // one Newton step: <= 1 ulp
-    const float ix = px * r, iy = py * r;
-    GTap tp;
-    // -1 < ix < W and -1 < iy < H (at least one tap column and row inside the image); false for NaN / inf
-    const bool sane = (fabsf(ix - cx) < cx + 1.0f) && (fabsf(iy - cy) < cy + 1.0f);
-    if (!sane) {
-        tp.pk = GL_NONE; tp.w00 = 0.0f; tp.w01 = 0.0f; tp.w10 = 0.0f; tp.w11 = 0.0f;
-        return tp;
-    }
-    const float fx0 = floorf(ix), fy0 = floorf(iy);
-    const int x0 = (int)fx0, y0 = (int)fy0;                    // in [-1, W-1] x [-1, H-1]
-    const float wx1 = ix - fx0, wy1 = iy - fy0;
-    const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
-    int xb = x0, yb = y0;
-    float wa = wx0, wb = wx1, wt = wy0, wd = wy1;             // weights of column xb, xb + 1, row yb, yb + 1
-    if ((unsigned)x0 > (unsigned)(W - 2) || (unsigned)y0 > (unsigned)(H - 2)) {   // rare: the 2x2 block touches the image border
-        xb = x0 < 0 ? 0 : (x0 > W - 2 ? W - 2 : x0);
-        yb = y0 < 0 ? 0 : (y0 > H - 2 ? H - 2 : y0);
-        wa = x0 < 0 ? wx1 : (x0 > W - 2 ? 0.0f : wx0);
-        wb = x0 < 0 ? 0.0f : (x0 > W - 2 ? wx0 : wx1);
-        wt = y0 < 0 ? wy1 : (y0 > H - 2 ? 0.0f : wy0);
-        wd = y0 < 0 ? 0.0f : (y0 > H - 2 ? wy0 : wy1);
-    }
-    tp.pk = ((unsigned)yb << 16) | (unsigned)xb;
-    tp.w00 = wa * wt; tp.w01 = wb * wt; tp.w10 = wa * wd; tp.w11 = wb * wd;
-    return tp;
-}
 
 __device__ __forceinline__ u16x2 gl_as_vec(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned gl_as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
