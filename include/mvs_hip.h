@@ -139,7 +139,9 @@ int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* 
  * Channel-last fp32 [N voxels][C], C in {8,16,32,64}.  The forward convolutions and the DATA gradients of the training path are
  * mvs_conv3d_bn_relu_fwd (relu = 0, zero bias) / mvs_deconv3d_linear_fwd with un-folded, re-packed weights (training.py).
  *   mvs_bn_stats       sums[2C] (double) = per-channel [sum x | sum x^2]                       nn.BatchNorm3d, training=True
- *   mvs_bn_finalize    mean / biased var / 1/sqrt(var+eps) from sums and the voxel count (after an optional SyncBN all-reduce)
+ *   mvs_bn_finalize    mean / biased var / 1/sqrt(var+eps) from sums and the voxel count (after an optional SyncBN all-reduce);
+ *                      running_mean / running_var != NULL: nn.BatchNorm's momentum step (unbiased variance) in the same launch;
+ *                      mvs_bn_running_update repeats that step alone
  *   mvs_bn_relu_apply  y = relu((z-mean)*invstd*gamma+beta) [+ skip]                            module.py:120-125, 402-405
  *   mvs_bn_relu_bwd    phase 0: sums[2C] = [d beta | d gamma] of dy through the ReLU mask; phase 1: dz (count = voxels of all
  *                      ranks, use_batch_stats = 0 for eval-mode BatchNorm inside a training graph)
@@ -149,12 +151,23 @@ int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* 
 int mvs_deconv3d_linear_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout,
                             int D, int H, int W, int sd, int precision, void* stream);
 int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C, void* stream);
-int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, int C, void* stream);
+int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, float* running_mean,
+                    float* running_var, float momentum, int C, void* stream);
+int mvs_bn_running_update(const float* mean, const float* var, double count, float momentum, float* running_mean,
+                          float* running_var, int C, void* stream);
 int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* skip_cl, float* y_cl, long long N, int C, int relu, void* stream);
 int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, double* sums, double count, float* dz_cl, long long N, int C, int relu,
                     int use_batch_stats, int phase, void* stream);
+/* MFMA weight packing on the device (bit-identical to packing.pack_conv_weights_bf16x3 / pack_deconv_weights_bf16x3; used by the
+ * training path, which re-packs every un-folded weight each iteration).  *_elems = number of bf16 elements of the packed tensor
+ * (-1: unsupported shape).  w: Conv3d [cout][cin][ntap] (tflip = 1: read as [cin][cout] with reversed taps = the data-gradient form
+ * of a stride-1 convolution) / ConvTranspose3d [cin][cout][27].                                                               */
+long long mvs_pack_conv_weights_elems(int cout, int cin, int ntap, int ch);
+int mvs_pack_conv_weights(const float* w, void* packed_bf16, int cout, int cin, int ntap, int ch, int tflip, void* stream);
+long long mvs_pack_deconv_weights_elems(int cin, int cout, int sd);
+int mvs_pack_deconv_weights(const float* w, void* packed_bf16, int cin, int cout, int sd, void* stream);
 int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int kd,
                      int sd, int sh, int sw, void* stream);
 

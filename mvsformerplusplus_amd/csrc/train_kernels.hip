@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     if (tid < 2 * C) atomicAdd(&sums[tid], part[tid]);
 }
 
-// mean / biased variance / 1 / sqrt(var + eps) from the sums (count = voxels summed, possibly over several ranks)
+// mean / biased variance / 1 / sqrt(var + eps) from the sums (count = voxels summed, possibly over several ranks); with
+// running_mean != NULL also nn.BatchNorm's momentum step of the running statistics (unbiased variance)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float* __restrict__ mean, float* __restrict__ var,
-                                   float* __restrict__ invstd, int C) {
+                                   float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, int C) {
     const int c = (int)threadIdx.x;
     if (c >= C) return;
     const double m = sums[c] / count;
@@ -51,6 +53,21 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
     mean[c] = (float)m;
     var[c] = (float)v;
     invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+    if (running_mean != nullptr) {
+        const float unbiased = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// the momentum step alone (the reference's checkpoint recomputation repeats it in the backward pass)
+__global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ var, double count, float momentum,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var, int C) {
+    const int c = (int)threadIdx.x;
+    if (c >= C) return;
+    const float unbiased = (float)((double)var[c] * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
 }
 
 // y = relu((z - mean) * invstd * gamma + beta) [+ skip]        (relu = 0: no clamp)
@@ -240,6 +257,72 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight packing on the device (the training path re-packs every weight twice per iteration - forward form and data-gradient
+// form; as PyTorch ops that was ~12 small launches per layer and direction).  Same layouts, bit for bit, as packing.py:
+//   conv   packed[pass][step][mb][hi|lo][g][j][e] = W'[16mb + j][pass*CH + 8oc + e][tap], (tap, oc) = divmod(4 step + g, CH / 8)
+//          tflip = 1: W'[co][ci][tap] = W[ci][co][ntap - 1 - tap]  (the data-gradient form of a stride-1 convolution)
+//   deconv per parity class (pair of classes for Cout = 8), packing.pack_deconv_weights_bf16x3
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_split_bf16(float v, uint16_t* hi, uint16_t* lo) {
+    const uint16_t h = from_f32<uint16_t>(v);
+    *hi = h;
+    *lo = from_f32<uint16_t>(v - to_f32(h));
+}
+
+__global__ __launch_bounds__(256) void pack_conv_bf16x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin, int ntap,
+                                                               int ch, int tflip, int mrep, int nstep, int total) {
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 7, j = (idx >> 3) & 15, g = (idx >> 7) & 3;
+    int r = idx >> 9;
+    const int mb = r % mrep;
+    r /= mrep;
+    const int step = r % nstep, pass = r / nstep;
+    const int opt = ch / 8, o = 4 * step + g, tap = o / opt, oc = o - tap * opt;
+    const int co = 16 * mb + j, ci = pass * ch + 8 * oc + e;
+    float v = 0.0f;
+    if (tap < ntap && co < cout) v = tflip ? w[((size_t)ci * cout + co) * ntap + (ntap - 1 - tap)] : w[((size_t)co * cin + ci) * ntap + tap];
+    uint16_t* base = out + (((size_t)(pass * nstep + step) * mrep + mb) * 2) * 512 + (g * 16 + j) * 8 + e;
+    store_split_bf16(v, base, base + 512);
+}
+
+struct DeconvPackPlan {
+    int nchunk;
+    int cls[8], ntap[8], nst[8], off[9];          // off in units of 1024 * mrep elements (one step of one chunk)
+};
+
+__global__ __launch_bounds__(256) void pack_deconv_bf16x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cin, int cout, int sd,
+                                                                 int mrep, DeconvPackPlan plan, int total) {
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 7, j = (idx >> 3) & 15, g = (idx >> 7) & 3;
+    int r = idx >> 9;
+    const int mb = r % mrep, gstep = r / mrep;                              // step index over all chunks
+    int c = 0;
+    while (c + 1 < plan.nchunk && gstep >= plan.off[c + 1]) ++c;
+    const int step = gstep - plan.off[c];
+    const int opt = cin / 8, o = 4 * step + g, ti = o / opt, oc = o - ti * opt;
+    const int cls = plan.cls[c];
+    const int pw = cls & 1, ph = (cls >> 1) & 1, pd = (sd == 2) ? (cls >> 2) : 0;
+    const int nkw = pw ? 2 : 1, nkh = ph ? 2 : 1;
+    const int a_w = ti % nkw, a_h = (ti / nkw) % nkh, a_d = ti / (nkw * nkh);
+    const int kd = (sd == 2) ? (pd ? 2 * a_d : 1) : a_d, kh = ph ? 2 * a_h : 1, kw = pw ? 2 * a_w : 1;
+    const int tap = (kd * 3 + kh) * 3 + kw;
+    const int cig = 8 * oc + e;
+    float v = 0.0f;
+    if (ti < plan.ntap[c]) {
+        if (cout == 8) {                                                   // rows 8-15: pw = 1 taps; rows 0-7: the pw = 0 tap sharing input mx
+            if (j >= 8) v = w[((size_t)cig * 8 + (j - 8)) * 27 + tap];
+            else if (kw == 2) v = w[((size_t)cig * 8 + j) * 27 + tap - 1];
+        } else if (16 * mb + j < cout) {
+            v = w[((size_t)cig * cout + 16 * mb + j) * 27 + tap];
+        }
+    }
+    uint16_t* base = out + (((size_t)gstep * mrep + mb) * 2) * 512 + (g * 16 + j) * 8 + e;
+    store_split_bf16(v, base, base + 512);
+}
+
 template <class Cfg>
 static int launch_wgrad(const float* a, const float* g, float* dw, int B, int D, int H, int W, int OD, int OH, int OW, int CA, int CB, hipStream_t st) {
     const int tx = (int)ceil_div(OW, 16), ty = (int)ceil_div(OH, Cfg::TH), tz = (int)ceil_div(OD, Cfg::TD);
@@ -283,10 +366,22 @@ extern "C" int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C,
     return check_launch("bn_stats_kernel");
 }
 
-extern "C" int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, int C, void* stream) {
-    if (!sums || !mean || !var || !invstd || count < 1.0 || !bn_shape_ok("mvs_bn_finalize", 1, C)) { set_error("mvs_bn_finalize: bad arguments"); return MVS_ERR_ARG; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, count, eps, mean, var, invstd, C);
+extern "C" int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, float* running_mean,
+                               float* running_var, float momentum, int C, void* stream) {
+    if (!sums || !mean || !var || !invstd || count < 1.0 || !bn_shape_ok("mvs_bn_finalize", 1, C) || ((running_mean == nullptr) != (running_var == nullptr))) {
+        set_error("mvs_bn_finalize: bad arguments");
+        return MVS_ERR_ARG;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, count, eps, mean, var, invstd, running_mean, running_var,
+                       momentum, C);
     return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int mvs_bn_running_update(const float* mean, const float* var, double count, float momentum, float* running_mean, float* running_var, int C,
+                                     void* stream) {
+    if (!mean || !var || !running_mean || !running_var || count < 1.0 || !bn_shape_ok("mvs_bn_running_update", 1, C)) { set_error("mvs_bn_running_update: bad arguments"); return MVS_ERR_ARG; }
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mean, var, count, momentum, running_mean, running_var, C);
+    return check_launch("bn_running_update_kernel");
 }
 
 extern "C" int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* skip_cl,
@@ -311,6 +406,59 @@ extern "C" int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const floa
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4, C, 0)), dim3(256), 0, st, dy_cl, z_cl, mean, invstd, gamma, beta, sums, count, dz_cl, n4, C, relu,
                        use_batch_stats);
     return check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" long long mvs_pack_conv_weights_elems(int cout, int cin, int ntap, int ch) {
+    if (cout < 1 || cin < 1 || ntap < 1 || ch < 8 || (ch % 8) || (cin % ch)) return -1;
+    const int opt = ch / 8, nstep = (ntap * opt + 3) / 4, mrep = (cout + 15) / 16;
+    return (long long)(cin / ch) * nstep * mrep * 1024;
+}
+
+extern "C" int mvs_pack_conv_weights(const float* w, void* packed_bf16, int cout, int cin, int ntap, int ch, int tflip, void* stream) {
+    const long long total2 = mvs_pack_conv_weights_elems(cout, cin, ntap, ch);
+    if (!w || !packed_bf16 || total2 < 0) { set_error("mvs_pack_conv_weights: bad arguments"); return MVS_ERR_ARG; }
+    const int opt = ch / 8, nstep = (ntap * opt + 3) / 4, mrep = (cout + 15) / 16, total = (int)(total2 / 2);
+    hipLaunchKernelGGL(pack_conv_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, static_cast<uint16_t*>(packed_bf16), cout,
+                       cin, ntap, ch, tflip ? 1 : 0, mrep, nstep, total);
+    return check_launch("pack_conv_bf16x3_kernel");
+}
+
+static bool deconv_plan(int cin, int cout, int sd, DeconvPackPlan* plan, int* mrep, long long* elems) {
+    if (cin < 8 || (cin % 8) || cout < 1 || (sd != 1 && sd != 2)) return false;
+    const int opt = cin / 8, ncls = (sd == 2 ? 2 : 1) * 4;
+    *mrep = (cout + 15) / 16;
+    plan->nchunk = 0;
+    plan->off[0] = 0;
+    for (int cls = 0; cls < ncls; ++cls) {
+        if (cout == 8 && !(cls & 1)) continue;                               // Cout = 8: one chunk per (pd, ph) pair, the taps of its pw = 1 class
+        const int pw = cls & 1, ph = (cls >> 1) & 1, pd = (sd == 2) ? (cls >> 2) : 0;
+        const int ntap = ((sd == 2) ? (pd ? 2 : 1) : 3) * (ph ? 2 : 1) * (pw ? 2 : 1);
+        const int c = plan->nchunk++;
+        plan->cls[c] = cls;
+        plan->ntap[c] = ntap;
+        plan->nst[c] = (ntap * opt + 3) / 4;
+        plan->off[c + 1] = plan->off[c] + plan->nst[c];
+    }
+    *elems = (long long)plan->off[plan->nchunk] * (*mrep) * 1024;
+    return true;
+}
+
+extern "C" long long mvs_pack_deconv_weights_elems(int cin, int cout, int sd) {
+    DeconvPackPlan plan;
+    int mrep;
+    long long elems;
+    return deconv_plan(cin, cout, sd, &plan, &mrep, &elems) ? elems : -1;
+}
+
+extern "C" int mvs_pack_deconv_weights(const float* w, void* packed_bf16, int cin, int cout, int sd, void* stream) {
+    DeconvPackPlan plan;
+    int mrep;
+    long long elems;
+    if (!w || !packed_bf16 || !deconv_plan(cin, cout, sd, &plan, &mrep, &elems)) { set_error("mvs_pack_deconv_weights: bad arguments"); return MVS_ERR_ARG; }
+    const int total = (int)(elems / 2);
+    hipLaunchKernelGGL(pack_deconv_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, static_cast<uint16_t*>(packed_bf16), cin,
+                       cout, sd, mrep, plan, total);
+    return check_launch("pack_deconv_bf16x3_kernel");
 }
 
 extern "C" int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw, int B, int CA, int CB, int D, int H, int W, int kd, int sd, int sh,

@@ -252,11 +252,19 @@ def bn_stats(x_cl: torch.Tensor) -> torch.Tensor:
     return sums
 
 
-def bn_finalize(sums: torch.Tensor, count: float, eps: float):
+def bn_finalize(sums: torch.Tensor, count: float, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
+    """-> (mean, biased var, invstd); with running statistics given, their momentum step happens in the same launch."""
     Cc = sums.numel() // 2
-    mean, var, invstd = (torch.empty(Cc, dtype=torch.float32, device=sums.device) for _ in range(3))
-    check(lib().mvs_bn_finalize(ptr(sums), float(count), float(eps), ptr(mean), ptr(var), ptr(invstd), Cc, stream_of(sums)), "mvs_bn_finalize")
+    buf = torch.empty(3, Cc, dtype=torch.float32, device=sums.device)
+    mean, var, invstd = buf[0], buf[1], buf[2]
+    check(lib().mvs_bn_finalize(ptr(sums), float(count), float(eps), ptr(mean), ptr(var), ptr(invstd), ptr(running_mean), ptr(running_var),
+                                float(momentum), Cc, stream_of(sums)), "mvs_bn_finalize")
     return mean, var, invstd
+
+
+def bn_running_update(mean, var, count: float, momentum: float, running_mean, running_var) -> None:
+    check(lib().mvs_bn_running_update(ptr(mean), ptr(var), float(count), float(momentum), ptr(running_mean), ptr(running_var), mean.numel(),
+                                      stream_of(mean)), "mvs_bn_running_update")
 
 
 def bn_relu_apply(z_cl, mean, invstd, gamma, beta, skip_cl=None, relu=True) -> torch.Tensor:
@@ -282,6 +290,32 @@ def bn_relu_bwd_apply(dy_cl, z_cl, mean, invstd, gamma, beta, sums, count: float
     check(lib().mvs_bn_relu_bwd(ptr(dy_cl), ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums), float(count), ptr(dz),
                                 z_cl.numel() // Cc, Cc, 1 if relu else 0, 1 if use_batch_stats else 0, 1, stream_of(z_cl)), "mvs_bn_relu_bwd")
     return dz
+
+
+def pack_conv_weights_device(w: torch.Tensor, ch: int, tflip: bool = False) -> torch.Tensor:
+    """packing.pack_conv_weights_bf16x3 in one launch on the weight's device.  w [Cout, Cin, kd, 3, 3]; tflip: the packed weight is
+    W'[co][ci][tap] = w[ci][co][reversed tap] (w then has shape [Cin', Cout'] = [W' columns, W' rows])."""
+    w = _f32c(w)
+    cout, cin = (w.shape[1], w.shape[0]) if tflip else (w.shape[0], w.shape[1])
+    ntap = w.shape[2] * w.shape[3] * w.shape[4]
+    n = lib().mvs_pack_conv_weights_elems(cout, cin, ntap, ch)
+    if n < 0:
+        raise _lib.MvsHipError("pack_conv_weights_device: unsupported shape %s / chunk %d" % (tuple(w.shape), ch))
+    out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    check(lib().mvs_pack_conv_weights(ptr(w), ptr(out), cout, cin, ntap, ch, 1 if tflip else 0, stream_of(w)), "mvs_pack_conv_weights")
+    return out
+
+
+def pack_deconv_weights_device(w: torch.Tensor, sd: int) -> torch.Tensor:
+    """packing.pack_deconv_weights_bf16x3 in one launch.  w [Cin, Cout, 3, 3, 3]."""
+    w = _f32c(w)
+    cin, cout = w.shape[:2]
+    n = lib().mvs_pack_deconv_weights_elems(cin, cout, sd)
+    if n < 0:
+        raise _lib.MvsHipError("pack_deconv_weights_device: unsupported shape %s" % (tuple(w.shape),))
+    out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    check(lib().mvs_pack_deconv_weights(ptr(w), ptr(out), cin, cout, sd, stream_of(w)), "mvs_pack_deconv_weights")
+    return out
 
 
 def conv3d_wgrad(a_cl: torch.Tensor, g_cl: torch.Tensor, stride: Tuple[int, int, int], kd: int = 3) -> torch.Tensor:

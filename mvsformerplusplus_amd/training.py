@@ -20,7 +20,7 @@ What is native and what is not, stated plainly:
 * still PyTorch-ROCm autograd, all of it element-wise or tiny: the visibility CNN's 1x1 Conv2d + sigmoid, CostRegNet3D's 1x1x1 `prob`,
   the softmax / argmax / regression head, the running-statistics momentum update.  ``MVS_TRAIN_REGNET=torch`` routes every conv /
   BatchNorm layer through autograd ops instead (the first form of this path; on the MI355X image MIOpen picks naive kernels for
-  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 15.5 ms natively).
+  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 12.6 ms natively).
 
 The reference differentiates neither the sampling grid (built under ``torch.no_grad()``, warping.py:80) nor the entropy
 (``sim_vol.detach()``, cost_volume.py:90); this path follows it: no gradient reaches the depth hypotheses, the cameras or - via
@@ -81,12 +81,15 @@ def _stride3(conv):
 
 
 
-def _conv_fwd(a_cl, w, stride, transposed, zero_bias, kd=3):
+def _conv_fwd(a_cl, w, stride, transposed, zero_bias, kd=3, tflip=False):
     """Linear (no bias / BatchNorm / ReLU) Conv3d(k (kd,3,3), 'same' padding, stride) or ConvTranspose3d(k3, stride (sd,2,2)) of a
     channel-last tensor on the split-bf16 MFMA kernels, from the un-folded weight tensor."""
     if transposed:
-        return ops.deconv3d_linear(a_cl, packing.pack_deconv_weights_bf16x3(w, stride[0]), zero_bias, w.shape[1], stride[0], _PREC)
-    wp = packing.pack_conv_weights_bf16x3(w, packing.conv_chunk(w.shape[1], stride))
+        return ops.deconv3d_linear(a_cl, ops.pack_deconv_weights_device(w, stride[0]), zero_bias, w.shape[1], stride[0], _PREC)
+    if tflip:                                             # the convolution with w's taps reversed and its channel axes exchanged
+        wp = ops.pack_conv_weights_device(w, packing.conv_chunk(w.shape[0], stride), tflip=True)
+        return ops.conv3d_bn_relu(a_cl, wp, zero_bias, w.shape[1], kd, stride, False, _PREC)
+    wp = ops.pack_conv_weights_device(w, packing.conv_chunk(w.shape[1], stride))
     return ops.conv3d_bn_relu(a_cl, wp, zero_bias, w.shape[0], kd, stride, False, _PREC)
 
 
@@ -102,7 +105,7 @@ def _conv_bwd(a_in, dz, w, stride, transposed, zero_bias, need_da=True):
     if not need_da:
         return dw, None
     if stride == (1, 1, 1):
-        return dw, _conv_fwd(dz, w.transpose(0, 1).flip(2, 3, 4).contiguous(), stride, False, zero_bias)
+        return dw, _conv_fwd(dz, w, stride, False, zero_bias, tflip=True)
     if any(d % s for d, s in zip(a_in.shape[1:4], stride)):
         raise _lib.MvsHipError("training: strided convolutions need even input sizes (got %s)" % (tuple(a_in.shape[1:4]),))
     return dw, _conv_fwd(dz, w, stride, True, zero_bias)
@@ -136,9 +139,14 @@ class _BnState:
                 torch.distributed.all_reduce(sums, group=self.group)
                 torch.distributed.all_reduce(cnt, group=self.group)
                 self.count = float(cnt.item())
-            self.mean, self.var, self.invstd = ops.bn_finalize(sums, self.count, bn.eps)
             self.bn = bn if (bn.training and bn.running_mean is not None) else None
-            self.update_running_stats()
+            if self.bn is not None and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous():
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
+                self.mean, self.var, self.invstd = ops.bn_finalize(sums, self.count, bn.eps, bn.running_mean, bn.running_var, self._momentum())
+            else:
+                self.mean, self.var, self.invstd = ops.bn_finalize(sums, self.count, bn.eps)
+                self.update_running_stats()
         else:
             self.bn = None
             self.mean = bn.running_mean.detach().float().contiguous()
@@ -153,9 +161,16 @@ class _BnState:
             return
         with torch.no_grad():
             bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1.0 - m).add_(self.mean, alpha=m)
-            bn.running_var.mul_(1.0 - m).add_(self.var * (self.count / max(self.count - 1.0, 1.0)), alpha=m)
+            if bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous():
+                ops.bn_running_update(self.mean, self.var, self.count, self._momentum(), bn.running_mean, bn.running_var)
+            else:
+                m = self._momentum()
+                bn.running_mean.mul_(1.0 - m).add_(self.mean, alpha=m)
+                bn.running_var.mul_(1.0 - m).add_(self.var * (self.count / max(self.count - 1.0, 1.0)), alpha=m)
+
+    def _momentum(self) -> float:
+        bn = self.bn
+        return float(bn.momentum) if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
 
 
 class RegNetTrain(torch.autograd.Function):
@@ -320,7 +335,7 @@ class VisTrain(torch.autograd.Function):
             dw2 = ops.conv3d_wgrad(a_in, dz, (1, 1, 1), kd=1)
             cin = 1 if i == 0 else w3.shape[1]
             grads[3 * i] = dw2[:, :cin, 0].contiguous()
-            g = _conv_fwd(dz, w3.transpose(0, 1).flip(2, 3, 4).contiguous(), (1, 1, 1), False, zero_bias) if i > 0 else None
+            g = _conv_fwd(dz, w3, (1, 1, 1), False, zero_bias, tflip=True) if i > 0 else None
         return (None, None) + tuple(grads)
 
 
@@ -336,7 +351,7 @@ class Prob3Train(torch.autograd.Function):
         w16[0] = w[0]
         zero_bias = torch.zeros(64, dtype=torch.float32, device=f.device)
         ctx.save_for_backward(f, w)
-        return ops.conv3d_logits(f, packing.pack_conv_weights_bf16x3(w16, 8), zero_bias, _PREC)
+        return ops.conv3d_logits(f, ops.pack_conv_weights_device(w16, 8), zero_bias, _PREC)
 
     @staticmethod
     def backward(ctx, grad_logits):

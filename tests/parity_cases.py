@@ -866,6 +866,30 @@ def case_train_kernels(device):
     assert (cpu(dwt) - wt.grad).abs().max() <= 2e-5 * float(wt.grad.abs().max()) + 1e-5
 
 
+def case_device_packing(device):
+    """The packing kernels against packing.py, bit for bit, for every layer shape of the U-Nets and the visibility CNN, plus the
+    flipped / transposed form used for data gradients."""
+    g = torch.Generator().manual_seed(4)
+    for co, ci, kd, ch in ((16, 8, 3, 8), (16, 16, 3, 16), (32, 16, 3, 8), (32, 32, 3, 16), (64, 32, 3, 8), (64, 64, 3, 16), (16, 16, 1, 16), (8, 16, 1, 16)):
+        w = torch.randn(co, ci, kd, 3, 3, generator=g)
+        ref = packing.pack_conv_weights_bf16x3(w, ch)
+        got = cpu(ops.pack_conv_weights_device(dev(w, device), ch))
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (co, ci, kd)
+        if co == ci or kd == 3:
+            wt = w.transpose(0, 1).flip(2, 3, 4).contiguous()
+            cht = packing.conv_chunk(co, (1, 1, 1)) if kd == 3 else 16
+            if co % cht == 0:
+                ref_t = packing.pack_conv_weights_bf16x3(wt, cht)
+                got_t = cpu(ops.pack_conv_weights_device(dev(w, device), cht, tflip=True))
+                assert torch.equal(got_t.view(torch.int16), ref_t.view(torch.int16)), ("tflip", co, ci, kd)
+    for ci, co in ((64, 32), (32, 16), (16, 8)):
+        for sd in (1, 2):
+            w = torch.randn(ci, co, 3, 3, 3, generator=g)
+            ref = packing.pack_deconv_weights_bf16x3(w, sd)
+            got = cpu(ops.pack_deconv_weights_device(dev(w, device), sd))
+            assert got.numel() == ref.numel() and torch.equal(got.view(torch.int16), ref.view(torch.int16)), (ci, co, sd)
+
+
 def case_regnet_train_native(device):
     """RegNetTrain (forward convolutions and data gradients on the split-bf16 MFMA kernels, weight gradients on fp32 MFMA, BatchNorm
     kernels) against PyTorch autograd through the same modules, CostRegNet (stride 2,2,2) and CostRegNet3D (1,2,2), train mode."""

@@ -113,3 +113,7 @@ def test_regnet_train_native(emu):
 
 def test_train_backward_transformer_golden(emu):
     P.case_train_backward_transformer_golden(emu)
+
+
+def test_device_packing(emu):
+    P.case_device_packing(emu)

@@ -203,3 +203,7 @@ def test_regnet_train_native():
 
 def test_train_backward_transformer_golden():
     P.case_train_backward_transformer_golden(DEV)
+
+
+def test_device_packing():
+    P.case_device_packing(DEV)
