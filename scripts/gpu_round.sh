@@ -48,6 +48,9 @@ echo "== rocprofv3 kernel trace (same bench command, 5 steps) =="
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof.log 2>&1
 tail -2 $ROOT/$OUT/rocprof.log
+# the same with ONE stream: kernels of different reference views do not overlap, so the average durations are the launches' own
+# (what bench.py's HIP-event table and its `roofline` object measure); with 3 streams co-running kernels stretch each other
+timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --streams 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof1.log 2>&1
 echo "== PMC: HBM traffic of every kernel (separate passes) =="
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile > $ROOT/$OUT/pmc_f.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile > $ROOT/$OUT/pmc_w.log 2>&1
@@ -57,7 +60,9 @@ python scripts/pmc_traffic.py $OUT/pmc_$TAG $OUT/profiles_$TAG/pmc_traffic.json 
 DB=$(find $OUT/prof_$TAG -name '*.db' | head -1)
 if [ -n "$DB" ]; then
   python scripts/rocpd_stats.py $DB > $OUT/profiles_$TAG/${TAG}_kernel_stats_whole_process.csv
-  python scripts/rocpd_stats.py $DB "mvs::" > $OUT/profiles_$TAG/${TAG}_kernel_stats.csv
+  python scripts/rocpd_stats.py $DB "mvs::" > $OUT/profiles_$TAG/${TAG}_kernel_stats_3streams.csv
+  DB1=$(find $OUT/prof1_$TAG -name '*.db' | head -1)
+  python scripts/rocpd_stats.py $DB1 "mvs::" > $OUT/profiles_$TAG/${TAG}_kernel_stats.csv
   head -14 $OUT/profiles_$TAG/${TAG}_kernel_stats.csv | cut -c1-150
 else
   echo "no rocpd database under $OUT/prof_$TAG"; find $OUT/prof_$TAG | head
@@ -68,5 +73,5 @@ cp $OUT/bench_n2.json $OUT/profiles_$TAG/${TAG}_bench_n2_flow_check_one_gpu_gloo
 cp $OUT/bench_tiled_bf16.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_tiled_bf16.json
 grep -v "amdgpu.ids" $OUT/bench.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table.txt
 grep -v "amdgpu.ids" $OUT/bench_shipped.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_shipped.txt
-rm -rf $OUT/prof_$TAG $OUT/pmc_$TAG
+rm -rf $OUT/prof_$TAG $OUT/prof1_$TAG $OUT/pmc_$TAG
 ls -la $OUT/profiles_$TAG
