@@ -778,6 +778,15 @@ def case_train_path_properties(device):
     assert rel_l1(cpu(out["depth"]), cpu(ref["depth"])) <= 2e-5
     out["prob_volume_pre"].square().mean().backward()
     assert float(fg.grad[:, 0].abs().sum()) > 0 and float(fg.grad[:, 1:].abs().sum()) > 0
+    # half-precision features (train.py under AMP hands fp16 / bf16 feature maps over): gradient comes back in the features' dtype and
+    # equals the fp32 run's on the rounded inputs
+    for dt in (torch.bfloat16, torch.float16):
+        fh = feats.to(dt).requires_grad_(True)
+        net(fh, proj, hyp, 1.0)["prob_volume_pre"].square().mean().backward()
+        f32 = feats.to(dt).float().requires_grad_(True)
+        net(f32, proj, hyp, 1.0)["prob_volume_pre"].square().mean().backward()
+        assert fh.grad.dtype == dt and torch.isfinite(fh.grad).all()
+        assert (fh.grad.float() - f32.grad).abs().max() <= 1e-2 * f32.grad.abs().max() + 1e-6, dt
     # the 4-stage cascade trains end to end: every stage's parameters and every stage's features receive a gradient
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
     fx = load_golden("f4_cascade.npz")
