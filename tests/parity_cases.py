@@ -804,20 +804,6 @@ def case_train_path_properties(device):
         assert torch.isfinite(feats["stage%d" % s].grad).all() and float(feats["stage%d" % s].grad.abs().sum()) > 0, s
     for name, p in head.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
-    # ... and so does the shipped mix (stage-1 transformer + Frustoconical PE through PyTorch autograd, the rest native)
-    f9 = load_golden("f9_cascade_shipped.npz")
-    sargs = dict(args, use_pe3d=True, cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(f9)])
-    shead = CascadeDepthHead(sargs)
-    for s in range(4):
-        shead.fusions[s].load_state_dict(golden_weights(f9, "w%d." % (s + 1)), strict=True)
-    shead = shead.to(device).train()
-    for t in feats.values():
-        t.grad = None
-    out = shead(feats, projs, dev(fx["depth_values"], device))
-    sum(out["stage%d" % s]["prob_volume_pre"].square().mean() for s in range(1, 5)).backward()
-    for name, p in shead.named_parameters():
-        assert p.grad is not None and torch.isfinite(p.grad).all(), name
-    assert float(feats["stage1"].grad.abs().sum()) > 0
 
 
 def case_train_kernels(device):
