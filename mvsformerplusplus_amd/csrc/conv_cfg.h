@@ -53,6 +53,9 @@ struct DeconvCfg {
 // 2-D (visibility CNN): 1x16x16 outputs.  8->16 stride 1 is CostRegNet's 3x3x3 `prob` head (one real output row of 16).  Deconvs 16->8 and 32->16 at (1,2,2): 2x4 input rows (0.376 -> 0.340 ms).
 // The (2,2,2) layers only run on the small stage-1/2 volumes (tens of blocks on 256 CUs): 2x2x16 tiles double the
 // number of blocks and halve each block's serial work (0.338 -> 0.257 ms for the six layers).
+#ifndef MVS_T6464_TD
+#define MVS_T6464_TD 2
+#endif
 #ifndef MVS_HEAD_TD
 #define MVS_HEAD_TD 2
 #define MVS_HEAD_TH 4
@@ -64,7 +67,7 @@ struct DeconvCfg {
 #define MVS_CONV_TABLE(X)            \
     X(16, 16, 3, 1, 1, 1, 4, 4, 16)  \
     X(32, 32, 3, 1, 1, 1, 4, 4, 16)  \
-    X(64, 64, 3, 1, 1, 1, 2, 4, 16)  \
+    X(64, 64, 3, 1, 1, 1, MVS_T6464_TD, 4, 16)  \
     X(8, 16, 3, 1, 1, 1, MVS_HEAD_TD, MVS_HEAD_TH, 8)    \
     X(8, 16, 3, 2, 2, 2, 2, 2, 8)    \
     X(16, 32, 3, 2, 2, 2, 2, 2, 8)   \
