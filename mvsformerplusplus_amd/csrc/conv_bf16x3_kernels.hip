@@ -23,6 +23,12 @@
 #ifndef MVS_WPF
 #define MVS_WPF 1          // weight prefetch distance of the forward convolutions, in contraction steps
 #endif
+#ifndef MVS_MSPLIT
+#define MVS_MSPLIT 1
+#endif
+#ifndef MVS_MSPLIT_MIN_MREP
+#define MVS_MSPLIT_MIN_MREP 4      // forward convs: 64 output channels only (16 -> 32: -2 %, the extra registers cost a resident block)
+#endif
 #ifndef MVS_PERSIST
 #define MVS_PERSIST 1
 #endif
@@ -74,6 +80,22 @@ __device__ __forceinline__ void bf_mfma_step(const bf16x8* ah, const bf16x8* al,
 // ------------------------------------------------------------------------------------------------
 // Conv3d
 // ------------------------------------------------------------------------------------------------
+// Wave mapping of the 64-output-channel layers: the packed weights of a step are fetched by every wave that needs them, through
+// the vector-memory path - with all four 16-channel output blocks on every wave that is 8 global_load_dwordx4 per 24 MFMAs and the
+// texture addresser is the busiest unit of the kernel (PMC: TA 54-71 % busy, 28.7 K TA cycles per tile against 21.5 K MFMA cycles
+// per SIMD on 64 -> 64).  MSPLIT = 2 gives each wave HALF of the output blocks and TWICE the rows: half the weight loads, twice the
+// LDS operand reads (conflict-free since round 2), the same MFMAs and accumulators.
+template <class Base, int MSPLIT_>
+struct SplitCfg : Base {
+    static constexpr int MSPLIT = MSPLIT_;
+    static constexpr int MREP_ALL = Base::MREP;
+    static constexpr int MREP = Base::MREP / MSPLIT_;
+    static constexpr int NREP = Base::NREP * MSPLIT_;
+    static_assert(Base::MREP % MSPLIT_ == 0 && 4 % MSPLIT_ == 0, "bad output-block split");
+};
+template <class Cfg, class = void> struct CfgSplit { static constexpr int MSPLIT = 1, MREP_ALL = Cfg::MREP; };
+template <class Cfg> struct CfgSplit<Cfg, decltype((void)Cfg::MSPLIT)> { static constexpr int MSPLIT = Cfg::MSPLIT, MREP_ALL = Cfg::MREP_ALL; };
+
 template <class Cfg>
 struct BfConv {
     static constexpr int OPT = Cfg::CH / 8;                              // octets per tap and voxel in one pass
@@ -116,8 +138,8 @@ __device__ __forceinline__ void bf_conv_load_w(const bf16x8* wq, bf16x8* ah, bf1
 #pragma unroll
     for (int mb = 0; mb < Cfg::MREP; ++mb) {
         if (MVS_ABL == 2 && T > 1) continue;
-        ah[mb] = wq[(size_t)((T * Cfg::MREP + mb) * 2) * 64];
-        al[mb] = wq[(size_t)((T * Cfg::MREP + mb) * 2 + 1) * 64];
+        ah[mb] = wq[(size_t)((T * CfgSplit<Cfg>::MREP_ALL + mb) * 2) * 64];
+        al[mb] = wq[(size_t)((T * CfgSplit<Cfg>::MREP_ALL + mb) * 2 + 1) * 64];
     }
 }
 
@@ -215,10 +237,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
 #pragma unroll
         for (int nb = 0; nb < NREP; ++nb) acc[mb][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+    constexpr int MSPLIT = CfgSplit<Cfg>::MSPLIT, MREP_ALL = CfgSplit<Cfg>::MREP_ALL;
+    const int mb0 = (wave % MSPLIT) * MREP, rowgrp = wave / MSPLIT;       // this wave's output blocks and rows (SplitCfg)
     int voxbase[NREP];
 #pragma unroll
     for (int nb = 0; nb < NREP; ++nb) {
-        const int nbg = wave * NREP + nb;
+        const int nbg = rowgrp * NREP + nb;
         const int oz = nbg / TH, oy = nbg % TH;
         voxbase[nb] = (((oz * SD) * IH + oy * SH) * IW + li * SW) * SB;
     }
@@ -263,7 +287,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     constexpr bool UNROLLED = BfConv<Cfg>::UNROLL_STAGE;
     if constexpr (UNROLLED) issue(0);
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
-        const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + (size_t)pass * NSTEP * MREP * 2 * 64 + lane;
+        const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + ((size_t)pass * NSTEP * MREP_ALL + mb0) * 2 * 64 + lane;
         bf16x8 ah[MVS_WPF + 1][MREP], al[MVS_WPF + 1][MREP];
         bf_conv_preload_w<Cfg>(wq, ah, al);
         if (pass > 0) __syncthreads();
@@ -298,13 +322,13 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     float* yb = y + (size_t)b * OD * OH * OW * COUT;
 #pragma unroll
     for (int nb = 0; nb < NREP; ++nb) {
-        const int nbg = wave * NREP + nb;
+        const int nbg = rowgrp * NREP + nb;
         const int oz = oz0 + nbg / TH, oy = oy0 + nbg % TH, ox = ox0 + li;
         if (oz >= OD || oy >= OH || ox >= OW) continue;
         float* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
 #pragma unroll
         for (int mb = 0; mb < MREP; ++mb) {
-            const int co = 16 * mb + 4 * g;
+            const int co = 16 * (mb0 + mb) + 4 * g;
             if (co >= COUT) continue;
             const float4 bb = *reinterpret_cast<const float4*>(bias + co);
             float4 v = make_float4(acc[mb][nb][0] + bb.x, acc[mb][nb][1] + bb.y, acc[mb][nb][2] + bb.z, acc[mb][nb][3] + bb.w);
@@ -491,8 +515,8 @@ __device__ __forceinline__ void bf_deconv_load_step(int st, int ntap, int pd, in
 #pragma unroll
     for (int mb = 0; mb < Cfg::MREP; ++mb) {
         if (MVS_ABL == 2 && st > 1) continue;
-        ah[mb] = wq[(size_t)((st * Cfg::MREP + mb) * 2) * 64];
-        al[mb] = wq[(size_t)((st * Cfg::MREP + mb) * 2 + 1) * 64];
+        ah[mb] = wq[(size_t)((st * CfgSplit<Cfg>::MREP_ALL + mb) * 2) * 64];
+        al[mb] = wq[(size_t)((st * CfgSplit<Cfg>::MREP_ALL + mb) * 2 + 1) * 64];
     }
 #pragma unroll
     for (int nb = 0; nb < Cfg::NREP; ++nb) {
@@ -544,16 +568,18 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     }
     __syncthreads();
 
+    constexpr int MSPLIT = CfgSplit<Cfg>::MSPLIT, MREP_ALL = CfgSplit<Cfg>::MREP_ALL;
+    const int mb0 = (wave % MSPLIT) * MREP, rowgrp = wave / MSPLIT;       // this wave's output blocks and rows (SplitCfg)
     int voxbase[NREP];
 #pragma unroll
     for (int nb = 0; nb < NREP; ++nb) {
-        const int nbg = wave * NREP + nb;
+        const int nbg = rowgrp * NREP + nb;
         const int mz = nbg / THM, my = nbg % THM;
         voxbase[nb] = (((mz + Cfg::ZO) * LH + my) * LW + li) * SB;
     }
     float* yb = y + (size_t)b * OD * OH * OW * COUT;
     const float* sb = skip ? skip + (size_t)b * OD * OH * OW * COUT : nullptr;
-    const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + lane;          // advanced class by class
+    const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + (size_t)mb0 * 2 * 64 + lane;          // advanced class by class
 
     // COUT == 8: the two x-parity classes of a (pd, ph) pair ride in one MFMA (rows 0-7: pw = 0, rows 8-15: pw = 1, tap set
     // of pw = 1; weights packed accordingly, packing.pack_deconv_weights_bf16x3)
@@ -571,13 +597,13 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             const int pw = PAIR ? 1 : (cls & 1), ph = (cls >> 1) & 1, pd = (SD == 2) ? (cls >> 2) : 0;
 #pragma unroll
             for (int nb = 0; nb < NREP; ++nb) {
-                const int nbg = wave * NREP + nb;
+                const int nbg = rowgrp * NREP + nb;
                 const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
                 const bool inside = mz < D && my < H && mx < W;
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = PAIR ? 2 * mx + (g >> 1) : 2 * mx + pw;
 #pragma unroll
                 for (int mb = 0; mb < MREP; ++mb) {
-                    const int co = PAIR ? 4 * (g & 1) : 16 * mb + 4 * g;
+                    const int co = PAIR ? 4 * (g & 1) : 16 * (mb0 + mb) + 4 * g;
                     skp[it][nb][mb] = (inside && co < COUT) ? *reinterpret_cast<const float4*>(sb + (((size_t)oz * OH + oy) * OW + ox) * COUT + co)
                                                             : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
@@ -607,11 +633,11 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             bf_mfma_step<MREP, NREP>(ah1, al1, bh1, bl1, acc);
         }
         if (nst & 1) bf_mfma_step<MREP, NREP>(ah0, al0, bh0, bl0, acc);
-        wq += (size_t)nst * MREP * 2 * 64;
+        wq += (size_t)nst * MREP_ALL * 2 * 64;
 
 #pragma unroll
         for (int nb = 0; nb < NREP; ++nb) {
-            const int nbg = wave * NREP + nb;
+            const int nbg = rowgrp * NREP + nb;
             const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
             const bool inside = mz < D && my < H && mx < W;
             if (!inside && !(PAIR && prob_w != nullptr)) continue;     // the fused head shuffles: every lane takes part, stores are guarded
@@ -645,7 +671,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             const size_t off = (((size_t)oz * OH + oy) * OW + ox) * COUT;
 #pragma unroll
             for (int mb = 0; mb < MREP; ++mb) {
-                const int co = 16 * mb + 4 * g;
+                const int co = 16 * (mb0 + mb) + 4 * g;
                 if (co >= COUT) continue;
                 const float4 bb = *reinterpret_cast<const float4*>(bias + co);
                 float4 v = make_float4(fmaxf(acc[mb][nb][0] + bb.x, lo_clamp), fmaxf(acc[mb][nb][1] + bb.y, lo_clamp),
@@ -895,6 +921,13 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
     }
 }
 
+// which layers use the split wave mapping: 64 output channels with at most two rows per wave (the 2 x 4 x 16 / 2 x 2 x 16 tiles)
+template <class Cfg>
+struct BfSplitOf {
+    static constexpr bool SPLIT = MVS_MSPLIT && Cfg::MREP >= MVS_MSPLIT_MIN_MREP && Cfg::NREP <= 2 && Cfg::TH % (Cfg::NREP * 2) == 0;
+    typedef typename std::conditional<SPLIT, SplitCfg<Cfg, 2>, Cfg>::type type;
+};
+
 template <class Cfg>
 static int launch_conv_bf(const float* x, const void* wp, const float* bias, float* y, int B, int D, int H, int W, int relu, hipStream_t st,
                           float* logits) {
@@ -928,6 +961,13 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
     hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), LDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
     return check_launch("conv3d_mfma_bf16x3_kernel");
 }
+
+// transposed convolutions with two output blocks (64 -> 32): one block per wave pair, twice the rows per wave
+template <class Cfg>
+struct BfDeconvSplitOf {
+    static constexpr bool SPLIT = MVS_MSPLIT && Cfg::MREP == 2 && Cfg::THM % (Cfg::NREP * 2) == 0;
+    typedef typename std::conditional<SPLIT, SplitCfg<Cfg, 2>, Cfg>::type type;
+};
 
 template <class Cfg>
 static int launch_deconv_bf(const float* x, const void* wp, const float* bias, const float* skip, float* y, const float* prob_w,
@@ -965,7 +1005,7 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
                            int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits) {
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW)                      \
-        return launch_conv_bf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>(x, wp, bias, y, B, D, H, W, relu, st, logits);
+        return launch_conv_bf<typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type>(x, wp, bias, y, B, D, H, W, relu, st, logits);
     MVS_CONV_TABLE(MVS_X)
 #undef MVS_X
     set_error("conv3d(bf16x3): no kernel for Cin=%d Cout=%d kernel=(%d,3,3) stride=(%d,%d,%d)", Cin, Cout, kd, sd, sh, sw);
@@ -977,7 +1017,7 @@ int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, 
     if (prob_w != nullptr && Cout != 8) { set_error("deconv3d(bf16x3): the fused prob head needs Cout == 8"); return MVS_ERR_UNSUPPORTED; }
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
     if (Cin == CI && Cout == CO && sd == SD)                                                            \
-        return launch_deconv_bf<DeconvCfg<CI, CO, SD, TDM, THM>>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);
+        return launch_deconv_bf<typename BfDeconvSplitOf<DeconvCfg<CI, CO, SD, TDM, THM>>::type>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);
     MVS_DECONV_TABLE(MVS_X)
 #undef MVS_X
     set_error("deconv3d(bf16x3): no kernel for Cin=%d Cout=%d stride=(%d,2,2)", Cin, Cout, sd);
