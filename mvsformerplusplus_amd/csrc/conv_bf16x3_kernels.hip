@@ -29,6 +29,10 @@
 #ifndef MVS_MSPLIT_MIN_MREP
 #define MVS_MSPLIT_MIN_MREP 4      // forward convs: 64 output channels only (16 -> 32: -2 %, the extra registers cost a resident block)
 #endif
+#ifndef MVS_PERSIST_PFD
+#define MVS_PERSIST_PFD 1      // tiles the persistent forward convolution prefetches ahead (1 or 2; 2 measured slower: the second
+                               // register set costs the first U-Net layer a resident block, 82 vs 75 us, and changes nothing elsewhere)
+#endif
 #ifndef MVS_PERSIST
 #define MVS_PERSIST 1
 #endif
@@ -411,8 +415,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
     float* yb = y ? y + (size_t)b * OD * OH * OW * COUT : nullptr;
 
     constexpr int NITEM = Cfg::NVOX * OPT, NIT = (NITEM + 255) / 256;
-    float4 su[NIT], sv[NIT];
-    auto issue = [&](int tile) {
+    // MVS_PERSIST_PFD register sets: the loads of tile t + PFD are issued while tile t is contracted
+    float4 su0[NIT], sv0[NIT], su1[NIT], sv1[NIT];
+    auto issue = [&](int tile, float4* su, float4* sv) {
         const int tx = tile % tiles_x;
         const int t1 = tile / tiles_x;
         const int ty = t1 % tiles_y, tz = t1 / tiles_y;
@@ -433,8 +438,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
             sv[it] = ok ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     };
-    issue(t_begin);
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    auto process = [&](int tile, float4* su, float4* sv) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int e = tid + it * 256;
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
             *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE + 16) = lo;
         }
         __syncthreads();
-        if (tile + 1 < t_end) issue(tile + 1);
+        if (tile + MVS_PERSIST_PFD < t_end) issue(tile + MVS_PERSIST_PFD, su, sv);
 
         f32x4 acc[MREP][NREP];
 #pragma unroll
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
             if (oz >= OD || oy >= OH || ox >= OW) continue;
             if (logits != nullptr) {
                 // single-output-channel head (CostRegNet.prob, module.py:391): row 0 of the 16-row tile, planar store
-                if (g == 0) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = acc[0][nb][0] + bb[0].x;
+                if (g == 0 && !(MVS_ABL == 5 && acc[0][nb][0] != 12345.678f)) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = acc[0][nb][0] + bb[0].x;
                 continue;
             }
             float* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
@@ -485,6 +489,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
             }
         }
         __syncthreads();                                                     // every wave is done reading this tile's LDS image
+    };
+    issue(t_begin, su0, sv0);
+    if (MVS_PERSIST_PFD == 2 && t_begin + 1 < t_end) issue(t_begin + 1, su1, sv1);
+    for (int tile = t_begin; tile < t_end; tile += MVS_PERSIST_PFD) {
+        process(tile, su0, sv0);
+        if (MVS_PERSIST_PFD == 2 && tile + 1 < t_end) process(tile + 1, su1, sv1);
     }
 }
 
