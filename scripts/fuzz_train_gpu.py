@@ -1,0 +1,95 @@
+"""Randomised differential test of the TRAINING path on the GPU box: the native route (HIP gather / convolution / BatchNorm forward and
+backward) against the same StageNet with every conv / BatchNorm layer on PyTorch-ROCm autograd (MVS_TRAIN_REGNET=torch; the gather and
+its backward are the HIP kernels on both routes), random shapes, view counts, batch sizes, channel counts, regulariser kinds.
+    gpurun -- 'python scripts/fuzz_train_gpu.py 40'
+Per case: loss, and for the feature gradient and every parameter gradient the cosine between the two routes and the max-norm error
+relative to the tensor's largest entry.  The test loss weights the probabilities with random signs, so every gradient is a random-walk
+sum over voxels and ONE ReLU unit flipped by the 2^-16-class forward difference between the routes moves a tensor's max-norm error to
+~1e-2 (DESIGN.md section 2
+row f #2).  Every case therefore carries its own yardstick - the autograd route against itself with 3e-6-relative noise on its 3-D
+conv outputs, printed beside the native route's numbers (which flips happen is a lottery on both sides: the two agree in magnitude,
+not case by case) - and is bad when the losses differ by more than 1e-3 + 1e-4 relative, any gradient tensor's cosine between the
+routes is below 0.99, or the median max-norm error exceeds 0.1."""
+import copy, os, random, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mvsformerplusplus_amd import synth
+from mvsformerplusplus_amd.cost_volume import StageNet
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+if os.environ.get("FUZZ_EMU"):          # build container: the kernels through the host emulator (tests/hipemu), everything on the CPU
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import hipemu_build
+    from mvsformerplusplus_amd import _lib
+    _lib._LIB = _lib.bind(hipemu_build.build())
+    _lib._REQUIRE_DEVICE = False
+    dev = torch.device("cpu")
+only = os.environ.get("FUZZ_ONLY")
+bad = 0
+for case in range(n_cases):
+    kind = rnd.choice(["unet", "unet3d"])
+    D = rnd.choice([16, 32]) if kind == "unet" else rnd.choice([4, 8])
+    H, W = 8 * rnd.randint(2, 9), 8 * rnd.randint(2, 12)
+    V, B, C = rnd.randint(2, 5), rnd.choice([1, 2, 2]), rnd.choice([8, 16, 32, 64])
+    desc = "%-7s D=%-2d %3dx%-3d V=%d B=%d C=%-2d" % (kind, D, H, W, V, B, C)
+    args = {"base_ch": [8] * 4, "depth_type": [rnd.choice(["ce", "reg"])] * 4, "model_th": 8}
+    bl, rot = rnd.uniform(10, 60), rnd.uniform(0, 4)
+    if only is not None and case != int(only):
+        continue
+    net = StageNet(args, D, 0)
+    net.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(net.state_dict()), 3000 + case), strict=True)
+    net = net.to(dev).train()
+    ref = copy.deepcopy(net)
+    cams = synth.make_cameras(V, H, W, baseline=bl, rot_deg=rot, seed=case, batch=B).to(dev)
+    g = torch.Generator().manual_seed(case)
+    feats = synth.make_features(cams.cpu(), C, H, W, dmin=480.0, dmax=880.0, seed=case).to(dev)
+    hyp = ((1.0 / torch.linspace(1 / 900.0, 1 / 430.0, D))[None, :, None, None] * (1 + 0.02 * torch.rand(B, D, H, W, generator=g))).to(dev).contiguous()
+    R = torch.randn(B, D, H, W, generator=g).to(dev)
+    res = []
+    for route, m in (("hip", net), ("torch", ref)):
+        os.environ["MVS_TRAIN_REGNET"] = route
+        f = feats.clone().requires_grad_(True)
+        out = m(f, cams, hyp, 1.0)
+        loss = (out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
+        loss.backward()
+        res.append((loss.item(), f.grad, {n: p.grad for n, p in m.named_parameters()}))
+    yard_med, yard_worst = 0.0, 0.0
+    if not os.environ.get("FUZZ_NO_YARDSTICK"):
+        # yardstick: the autograd route against ITSELF with 1e-5-relative noise on every 3-D conv output (the size of the split-bf16
+        # forward's rounding difference): what a handful of flipped ReLU units do to these random-sign gradient sums
+        noisy = copy.deepcopy(ref)
+        noisy.zero_grad()
+        gen = torch.Generator(device="cpu").manual_seed(99)
+        hooks = [mod.register_forward_hook(lambda mod_, inp, out_: out_ + 3e-6 * float(out_.abs().max()) * torch.randn(out_.shape, generator=gen).to(out_.device))
+                 for mod in noisy.cost_reg.modules() if isinstance(mod, (torch.nn.Conv3d, torch.nn.ConvTranspose3d))]
+        os.environ["MVS_TRAIN_REGNET"] = "torch"
+        f = feats.clone().requires_grad_(True)
+        out = noisy(f, cams, hyp, 1.0)
+        ((out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()).backward()
+        gpn = {n: p.grad for n, p in noisy.named_parameters()}
+        en = [float((gpn[n] - res[1][2][n]).abs().max() / res[1][2][n].abs().max().clamp_min(1e-20)) for n in gpn if n.startswith("cost_reg")]
+        yard_med, yard_worst = sorted(en)[len(en) // 2], max(en)
+    os.environ["MVS_TRAIN_REGNET"] = "hip"
+    (l0, gf0, gp0), (l1, gf1, gp1) = res
+    cos = lambda a, b: float(torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
+    errs, coss = [float((gf0 - gf1).abs().max() / gf1.abs().max().clamp_min(1e-20))], [cos(gf0, gf1)]
+    top = max(float(v.abs().max()) for v in gp1.values())
+    for n in gp1:
+        if V == 2 and n.startswith("vis."):
+            continue        # one source view: volume = sim * vis / (vis + 1e-6), the visibility gradient is a cancellation residue on both routes
+        if float(gp1[n].abs().max()) > 1e-6 * top:                      # analytically-zero gradients hold noise on both routes
+            errs.append(float((gp0[n] - gp1[n]).abs().max() / gp1[n].abs().max()))
+            coss.append(cos(gp0[n], gp1[n]))
+    med, worst, cmin = sorted(errs)[len(errs) // 2], max(errs), min(coss)
+    # the loss is a random-sign sum of B*D*H*W terms; gradients are judged against the case's own yardstick
+    ok = cmin >= 0.99 and med <= 0.1 and abs(l0 - l1) <= 1e-3 + 1e-4 * abs(l1)
+    bad += 0 if ok else 1
+    if only is not None:
+        for n in gp1:
+            print("   %-34s cos %.6f  err %.1e" % (n, cos(gp0[n], gp1[n]), float((gp0[n] - gp1[n]).abs().max() / gp1[n].abs().max().clamp_min(1e-20))))
+    print("%s %s  loss %.5f / %.5f  min cosine %.6f  max-norm error median %.1e worst %.1e (yardstick %.1e / %.1e) over %d tensors"
+          % ("ok " if ok else "BAD", desc, l0, l1, cmin, med, worst, yard_med, yard_worst, len(errs)))
+print("%d cases, %d bad" % (n_cases, bad))
+sys.exit(1 if bad else 0)
