@@ -17,27 +17,29 @@
 
 #include "conv_cfg.h"
 
+// ---- experiment switches -------------------------------------------------------------------------------------------
+// The defaults ARE the shipped configuration; scripts/conv_ablate.py builds variants of this file with other values to measure
+// what each choice is worth (DESIGN.md section 4.2 quotes the numbers).  Nothing outside this file and conv_cfg.h reads them.
 #ifndef MVS_ABL
-#define MVS_ABL 0
-#endif
+#define MVS_ABL 0                  // ablation: 1 no activation loads, 2 no weight loads after step 1, 3 no LDS operand reads after step 1,
+#endif                             // 4 one MFMA term of three, 5 no output stores, 6 one contraction step only (results are then meaningless)
 #ifndef MVS_WPF
-#define MVS_WPF 1          // weight prefetch distance of the forward convolutions, in contraction steps
+#define MVS_WPF 1                  // weight prefetch distance of the forward convolutions in contraction steps (2, 3: +-2 %, not kept)
 #endif
 #ifndef MVS_MSPLIT
-#define MVS_MSPLIT 1
+#define MVS_MSPLIT 1               // split wave mapping (SplitCfg) for the layers bound by the texture addresser
 #endif
 #ifndef MVS_MSPLIT_MIN_MREP
-#define MVS_MSPLIT_MIN_MREP 4      // forward convs: 64 output channels only (16 -> 32: -2 %, the extra registers cost a resident block)
-#endif
-#ifndef MVS_PERSIST_PFD
-#define MVS_PERSIST_PFD 1      // tiles the persistent forward convolution prefetches ahead (1 or 2; 2 measured slower: the second
-                               // register set costs the first U-Net layer a resident block, 82 vs 75 us, and changes nothing elsewhere)
+#define MVS_MSPLIT_MIN_MREP 4      // ... forward convs: 64 output channels only (16 -> 32: -2 %, the extra registers cost a resident block)
 #endif
 #ifndef MVS_PERSIST
-#define MVS_PERSIST 1
+#define MVS_PERSIST 1              // persistent kernels for the Cin = 8 convolutions and the 16 -> 8 transposed convolution
 #endif
+#ifndef MVS_PERSIST_PFD
+#define MVS_PERSIST_PFD 1          // tiles the persistent forward convolution prefetches ahead (2: a second register set costs the first
+#endif                             // U-Net layer a resident block, 82 vs 75 us, and changes nothing elsewhere)
 #ifndef MVS_XPASS_PREFETCH
-#define MVS_XPASS_PREFETCH 1
+#define MVS_XPASS_PREFETCH 1       // loads of channel pass p + 1 issued before the contraction of pass p
 #endif
 
 namespace mvs {
