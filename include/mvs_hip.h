@@ -136,7 +136,8 @@ int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* 
                           int W, int precision, void* stream);
 
 /* ---- section 8f #2: training-mode regulariser (batch-statistics BatchNorm, weight gradients) -------------------------------
- * Channel-last fp32 [N voxels][C], C in {8,16,32,64}.  The forward convolutions and the DATA gradients of the training path are
+ * Channel-last fp32 [N voxels][C], C in {8,16,32,64}; `groups` independent statistics sets of N voxels each (tensor [groups][N][C],
+ * statistics [groups][...]; the visibility CNN normalises each source view's batch on its own).  The forward convolutions and the DATA gradients of the training path are
  * mvs_conv3d_bn_relu_fwd (relu = 0, zero bias) / mvs_deconv3d_linear_fwd with un-folded, re-packed weights (training.py).
  *   mvs_bn_stats       sums[2C] (double) = per-channel [sum x | sum x^2]                       nn.BatchNorm3d, training=True
  *   mvs_bn_finalize    mean / biased var / 1/sqrt(var+eps) from sums and the voxel count (after an optional SyncBN all-reduce);
@@ -150,16 +151,16 @@ int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* 
  *                      with a = its output gradient and g = its input (result in ConvTranspose3d's [Cin][Cout][27] layout)    */
 int mvs_deconv3d_linear_fwd(const float* x_cl, const void* w_packed, const float* bias, float* y_cl, int B, int Cin, int Cout,
                             int D, int H, int W, int sd, int precision, void* stream);
-int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C, void* stream);
+int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C, int groups, void* stream);
 int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, float* running_mean,
-                    float* running_var, float momentum, int C, void* stream);
+                    float* running_var, float momentum, int C, int groups, void* stream);
 int mvs_bn_running_update(const float* mean, const float* var, double count, float momentum, float* running_mean,
-                          float* running_var, int C, void* stream);
+                          float* running_var, int C, int groups, void* stream);
 int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      const float* skip_cl, float* y_cl, long long N, int C, int relu, void* stream);
+                      const float* skip_cl, float* y_cl, long long N, int C, int relu, int groups, void* stream);
 int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, double* sums, double count, float* dz_cl, long long N, int C, int relu,
-                    int use_batch_stats, int phase, void* stream);
+                    int use_batch_stats, int phase, int groups, void* stream);
 /* MFMA weight packing on the device (bit-identical to packing.pack_conv_weights_bf16x3 / pack_deconv_weights_bf16x3; used by the
  * training path, which re-packs every un-folded weight each iteration).  *_elems = number of bf16 elements of the packed tensor
  * (-1: unsupported shape).  w: Conv3d [cout][cin][ntap] (tflip = 1: read as [cin][cout] with reversed taps = the data-gradient form

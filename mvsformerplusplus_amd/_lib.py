@@ -46,11 +46,11 @@ SIGNATURES = {
     "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "mvs_conv3d_logits_fwd": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "mvs_deconv3d_linear_fwd": (_i, [_vp] * 4 + [_i] * 8 + [_vp]),
-    "mvs_bn_stats": (_i, [_vp, _vp, C.c_longlong, _i, _vp]),
-    "mvs_bn_finalize": (_i, [_vp, C.c_double, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _vp]),
-    "mvs_bn_running_update": (_i, [_vp, _vp, C.c_double, C.c_float, _vp, _vp, _i, _vp]),
-    "mvs_bn_relu_apply": (_i, [_vp] * 7 + [C.c_longlong, _i, _i, _vp]),
-    "mvs_bn_relu_bwd": (_i, [_vp] * 7 + [C.c_double, _vp, C.c_longlong, _i, _i, _i, _i, _vp]),
+    "mvs_bn_stats": (_i, [_vp, _vp, C.c_longlong, _i, _i, _vp]),
+    "mvs_bn_finalize": (_i, [_vp, C.c_double, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp]),
+    "mvs_bn_running_update": (_i, [_vp, _vp, C.c_double, C.c_float, _vp, _vp, _i, _i, _vp]),
+    "mvs_bn_relu_apply": (_i, [_vp] * 7 + [C.c_longlong, _i, _i, _i, _vp]),
+    "mvs_bn_relu_bwd": (_i, [_vp] * 7 + [C.c_double, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),
     "mvs_pack_conv_weights_elems": (C.c_longlong, [_i] * 4),
     "mvs_pack_conv_weights": (_i, [_vp, _vp] + [_i] * 5 + [_vp]),
     "mvs_pack_deconv_weights_elems": (C.c_longlong, [_i] * 3),

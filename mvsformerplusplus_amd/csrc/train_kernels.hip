@@ -16,9 +16,14 @@ namespace mvs {
 // BatchNorm statistics: per-channel sum and sum of squares in double (N reaches 10^7 voxels).
 // sums[0..C) = sum x, sums[C..2C) = sum x^2 (zeroed by the entry point, accumulated with one f64 atomic per block and value).
 // ------------------------------------------------------------------------------------------------
+// Every BatchNorm kernel takes `groups` independent statistics sets along blockIdx.y (the visibility CNN normalises each source
+// view's batch on its own, like the reference's per-view calls): group g owns voxels [g * N, (g + 1) * N) and row g of the
+// [groups][...] statistics arrays.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, size_t n4, int C) {
     __shared__ double part[2 * 64];
     const int tid = (int)threadIdx.x;
+    x += (size_t)blockIdx.y * n4 * 4;
+    sums += (size_t)blockIdx.y * 2 * C;
     if (tid < 2 * C) part[tid] = 0.0;
     __syncthreads();
     const int q4 = C / 4;                                                  // float4s per voxel; gridDim.x * 256 is a multiple of it
@@ -44,30 +49,34 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // running_mean != NULL also nn.BatchNorm's momentum step of the running statistics (unbiased variance)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float* __restrict__ mean, float* __restrict__ var,
                                    float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float momentum, int C) {
+                                   float momentum, int C, int groups) {
     const int c = (int)threadIdx.x;
     if (c >= C) return;
-    const double m = sums[c] / count;
-    double v = sums[C + c] / count - m * m;
-    v = v > 0.0 ? v : 0.0;
-    mean[c] = (float)m;
-    var[c] = (float)v;
-    invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
-    if (running_mean != nullptr) {
-        const float unbiased = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
-        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
-        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    for (int g = 0; g < groups; ++g) {                                     // in order: the running statistics take one momentum step per group
+        const double m = sums[(size_t)g * 2 * C + c] / count;
+        double v = sums[(size_t)g * 2 * C + C + c] / count - m * m;
+        v = v > 0.0 ? v : 0.0;
+        mean[g * C + c] = (float)m;
+        var[g * C + c] = (float)v;
+        invstd[g * C + c] = (float)(1.0 / sqrt(v + (double)eps));
+        if (running_mean != nullptr) {
+            const float unbiased = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+        }
     }
 }
 
 // the momentum step alone (the reference's checkpoint recomputation repeats it in the backward pass)
 __global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ var, double count, float momentum,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var, int C) {
+                                         float* __restrict__ running_mean, float* __restrict__ running_var, int C, int groups) {
     const int c = (int)threadIdx.x;
     if (c >= C) return;
-    const float unbiased = (float)((double)var[c] * (count / (count > 1.0 ? count - 1.0 : 1.0)));
-    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean[c];
-    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    for (int g = 0; g < groups; ++g) {
+        const float unbiased = (float)((double)var[g * C + c] * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean[g * C + c];
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    }
 }
 
 // y = relu((z - mean) * invstd * gamma + beta) [+ skip]        (relu = 0: no clamp)
@@ -76,6 +85,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ skip, float* __restrict__ y, size_t n4, int C, int relu) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    const size_t goff = (size_t)blockIdx.y * n4 * 4;
+    z += goff; y += goff; mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C;
+    if (skip != nullptr) skip += goff;
     const int c0 = (int)(i % (size_t)(C / 4)) * 4;
     const float4 v = reinterpret_cast<const float4*>(z)[i];
     const float in[4] = {v.x, v.y, v.z, v.w};
@@ -100,6 +112,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ beta, double* __restrict__ sums, size_t n4, int C, int relu) {
     __shared__ double part[2 * 64];
     const int tid = (int)threadIdx.x;
+    {
+        const size_t goff = (size_t)blockIdx.y * n4 * 4;
+        dy += goff; z += goff; mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C; sums += (size_t)blockIdx.y * 2 * C;
+    }
     if (tid < 2 * C) part[tid] = 0.0;
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * 256;
@@ -137,6 +153,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dz, size_t n4, int C, int relu, int use_batch_stats) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    {
+        const size_t goff = (size_t)blockIdx.y * n4 * 4;
+        dy += goff; z += goff; dz += goff; mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C; sums += (size_t)blockIdx.y * 2 * C;
+    }
     const int c0 = (int)(i % (size_t)(C / 4)) * 4;
     const float4 zv = reinterpret_cast<const float4*>(z)[i], gv = reinterpret_cast<const float4*>(dy)[i];
     const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -357,53 +377,55 @@ static bool bn_shape_ok(const char* who, size_t N, int C) {
 
 using namespace mvs;
 
-extern "C" int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C, void* stream) {
-    if (!x_cl || !sums || !bn_shape_ok("mvs_bn_stats", (size_t)N, C)) { if (!x_cl || !sums) set_error("mvs_bn_stats: null pointer"); return MVS_ERR_ARG; }
+extern "C" int mvs_bn_stats(const float* x_cl, double* sums, long long N, int C, int groups, void* stream) {
+    if (!x_cl || !sums || groups < 1 || !bn_shape_ok("mvs_bn_stats", (size_t)N, C)) { if (!x_cl || !sums || groups < 1) set_error("mvs_bn_stats: bad arguments"); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), st) != hipSuccess) { set_error("mvs_bn_stats: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
+    if (hipMemsetAsync(sums, 0, (size_t)groups * 2 * C * sizeof(double), st) != hipSuccess) { set_error("mvs_bn_stats: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
     const size_t n4 = (size_t)N * C / 4;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(ew_blocks(n4, C, 2048)), dim3(256), 0, st, x_cl, sums, n4, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(ew_blocks(n4, C, 2048), groups), dim3(256), 0, st, x_cl, sums, n4, C);
     return check_launch("bn_stats_kernel");
 }
 
 extern "C" int mvs_bn_finalize(const double* sums, double count, float eps, float* mean, float* var, float* invstd, float* running_mean,
-                               float* running_var, float momentum, int C, void* stream) {
-    if (!sums || !mean || !var || !invstd || count < 1.0 || !bn_shape_ok("mvs_bn_finalize", 1, C) || ((running_mean == nullptr) != (running_var == nullptr))) {
+                               float* running_var, float momentum, int C, int groups, void* stream) {
+    if (!sums || !mean || !var || !invstd || count < 1.0 || groups < 1 || !bn_shape_ok("mvs_bn_finalize", 1, C) ||
+        ((running_mean == nullptr) != (running_var == nullptr))) {
         set_error("mvs_bn_finalize: bad arguments");
         return MVS_ERR_ARG;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, count, eps, mean, var, invstd, running_mean, running_var,
-                       momentum, C);
+                       momentum, C, groups);
     return check_launch("bn_finalize_kernel");
 }
 
 extern "C" int mvs_bn_running_update(const float* mean, const float* var, double count, float momentum, float* running_mean, float* running_var, int C,
-                                     void* stream) {
-    if (!mean || !var || !running_mean || !running_var || count < 1.0 || !bn_shape_ok("mvs_bn_running_update", 1, C)) { set_error("mvs_bn_running_update: bad arguments"); return MVS_ERR_ARG; }
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mean, var, count, momentum, running_mean, running_var, C);
+                                     int groups, void* stream) {
+    if (!mean || !var || !running_mean || !running_var || count < 1.0 || groups < 1 || !bn_shape_ok("mvs_bn_running_update", 1, C)) { set_error("mvs_bn_running_update: bad arguments"); return MVS_ERR_ARG; }
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mean, var, count, momentum, running_mean, running_var, C, groups);
     return check_launch("bn_running_update_kernel");
 }
 
 extern "C" int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* skip_cl,
-                                 float* y_cl, long long N, int C, int relu, void* stream) {
-    if (!z_cl || !mean || !invstd || !gamma || !beta || !y_cl || !bn_shape_ok("mvs_bn_relu_apply", (size_t)N, C)) { set_error("mvs_bn_relu_apply: bad arguments"); return MVS_ERR_ARG; }
+                                 float* y_cl, long long N, int C, int relu, int groups, void* stream) {
+    if (!z_cl || !mean || !invstd || !gamma || !beta || !y_cl || groups < 1 || !bn_shape_ok("mvs_bn_relu_apply", (size_t)N, C)) { set_error("mvs_bn_relu_apply: bad arguments"); return MVS_ERR_ARG; }
     const size_t n4 = (size_t)N * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4, C, 0)), dim3(256), 0, (hipStream_t)stream, z_cl, mean, invstd, gamma, beta, skip_cl, y_cl, n4, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4, C, 0), groups), dim3(256), 0, (hipStream_t)stream, z_cl, mean, invstd, gamma, beta, skip_cl, y_cl, n4, C, relu);
     return check_launch("bn_apply_kernel");
 }
 
 extern "C" int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                               double* sums, double count, float* dz_cl, long long N, int C, int relu, int use_batch_stats, int phase, void* stream) {
-    if (!dy_cl || !z_cl || !mean || !invstd || !gamma || !beta || !sums || !bn_shape_ok("mvs_bn_relu_bwd", (size_t)N, C)) { set_error("mvs_bn_relu_bwd: bad arguments"); return MVS_ERR_ARG; }
+                               double* sums, double count, float* dz_cl, long long N, int C, int relu, int use_batch_stats, int phase, int groups,
+                               void* stream) {
+    if (!dy_cl || !z_cl || !mean || !invstd || !gamma || !beta || !sums || groups < 1 || !bn_shape_ok("mvs_bn_relu_bwd", (size_t)N, C)) { set_error("mvs_bn_relu_bwd: bad arguments"); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const size_t n4 = (size_t)N * C / 4;
     if (phase == 0) {                                                      // reduce: sums = [d beta | d gamma] of THIS rank's voxels
-        if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), st) != hipSuccess) { set_error("mvs_bn_relu_bwd: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ew_blocks(n4, C, 2048)), dim3(256), 0, st, dy_cl, z_cl, mean, invstd, gamma, beta, sums, n4, C, relu);
+        if (hipMemsetAsync(sums, 0, (size_t)groups * 2 * C * sizeof(double), st) != hipSuccess) { set_error("mvs_bn_relu_bwd: hipMemsetAsync failed"); return MVS_ERR_LAUNCH; }
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ew_blocks(n4, C, 2048), groups), dim3(256), 0, st, dy_cl, z_cl, mean, invstd, gamma, beta, sums, n4, C, relu);
         return check_launch("bn_bwd_reduce_kernel");
     }
     if (!dz_cl || count < 1.0) { set_error("mvs_bn_relu_bwd: bad arguments"); return MVS_ERR_ARG; }
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4, C, 0)), dim3(256), 0, st, dy_cl, z_cl, mean, invstd, gamma, beta, sums, count, dz_cl, n4, C, relu,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4, C, 0), groups), dim3(256), 0, st, dy_cl, z_cl, mean, invstd, gamma, beta, sums, count, dz_cl, n4, C, relu,
                        use_batch_stats);
     return check_launch("bn_bwd_apply_kernel");
 }

@@ -244,51 +244,61 @@ def deconv3d_linear(x_cl: torch.Tensor, w_packed: torch.Tensor, zero_bias: torch
     return y
 
 
-def bn_stats(x_cl: torch.Tensor) -> torch.Tensor:
-    """-> float64 [2C]: per-channel [sum x | sum x^2] over all voxels of a channel-last tensor."""
+def bn_stats(x_cl: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """-> float64 [groups, 2C] (or [2C]): per-channel [sum x | sum x^2] of each of `groups` equal slices along the leading axis."""
     Cc = x_cl.shape[-1]
-    sums = torch.empty(2 * Cc, dtype=torch.float64, device=x_cl.device)
-    check(lib().mvs_bn_stats(ptr(x_cl), ptr(sums), x_cl.numel() // Cc, Cc, stream_of(x_cl)), "mvs_bn_stats")
-    return sums
+    sums = torch.empty(groups, 2 * Cc, dtype=torch.float64, device=x_cl.device)
+    check(lib().mvs_bn_stats(ptr(x_cl), ptr(sums), x_cl.numel() // Cc // groups, Cc, groups, stream_of(x_cl)), "mvs_bn_stats")
+    return sums if groups > 1 else sums[0]
 
 
 def bn_finalize(sums: torch.Tensor, count: float, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
-    """-> (mean, biased var, invstd); with running statistics given, their momentum step happens in the same launch."""
-    Cc = sums.numel() // 2
-    buf = torch.empty(3, Cc, dtype=torch.float32, device=sums.device)
-    mean, var, invstd = buf[0], buf[1], buf[2]
-    check(lib().mvs_bn_finalize(ptr(sums), float(count), float(eps), ptr(mean), ptr(var), ptr(invstd), ptr(running_mean), ptr(running_var),
-                                float(momentum), Cc, stream_of(sums)), "mvs_bn_finalize")
-    return mean, var, invstd
+    """-> (mean, biased var, invstd), each [C] or [groups, C]; with running statistics given, their momentum step(s) - one per group,
+    in order - happen in the same launch."""
+    groups = sums.shape[0] if sums.dim() == 2 else 1
+    Cc = sums.shape[-1] // 2
+    buf = torch.empty(3, groups, Cc, dtype=torch.float32, device=sums.device)
+    check(lib().mvs_bn_finalize(ptr(sums), float(count), float(eps), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(running_mean), ptr(running_var),
+                                float(momentum), Cc, groups, stream_of(sums)), "mvs_bn_finalize")
+    if sums.dim() == 2:
+        return buf[0], buf[1], buf[2]
+    return buf[0, 0], buf[1, 0], buf[2, 0]
 
 
 def bn_running_update(mean, var, count: float, momentum: float, running_mean, running_var) -> None:
-    check(lib().mvs_bn_running_update(ptr(mean), ptr(var), float(count), float(momentum), ptr(running_mean), ptr(running_var), mean.numel(),
-                                      stream_of(mean)), "mvs_bn_running_update")
+    groups = mean.shape[0] if mean.dim() == 2 else 1
+    check(lib().mvs_bn_running_update(ptr(mean), ptr(var), float(count), float(momentum), ptr(running_mean), ptr(running_var), mean.shape[-1],
+                                      groups, stream_of(mean)), "mvs_bn_running_update")
+
+
+def _bn_groups(mean):
+    return mean.shape[0] if mean.dim() == 2 else 1
 
 
 def bn_relu_apply(z_cl, mean, invstd, gamma, beta, skip_cl=None, relu=True) -> torch.Tensor:
-    Cc = z_cl.shape[-1]
+    """mean / invstd [C], or [groups, C] for `groups` equal slices of z_cl along its leading axis."""
+    Cc, groups = z_cl.shape[-1], _bn_groups(mean)
     y = torch.empty_like(z_cl)
-    check(lib().mvs_bn_relu_apply(ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(skip_cl), ptr(y), z_cl.numel() // Cc, Cc,
-                                  1 if relu else 0, stream_of(z_cl)), "mvs_bn_relu_apply")
+    check(lib().mvs_bn_relu_apply(ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(skip_cl), ptr(y), z_cl.numel() // Cc // groups, Cc,
+                                  1 if relu else 0, groups, stream_of(z_cl)), "mvs_bn_relu_apply")
     return y
 
 
 def bn_relu_bwd_reduce(dy_cl, z_cl, mean, invstd, gamma, beta, relu=True) -> torch.Tensor:
-    """-> float64 [2C]: [sum g | sum g * xhat] with g = dy through the ReLU mask (= [d beta | d gamma] of these voxels)."""
-    Cc = z_cl.shape[-1]
-    sums = torch.empty(2 * Cc, dtype=torch.float64, device=z_cl.device)
-    check(lib().mvs_bn_relu_bwd(ptr(dy_cl), ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums), 1.0, None, z_cl.numel() // Cc, Cc,
-                                1 if relu else 0, 1, 0, stream_of(z_cl)), "mvs_bn_relu_bwd")
-    return sums
+    """-> float64 [2C] (or [groups, 2C]): [sum g | sum g * xhat] with g = dy through the ReLU mask (= [d beta | d gamma] of these voxels)."""
+    Cc, groups = z_cl.shape[-1], _bn_groups(mean)
+    sums = torch.empty(groups, 2 * Cc, dtype=torch.float64, device=z_cl.device)
+    check(lib().mvs_bn_relu_bwd(ptr(dy_cl), ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums), 1.0, None,
+                                z_cl.numel() // Cc // groups, Cc, 1 if relu else 0, 1, 0, groups, stream_of(z_cl)), "mvs_bn_relu_bwd")
+    return sums if mean.dim() == 2 else sums[0]
 
 
 def bn_relu_bwd_apply(dy_cl, z_cl, mean, invstd, gamma, beta, sums, count: float, relu=True, use_batch_stats=True) -> torch.Tensor:
-    Cc = z_cl.shape[-1]
+    Cc, groups = z_cl.shape[-1], _bn_groups(mean)
     dz = torch.empty_like(z_cl)
     check(lib().mvs_bn_relu_bwd(ptr(dy_cl), ptr(z_cl), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums), float(count), ptr(dz),
-                                z_cl.numel() // Cc, Cc, 1 if relu else 0, 1 if use_batch_stats else 0, 1, stream_of(z_cl)), "mvs_bn_relu_bwd")
+                                z_cl.numel() // Cc // groups, Cc, 1 if relu else 0, 1 if use_batch_stats else 0, 1, groups, stream_of(z_cl)),
+          "mvs_bn_relu_bwd")
     return dz
 
 

@@ -124,15 +124,18 @@ class _BnState:
     """Forward statistics of one BatchNorm layer (batch statistics in train mode, running statistics otherwise) and the
     bookkeeping nn.BatchNorm3d / nn.SyncBatchNorm do: momentum update of the running statistics, all-reduce of the sums."""
 
-    def __init__(self, bn, z_cl):
+    def __init__(self, bn, z_cl, groups: int = 1):
+        """groups > 1: `groups` equal slices of z_cl along its leading axis are normalised independently (one nn.BatchNorm call each,
+        in order, in the reference): statistics come back as [groups, C]."""
+        self.groups = groups
         self.batch = bn.training or bn.running_mean is None
         self.sync = False                                  # SyncBatchNorm: the sums are all-reduced over bn.process_group (None = WORLD)
         self.group = None
         C = z_cl.shape[-1]
-        n_local = z_cl.numel() // C
+        n_local = z_cl.numel() // C // groups
         self.count = float(n_local)
         if self.batch:
-            sums = ops.bn_stats(z_cl)
+            sums = ops.bn_stats(z_cl, groups)
             if isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
                 self.sync, self.group = True, bn.process_group
                 cnt = torch.tensor([float(n_local)], dtype=torch.float64, device=z_cl.device)
@@ -140,9 +143,9 @@ class _BnState:
                 torch.distributed.all_reduce(cnt, group=self.group)
                 self.count = float(cnt.item())
             self.bn = bn if (bn.training and bn.running_mean is not None) else None
-            if self.bn is not None and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous():
+            if self.bn is not None and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and (groups == 1 or bn.momentum is not None):
                 with torch.no_grad():
-                    bn.num_batches_tracked += 1
+                    bn.num_batches_tracked += groups
                 self.mean, self.var, self.invstd = ops.bn_finalize(sums, self.count, bn.eps, bn.running_mean, bn.running_var, self._momentum())
             else:
                 self.mean, self.var, self.invstd = ops.bn_finalize(sums, self.count, bn.eps)
@@ -151,6 +154,8 @@ class _BnState:
             self.bn = None
             self.mean = bn.running_mean.detach().float().contiguous()
             self.invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous()
+            if groups > 1:
+                self.mean, self.invstd = self.mean.expand(groups, -1).contiguous(), self.invstd.expand(groups, -1).contiguous()
 
     def update_running_stats(self):
         """One momentum step of nn.BatchNorm's running statistics (unbiased variance).  Called once in the forward and once more
@@ -160,13 +165,17 @@ class _BnState:
         if bn is None:
             return
         with torch.no_grad():
-            bn.num_batches_tracked += 1
-            if bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous():
+            if bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and (self.groups == 1 or bn.momentum is not None):
+                bn.num_batches_tracked += self.groups
                 ops.bn_running_update(self.mean, self.var, self.count, self._momentum(), bn.running_mean, bn.running_var)
-            else:
+                return
+            means = self.mean.reshape(self.groups, -1)
+            vars_ = self.var.reshape(self.groups, -1)
+            for gi in range(self.groups):                    # one momentum step per group, in order (cumulative average: m = 1 / n)
+                bn.num_batches_tracked += 1
                 m = self._momentum()
-                bn.running_mean.mul_(1.0 - m).add_(self.mean, alpha=m)
-                bn.running_var.mul_(1.0 - m).add_(self.var * (self.count / max(self.count - 1.0, 1.0)), alpha=m)
+                bn.running_mean.mul_(1.0 - m).add_(means[gi].to(bn.running_mean.dtype), alpha=m)
+                bn.running_var.mul_(1.0 - m).add_((vars_[gi] * (self.count / max(self.count - 1.0, 1.0))).to(bn.running_var.dtype), alpha=m)
 
     def _momentum(self) -> float:
         bn = self.bn
@@ -291,15 +300,11 @@ class VisTrain(torch.autograd.Function):
                 z = _conv_fwd(a, w3[:, :, 1:2].contiguous(), (1, 1, 1), False, zero_bias, kd=1)
             else:
                 z = _conv_fwd(a, w3, (1, 1, 1), False, zero_bias)
-            C = z.shape[-1]
-            y = torch.empty_like(z)
-            states = []
-            for v in range(NV):
-                zs = z[v * B:(v + 1) * B]
-                st = _BnState(vis_seq[i].bn, zs)
-                y[v * B:(v + 1) * B] = ops.bn_relu_apply(zs, st.mean, st.invstd, gamma, beta, None, relu=True)
-                states.append((st.mean, st.invstd, st.batch, st.count, (st.sync, st.group)))
-            blocks.append(states)
+            st = _BnState(vis_seq[i].bn, z, groups=NV)                            # one statistics set per source view
+            mean, invstd = (st.mean, st.invstd) if NV > 1 else (st.mean.reshape(1, -1), st.invstd.reshape(1, -1))
+            y = ops.bn_relu_apply(z, mean, invstd, gamma, beta, None, relu=True)
+            blocks.append((st.batch, st.count, (st.sync, st.group)))
+            saved += [mean, invstd]
             saved += [a, z, w3, gamma, beta]
             a = y
         ctx.blocks, ctx.B, ctx.NV = blocks, B, NV
@@ -314,22 +319,15 @@ class VisTrain(torch.autograd.Function):
         zero_bias = torch.zeros(64, dtype=torch.float32, device=g.device)
         grads = [None] * 9
         for i in (2, 1, 0):
-            a_in, z, w3, gamma, beta = S[5 * i:5 * i + 5]
+            mean, invstd, a_in, z, w3, gamma, beta = S[7 * i:7 * i + 7]
             C = z.shape[-1]
-            dz = torch.empty_like(z)
-            dgamma = torch.zeros(C, dtype=torch.float64, device=g.device)
-            dbeta = torch.zeros(C, dtype=torch.float64, device=g.device)
-            for v in range(NV):
-                mean, invstd, batch, count, group = ctx.blocks[i][v]
-                sl = slice(v * B, (v + 1) * B)
-                sums = ops.bn_relu_bwd_reduce(g[sl], z[sl], mean, invstd, gamma, beta, relu=True)
-                dbeta += sums[:C]
-                dgamma += sums[C:]
-                if group[0]:
-                    sums = sums.clone()
-                    torch.distributed.all_reduce(sums, group=group[1])
-                dz[sl] = ops.bn_relu_bwd_apply(g[sl], z[sl], mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
-            grads[3 * i + 1], grads[3 * i + 2] = dgamma.float(), dbeta.float()
+            batch, count, group = ctx.blocks[i]
+            sums = ops.bn_relu_bwd_reduce(g, z, mean, invstd, gamma, beta, relu=True)             # [NV, 2C]
+            grads[3 * i + 2], grads[3 * i + 1] = sums[:, :C].sum(0).float(), sums[:, C:].sum(0).float()
+            if group[0]:
+                sums = sums.clone()
+                torch.distributed.all_reduce(sums, group=group[1])
+            dz = ops.bn_relu_bwd_apply(g, z, mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
             # weight gradient on the k = (1,3,3) form of the kernel (the maps are D = 1 volumes); data gradient = the convolution with
             # flipped, transposed taps (nothing to propagate below the first layer: the entropy carries no gradient)
             dw2 = ops.conv3d_wgrad(a_in, dz, (1, 1, 1), kd=1)

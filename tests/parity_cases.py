@@ -833,6 +833,32 @@ def case_train_kernels(device):
         assert (cpu(s2[:C]).float() - beta.grad).abs().max() <= 1e-4 * max(1.0, float(beta.grad.abs().max()))
         assert (cpu(s2[C:]).float() - gamma.grad).abs().max() <= 1e-4 * max(1.0, float(gamma.grad.abs().max()))
         assert (cpu(dz) - z.grad).abs().max() <= 1e-4 * max(1.0, float(z.grad.abs().max())), C
+    # ---- grouped statistics: three slices normalised independently in one launch each (the visibility CNN's per-view BatchNorm)
+    C, G3 = 16, 3
+    z = torch.randn(G3 * 2, 5, 7, C, generator=g) * torch.tensor([1.0, 3.0, 0.5]).repeat_interleave(2).view(-1, 1, 1, 1) + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(z.shape, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    zd = dev(z, device)
+    rmd, rvd = dev(rm.clone(), device), dev(rv.clone(), device)
+    sums = ops.bn_stats(zd, G3)
+    n = z.numel() // C // G3
+    mean, var, invstd = ops.bn_finalize(sums, n, 1e-5, rmd, rvd, 0.1)
+    y = ops.bn_relu_apply(zd, mean, invstd, dev(gamma, device), dev(beta, device))
+    s2 = ops.bn_relu_bwd_reduce(dev(dy, device), zd, mean, invstd, dev(gamma, device), dev(beta, device))
+    dz = ops.bn_relu_bwd_apply(dev(dy, device), zd, mean, invstd, dev(gamma, device), dev(beta, device), s2, n)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    for gi in range(G3):
+        zs = z[2 * gi:2 * gi + 2].clone().requires_grad_(True)
+        ys = F.relu(bn(zs.reshape(-1, C))).reshape(zs.shape)
+        (ys * dy[2 * gi:2 * gi + 2]).sum().backward()
+        assert (cpu(y)[2 * gi:2 * gi + 2] - ys.detach()).abs().max() <= 2e-5, gi
+        assert (cpu(dz)[2 * gi:2 * gi + 2] - zs.grad).abs().max() <= 1e-4 * max(1.0, float(zs.grad.abs().max())), gi
+    assert (cpu(s2)[:, :C].sum(0).float() - bn.bias.grad).abs().max() <= 1e-4 * max(1.0, float(bn.bias.grad.abs().max()))
+    assert (cpu(s2)[:, C:].sum(0).float() - bn.weight.grad).abs().max() <= 1e-4 * max(1.0, float(bn.weight.grad.abs().max()))
+    assert (cpu(rmd) - bn.running_mean).abs().max() <= 1e-5 and (cpu(rvd) - bn.running_var).abs().max() <= 1e-4     # three momentum steps, in order
     # ---- weight gradient (and the transposed-convolution form)
     for CA, CB, stride, shape in ((8, 16, (1, 2, 2), (2, 4, 10, 36)), (16, 16, (1, 1, 1), (1, 5, 9, 20)), (32, 64, (2, 2, 2), (1, 4, 6, 8)),
                                  (64, 64, (1, 1, 1), (1, 2, 3, 5)), (8, 16, (2, 2, 2), (2, 6, 8, 18))):
