@@ -20,7 +20,7 @@ What is native and what is not, stated plainly:
 * still PyTorch-ROCm autograd, all of it element-wise or tiny: the visibility CNN's 1x1 Conv2d + sigmoid, CostRegNet3D's 1x1x1 `prob`,
   the softmax / argmax / regression head, the running-statistics momentum update.  ``MVS_TRAIN_REGNET=torch`` routes every conv /
   BatchNorm layer through autograd ops instead (the first form of this path; on the MI355X image MIOpen picks naive kernels for
-  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 12.6 ms natively).
+  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 11.8 ms natively).
 
 The reference differentiates neither the sampling grid (built under ``torch.no_grad()``, warping.py:80) nor the entropy
 (``sim_vol.detach()``, cost_volume.py:90); this path follows it: no gradient reaches the depth hypotheses, the cameras or - via
