@@ -161,6 +161,24 @@ int mvs_bn_relu_apply(const float* z_cl, const float* mean, const float* invstd,
 int mvs_bn_relu_bwd(const float* dy_cl, const float* z_cl, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, double* sums, double count, float* dz_cl, long long N, int C, int relu,
                     int use_batch_stats, int phase, int groups, void* stream);
+/* One conv / transposed-conv + batch-statistics BatchNorm + ReLU [+ skip] block per call (the launches of the granular entry points
+ * chained in C): forward = pack, linear convolution -> z, statistics, finalize (+ running-statistics step), normalise -> y;
+ * backward = running-statistics step (the reference's checkpoint recomputation), reduce -> dgamma / dbeta, dz, weight gradient dw
+ * ([Cout][Cin][kd*9], ConvTranspose: [Cin][Cout][27]), data gradient da (NULL: not needed).  w = the layer's own fp32 weight;
+ * zero_bias: >= 64 zeros; wpack_ws: bf16 scratch of mvs_pack_*_weights_elems elements (max over the block's three packings);
+ * sums_ws: double [groups][2C]; B, D, H, W = the block INPUT's batch and size.  SyncBatchNorm / eval-mode BatchNorm: use the
+ * granular entry points (an all-reduce sits between statistics and finalize).                                                  */
+int mvs_train_block_fwd(const float* a_in_cl, const float* w, int transposed, int Cin, int Cout, int kd, int sd, int sh, int sw,
+                        int B, int D, int H, int W, const float* gamma, const float* beta, float eps, float* running_mean,
+                        float* running_var, float momentum, const float* skip_cl, const float* zero_bias, void* wpack_ws,
+                        double* sums_ws, float* z_cl, float* mean, float* var, float* invstd, float* y_cl, int groups,
+                        void* stream);
+int mvs_train_block_bwd(const float* dy_cl, const float* a_in_cl, const float* z_cl, const float* mean, const float* var,
+                        const float* invstd, const float* w, int transposed, int Cin, int Cout, int kd, int sd, int sh, int sw,
+                        int B, int D, int H, int W, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, const float* zero_bias, void* wpack_ws, double* sums_ws,
+                        float* dz_cl, float* dw, float* dgamma, float* dbeta, float* da_cl, int groups, void* stream);
+
 /* MFMA weight packing on the device (bit-identical to packing.pack_conv_weights_bf16x3 / pack_deconv_weights_bf16x3; used by the
  * training path, which re-packs every un-folded weight each iteration).  *_elems = number of bf16 elements of the packed tensor
  * (-1: unsupported shape).  w: Conv3d [cout][cin][ntap] (tflip = 1: read as [cin][cout] with reversed taps = the data-gradient form

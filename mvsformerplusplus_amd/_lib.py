@@ -51,6 +51,8 @@ SIGNATURES = {
     "mvs_bn_running_update": (_i, [_vp, _vp, C.c_double, C.c_float, _vp, _vp, _i, _i, _vp]),
     "mvs_bn_relu_apply": (_i, [_vp] * 7 + [C.c_longlong, _i, _i, _i, _vp]),
     "mvs_bn_relu_bwd": (_i, [_vp] * 7 + [C.c_double, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),
+    "mvs_train_block_fwd": (_i, [_vp, _vp] + [_i] * 11 + [_vp, _vp, C.c_float, _vp, _vp, C.c_float] + [_vp] * 9 + [_i, _vp]),
+    "mvs_train_block_bwd": (_i, [_vp] * 7 + [_i] * 11 + [_vp, _vp, _vp, _vp, C.c_float] + [_vp] * 8 + [_i, _vp]),
     "mvs_pack_conv_weights_elems": (C.c_longlong, [_i] * 4),
     "mvs_pack_conv_weights": (_i, [_vp, _vp] + [_i] * 5 + [_vp]),
     "mvs_pack_deconv_weights_elems": (C.c_longlong, [_i] * 3),

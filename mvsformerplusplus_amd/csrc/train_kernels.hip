@@ -8,7 +8,7 @@
 // convolution the transposed convolution with the same taps; of a transposed convolution the strided convolution (training.py).
 //
 // Everything is channel-last fp32 [N voxels][C], C in {8, 16, 32, 64}.
-#include "mvs_common.h"
+#include "conv_cfg.h"
 
 namespace mvs {
 
@@ -343,6 +343,16 @@ __global__ __launch_bounds__(256) void pack_deconv_bf16x3_kernel(const float* __
     store_split_bf16(v, base, base + 512);
 }
 
+// d gamma / d beta as fp32 from the (per group) backward sums
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, int groups, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = (int)threadIdx.x;
+    if (c >= C) return;
+    double b = 0.0, g = 0.0;
+    for (int k = 0; k < groups; ++k) { b += sums[(size_t)k * 2 * C + c]; g += sums[(size_t)k * 2 * C + C + c]; }
+    dbeta[c] = (float)b;
+    dgamma[c] = (float)g;
+}
+
 template <class Cfg>
 static int launch_wgrad(const float* a, const float* g, float* dw, int B, int D, int H, int W, int OD, int OH, int OW, int CA, int CB, hipStream_t st) {
     const int tx = (int)ceil_div(OW, 16), ty = (int)ceil_div(OH, Cfg::TH), tz = (int)ceil_div(OD, Cfg::TD);
@@ -501,4 +511,78 @@ extern "C" int mvs_conv3d_wgrad(const float* a_cl, const float* g_cl, float* dw,
     if (sd == 2 && sh == 2 && sw == 2) return launch_wgrad<WgCfg<2, 2, 2, 2, 2>>(a_cl, g_cl, dw, B, D, H, W, OD, OH, OW, CA, CB, st);
     set_error("mvs_conv3d_wgrad: stride (%d,%d,%d) unsupported", sd, sh, sw);
     return MVS_ERR_UNSUPPORTED;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// One conv / transposed-conv + BatchNorm(batch statistics) + ReLU [+ skip] block per call, forward and backward: the launches the
+// granular entry points above make one by one from Python (pack, convolve, statistics, finalize, normalise / reduce, apply, weight
+// gradient, pack, data gradient), chained on the stream in C - a training step of the coarse stages was bound by the ~20 Python-level
+// operations per block, not by the GPU.  SyncBatchNorm (an all-reduce between statistics and finalize) and eval-mode BatchNorm keep
+// using the granular path.
+// ------------------------------------------------------------------------------------------------
+static int conv_chunk_of(int cin, int sd, int sh, int sw) { return (sd == 1 && sh == 1 && sw == 1 && cin >= 16) ? 16 : 8; }
+
+static int linear_conv(const float* x, const float* w, int transposed, int tflip, int Cin, int Cout, int kd, int sd, int sh, int sw, int B, int D, int H, int W,
+                       void* wpack, const float* zero_bias, float* y, hipStream_t st) {
+    int rc;
+    if (transposed) {
+        if ((rc = mvs_pack_deconv_weights(w, wpack, Cin, Cout, sd, st)) != MVS_OK) return rc;
+        return deconv3d_dispatch_bf16x3(x, wpack, zero_bias, nullptr, y, B, Cin, Cout, D, H, W, sd, st, nullptr, nullptr, nullptr, 0);
+    }
+    if ((rc = mvs_pack_conv_weights(w, wpack, Cout, Cin, kd * 9, conv_chunk_of(Cin, sd, sh, sw), tflip, st)) != MVS_OK) return rc;
+    return conv3d_dispatch_bf16x3(x, wpack, zero_bias, y, B, Cin, Cout, D, H, W, kd, sd, sh, sw, 0, st);
+}
+
+extern "C" int mvs_train_block_fwd(const float* a_in_cl, const float* w, int transposed, int Cin, int Cout, int kd, int sd, int sh, int sw, int B, int D,
+                                   int H, int W, const float* gamma, const float* beta, float eps, float* running_mean, float* running_var,
+                                   float momentum, const float* skip_cl, const float* zero_bias, void* wpack_ws, double* sums_ws, float* z_cl,
+                                   float* mean, float* var, float* invstd, float* y_cl, int groups, void* stream) {
+    if (!a_in_cl || !w || !gamma || !beta || !zero_bias || !wpack_ws || !sums_ws || !z_cl || !mean || !var || !invstd || !y_cl || groups < 1 || B % groups) {
+        set_error("mvs_train_block_fwd: bad arguments");
+        return MVS_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = linear_conv(a_in_cl, w, transposed, 0, Cin, Cout, kd, sd, sh, sw, B, D, H, W, wpack_ws, zero_bias, z_cl, st);
+    if (rc != MVS_OK) return rc;
+    const long long OD = transposed ? (long long)D * sd : (D + 2 * (kd / 2) - kd) / sd + 1, OH = transposed ? 2LL * H : (H - 1) / sh + 1,
+                    OW = transposed ? 2LL * W : (W - 1) / sw + 1;
+    const long long n = (long long)(B / groups) * OD * OH * OW;
+    if ((rc = mvs_bn_stats(z_cl, sums_ws, n, Cout, groups, stream)) != MVS_OK) return rc;
+    if ((rc = mvs_bn_finalize(sums_ws, (double)n, eps, mean, var, invstd, running_mean, running_var, momentum, Cout, groups, stream)) != MVS_OK) return rc;
+    return mvs_bn_relu_apply(z_cl, mean, invstd, gamma, beta, skip_cl, y_cl, n, Cout, 1, groups, stream);
+}
+
+extern "C" int mvs_train_block_bwd(const float* dy_cl, const float* a_in_cl, const float* z_cl, const float* mean, const float* var, const float* invstd,
+                                   const float* w, int transposed, int Cin, int Cout, int kd, int sd, int sh, int sw, int B, int D, int H, int W,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                   const float* zero_bias, void* wpack_ws, double* sums_ws, float* dz_cl, float* dw, float* dgamma, float* dbeta,
+                                   float* da_cl, int groups, void* stream) {
+    if (!dy_cl || !a_in_cl || !z_cl || !mean || !var || !invstd || !w || !gamma || !beta || !zero_bias || !wpack_ws || !sums_ws || !dz_cl || !dw || !dgamma ||
+        !dbeta || groups < 1 || B % groups) {
+        set_error("mvs_train_block_bwd: bad arguments");
+        return MVS_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int OD = transposed ? D * sd : (D + 2 * (kd / 2) - kd) / sd + 1, OH = transposed ? 2 * H : (H - 1) / sh + 1, OW = transposed ? 2 * W : (W - 1) / sw + 1;
+    const long long n = (long long)(B / groups) * OD * OH * OW;
+    int rc;
+    // the reference's checkpoint recomputation = a second train-mode forward: one more momentum step of the running statistics
+    if (running_mean != nullptr && (rc = mvs_bn_running_update(mean, var, (double)n, momentum, running_mean, running_var, Cout, groups, stream)) != MVS_OK) return rc;
+    if ((rc = mvs_bn_relu_bwd(dy_cl, z_cl, mean, invstd, gamma, beta, sums_ws, 1.0, nullptr, n, Cout, 1, 1, 0, groups, stream)) != MVS_OK) return rc;
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(1), dim3(64), 0, st, sums_ws, groups, Cout, dgamma, dbeta);
+    if ((rc = check_launch("bn_param_grads_kernel")) != MVS_OK) return rc;
+    if ((rc = mvs_bn_relu_bwd(dy_cl, z_cl, mean, invstd, gamma, beta, sums_ws, (double)n, dz_cl, n, Cout, 1, 1, 1, groups, stream)) != MVS_OK) return rc;
+    if (transposed) {
+        // weight gradient with the roles of input and output exchanged; data gradient = the strided convolution with the same taps
+        if ((rc = mvs_conv3d_wgrad(dz_cl, a_in_cl, dw, B, Cout, Cin, OD, OH, OW, 3, sd, 2, 2, stream)) != MVS_OK) return rc;
+        if (da_cl == nullptr) return MVS_OK;
+        return linear_conv(dz_cl, w, 0, 0, Cout, Cin, 3, sd, 2, 2, B, OD, OH, OW, wpack_ws, zero_bias, da_cl, st);
+    }
+    if ((rc = mvs_conv3d_wgrad(a_in_cl, dz_cl, dw, B, Cin, Cout, D, H, W, kd, sd, sh, sw, stream)) != MVS_OK) return rc;
+    if (da_cl == nullptr) return MVS_OK;
+    if (sd == 1 && sh == 1 && sw == 1)                                     // the convolution with flipped, transposed taps
+        return linear_conv(dz_cl, w, 0, 1, Cout, Cin, kd, 1, 1, 1, B, OD, OH, OW, wpack_ws, zero_bias, da_cl, st);
+    if ((D % sd) || (H % sh) || (W % sw) || sh != 2 || sw != 2 || kd != 3) { set_error("mvs_train_block_bwd: strided convolutions need even input sizes and stride (1|2,2,2)"); return MVS_ERR_ARG; }
+    return linear_conv(dz_cl, w, 1, 0, Cout, Cin, 3, sd, 2, 2, B, OD, OH, OW, wpack_ws, zero_bias, da_cl, st);   // the transposed convolution with the same taps
 }

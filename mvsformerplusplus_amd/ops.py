@@ -302,6 +302,54 @@ def bn_relu_bwd_apply(dy_cl, z_cl, mean, invstd, gamma, beta, sums, count: float
     return dz
 
 
+class TrainWorkspace:
+    """Scratch shared by the block calls of one autograd Function: zero bias, packed-weight buffer, statistics sums."""
+
+    def __init__(self, device):
+        self.zero_bias = torch.zeros(64, dtype=torch.float32, device=device)
+        self.wpack = torch.empty(64 * 64 * 32 * 2, dtype=torch.bfloat16, device=device)      # >= any packed U-Net weight (64 x 64 x 27, hi + lo)
+        self.sums = torch.empty(16 * 2 * 64, dtype=torch.float64, device=device)             # up to 16 statistics groups
+
+
+def _out_dims(transposed, kd, stride, D, H, W):
+    sd, sh, sw = stride
+    if transposed:
+        return D * sd, 2 * H, 2 * W
+    return (D + 2 * (kd // 2) - kd) // sd + 1, (H - 1) // sh + 1, (W - 1) // sw + 1
+
+
+def train_block_fwd(ws: TrainWorkspace, a_in, w, transposed: bool, kd: int, stride, gamma, beta, eps: float, running_mean, running_var,
+                    momentum: float, skip=None, groups: int = 1):
+    """conv / transposed conv + batch-statistics BatchNorm + ReLU [+ skip] in one C call -> (z, stats [3, groups, C], y)."""
+    B, D, H, W, cin = a_in.shape
+    cout = w.shape[1] if transposed else w.shape[0]
+    od, oh, ow = _out_dims(transposed, kd, stride, D, H, W)
+    z = torch.empty(B, od, oh, ow, cout, dtype=torch.float32, device=a_in.device)
+    y = torch.empty_like(z)
+    stats = torch.empty(3, groups, cout, dtype=torch.float32, device=a_in.device)
+    check(lib().mvs_train_block_fwd(ptr(a_in), ptr(w), 1 if transposed else 0, cin, cout, kd, stride[0], stride[1], stride[2], B, D, H, W,
+                                    ptr(gamma), ptr(beta), float(eps), ptr(running_mean), ptr(running_var), float(momentum), ptr(skip),
+                                    ptr(ws.zero_bias), ptr(ws.wpack), ptr(ws.sums), ptr(z), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(y),
+                                    groups, stream_of(a_in)), "mvs_train_block_fwd")
+    return z, stats, y
+
+
+def train_block_bwd(ws: TrainWorkspace, dy, a_in, z, stats, w, transposed: bool, kd: int, stride, gamma, beta, running_mean, running_var,
+                    momentum: float, need_da: bool = True, groups: int = 1):
+    """Backward of train_block_fwd in one C call -> (dw, dgamma, dbeta, da or None)."""
+    B, D, H, W, cin = a_in.shape
+    cout = z.shape[-1]
+    dz = torch.empty_like(z)
+    dw = torch.empty(w.shape[0], w.shape[1], kd, 3, 3, dtype=torch.float32, device=z.device)
+    dgb = torch.empty(2, cout, dtype=torch.float32, device=z.device)
+    da = torch.empty_like(a_in) if need_da else None
+    check(lib().mvs_train_block_bwd(ptr(dy), ptr(a_in), ptr(z), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(w), 1 if transposed else 0, cin, cout, kd,
+                                    stride[0], stride[1], stride[2], B, D, H, W, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                    float(momentum), ptr(ws.zero_bias), ptr(ws.wpack), ptr(ws.sums), ptr(dz), ptr(dw), ptr(dgb[0]), ptr(dgb[1]), ptr(da),
+                                    groups, stream_of(z)), "mvs_train_block_bwd")
+    return dw, dgb[0], dgb[1], da
+
+
 def pack_conv_weights_device(w: torch.Tensor, ch: int, tflip: bool = False) -> torch.Tensor:
     """packing.pack_conv_weights_bf16x3 in one launch on the weight's device.  w [Cout, Cin, kd, 3, 3]; tflip: the packed weight is
     W'[co][ci][tap] = w[ci][co][reversed tap] (w then has shape [Cin', Cout'] = [W' columns, W' rows])."""

@@ -120,6 +120,16 @@ def _embed_2d(w2d, cin_pad=None):
     return w3
 
 
+def _fast_bn(bn) -> bool:
+    """The one-call block kernels cover batch-statistics BatchNorm with fp32 running statistics and a fixed momentum on one rank;
+    SyncBatchNorm with an initialised process group, eval-mode BatchNorm and cumulative averaging take the granular path."""
+    if not bn.training or bn.running_mean is None or bn.momentum is None:
+        return False
+    if isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
+        return False
+    return bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous()
+
+
 class _BnState:
     """Forward statistics of one BatchNorm layer (batch statistics in train mode, running statistics otherwise) and the
     bookkeeping nn.BatchNorm3d / nn.SyncBatchNorm do: momentum update of the running statistics, all-reduce of the sums."""
@@ -192,7 +202,8 @@ class RegNetTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, volume_cl, reg, *params):
         x = ops._f32c(volume_cl.detach())
-        zero_bias = torch.zeros(64, dtype=torch.float32, device=x.device)
+        wsp = ops.TrainWorkspace(x.device)
+        zero_bias = wsp.zero_bias
         blocks, acts, saved = [], [x], []
         for i, name in enumerate(RegNetTrain.NAMES):
             conv, bn, transposed = _block_parts(getattr(reg, name))
@@ -200,10 +211,19 @@ class RegNetTrain(torch.autograd.Function):
             gamma, beta = params[3 * i + 1].detach().float().contiguous(), params[3 * i + 2].detach().float().contiguous()
             stride = _stride3(conv)
             a_in = acts[-1]
-            z = _conv_fwd(a_in, w, stride, transposed, zero_bias)
-            st = _BnState(bn, z)
             skip_idx = RegNetTrain.SKIP.get(i)
             skip = None if skip_idx is None else acts[skip_idx + 1]
+            if _fast_bn(bn):
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
+                z, stats, y = ops.train_block_fwd(wsp, a_in, w, transposed, 3, stride, gamma, beta, bn.eps, bn.running_mean, bn.running_var,
+                                                  bn.momentum, skip)
+                acts.append(y)
+                blocks.append((transposed, stride, True, 0.0, (False, None), bn))
+                saved += [a_in, z, stats, stats, w, gamma, beta]
+                continue
+            z = _conv_fwd(a_in, w, stride, transposed, zero_bias)
+            st = _BnState(bn, z)
             acts.append(ops.bn_relu_apply(z, st.mean, st.invstd, gamma, beta, skip, relu=True))
             blocks.append((transposed, stride, st.batch, st.count, (st.sync, st.group), st))
             saved += [a_in, z, st.mean, st.invstd, w, gamma, beta]
@@ -218,16 +238,25 @@ class RegNetTrain(torch.autograd.Function):
         grads = [None] * (3 * n)
         pending = {}                                     # activation index (0 = volume, i + 1 = output of block i) -> gradient so far
         pending[n] = ops._f32c(grad_out)
-        zero_bias = torch.zeros(64, dtype=torch.float32, device=grad_out.device)
+        wsp = ops.TrainWorkspace(grad_out.device)
+        zero_bias = wsp.zero_bias
         for i in range(n - 1, -1, -1):
             transposed, stride, batch, count, group, bn_state = ctx.blocks[i]
-            bn_state.update_running_stats()              # the reference's checkpoint recomputation (see _BnState)
             a_in, z, mean, invstd, w, gamma, beta = S[7 * i:7 * i + 7]
             g = pending.pop(i + 1)
             skip_idx = RegNetTrain.SKIP.get(i)
             if skip_idx is not None:                     # the skip source receives the block output's gradient unchanged
                 k = skip_idx + 1
                 pending[k] = g if k not in pending else pending[k] + g
+            if not isinstance(bn_state, _BnState):       # one-call block: bn_state is the BatchNorm module, `mean` the [3, 1, C] statistics
+                bn = bn_state
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1          # the reference's checkpoint recomputation: a second momentum step (in the call)
+                grads[3 * i], grads[3 * i + 1], grads[3 * i + 2], da = ops.train_block_bwd(
+                    wsp, g, a_in, z, mean, w, transposed, 3, stride, gamma, beta, bn.running_mean, bn.running_var, bn.momentum)
+                pending[i] = da if i not in pending else pending[i] + da
+                continue
+            bn_state.update_running_stats()              # the reference's checkpoint recomputation (see _BnState)
             sums = ops.bn_relu_bwd_reduce(g, z, mean, invstd, gamma, beta, relu=True)
             grads[3 * i + 2] = sums[: sums.numel() // 2].float()                     # d beta (this rank's voxels; DDP averages)
             grads[3 * i + 1] = sums[sums.numel() // 2:].float()                      # d gamma
