@@ -12,7 +12,9 @@ What is native and what is not, stated plainly:
   split-bf16 MFMA kernels of the inference path with un-folded, re-packed weights (the data gradient of a stride-1 convolution is
   the convolution with flipped, transposed taps; of a strided convolution the transposed convolution; of a transposed convolution
   the strided convolution), WEIGHT gradients on an fp32-MFMA kernel (``mvs_conv3d_wgrad``), batch-statistics BatchNorm + ReLU +
-  skip forward and backward on ``mvs_bn_*`` (sums in double, SyncBatchNorm's all-reduce of the sums included).  Activations are
+  skip forward and backward on ``mvs_bn_*`` (sums in double, SyncBatchNorm's all-reduce of the sums included); on one rank each
+  block is ONE C call per direction (``mvs_train_block_fwd`` / ``_bwd`` chain pack, convolution, statistics, finalize, normalise /
+  reduce, apply, weight gradient, pack, data gradient on the stream).  Activations are
   kept (pre-BatchNorm convolution outputs and block outputs) instead of being recomputed under ``torch.utils.checkpoint``
   (module.py:393-396): at training sizes they are tens of MB per stage;
 * the visibility CNN's three Conv2d + BatchNorm2d + ReLU blocks (``VisTrain``: the same kernels on D = 1 volumes, BatchNorm per
