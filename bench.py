@@ -25,7 +25,8 @@ N > 1: one process per GPU; reference views are independent, so every rank runs 
 (source views over ranks, partial cost volumes combined per stage over RCCL) is timed afterwards on
 BASELINE configs[2]'s shape (V = 10) and reported in the extra `view_sharded` object.
 
-Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, HIP-event timing on the launch stream) and
+Rank 0 prints ONE JSON line.  Extra objects: `training_step` (N = 1: forward + backward of each cascade stage through the native
+training kernels at DTU-training-like sizes, outside the timed region), `roofline` (dominant kernel, HIP-event timing on the launch stream) and
 `cpu_baseline` (the oracle - a CPU restatement of the reference path - timed on this host's cores, N=1 only).
 """
 import argparse
@@ -102,6 +103,7 @@ def main():
     ap.add_argument("--width", type=int, default=1536)
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the extra `training_step` object (forward + backward of each cascade stage)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--streams", type=int, default=3,
@@ -307,6 +309,13 @@ def main():
         except Exception as e:
             result["attention_bf16p"] = {"error": repr(e)}
 
+    # ---- extra: one training step (forward + backward) per cascade stage through the native kernels ----
+    if world == 1 and not a.no_train_leg and a.cost_reg != "shipped":
+        try:
+            result["training_step"] = training_leg(device)
+        except Exception as e:  # the headline does not depend on it
+            result["training_step"] = {"error": repr(e)}
+
     # ---- view-sharded latency mode (N > 1): source views over ranks + RCCL collectives per stage ----
     if world > 1:
         # The headline above is already measured.  The extra leg exercises collectives that have only ever run on gloo in the build
@@ -342,6 +351,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def training_leg(device):
+    """Forward + backward of each cascade stage in train mode (native gather / convolution / BatchNorm kernels behind autograd
+    Functions, mvsformerplusplus_amd/training.py) at DTU-training-like sizes: B = 2, V = 5, 512 x 640 at the finest stage."""
+    import torch
+    from mvsformerplusplus_amd import synth
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    out = {"batch": 2, "views": 5, "unit": "ms per stage step (forward + backward)", "stages": {},
+           "note": "not part of the timed headline; see DESIGN.md section 8 for the comparison with the PyTorch-autograd route"}
+    B, V = 2, 5
+    for stage, C, D, H, W in ((0, 64, 32, 64, 80), (1, 32, 16, 128, 160), (2, 16, 8, 256, 320), (3, 8, 4, 512, 640)):
+        net = StageNet({"base_ch": [8] * 4, "depth_type": ["ce"] * 4}, D, stage).to(device).train()
+        cams = synth.make_cameras(V, H, W, baseline=30.0, seed=1, batch=B).to(device)
+        g = torch.Generator().manual_seed(stage)
+        feats = torch.randn(B, V, C, H, W, generator=g).to(device).requires_grad_(True)
+        hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.02 * torch.rand(B, D, H, W, generator=g))).to(device).contiguous()
+
+        def step():
+            net(feats, cams, hyp, 1.0)["prob_volume_pre"].square().mean().backward()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        out["stages"]["stage%d" % (stage + 1)] = {"C": C, "D": D, "H": H, "W": W, "ms": (time.perf_counter() - t0) / 5 * 1e3}
+        assert torch.isfinite(feats.grad).all()
+    out["ms_all_stages"] = sum(v["ms"] for v in out["stages"].values())
+    return out
 
 
 def view_sharded_leg(head, a, device, world, rank, sync_all, fdt):
