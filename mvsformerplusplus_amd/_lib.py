@@ -7,12 +7,14 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
+# MVS_HIP_LIB: measurement scripts point the binding at a variant build of the SAME C ABI (build.build(out=...)); unset = the product library
+LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
 ABI_VERSION = 5
@@ -123,7 +125,15 @@ def check(rc: int, what: str = "") -> None:
         raise MvsHipError("%s failed (code %d): %s" % (what or "libmvs_hip call", rc, msg.decode() if msg else "?"))
 
 
-_CALL_DEVICE: list = []       # devices of the tensors handed to ptr() since the last device_call()
+class _CallDevices(threading.local):
+    """Devices of the tensors handed to ptr() while the arguments of ONE C-ABI call are evaluated - per thread (DataParallel
+    replicas and autograd's per-device worker threads issue calls concurrently)."""
+
+    def __init__(self):
+        self.devs = []
+
+
+_CALL_DEVICE = _CallDevices()
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -135,14 +145,15 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if _REQUIRE_DEVICE and not t.is_cuda:
         raise MvsHipError("libmvs_hip needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
     if t.is_cuda:
-        _CALL_DEVICE.append(t.device)
+        _CALL_DEVICE.devs.append(t.device)
     return t.data_ptr()
 
 
 class _GuardedLib:
     """Every C-ABI call runs with the tensors' device made current (HIP resolves the null stream and launches on the CURRENT
     device, not on the device that owns the pointers), and refuses tensors spread over several devices - what torch's own ops
-    do with their device guard.  Arguments are evaluated (ptr() records the devices) before the call is made."""
+    do with their device guard.  Python evaluates `lib.mvs_x` (this __getattr__: the record is cleared, so a ptr() that raised in an
+    earlier, abandoned argument list leaves nothing behind), then the arguments (ptr() records the devices), then makes the call."""
 
     def __init__(self, cdll):
         self._cdll = cdll
@@ -152,9 +163,11 @@ class _GuardedLib:
         if not name.startswith("mvs_") or name in ("mvs_abi_version", "mvs_last_error") or name.endswith("_bytes") or name.endswith("_floats"):
             return fn
 
+        del _CALL_DEVICE.devs[:]
+
         def call(*args):
-            devs = set(_CALL_DEVICE)
-            del _CALL_DEVICE[:]
+            devs = set(_CALL_DEVICE.devs)
+            del _CALL_DEVICE.devs[:]
             if len(devs) > 1:
                 raise MvsHipError("%s: tensors on different devices %s" % (name, sorted(str(d) for d in devs)))
             if devs:

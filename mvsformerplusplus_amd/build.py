@@ -34,29 +34,32 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """out: build a VARIANT of the library (measurement scripts: other -D switches) next to the product library; never stamped."""
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+    if out is None and not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
         return LIB
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     objs, procs = [], []
+    tag = "" if out is None else "." + os.path.basename(out)
     for s in srcs:
-        o = s[:-4] + ".o"
+        o = s[:-4] + tag + ".o"
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + list(extra_flags) + ["-c", s, "-o", o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for cmd, p in procs:
-        out = p.communicate()[0].decode()
+        log = p.communicate()[0].decode()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
-        if verbose and out.strip():
-            print(out)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
+        if verbose and log.strip():
+            print(log)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs)
     for o in objs:
         os.remove(o)
-    with open(STAMP, "w") as f:
-        f.write(dig)
-    return LIB
+    if out is None:
+        with open(STAMP, "w") as f:
+            f.write(dig)
+    return out or LIB
 
 
 if __name__ == "__main__":

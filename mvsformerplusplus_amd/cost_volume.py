@@ -8,8 +8,11 @@ returns exactly what the reference does (cost_volume.py:21-133) and owns the sam
     -> regulariser U-Net (9 MFMA conv launches) -> prob + softmax + regression + confidence
 
 With ``view_group`` set (a torch.distributed process group over RCCL) the source views are sharded over the
-ranks of the group and the partial ``volume_sum`` / ``vis_sum`` are combined with ONE all-reduce per stage
-(SURVEY.md section 8e); everything after the all-reduce is replicated, so all ranks return identical results.
+ranks of the group.  Per stage the partial ``volume_sum`` / ``vis_sum`` are combined either with
+ONE all-reduce (coarse stages: everything after it is replicated) or, where a row slab is at least one halo tall, by a
+slab exchange after which every rank regularises 1 / R of the volume (plus a 40-row halo) and an all-gather of the per-row
+outputs gives every rank the whole stage result - bit-identical on all ranks in both forms (``shard_mode``).
+In train mode / with features that require grad the stage runs the native training path of ``training.py``.
 """
 from __future__ import annotations
 
@@ -92,8 +95,8 @@ class StageNet(nn.Module):
 
     def forward(self, features, proj_matrices, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
         if self._wants_autograd(features):
-            # SURVEY.md section 8f #2, first slice: HIP gather forward + backward, PyTorch-ROCm autograd for the conv / BatchNorm
-            # layers (training.py says exactly what runs where)
+            # autograd Functions over the library's training kernels (gather forward / backward, U-Net and
+            # visibility CNN convolutions, BatchNorm, weight gradients); training.py says exactly what runs where
             from .training import stage_forward_train
             assert features.shape[1] == proj_matrices.shape[1], "Different number of images and projection matrices"
             return stage_forward_train(self, features, proj_matrices, depth_values, tmp, position3d)
@@ -162,13 +165,23 @@ class StageNet(nn.Module):
                 "depth_values": depth_values, "prob_volume_pre": prob_volume_pre}
 
     # ---- source views sharded over the ranks of `view_group` ---------------------------------------
+    MAX_CACHED_SHAPES = 2          # input resolutions whose scratch is kept (mixed-resolution datasets would otherwise grow it without bound)
+
+    def clear_buffers(self):
+        """Free the persistent scratch of the sharded path."""
+        self._buffers_cache.clear()
+
     def _buffer(self, name, shape, device, zero=False):
-        """Persistent scratch per (name, shape): the sharded path allocates nothing in steady state."""
+        """Persistent scratch per (name, shape): the sharded path allocates nothing in steady state.  One buffer per name is kept
+        for each of the MAX_CACHED_SHAPES most recently used shapes (LRU)."""
         key = (name, tuple(shape), device)
-        buf = self._buffers_cache.get(key)
+        buf = self._buffers_cache.pop(key, None)
         if buf is None:
+            same = [k for k in self._buffers_cache if k[0] == name and k[2] == device]
+            for k in same[: max(0, len(same) - (self.MAX_CACHED_SHAPES - 1))]:        # dicts keep insertion order: oldest first
+                del self._buffers_cache[k]
             buf = torch.empty(shape, dtype=torch.float32, device=device)
-            self._buffers_cache[key] = buf
+        self._buffers_cache[key] = buf                              # (re-)inserted last = most recently used
         if zero:
             buf.zero_()
         return buf
@@ -294,7 +307,9 @@ class StageNet(nn.Module):
             dist.all_gather(list(allb.unbind(0)), mine, group=self.view_group)
         self.last_collective_bytes += allb.numel() * 4
         full = allb.permute(1, 2, 0, 3, 4).reshape(B, nch, world * S, W)[:, :, :H]
-        res = {"depth": full[:, 0].contiguous(), "photometric_confidence": full[:, 1].contiguous(), "depth_values": depth_values,
-               "prob_volume": full[:, 2: 2 + D].contiguous() if self.return_prob_volumes else None,
-               "prob_volume_pre": full[:, 2 + D: 2 + 2 * D].contiguous() if self.return_prob_volumes else None}
+        # .clone(), not .contiguous(): with world == 1 and B == 1 the slices are already contiguous VIEWS of the persistent
+        # gather_out buffer and the next forward of the same shape would overwrite the results the caller holds
+        res = {"depth": full[:, 0].clone(), "photometric_confidence": full[:, 1].clone(), "depth_values": depth_values,
+               "prob_volume": full[:, 2: 2 + D].clone() if self.return_prob_volumes else None,
+               "prob_volume_pre": full[:, 2 + D: 2 + 2 * D].clone() if self.return_prob_volumes else None}
         return res

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float xh = (zz[k] - mu[k]) * is[k];
-            const float g = (!relu || xh * ga[k] + be[k] > 0.0f) ? gg[k] : 0.0f;
+            // the ReLU mask is rebuilt with the forward's own expression, rounding for rounding (bn_apply_kernel): t = (z - mean) * (invstd * gamma) + beta
+            const float g = (!relu || (zz[k] - mu[k]) * (is[k] * ga[k]) + be[k] > 0.0f) ? gg[k] : 0.0f;
             s[k] += g;
             sx[k] += (double)g * xh;
         }
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int k = 0; k < 4; ++k) {
         const float is = invstd[c0 + k], ga = gamma[c0 + k];
         const float xh = (zz[k] - mean[c0 + k]) * is;
-        const float g = (!relu || xh * ga + beta[c0 + k] > 0.0f) ? gg[k] : 0.0f;
+        const float g = (!relu || (zz[k] - mean[c0 + k]) * (is * ga) + beta[c0 + k] > 0.0f) ? gg[k] : 0.0f;      // the forward's expression (bn_apply_kernel)
         float t = g;
         if (use_batch_stats) t -= (float)(sums[c0 + k] / count) + xh * (float)(sums[C + c0 + k] / count);
         out[k] = t * ga * is;

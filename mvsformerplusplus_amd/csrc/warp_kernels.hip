@@ -478,11 +478,20 @@ int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* ho
                         float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
 int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W, hipStream_t st);
 
-// MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels (A/B measurements); anything else = LDS-staged where supported
-static bool use_lds_gather(int C, int G, int D, int H, int W) {
+// wave-autonomous form (gather_wave_kernels.hip, round 3)
+bool gw_supported(int C, int G, int D, int H, int W);
+int gw_launch_entropy(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H,
+                      int W, int vb, int ve, hipStream_t st);
+int gw_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol,
+                        float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
+
+// Which form of the gather passes runs (A/B measurements): MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels,
+// =lds the round-2 workgroup-window kernels; anything else = the wave-autonomous kernels where supported (0 direct, 1 lds, 2 wave)
+static int gather_impl(int C, int G, int D, int H, int W) {
     const char* e = getenv("MVS_GATHER_IMPL");
-    if (e && e[0] == 'd') return false;
-    return gl_supported(C, G, D, H, W);
+    if (e && e[0] == 'd') return 0;
+    if (!(e && e[0] == 'l') && gw_supported(C, G, D, H, W)) return 2;
+    return gl_supported(C, G, D, H, W) ? 1 : 0;
 }
 
 }  // namespace mvs
@@ -542,7 +551,9 @@ extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int la
     hipStream_t st = (hipStream_t)stream;
     rc = check_layout("mvs_warp_corr_entropy_fwd", layout, C, G, D, H, W);
     if (rc != MVS_OK) return rc;
-    if (layout == MVS_LAYOUT_OCTET_TILED || use_lds_gather(C, G, D, H, W))
+    const int impl = gather_impl(C, G, D, H, W);
+    if (impl == 2) return gw_launch_entropy(features, dtype, layout, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
+    if (layout == MVS_LAYOUT_OCTET_TILED || impl == 1)
         return gl_launch_entropy(features, dtype, layout, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
@@ -561,7 +572,10 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int 
     hipStream_t st = (hipStream_t)stream;
     rc = check_layout("mvs_warp_corr_aggregate_fwd", layout, C, G, D, H, W);
     if (rc != MVS_OK) return rc;
-    if (layout == MVS_LAYOUT_OCTET_TILED || use_lds_gather(C, G, D, H, W))
+    const int impl = gather_impl(C, G, D, H, W);
+    if (impl == 2)
+        return gw_launch_aggregate(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, D, H, W, view_begin, view_end, st);
+    if (layout == MVS_LAYOUT_OCTET_TILED || impl == 1)
         return gl_launch_aggregate(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F32, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);

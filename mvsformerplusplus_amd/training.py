@@ -20,9 +20,10 @@ What is native and what is not, stated plainly:
 * the visibility CNN's three Conv2d + BatchNorm2d + ReLU blocks (``VisTrain``: the same kernels on D = 1 volumes, BatchNorm per
   source view like the reference's per-view calls) and CostRegNet's 3x3x3 `prob` (``Prob3Train``) are native as well;
 * still PyTorch-ROCm autograd, all of it element-wise or tiny: the visibility CNN's 1x1 Conv2d + sigmoid, CostRegNet3D's 1x1x1 `prob`,
-  the softmax / argmax / regression head, the running-statistics momentum update.  ``MVS_TRAIN_REGNET=torch`` routes every conv /
-  BatchNorm layer through autograd ops instead (the first form of this path; on the MI355X image MIOpen picks naive kernels for
-  these 3-D and 2-D convolutions: 400 ms per stage-4 step against 11.8 ms natively).
+  the softmax / argmax / regression head, the running-statistics momentum update.  There is no second backend in this module: a
+  stage the native kernels do not cover (base_ch != 8, conv_precision "fp32") raises.  The comparator that routes every conv /
+  BatchNorm layer through PyTorch-ROCm autograd ops lives with the tests (``tests/train_torch_route.py``; on the MI355X image MIOpen
+  picks naive kernels for these 3-D and 2-D convolutions: 400 ms per stage-4 step against 11.8 ms natively).
 
 The reference differentiates neither the sampling grid (built under ``torch.no_grad()``, warping.py:80) nor the entropy
 (``sim_vol.detach()``, cost_volume.py:90); this path follows it: no gradient reaches the depth hypotheses, the cameras or - via
@@ -32,13 +33,11 @@ native cost volume and head; a hand-written attention backward is not built.
 """
 from __future__ import annotations
 
-import os
 from typing import Dict
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-import torch.utils.checkpoint as cp
 
 from . import _lib, ops, packing
 
@@ -284,30 +283,6 @@ def regnet_forward_native(reg, volume_cl: torch.Tensor) -> torch.Tensor:
     return RegNetTrain.apply(volume_cl, reg, *params)
 
 
-def regnet_forward_torch(reg, x: torch.Tensor) -> torch.Tensor:
-    """CostRegNet / CostRegNet3D forward (module.py:398-408, 494-504) as autograd ops on the module's own layers."""
-    def block(layer, t):
-        if isinstance(layer, torch.nn.Sequential):                 # CostRegNet3D's conv7/9/11: ConvTranspose3d, BatchNorm3d, ReLU
-            return layer(t)
-        t = layer.conv(t)
-        if layer.bn is not None:
-            t = layer.bn(t)
-        return F.relu(t) if layer.relu else t
-
-    def once(v):
-        conv0 = v
-        conv2 = block(reg.conv2, block(reg.conv1, conv0))
-        conv4 = block(reg.conv4, block(reg.conv3, conv2))
-        t = block(reg.conv6, block(reg.conv5, conv4))
-        t = conv4 + block(reg.conv7, t)
-        t = conv2 + block(reg.conv9, t)
-        t = reg.inner(conv0) + block(reg.conv11, t)
-        return reg.prob(t)
-    if torch.is_grad_enabled() and x.requires_grad:
-        return cp.checkpoint(once, x, use_reentrant=True)
-    return once(x)
-
-
 class VisTrain(torch.autograd.Function):
     """The three Conv2d + BatchNorm2d + ReLU blocks of the visibility CNN (cost_volume.py:36, module.py:168-197) on the library's
     kernels: entropy [B, V-1, H, W] (no gradient: it comes from sim.detach()) -> features [V-1, B, H, W, 8] channel-last, with
@@ -410,15 +385,6 @@ def vis_forward_native(vis_seq, entropy: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(v).permute(1, 0, 2, 3)
 
 
-def vis_forward_torch(vis_seq, entropy: torch.Tensor) -> torch.Tensor:
-    """self.vis(entropy) (cost_volume.py:36,93): three Conv2d + BatchNorm2d + ReLU, a 1x1 Conv2d and a sigmoid.
-    entropy [B,1,H,W] -> [B,1,H,W]."""
-    t = entropy
-    for i in range(3):
-        t = F.relu(vis_seq[i].bn(vis_seq[i].conv(t)))
-    return torch.sigmoid(vis_seq[3](t))
-
-
 def _position_encoding_3d(position3d: torch.Tensor, C: int, rescale: float = 4.0) -> torch.Tensor:
     """PositionEncoding3D (position_encoding.py:166-189): per axis C channels, sin on the even and cos on the odd ones of
     position * rescale * 10000^(-2i/C) -> [B, 3C, D, H, W].  No gradient: the positions come from the hypotheses."""
@@ -482,17 +448,15 @@ def stage_forward_train(net, features, proj_matrices, depth_values, tmp, positio
         entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)                                 # [B,V-1,H,W], from sim.detach() in the reference
     # the reference runs the visibility CNN once per source view on a batch of B maps (cost_volume.py:93); BatchNorm statistics
     # are per call there, so the views are kept as separate calls here as well
-    native = os.environ.get("MVS_TRAIN_REGNET", "hip") != "torch" and G == 8
-    if native:
-        vis = vis_forward_native(net.vis, entropy)                                                # [B,V-1,H,W]
-    else:
-        vis = torch.cat([vis_forward_torch(net.vis, entropy[:, v:v + 1]) for v in range(V - 1)], dim=1)
+    if G != 8:
+        raise NotImplementedError("base_ch=%d: the HIP training kernels are built for 8 groups (all shipped configs)" % G)   # as in inference
+    if getattr(net, "conv_precision", "bf16x3") != "bf16x3":
+        raise NotImplementedError("conv_precision=%r: the native training kernels contract in split bf16 (forward and data gradients) "
+                                  "and fp32 MFMA (weight gradients)" % net.conv_precision)
+    vis = vis_forward_native(net.vis, entropy)                                                    # [B,V-1,H,W]
     if transformer:
         volume = WarpCorrAggregate.apply(features, vis, hom, hyp, G)                               # [B,G,D,H,W]
         prob_volume_pre = transformer_forward_torch(net.cost_reg, volume, position3d).squeeze(1)
-    elif not native:
-        volume = WarpCorrAggregate.apply(features, vis, hom, hyp, G)                               # [B,G,D,H,W]
-        prob_volume_pre = regnet_forward_torch(net.cost_reg, volume).squeeze(1)
     else:
         volume_cl = WarpCorrAggregate.apply(features, vis, hom, hyp, G, True)                      # [B,D,H,W,G]
         feat_cl = regnet_forward_native(net.cost_reg, volume_cl)                                   # [B,D,H,W,8]
@@ -503,8 +467,13 @@ def stage_forward_train(net, features, proj_matrices, depth_values, tmp, positio
                 prob_volume_pre = prob_volume_pre + prob.bias
         else:
             prob_volume_pre = Prob3Train.apply(feat_cl, prob.weight)                               # module.py:391,407
+    return stage_head_train(net, prob_volume_pre, depth_values, tmp)
+
+
+def stage_head_train(net, prob_volume_pre, depth_values, tmp) -> Dict[str, torch.Tensor]:
+    """softmax / regression / confidence of a stage in autograd ops (cost_volume.py:105-131), from the logits [B,D,H,W]."""
     prob_volume = F.softmax(prob_volume_pre, dim=1)
-    D = hyp.shape[1]
+    D = prob_volume_pre.shape[1]
     if net.depth_type == "ce":
         if net.training:
             idx = prob_volume.argmax(dim=1, keepdim=True)

@@ -1,26 +1,33 @@
 """Randomised differential test of the TRAINING path on the GPU box: the native route (HIP gather / convolution / BatchNorm forward and
-backward) against the same StageNet with every conv / BatchNorm layer on PyTorch-ROCm autograd (MVS_TRAIN_REGNET=torch; the gather and
+backward) against the same StageNet with every conv / BatchNorm layer on PyTorch-ROCm autograd (tests/train_torch_route.py; the gather and
 its backward are the HIP kernels on both routes), random shapes, view counts, batch sizes, channel counts, regulariser kinds.
     gpurun -- 'python scripts/fuzz_train_gpu.py 40'
 Per case: loss, and for the feature gradient and every parameter gradient the cosine between the two routes and the max-norm error
 relative to the tensor's largest entry.  The test loss weights the probabilities with random signs, so every gradient is a random-walk
 sum over voxels and ONE ReLU unit flipped by the 2^-16-class forward difference between the routes moves a tensor's max-norm error to
 ~1e-2 (DESIGN.md section 2
-row f #2).  Every case therefore carries its own yardstick - the autograd route against itself with 3e-6-relative noise on its 3-D
-conv outputs, printed beside the native route's numbers (which flips happen is a lottery on both sides: the two agree in magnitude,
+row f #2).  Every case therefore carries its own yardstick - the autograd route against itself with 3e-6-relative noise on every
+conv output (3-D and the visibility CNN's 2-D ones), printed beside the native route's numbers (which flips happen is a lottery on both sides: the two agree in magnitude,
 not case by case) - and is bad when the losses differ by more than 1e-3 + 1e-4 relative, any gradient tensor's cosine between the
-routes is below 0.99, or the median max-norm error exceeds 0.1."""
+routes is below 0.99, the median max-norm error exceeds 0.1, or ANY tensor's max-norm error exceeds max(0.2, 10 x the yardstick's
+error for the SAME tensor).  The per-tensor yardstick matters for cancellation residues: with V = 3 the gradient of the visibility
+CNN's last bias is the sum of two per-view sums of opposite sign (a common shift of both visibility logits nearly cancels in
+sum(sim * vis) / sum(vis)); in the round-2 run's one "BAD" case (seed 1, case 15: unet D=32 32x16 V=3 B=2 C=64, tensor vis.3.bias)
+the two view sums are +2.698 and -2.712, the gradient -0.0132 is 1.8e-4 of its terms' absolute sum 71.8, and 0.56 relative error on
+it is 1e-4 of that scale - the yardstick route moves the same scalar by as much.  FUZZ_EMU=1 reproduces the GPU numbers bit for bit
+on the host emulator (same losses to every printed digit)."""
 import copy, os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from mvsformerplusplus_amd import synth
 from mvsformerplusplus_amd.cost_volume import StageNet
+from train_torch_route import stage_forward_train_torch
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 if os.environ.get("FUZZ_EMU"):          # build container: the kernels through the host emulator (tests/hipemu), everything on the CPU
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     import hipemu_build
     from mvsformerplusplus_amd import _lib
     _lib._LIB = _lib.bind(hipemu_build.build())
@@ -49,32 +56,39 @@ for case in range(n_cases):
     R = torch.randn(B, D, H, W, generator=g).to(dev)
     res = []
     for route, m in (("hip", net), ("torch", ref)):
-        os.environ["MVS_TRAIN_REGNET"] = route
         f = feats.clone().requires_grad_(True)
-        out = m(f, cams, hyp, 1.0)
+        out = m(f, cams, hyp, 1.0) if route == "hip" else stage_forward_train_torch(m, f, cams, hyp, 1.0)
         loss = (out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
         loss.backward()
         res.append((loss.item(), f.grad, {n: p.grad for n, p in m.named_parameters()}))
-    yard_med, yard_worst = 0.0, 0.0
+    yard_med, yard_worst, yard = 0.0, 0.0, {}
     if not os.environ.get("FUZZ_NO_YARDSTICK"):
         # yardstick: the autograd route against ITSELF with 1e-5-relative noise on every 3-D conv output (the size of the split-bf16
         # forward's rounding difference): what a handful of flipped ReLU units do to these random-sign gradient sums
-        noisy = copy.deepcopy(ref)
-        noisy.zero_grad()
-        gen = torch.Generator(device="cpu").manual_seed(99)
-        hooks = [mod.register_forward_hook(lambda mod_, inp, out_: out_ + 3e-6 * float(out_.abs().max()) * torch.randn(out_.shape, generator=gen).to(out_.device))
-                 for mod in noisy.cost_reg.modules() if isinstance(mod, (torch.nn.Conv3d, torch.nn.ConvTranspose3d))]
-        os.environ["MVS_TRAIN_REGNET"] = "torch"
-        f = feats.clone().requires_grad_(True)
-        out = noisy(f, cams, hyp, 1.0)
-        ((out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()).backward()
-        gpn = {n: p.grad for n, p in noisy.named_parameters()}
-        en = [float((gpn[n] - res[1][2][n]).abs().max() / res[1][2][n].abs().max().clamp_min(1e-20)) for n in gpn if n.startswith("cost_reg")]
+        # several noise draws, per-tensor maximum: ONE ReLU unit within 1e-6 of zero at the deepest U-Net level (tens of voxels per
+        # channel) flips in about half of the draws and moves a whole weight-gradient tensor by tens of percent - bimodal, e.g. seed 1
+        # case 17 (unet D=16 48x24 V=2 B=2 C=32): cost_reg.conv6.conv.weight is off by 0.35 in 4 of 8 draws of 1e-6 noise and by
+        # 5e-3 in the others; the native route sits in one of the two modes
+        yard = {}
+        for draw in range(int(os.environ.get("FUZZ_YARD_DRAWS", "6"))):
+            noisy = copy.deepcopy(ref)
+            noisy.zero_grad()
+            gen = torch.Generator(device="cpu").manual_seed(99 + draw)
+            hooks = [mod.register_forward_hook(lambda mod_, inp, out_: out_ + 3e-6 * float(out_.abs().max()) * torch.randn(out_.shape, generator=gen).to(out_.device))
+                     for mod in list(noisy.cost_reg.modules()) + list(noisy.vis.modules())
+                     if isinstance(mod, (torch.nn.Conv3d, torch.nn.ConvTranspose3d, torch.nn.Conv2d))]
+            f = feats.clone().requires_grad_(True)
+            out = stage_forward_train_torch(noisy, f, cams, hyp, 1.0)
+            ((out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()).backward()
+            gpn = {n: p.grad for n, p in noisy.named_parameters()}
+            for n in gpn:
+                yard[n] = max(yard.get(n, 0.0), float((gpn[n] - res[1][2][n]).abs().max() / res[1][2][n].abs().max().clamp_min(1e-20)))
+        en = [yard[n] for n in gpn if n.startswith("cost_reg")]
         yard_med, yard_worst = sorted(en)[len(en) // 2], max(en)
-    os.environ["MVS_TRAIN_REGNET"] = "hip"
     (l0, gf0, gp0), (l1, gf1, gp1) = res
     cos = lambda a, b: float(torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
     errs, coss = [float((gf0 - gf1).abs().max() / gf1.abs().max().clamp_min(1e-20))], [cos(gf0, gf1)]
+    over = []                                                          # tensors beyond their own yardstick
     top = max(float(v.abs().max()) for v in gp1.values())
     for n in gp1:
         if V == 2 and n.startswith("vis."):
@@ -82,14 +96,18 @@ for case in range(n_cases):
         if float(gp1[n].abs().max()) > 1e-6 * top:                      # analytically-zero gradients hold noise on both routes
             errs.append(float((gp0[n] - gp1[n]).abs().max() / gp1[n].abs().max()))
             coss.append(cos(gp0[n], gp1[n]))
+            if errs[-1] > max(0.2, 10.0 * yard.get(n, 0.0)):
+                over.append("%s %.1e (yardstick %.1e)" % (n, errs[-1], yard.get(n, 0.0)))
     med, worst, cmin = sorted(errs)[len(errs) // 2], max(errs), min(coss)
     # the loss is a random-sign sum of B*D*H*W terms; gradients are judged against the case's own yardstick
-    ok = cmin >= 0.99 and med <= 0.1 and abs(l0 - l1) <= 1e-3 + 1e-4 * abs(l1)
+    ok = cmin >= 0.99 and med <= 0.1 and abs(l0 - l1) <= 1e-3 + 1e-4 * abs(l1) and (not over or not yard)
     bad += 0 if ok else 1
     if only is not None:
         for n in gp1:
             print("   %-34s cos %.6f  err %.1e" % (n, cos(gp0[n], gp1[n]), float((gp0[n] - gp1[n]).abs().max() / gp1[n].abs().max().clamp_min(1e-20))))
     print("%s %s  loss %.5f / %.5f  min cosine %.6f  max-norm error median %.1e worst %.1e (yardstick %.1e / %.1e) over %d tensors"
           % ("ok " if ok else "BAD", desc, l0, l1, cmin, med, worst, yard_med, yard_worst, len(errs)))
+    for o in over:
+        print("   beyond its yardstick: " + o)
 print("%d cases, %d bad" % (n_cases, bad))
 sys.exit(1 if bad else 0)

@@ -1,5 +1,6 @@
-"""Per-stage HIP-event times of the two gather passes at the bench workload (cfg2), LDS-staged vs direct kernels.
-Usage (GPU box): python scripts/prof_gather.py [--views 5] [--reps 20]"""
+"""Per-stage HIP-event times of the two gather passes at the bench workload (cfg2): wave-autonomous (round 3, default) vs
+workgroup-window (round 2, MVS_GATHER_IMPL=lds) vs direct (round 1) kernels.  MVS_HIP_LIB selects a variant build.
+Usage (GPU box): python scripts/prof_gather.py [--views 5] [--reps 20] [--impls wave,lds]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -11,6 +12,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--height", type=int, default=1152)
 ap.add_argument("--width", type=int, default=1536)
 ap.add_argument("--feat-dtype", default="fp32")
+ap.add_argument("--impls", default="wave,lds")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 head = bench.build_head(dev)
@@ -45,20 +47,21 @@ for s in range(4):
     vis = torch.rand(B, V - 1, H, W, device=dev)
     row = {}
     res = {}
-    for impl in ("lds", "direct"):
+    impls = a.impls.split(",")
+    for impl in impls:
         os.environ["MVS_GATHER_IMPL"] = impl
         row[impl + "_entropy"] = timed(lambda: ops.warp_corr_entropy(f, code, hom, hyp, 8), a.reps)
         row[impl + "_aggregate"] = timed(lambda: ops.warp_corr_aggregate(f, code, hom, hyp, vis, 8), a.reps)
         res[impl] = (ops.warp_corr_entropy(f, code, hom, hyp, 8), ops.warp_corr_aggregate(f, code, hom, hyp, vis, 8)[0])
-    os.environ["MVS_GATHER_IMPL"] = "lds"
-    de = float((res["lds"][0] - res["direct"][0]).abs().max())
-    dvv = float((res["lds"][1] - res["direct"][1]).abs().max())
+    os.environ.pop("MVS_GATHER_IMPL", None)
+    de = max(float((res[impls[0]][0] - res[i][0]).abs().max()) for i in impls)
+    dvv = max(float((res[impls[0]][1] - res[i][1]).abs().max()) for i in impls)
     esz = f.element_size()
     alg_e = B * (V * C * H * W * esz + D * H * W * 4 + (V - 1) * H * W * 4)
     alg_a = B * (V * C * H * W * esz + D * H * W * 4 + (V - 1) * H * W * 4 + 8 * D * H * W * 4)
-    print("stage %d C=%d D=%d %dx%d: entropy lds %.3f ms (%.0f GB/s) direct %.3f | aggregate lds %.3f ms (%.0f GB/s) direct %.3f | max|d entropy| %.2e max|d vol| %.2e"
-          % (s + 1, C, D, H, W, row["lds_entropy"], alg_e / row["lds_entropy"] / 1e6, row["direct_entropy"], row["lds_aggregate"],
-             alg_a / row["lds_aggregate"] / 1e6, row["direct_aggregate"], de, dvv))
+    print("stage %d C=%d D=%d %dx%d: entropy %s | aggregate %s | max|d entropy| %.2e max|d vol| %.2e"
+          % (s + 1, C, D, H, W, "  ".join("%s %.3f ms (%.0f GB/s)" % (i, row[i + "_entropy"], alg_e / row[i + "_entropy"] / 1e6) for i in impls),
+             "  ".join("%s %.3f ms (%.0f GB/s)" % (i, row[i + "_aggregate"], alg_a / row[i + "_aggregate"] / 1e6) for i in impls), de, dvv))
     for k, v in row.items():
         tot[k] = tot.get(k, 0.0) + v
 print("totals per reference view:", {k: round(v, 3) for k, v in tot.items()})

@@ -2,7 +2,9 @@
 the conv / BatchNorm layers) at a DTU-training-like size, with the share of the two HIP gather kernels and the peak memory."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
+from train_torch_route import stage_forward_train_torch
 from mvsformerplusplus_amd import ops, synth
 from mvsformerplusplus_amd.cost_volume import StageNet
 dev = torch.device("cuda:0")
@@ -16,12 +18,11 @@ for stage, C, D, H, W in ((3, 8, 4, 512, 640), (2, 16, 8, 256, 320), (1, 32, 16,
     hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.02 * torch.rand(B, D, H, W, generator=g))).to(dev).contiguous()
 
     def step():
-        out = net(feats, cams, hyp, 1.0)
+        out = net(feats, cams, hyp, 1.0) if mode == "hip" else stage_forward_train_torch(net, feats, cams, hyp, 1.0)
         out["prob_volume_pre"].square().mean().backward()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     res = {}
     for mode in (("hip",) if os.environ.get("PROF_TRAIN_HIP_ONLY") else ("hip", "torch")):
-        os.environ["MVS_TRAIN_REGNET"] = mode
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -32,7 +33,6 @@ for stage, C, D, H, W in ((3, 8, 4, 512, 640), (2, 16, 8, 256, 320), (1, 32, 16,
         e[1].record()
         torch.cuda.synchronize()
         res[mode] = (e[0].elapsed_time(e[1]) / 5, torch.cuda.max_memory_allocated() / 2 ** 20)
-    os.environ["MVS_TRAIN_REGNET"] = "hip"
     total = res["hip"][0]
     # the two HIP gather kernels on their own
     with torch.no_grad():

@@ -177,6 +177,37 @@ static inline int hipemu_readfirstlane(int v) {
     return all[0];
 }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
+static inline int hipemu_readlane(int v, int src) {
+    int all[64];
+    hipemu::wave_gather(&v, all, sizeof(int));
+    return all[src & 63];
+}
+#define __builtin_amdgcn_readlane hipemu_readlane
+#define __builtin_amdgcn_fence(order, scope) ((void)0)      // the emulated lanes rendezvous in wave_barrier / __syncthreads
+
+// buffer descriptors (raw buffer loads): base + range; a dword whose offset lies beyond the range reads as zero
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned bytes; };
+static inline __amdgpu_buffer_rsrc_t hipemu_make_buffer_rsrc(void* p, short, int num, int) {
+    return __amdgpu_buffer_rsrc_t{static_cast<const char*>(p), (unsigned)num};
+}
+#define __builtin_amdgcn_make_buffer_rsrc hipemu_make_buffer_rsrc
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+template <int N>
+static inline void hipemu_buffer_read(__amdgpu_buffer_rsrc_t r, int voff, int soff, void* dst) {
+    const unsigned off = (unsigned)voff + (unsigned)soff;
+    memset(dst, 0, N);
+    for (int b = 0; b < N; b += (N < 4 ? N : 4))
+        if ((unsigned long long)off + b + (N < 4 ? N : 4) <= r.bytes) memcpy(static_cast<char*>(dst) + b, r.base + off + b, N < 4 ? N : 4);
+}
+static inline hipemu_u32x4 hipemu_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) { hipemu_u32x4 v; hipemu_buffer_read<16>(r, voff, soff, &v); return v; }
+static inline hipemu_u32x2 hipemu_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) { hipemu_u32x2 v; hipemu_buffer_read<8>(r, voff, soff, &v); return v; }
+static inline unsigned hipemu_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) { unsigned v; hipemu_buffer_read<4>(r, voff, soff, &v); return v; }
+static inline unsigned short hipemu_raw_buffer_load_b16(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) { unsigned short v; hipemu_buffer_read<2>(r, voff, soff, &v); return v; }
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_load_b64 hipemu_raw_buffer_load_b64
+#define __builtin_amdgcn_raw_buffer_load_b32 hipemu_raw_buffer_load_b32
+#define __builtin_amdgcn_raw_buffer_load_b16 hipemu_raw_buffer_load_b16
 
 // DPP (gfx9 controls used by the kernels): quad_perm 0x00-0xFF, row_shr:n 0x111-0x11F, wave_shr:1 0x138, row_mirror 0x140,
 // row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.  A lane whose row / bank is masked off, or whose source

@@ -350,6 +350,70 @@ def case_gather_variants(device, quick=False):
         assert (cpu(both) - cpu(vol)).abs().max() <= 2e-6 * scale, (C, D, "partial sums")
 
 
+def gather_window_sizes(hom, hyp, H, W, nsw):
+    """Source-window sizes (positions) of the wave-autonomous gather kernels (csrc/gather_wave.h) per (view, chunk group, wave
+    tile), recomputed on the host: tile = PW x PH reference pixels x the 4 * nsw planes of a chunk group, window = bounding box of
+    the 2x2 tap blocks with its x origin / width rounded to 8 positions."""
+    NP = 64 // nsw
+    PW = 16 if NP >= 64 else (8 if NP >= 32 else 4)
+    PH = NP // PW
+    D = hyp.shape[1]
+    out = []
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    for v in range(hom.shape[1]):
+        h = hom[0, v]
+        q = h[:9].view(3, 3) @ torch.stack([xs.flatten(), ys.flatten(), torch.ones(H * W)])
+        for g0 in range(0, D, 4 * nsw):
+            d = hyp[0, g0:g0 + 4 * nsw].reshape(-1, H * W)
+            p = q[None] * d[:, None] + h[9:][None, :, None]
+            ix, iy = (p[:, 0] / (p[:, 2] + 1e-6)).view(-1, H, W), (p[:, 1] / (p[:, 2] + 1e-6)).view(-1, H, W)
+            ok = (ix > -1) & (ix < W) & (iy > -1) & (iy < H)
+            xb, yb = ix.floor().clamp(0, W - 2), iy.floor().clamp(0, H - 2)
+            for ty in range(0, H, PH):
+                for tx in range(0, W, PW):
+                    m = ok[:, ty:ty + PH, tx:tx + PW]
+                    if not bool(m.any()):
+                        out.append(0)
+                        continue
+                    xx, yy = xb[:, ty:ty + PH, tx:tx + PW][m], yb[:, ty:ty + PH, tx:tx + PW][m]
+                    wx0 = int(xx.min()) & ~7
+                    out.append(((int(xx.max()) + 2 - wx0 + 7) & ~7) * (int(yy.max()) + 2 - int(yy.min())))
+    return out
+
+
+def case_gather_windows(device):
+    """The three window regimes of the wave-autonomous gather kernels against the oracle in ONE launch each: windows of at most 256
+    positions (one staging round, prefetched), 257 .. 384 positions (a second, synchronous round), more than the 384-position
+    capacity (wave-uniform fallback to pair loads from global memory) and tiles with no tap inside the source image.  The
+    geometry (wide baseline, per-pixel hypothesis jitter) is checked on the host to really contain all of them."""
+    g = torch.Generator().manual_seed(5)
+    for C, D, H, W, amp in ((8, 4, 24, 64, 0.3), (16, 8, 24, 64, 0.1)):
+        B, V, G = 1, 3, 8
+        cams = synth.make_cameras(V, H * 8, W * 8, baseline=300.0, rot_deg=2.0, seed=C + D, batch=B)
+        cams[:, :, 1, :2, :] /= 8
+        feats = torch.randn(B, V, C, H, W, generator=g)
+        hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + amp * torch.rand(B, D, H, W, generator=g))).contiguous()
+        hom = ops.compose_homography(dev(cams, device))
+        n = torch.tensor(gather_window_sizes(cpu(hom), hyp, H, W, {4: 1, 8: 2}[D]))
+        assert int((n == 0).sum()) > 0 and int(((n > 0) & (n <= 256)).sum()) > 0 and int(((n > 256) & (n <= 384)).sum()) > 0, n.tolist()
+        if D == 4:
+            assert int((n > 384).sum()) > 0, n.tolist()
+        f, code = ops._feat(dev(feats, device))
+        ent = cpu(ops.warp_corr_entropy(f, code, hom, dev(hyp, device), G))
+        vis = torch.rand(B, V - 1, H, W, generator=g)
+        vol = cpu(ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), dev(vis, device), G)[0])
+        ref_p = O.compose_proj(cams[:, 0])
+        acc, vsum = 0.0, 0.0
+        for v in range(1, V):
+            warped, _ = O.homo_warping_3D_with_mask(feats[:, v], O.compose_proj(cams[:, v]), ref_p, hyp)
+            ip = O.group_correlation(feats[:, 0], warped, G)
+            assert (ent[:, v - 1] - O.entropy_of_similarity(ip)[:, 0]).abs().max() <= 5e-5, (C, D, "entropy")
+            acc = acc + ip * vis[:, v - 1][:, None, None]
+            vsum = vsum + vis[:, v - 1]
+        expect = acc / (vsum[:, None, None] + 1e-6)
+        assert (vol.permute(0, 4, 1, 2, 3) - expect).abs().max() <= 5e-5 * max(1.0, float(expect.abs().max())), (C, D, "volume")
+
+
 # ---------------------------------------------------------------- a16 cascade
 def case_cascade_golden(device):
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
@@ -916,6 +980,7 @@ def case_regnet_train_native(device):
     kernels) against PyTorch autograd through the same modules, CostRegNet (stride 2,2,2) and CostRegNet3D (1,2,2), train mode."""
     import copy
     from mvsformerplusplus_amd import training as T
+    from train_torch_route import regnet_forward_torch
     for cls, shape in ((M.CostRegNet3D, (2, 4, 16, 24)), (M.CostRegNet, (2, 16, 16, 24))):
         reg = cls(8, 8)
         reg.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(reg.state_dict()), 3))
@@ -925,7 +990,7 @@ def case_regnet_train_native(device):
         x = torch.randn(shape[0], 8, *shape[1:], generator=g) * 0.3
         R = torch.randn(shape[0], *shape[1:], 8, generator=g)
         xa = x.clone().requires_grad_(True)
-        ya = T.regnet_forward_torch(reg, xa)                          # [B,1,D,H,W] logits incl. `prob`
+        ya = regnet_forward_torch(reg, xa)                          # [B,1,D,H,W] logits incl. `prob`
         xb = dev(x.permute(0, 2, 3, 4, 1).contiguous(), device).requires_grad_(True)
         fb = T.regnet_forward_native(native, xb)
         yb = native.prob(fb.permute(0, 4, 1, 2, 3))

@@ -61,6 +61,10 @@ def test_gather_variants(emu):
     P.case_gather_variants(emu)
 
 
+def test_gather_windows(emu):
+    P.case_gather_windows(emu)
+
+
 def test_cascade_golden(emu):
     P.case_cascade_golden(emu)
 

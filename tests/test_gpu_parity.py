@@ -76,6 +76,10 @@ def test_gather_variants():
     P.case_gather_variants(DEV)
 
 
+def test_gather_windows():
+    P.case_gather_windows(DEV)
+
+
 def test_aggregate_backward():
     P.case_aggregate_backward(DEV)
 
