@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 5
+#define MVS_ABI_VERSION 6
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -46,8 +46,17 @@ enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
  *   MVS_PREC_BF16X3  three-term split-bf16 product on v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32
  *                    accumulate, ~2^-16 relative product error; weights packed as hi/lo bf16)
  *   MVS_PREC_BF16P   mvs_tr_attention_fwd only: as BF16X3 (four-term scores, split v) but the softmax probabilities
- *                    enter p.v as one bf16 term (the reference's flash-attn path keeps q, k, v and p in bf16)     */
-enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2 };
+ *                    enter p.v as one bf16 term (the reference's flash-attn path keeps q, k, v and p in bf16)
+ *   MVS_PREC_BF16X3_SPLIT  the BF16X3 contraction with the activations IN HBM already split: every x_cl / skip_cl / y_cl / feat_cl /
+ *                    volume_cl of the call is channel-last with, per voxel, C / 8 octets of [hi x8 | lo x8] bf16 (hi = bf16(x),
+ *                    lo = bf16(x - hi); the same 4 bytes per element as fp32, element type still declared float).  The producing
+ *                    epilogue splits once, the consumers' staging is a copy.  Logits stay planar fp32.  The inference U-Net runs in
+ *                    this form (mvs_regnet_fwd / mvs_regnet_logits_fwd / mvs_conv3d_logits_fwd and the single layers accept it);
+ *                    the training path and the fp32-contraction path keep fp32 activations.                                       */
+enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2, MVS_PREC_BF16X3_SPLIT = 3 };
+/* format of the cost volume mvs_warp_corr_aggregate_fwd / mvs_volume_normalise leave behind: fp32 [B,D,H,W,8] or the split activation
+ * format of MVS_PREC_BF16X3_SPLIT (normalised volumes of 8 groups only; partial sums are always fp32) */
+enum { MVS_VOLUME_F32 = 0, MVS_VOLUME_SPLIT = 1 };
 /* epilogues of mvs_tr_linear_fwd */
 enum { MVS_TR_EPI_BIAS = 0, MVS_TR_EPI_GELU = 1, MVS_TR_EPI_RES_LN = 2 };
 
@@ -104,9 +113,10 @@ int mvs_vis_out_fwd(const float* x_cl8, const float* w4, const float* b4, float*
  *   normalise = 0 : volume = partial sum over [view_begin, view_end), vis_sum [B,H,W] = partial
  *                   sum of vis (view-sharded multi-GPU: all-reduce both, then mvs_volume_normalise) */
 int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp,
-                                const float* vis, float* volume_cl, float* vis_sum, int normalise, int B, int V,
-                                int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream);
-int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, void* stream);
+                                const float* vis, float* volume_cl, float* vis_sum, int normalise, int volume_format, int B,
+                                int V, int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream);
+/* volume_cl /= (vis_sum + 1e-6) in place; volume_format = MVS_VOLUME_SPLIT additionally converts it to the split format */
+int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, int volume_format, void* stream);
 
 /* ---- section 8f #2 (first slice): backward of mvs_warp_corr_aggregate_fwd(normalise = 1) ----------------------------
  * The gradient the reference's autograd produces for cost_volume.py:74-101: the sampling grid is built under torch.no_grad()

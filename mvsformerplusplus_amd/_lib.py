@@ -17,14 +17,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 LAYOUT_PLANAR, LAYOUT_OCTET_TILED = 0, 1
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
-PREC_FP32, PREC_BF16X3, PREC_BF16P = 0, 1, 2
+PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
+VOLUME_F32, VOLUME_SPLIT = 0, 1
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -41,8 +42,8 @@ SIGNATURES = {
     "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _i, _vp]),
     "mvs_vis_conv1_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvs_vis_out_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i] + [_i] * 9 + [_vp]),
-    "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i] + [_i] * 9 + [_vp]),
+    "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),

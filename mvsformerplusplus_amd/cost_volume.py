@@ -121,13 +121,20 @@ class StageNet(nn.Module):
             if slab is not None and not isinstance(self.cost_reg, PureTransformerCostReg):
                 return self._forward_slab(feats, code, hom, hyp, depth_values, G, vis_params, float(tmp), slab)
             volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
+            split = self._split_activations()
         else:
             # pass 1 (entropy per view) -> visibility CNN -> pass 2 gathers again and writes the cost volume once: the per-view
             # correlation volumes are never kept (round 1 kept them for D >= 8: 2 x 32 B per voxel and view of HBM traffic)
             entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
             vis = ops.vis_weight(entropy, vis_params, prec)
-            volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)
-        return self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d)
+            split = self._split_activations()
+            volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, split=split)
+        return self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split)
+
+    def _split_activations(self) -> bool:
+        """The bf16x3 U-Net keeps its activations - cost volume included - in the split hi | lo bf16 format between layers
+        (MVS_PREC_BF16X3_SPLIT, csrc/conv_bf16x3_kernels.hip); the transformer regulariser and the fp32 contraction read fp32."""
+        return self.conv_precision == "bf16x3" and not isinstance(self.cost_reg, PureTransformerCostReg)
 
     def _head_mode(self, D):
         conf_n = 0
@@ -138,9 +145,11 @@ class StageNet(nn.Module):
             conf_n = 4 if D >= 32 else (3 if D == 16 else (2 if D == 8 else 0))                    # cost_volume.py:121-128
         return mode, conf_n
 
-    def _regularise_and_regress(self, volume, hyp, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
-        """cost_volume.py:103-131 on a normalised channel-last volume [B,D,H,W,8] (H may be a row slab of the stage)."""
+    def _regularise_and_regress(self, volume, hyp, depth_values, tmp, position3d=None, split=False) -> Dict[str, torch.Tensor]:
+        """cost_volume.py:103-131 on a normalised channel-last volume [B,D,H,W,8] (H may be a row slab of the stage); split: the
+        volume is in the split activation format and the U-Net runs MVS_PREC_BF16X3_SPLIT."""
         D = hyp.shape[1]
+        pcode = _lib.PREC_BF16X3_SPLIT if split else precision_code(self.conv_precision)
         mode, conf_n = self._head_mode(D)
         if isinstance(self.cost_reg, PureTransformerCostReg):
             prob_volume_pre = self.cost_reg.logits_cl(volume, position3d)
@@ -150,15 +159,17 @@ class StageNet(nn.Module):
             if self.cost_reg.prob_ksize == 1 and self.conv_precision == "bf16x3" and self.fuse_prob_head:
                 # CostRegNet3D: the 1x1x1 head rides in the last deconvolution's epilogue (module.py:500-502): logits out, the
                 # 8-channel full-resolution features never reach HBM
-                prob_volume_pre = ops.regnet_logits(self.cost_reg.kind, volume, ws, bs, prob_w, prob_b, precision_code(self.conv_precision))
+                prob_volume_pre = ops.regnet_logits(self.cost_reg.kind, volume, ws, bs, prob_w, prob_b, pcode)
                 depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
             elif self.cost_reg.prob_ksize == 3 and self.conv_precision == "bf16x3":
                 # CostRegNet: the 3x3x3 head (module.py:391,407) as an MFMA convolution with one real output row, logits out
-                feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, precision_code(self.conv_precision))
-                prob_volume_pre = ops.conv3d_logits(feat_cl, prob_w, prob_b, precision_code(self.conv_precision))
+                feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, pcode)
+                prob_volume_pre = ops.conv3d_logits(feat_cl, prob_w, prob_b, pcode)
                 depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
             else:
-                feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, precision_code(self.conv_precision))
+                feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, pcode)
+                if split:                                       # fuse_prob_head = False (A/B switch): the standalone head reads fp32
+                    feat_cl = ops.from_split(feat_cl)
                 depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(
                     feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, tmp, mode, conf_n, self.return_prob_volumes)
         return {"depth": depth, "prob_volume": prob_volume, "photometric_confidence": conf,
@@ -217,7 +228,7 @@ class StageNet(nn.Module):
         vol, vsum = self._partial_volume(feats, code, hom, hyp, G, vis_params, flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.view_group)
         self.last_collective_bytes = flat.numel() * 4
-        return ops.volume_normalise_(vol, vsum)
+        return ops.volume_normalise_(vol, vsum, split=self._split_activations())
 
     # slab mode -----------------------------------------------------------------------------------
     SLAB_HALO = 40      # rows: >= the U-Net + prob receptive radius (1+2+2+4+4+8+8+4+2+1 = 36) and a multiple of 8 (stride phase)
@@ -285,9 +296,9 @@ class StageNet(nn.Module):
                 acc.add_(recvs[j])
             svol = acc[: nmine - B * rows * W].view(B, D, rows, W, G)
             ssum = acc[nmine - B * rows * W:].view(B, rows, W)
-            ops.volume_normalise_(svol, ssum)
+            ops.volume_normalise_(svol, ssum, split=self._split_activations())
             shyp = hyp[:, :, ea:eb].contiguous()
-            st = self._regularise_and_regress(svol, shyp, None, tmp)
+            st = self._regularise_and_regress(svol, shyp, None, tmp, split=self._split_activations())
             lo, hi = a - ea, b - ea
             out_rows = {k: st[k][..., lo:hi, :] for k in ("depth", "photometric_confidence", "prob_volume", "prob_volume_pre") if st[k] is not None}
         # ---- all-gather of the owners' rows: [channels, S, W] per rank, channels = depth, conf (+ 2 D probability planes) ----

@@ -13,7 +13,10 @@
 //     [voxel][octet of 8 channels][hi x8 | lo x8] (same bytes per voxel as fp32)
 //   * weights are split on the host (packing.pack_conv_weights_bf16x3) in per-lane MFMA operand order
 //   * one contraction step = 32 k-values = 4 channel octets; lane group g = lane>>4 owns octet 4*step + g
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "conv_cfg.h"
 
@@ -53,6 +56,68 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
         const __bf16 h = (__bf16)x[j];                 // round to nearest even (v_cvt_pk_bf16_f32)
         hi[j] = h;
         lo[j] = (__bf16)(x[j] - (float)h);
+    }
+}
+
+// ---- the split activation format (MVS_PREC_BF16X3_SPLIT) ---------------------------------------------------------------
+// Between the layers of the inference U-Net the activations live in HBM ALREADY SPLIT: channel-last, per voxel C / 8 octets of
+// [hi x8 | lo x8] bf16 = the same 4 bytes per element as fp32.  The producing epilogue splits each value once; the consumers'
+// staging is a plain copy of 32-byte runs into the LDS image (round 2 split every staged element - halo voxels included, 2.5x
+// the tile for the 4x4x16 stride-1 tile - on the consumer side: ~45 VALU per 8 channels in the memory phase of every tile).
+// An accumulator lane holds 4 consecutive channels of a voxel = one QUAD of an octet; its partner 16 lanes up holds the other
+// quad of the same octet and voxel.  v_permlane16_swap exchanges the halves so that the even lane row owns hi x8 and the odd row
+// lo x8 of the octet: one 16-byte store per lane, 32 contiguous bytes per lane pair.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(__bf16 a, __bf16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ float bf16_lo_f32(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi_f32(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// store the channel quad `v` of this lane (quad g & 1 of the octet at `octet`) - EVERY lane of the wave must call (lane exchange);
+// `guard` = the voxel exists
+__device__ __forceinline__ void split_store_quad(float* octet, int g, const float4& v, bool guard) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    __bf16 h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)x[j];
+        l[j] = (__bf16)(x[j] - (float)h[j]);
+    }
+    unsigned h0 = pack_bf16x2(h[0], h[1]), h1 = pack_bf16x2(h[2], h[3]), l0 = pack_bf16x2(l[0], l[1]), l1 = pack_bf16x2(l[2], l[3]);
+    // rows 1, 3 of the first operand <-> rows 0, 2 of the second: even rows end up with {own hi, partner's hi}, odd rows with
+    // {partner's lo, own lo}
+    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false);
+    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
+    if (guard) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(octet) + (g & 1) * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
+// the fp32 values of channel quad q of the octet at `octet` (skip connections): raw = {hi, hi, lo, lo} dwords
+__device__ __forceinline__ float4 split_raw_quad(const float* octet, int q) {
+    const u32x2 h = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(octet) + q * 8);
+    const u32x2 l = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(octet) + 16 + q * 8);
+    // (scalars first: __builtin_bit_cast applied directly to an ext-vector ELEMENT expression yields element 0 with this clang)
+    const unsigned h0 = h[0], h1 = h[1], l0 = l[0], l1 = l[1];
+    return make_float4(__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1), __builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1));
+}
+__device__ __forceinline__ float4 split_join_quad(const float4& raw) {
+    const unsigned h0 = __builtin_bit_cast(unsigned, raw.x), h1 = __builtin_bit_cast(unsigned, raw.y);
+    const unsigned l0 = __builtin_bit_cast(unsigned, raw.z), l1 = __builtin_bit_cast(unsigned, raw.w);
+    return make_float4(bf16_lo_f32(h0) + bf16_lo_f32(l0), bf16_hi_f32(h0) + bf16_hi_f32(l0), bf16_lo_f32(h1) + bf16_lo_f32(l1), bf16_hi_f32(h1) + bf16_hi_f32(l1));
+}
+// staged 32-byte run (one voxel x one octet) -> the LDS image [hi x8 | lo x8]
+template <bool SPLIT>
+__device__ __forceinline__ void stage_to_lds(char* dst, const float4& u, const float4& v) {
+    if (SPLIT) {
+        *reinterpret_cast<float4*>(dst) = u;
+        *reinterpret_cast<float4*>(dst + 16) = v;
+    } else {
+        bf16x8 hi, lo;
+        split8(u, v, hi, lo);
+        *reinterpret_cast<bf16x8*>(dst) = hi;
+        *reinterpret_cast<bf16x8*>(dst + 16) = lo;
     }
 }
 
@@ -218,7 +283,7 @@ __device__ __forceinline__ void bf_conv_contract(const bf16x8* wq, const char* l
     BfConvSteps<Cfg, 0>::run(g, wq, ldsb, voxbase[0], acc, ah, al, bh0, bl0, bh1, bl1);
 }
 
-template <class Cfg>
+template <class Cfg, bool SPLIT>
 __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
                                                                  float* __restrict__ y, int D, int H, int W, int OD, int OH, int OW,
                                                                  int relu, int tiles_x, int tiles_y, int ntiles) {
@@ -284,10 +349,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
             const int e = tid + it * 256;
             if (e >= NITEM) break;
             const int vox = e / OPT, oc = e - vox * OPT;
-            bf16x8 hi, lo;
-            split8(su[it], sv[it], hi, lo);
-            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE) = hi;
-            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE + 16) = lo;
+            stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, su[it], sv[it]);
         }
     };
     constexpr bool UNROLLED = BfConv<Cfg>::UNROLL_STAGE;
@@ -313,10 +375,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
                     u = src[0];
                     v = src[1];
                 }
-                bf16x8 hi, lo;
-                split8(u, v, hi, lo);
-                *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE) = hi;
-                *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE + 16) = lo;
+                stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, u, v);
             }
         }
         __syncthreads();
@@ -330,17 +389,19 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     for (int nb = 0; nb < NREP; ++nb) {
         const int nbg = rowgrp * NREP + nb;
         const int oz = oz0 + nbg / TH, oy = oy0 + nbg % TH, ox = ox0 + li;
-        if (oz >= OD || oy >= OH || ox >= OW) continue;
+        const bool inside = oz < OD && oy < OH && ox < OW;
+        if (!SPLIT && !inside) continue;                                   // split stores exchange lanes: every lane takes part
         float* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
 #pragma unroll
         for (int mb = 0; mb < MREP; ++mb) {
             const int co = 16 * (mb0 + mb) + 4 * g;
-            if (co >= COUT) continue;
-            const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+            if (!SPLIT && co >= COUT) continue;
+            const float4 bb = *reinterpret_cast<const float4*>(bias + (co < COUT ? co : 0));
             float4 v = make_float4(acc[mb][nb][0] + bb.x, acc[mb][nb][1] + bb.y, acc[mb][nb][2] + bb.z, acc[mb][nb][3] + bb.w);
             if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
             if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-            *reinterpret_cast<float4*>(o + co) = v;
+            if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
+            else *reinterpret_cast<float4*>(o + co) = v;
         }
     }
 }
@@ -374,7 +435,7 @@ struct BfConvStepsWreg {
     }
 };
 
-template <class Cfg>
+template <class Cfg, bool SPLIT>
 __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
                                                                          float* __restrict__ y, float* __restrict__ logits, int D, int H, int W,
                                                                          int OD, int OH, int OW, int relu, int tiles_x, int tiles_y, int ntiles) {
@@ -446,10 +507,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
             const int e = tid + it * 256;
             if (e >= NITEM) break;
             const int vox = e / OPT, oc = e - vox * OPT;
-            bf16x8 hi, lo;
-            split8(su[it], sv[it], hi, lo);
-            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE) = hi;
-            *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE + 16) = lo;
+            stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, su[it], sv[it]);
         }
         __syncthreads();
         if (tile + MVS_PERSIST_PFD < t_end) issue(tile + MVS_PERSIST_PFD, su, sv);
@@ -473,7 +531,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
         for (int nb = 0; nb < NREP; ++nb) {
             const int nbg = wave * NREP + nb;
             const int oz = oz0 + nbg / TH, oy = oy0 + nbg % TH, ox = ox0 + li;
-            if (oz >= OD || oy >= OH || ox >= OW) continue;
+            const bool inside = oz < OD && oy < OH && ox < OW;
+            if (!inside && (!SPLIT || logits != nullptr)) continue;          // split stores exchange lanes: every lane takes part
             if (logits != nullptr) {
                 // single-output-channel head (CostRegNet.prob, module.py:391): row 0 of the 16-row tile, planar store
                 if (g == 0 && !(MVS_ABL == 5 && acc[0][nb][0] != 12345.678f)) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = acc[0][nb][0] + bb[0].x;
@@ -483,11 +542,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
 #pragma unroll
             for (int mb = 0; mb < MREP; ++mb) {
                 const int co = 16 * mb + 4 * g;
-                if (co >= COUT) continue;
+                if (!SPLIT && co >= COUT) continue;
                 float4 v = make_float4(acc[mb][nb][0] + bb[mb].x, acc[mb][nb][1] + bb[mb].y, acc[mb][nb][2] + bb[mb].z, acc[mb][nb][3] + bb[mb].w);
                 if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
                 if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-                *reinterpret_cast<float4*>(o + co) = v;
+                if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
+                else *reinterpret_cast<float4*>(o + co) = v;
             }
         }
         __syncthreads();                                                     // every wave is done reading this tile's LDS image
@@ -538,7 +598,7 @@ __device__ __forceinline__ void bf_deconv_load_step(int st, int ntap, int pd, in
     }
 }
 
-template <class Cfg>
+template <class Cfg, bool SPLIT>
 __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
                                                                    const float* __restrict__ skip, float* __restrict__ y,
                                                                    const float* __restrict__ prob_w, const float* __restrict__ prob_b,
@@ -573,10 +633,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             u = src[0];
             v = src[1];
         }
-        bf16x8 hi, lo;
-        split8(u, v, hi, lo);
-        *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32) = hi;
-        *reinterpret_cast<bf16x8*>(ldsb + vox * SB + oc * 32 + 16) = lo;
+        stage_to_lds<SPLIT>(ldsb + vox * SB + oc * 32, u, v);
     }
     __syncthreads();
 
@@ -616,8 +673,9 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
 #pragma unroll
                 for (int mb = 0; mb < MREP; ++mb) {
                     const int co = PAIR ? 4 * (g & 1) : 16 * (mb0 + mb) + 4 * g;
-                    skp[it][nb][mb] = (inside && co < COUT) ? *reinterpret_cast<const float4*>(sb + (((size_t)oz * OH + oy) * OW + ox) * COUT + co)
-                                                            : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const float* sv = sb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
+                    skp[it][nb][mb] = !(inside && co < COUT) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f)
+                                      : SPLIT ? split_raw_quad(sv + (co & ~7), (co >> 2) & 1) : *reinterpret_cast<const float4*>(sv + co);
                 }
             }
         }
@@ -652,7 +710,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             const int nbg = rowgrp * NREP + nb;
             const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
             const bool inside = mz < D && my < H && mx < W;
-            if (!inside && !(PAIR && prob_w != nullptr)) continue;     // the fused head shuffles: every lane takes part, stores are guarded
+            if (!inside && !(PAIR && prob_w != nullptr) && !SPLIT) continue;     // the fused head and the split stores exchange lanes: every lane takes part, stores are guarded
             if (PAIR) {
                 // lane groups 0/1: channels 0-3 / 4-7 of output voxel 2mx; groups 2/3: the same of voxel 2mx + 1
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1), co = 4 * (g & 1);
@@ -661,7 +719,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 float4 v = make_float4(fmaxf(acc[0][nb][0] + bb.x, lo_clamp), fmaxf(acc[0][nb][1] + bb.y, lo_clamp), fmaxf(acc[0][nb][2] + bb.z, lo_clamp),
                                        fmaxf(acc[0][nb][3] + bb.w, lo_clamp));
                 if (sb && inside) {
-                    const float4 sk = skp[it][nb][0];
+                    const float4 sk = SPLIT ? split_join_quad(skp[it][nb][0]) : skp[it][nb][0];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 if (prob_w != nullptr) {
@@ -674,6 +732,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                     part += v.w * pw4.w;
                     part += __shfl_xor(part, 16);
                     if ((g & 1) == 0 && inside && !(MVS_ABL == 5 && part != 12345.678f)) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = part + prob_b[0];
+                } else if (SPLIT) {
+                    split_store_quad(yb + off - co, g, v, inside);
                 } else {
                     if (!(MVS_ABL == 5 && v.x != 12345.678f)) *reinterpret_cast<float4*>(yb + off) = v;
                 }
@@ -684,16 +744,17 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
 #pragma unroll
             for (int mb = 0; mb < MREP; ++mb) {
                 const int co = 16 * (mb0 + mb) + 4 * g;
-                if (co >= COUT) continue;
-                const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+                if (!SPLIT && co >= COUT) continue;
+                const float4 bb = *reinterpret_cast<const float4*>(bias + (co < COUT ? co : 0));
                 float4 v = make_float4(fmaxf(acc[mb][nb][0] + bb.x, lo_clamp), fmaxf(acc[mb][nb][1] + bb.y, lo_clamp),
                                        fmaxf(acc[mb][nb][2] + bb.z, lo_clamp), fmaxf(acc[mb][nb][3] + bb.w, lo_clamp));
                 if (sb) {
-                    const float4 sk = skp[it][nb][mb];
+                    const float4 sk = SPLIT ? split_join_quad(skp[it][nb][mb]) : skp[it][nb][mb];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-                *reinterpret_cast<float4*>(yb + off + co) = v;
+                if (SPLIT) split_store_quad(yb + off + (co & ~7), g, v, inside && co < COUT);
+                else *reinterpret_cast<float4*>(yb + off + co) = v;
             }
         }
     }
@@ -777,7 +838,7 @@ struct BfDeconvSteps {
     }
 };
 
-template <class Cfg>
+template <class Cfg, bool SPLIT>
 __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
                                                                            const float* __restrict__ skip, float* __restrict__ y,
                                                                            const float* __restrict__ prob_w, const float* __restrict__ prob_b,
@@ -857,8 +918,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                 const int mz = mz0 + nbg / THM, my = my0 + nbg % THM, mx = mx0 + li;
                 const bool inside = mz < D && my < H && mx < W;
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1);
-                const size_t off = inside ? (((size_t)oz * OH + oy) * OW + ox) * COUT + co : 0;
-                const float4 sk = *reinterpret_cast<const float4*>(sb + off);
+                const size_t vbase = inside ? (((size_t)oz * OH + oy) * OW + ox) * COUT : 0;
+                const float4 sk = SPLIT ? split_raw_quad(sb + vbase, co >> 2) : *reinterpret_cast<const float4*>(sb + vbase + co);
                 skp[it][nb] = inside ? sk : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         }
@@ -871,10 +932,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
             const int e = tid + it * 256;
             if (e >= NITEM) break;
             const int vox = e / OPT, oc = e - vox * OPT;
-            bf16x8 hi, lo;
-            split8(su[it], sv[it], hi, lo);
-            *reinterpret_cast<bf16x8*>(ldsx + vox * SB + oc * P::PLANE) = hi;
-            *reinterpret_cast<bf16x8*>(ldsx + vox * SB + oc * P::PLANE + 16) = lo;
+            stage_to_lds<SPLIT>(ldsx + vox * SB + oc * P::PLANE, su[it], sv[it]);
         }
         __syncthreads();
         if (tile + 1 < t_end) issue_x(tile + 1);
@@ -914,7 +972,10 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                 const bool inside = mz < D && my < H && mx < W;
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1);
                 float4 v = outv[it][nb];
-                if (sb) { v.x += skp[it][nb].x; v.y += skp[it][nb].y; v.z += skp[it][nb].z; v.w += skp[it][nb].w; }
+                if (sb) {
+                    const float4 sk = SPLIT ? split_join_quad(skp[it][nb]) : skp[it][nb];      // an all-zero raw quad joins to zero
+                    v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
+                }
                 if (head) {
                     float part = v.x * pw4.x;
                     part += v.y * pw4.y;
@@ -923,6 +984,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                     part += __shfl_xor(part, 16);                            // the voxel's other four channels (every lane takes part)
                     if ((g & 1) == 0 && inside && !(MVS_ABL == 5 && part != 12345.678f))
                         logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = part + pb;
+                } else if (SPLIT) {
+                    split_store_quad(yb + (((size_t)oz * OH + oy) * OW + ox) * COUT, g, v, inside);
                 } else if (inside && !(MVS_ABL == 5 && v.x != 12345.678f)) {
                     *reinterpret_cast<float4*>(yb + (((size_t)oz * OH + oy) * OW + ox) * COUT + co) = v;
                 }
@@ -933,6 +996,25 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
     }
 }
 
+// blocks of 256 threads the current device holds at once for a persistent kernel (-1: query failed).  Cached per (kernel, device)
+// under a mutex; the dynamic-LDS attribute is set on every query miss, i.e. once per device (a function-local static
+// shared one device's answer with all others and was not thread-safe).
+static int resident_blocks(const void* func, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(std::make_pair(func, dev));
+    if (it != cache.end()) return it->second;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (lds > 48 * 1024) hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, 256, lds) != hipSuccess || per_cu < 1)
+        return -1;
+    return cache[std::make_pair(func, dev)] = per_cu * prop.multiProcessorCount;
+}
+
 // which layers use the split wave mapping: 64 output channels with at most two rows per wave (the 2 x 4 x 16 / 2 x 2 x 16 tiles)
 template <class Cfg>
 struct BfSplitOf {
@@ -940,7 +1022,7 @@ struct BfSplitOf {
     typedef typename std::conditional<SPLIT, SplitCfg<Cfg, 2>, Cfg>::type type;
 };
 
-template <class Cfg>
+template <class Cfg, bool SPLIT>
 static int launch_conv_bf(const float* x, const void* wp, const float* bias, float* y, int B, int D, int H, int W, int relu, hipStream_t st,
                           float* logits) {
     const int OD = (D + 2 * Cfg::PD - Cfg::KD) / Cfg::SD + 1, OH = (H - 1) / Cfg::SH + 1, OW = (W - 1) / Cfg::SW + 1;
@@ -948,29 +1030,18 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
     const int ntiles = tx * ty * tz;
     constexpr size_t LDS = BfConv<Cfg>::LDS_BYTES;
     if constexpr (BfConv<Cfg>::PERSIST) {
-        // grid = the number of blocks the chip holds at once (occupancy query once per kernel and process)
-        static int resident = 0;
-        if (resident == 0) {
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop;
-            if (LDS > 48 * 1024)
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_persist_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3d_mfma_bf16x3_persist_kernel<Cfg>, 256, LDS) != hipSuccess || per_cu < 1) {
-                set_error("conv3d(bf16x3): occupancy query failed");
-                return MVS_ERR_LAUNCH;
-            }
-            resident = per_cu * prop.multiProcessorCount;
-        }
+        // grid = the number of blocks the chip holds at once (occupancy query once per kernel and DEVICE)
+        const int resident = resident_blocks(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_persist_kernel<Cfg, SPLIT>), LDS);
+        if (resident < 1) { set_error("conv3d(bf16x3): occupancy query failed"); return MVS_ERR_LAUNCH; }
         const int nblk = ntiles < resident ? ntiles : resident;
-        hipLaunchKernelGGL((conv3d_mfma_bf16x3_persist_kernel<Cfg>), dim3(nblk, B), dim3(256), LDS, st, x, wp, bias, y, logits, D, H, W, OD, OH, OW, relu, tx,
+        hipLaunchKernelGGL((conv3d_mfma_bf16x3_persist_kernel<Cfg, SPLIT>), dim3(nblk, B), dim3(256), LDS, st, x, wp, bias, y, logits, D, H, W, OD, OH, OW, relu, tx,
                            ty, ntiles);
         return check_launch("conv3d_mfma_bf16x3_persist_kernel");
     }
     if (logits != nullptr) { set_error("conv3d(bf16x3): the planar single-channel output needs a persistent (Cin = 8) kernel"); return MVS_ERR_UNSUPPORTED; }
     if (LDS > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), LDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), dim3(ntiles, B), dim3(256), LDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
     return check_launch("conv3d_mfma_bf16x3_kernel");
 }
 
@@ -981,43 +1052,35 @@ struct BfDeconvSplitOf {
     typedef typename std::conditional<SPLIT, SplitCfg<Cfg, 2>, Cfg>::type type;
 };
 
-template <class Cfg>
+template <class Cfg, bool SPLIT>
 static int launch_deconv_bf(const float* x, const void* wp, const float* bias, const float* skip, float* y, const float* prob_w,
                             const float* prob_b, float* logits, int B, int D, int H, int W, hipStream_t st, int relu) {
     const int tx = (int)ceil_div(W, 16), ty = (int)ceil_div(H, Cfg::THM), tz = (int)ceil_div(D, Cfg::TDM);
     const int ntiles = tx * ty * tz;
     if constexpr (MVS_PERSIST && Cfg::CIN == 16 && Cfg::COUT == 8) {
         constexpr size_t LDS = BfDeconvP<Cfg>::LDS_BYTES;
-        static int resident = 0;
-        if (resident == 0) {
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop;
-            if (LDS > 48 * 1024)
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_persist_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, deconv3d_mfma_bf16x3_persist_kernel<Cfg>, 256, LDS) != hipSuccess || per_cu < 1) {
-                set_error("deconv3d(bf16x3): occupancy query failed");
-                return MVS_ERR_LAUNCH;
-            }
-            resident = per_cu * prop.multiProcessorCount;
-        }
+        const int resident = resident_blocks(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_persist_kernel<Cfg, SPLIT>), LDS);
+        if (resident < 1) { set_error("deconv3d(bf16x3): occupancy query failed"); return MVS_ERR_LAUNCH; }
         const int nblk = ntiles < resident ? ntiles : resident;
-        hipLaunchKernelGGL((deconv3d_mfma_bf16x3_persist_kernel<Cfg>), dim3(nblk, B), dim3(256), LDS, st, x, wp, bias, skip, y, prob_w, prob_b, logits, D, H,
+        hipLaunchKernelGGL((deconv3d_mfma_bf16x3_persist_kernel<Cfg, SPLIT>), dim3(nblk, B), dim3(256), LDS, st, x, wp, bias, skip, y, prob_w, prob_b, logits, D, H,
                            W, tx, ty, ntiles, relu);
         return check_launch("deconv3d_mfma_bf16x3_persist_kernel");
     }
     if (Cfg::LDS_BYTES > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((deconv3d_mfma_bf16x3_kernel<Cfg>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, skip, y, prob_w, prob_b,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((deconv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, skip, y, prob_w, prob_b,
                        logits, D, H, W, tx, ty, ntiles, relu);
     return check_launch("deconv3d_mfma_bf16x3_kernel");
 }
 
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
-                           int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits) {
+                           int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits, int split) {
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
-    if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW)                      \
-        return launch_conv_bf<typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type>(x, wp, bias, y, B, D, H, W, relu, st, logits);
+    if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW) {                    \
+        typedef typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type K;              \
+        return split ? launch_conv_bf<K, true>(x, wp, bias, y, B, D, H, W, relu, st, logits)          \
+                     : launch_conv_bf<K, false>(x, wp, bias, y, B, D, H, W, relu, st, logits);        \
+    }
     MVS_CONV_TABLE(MVS_X)
 #undef MVS_X
     set_error("conv3d(bf16x3): no kernel for Cin=%d Cout=%d kernel=(%d,3,3) stride=(%d,%d,%d)", Cin, Cout, kd, sd, sh, sw);
@@ -1025,11 +1088,14 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
 }
 
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,
-                             int D, int H, int W, int sd, hipStream_t st, const float* prob_w, const float* prob_b, float* logits, int relu) {
+                             int D, int H, int W, int sd, hipStream_t st, const float* prob_w, const float* prob_b, float* logits, int relu, int split) {
     if (prob_w != nullptr && Cout != 8) { set_error("deconv3d(bf16x3): the fused prob head needs Cout == 8"); return MVS_ERR_UNSUPPORTED; }
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
-    if (Cin == CI && Cout == CO && sd == SD)                                                            \
-        return launch_deconv_bf<typename BfDeconvSplitOf<DeconvCfg<CI, CO, SD, TDM, THM>>::type>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);
+    if (Cin == CI && Cout == CO && sd == SD) {                                                          \
+        typedef typename BfDeconvSplitOf<DeconvCfg<CI, CO, SD, TDM, THM>>::type K;                      \
+        return split ? launch_deconv_bf<K, true>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu)    \
+                     : launch_deconv_bf<K, false>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);  \
+    }
     MVS_DECONV_TABLE(MVS_X)
 #undef MVS_X
     set_error("deconv3d(bf16x3): no kernel for Cin=%d Cout=%d stride=(%d,2,2)", Cin, Cout, sd);

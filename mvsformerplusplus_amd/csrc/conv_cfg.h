@@ -93,14 +93,15 @@ struct DeconvCfg {
 
 // precision of the MFMA contraction (C ABI: MVS_PREC_*)
 // logits != NULL (persistent Cin = 8 kernels only): output channel 0 is written as a planar volume [B,OD,OH,OW] instead of y
+// split != 0: x, y (and skip) are in the split activation format of MVS_PREC_BF16X3_SPLIT (conv_bf16x3_kernels.hip)
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
-                           int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits = nullptr);
+                           int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits = nullptr, int split = 0);
 int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                              const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st);
 // prob_w / prob_b / logits != NULL (Cout == 8 only): the 1x1x1 `prob` head is applied in the epilogue and the planar logits
 // [B,OD,OH,OW] are written instead of y
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,
                              int D, int H, int W, int sd, hipStream_t st, const float* prob_w = nullptr, const float* prob_b = nullptr,
-                             float* logits = nullptr, int relu = 1);
+                             float* logits = nullptr, int relu = 1, int split = 0);
 
 }  // namespace mvs

@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     float vsum = 0.0f;
     for (int v = view_begin; v < view_end; ++v) vsum += vp[(unsigned)(v - 1) * HW];               // cost_volume.py:98
     if (vis_sum != nullptr && it == 0 && t.slot == 0 && t.valid) vis_sum[(size_t)b * HW + t.pc] = vsum;
-    const float rdenom = normalise ? 1.0f / (vsum + 1e-6f) : 1.0f;                                // cost_volume.py:101
+    const float rdenom = (normalise & 1) ? 1.0f / (vsum + 1e-6f) : 1.0f;                          // cost_volume.py:101
+    const bool split_out = (normalise & 2) != 0;                 // volume in the split activation format of the bf16x3 U-Net
     const float inv_cpg = 1.0f / (float)NOCT;
     float rf0[8];                                               // C = 8: the pixel's reference features, once per block
     if (NOCT == 1) gl_load8<TILED, T>(ref, HW, t.pc, rf0);
@@ -358,6 +359,19 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
 #pragma unroll
             for (int g = 0; g < 8; ++g) r[g] = acc[g * GL_DCH + dd] * rdenom;
             f32x4* o = reinterpret_cast<f32x4*>(vb + ((size_t)(unsigned)(d0 + dd) * HW + t.pc) * 8);
+            if (split_out) {                                    // [hi x8 | lo x8] bf16: the same 32 bytes (conv_bf16x3_kernels.hip)
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint16_t h0 = from_f32<uint16_t>(r[2 * j]), h1 = from_f32<uint16_t>(r[2 * j + 1]);
+                    const uint16_t l0 = from_f32<uint16_t>(r[2 * j] - to_f32(h0)), l1 = from_f32<uint16_t>(r[2 * j + 1] - to_f32(h1));
+                    hw[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    lw[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+                o[0] = f32x4{__builtin_bit_cast(float, hw[0]), __builtin_bit_cast(float, hw[1]), __builtin_bit_cast(float, hw[2]), __builtin_bit_cast(float, hw[3])};
+                o[1] = f32x4{__builtin_bit_cast(float, lw[0]), __builtin_bit_cast(float, lw[1]), __builtin_bit_cast(float, lw[2]), __builtin_bit_cast(float, lw[3])};
+                continue;
+            }
             o[0] = f32x4{r[0], r[1], r[2], r[3]};
             o[1] = f32x4{r[4], r[5], r[6], r[7]};
         }

@@ -382,6 +382,35 @@ __global__ void volume_normalise_kernel(float* __restrict__ vol, const float* __
     }
 }
 
+// fp32 channel-last volume [.., 8] -> the split activation format of MVS_PREC_BF16X3_SPLIT (per voxel [hi x8 | lo x8] bf16), in
+// place (same 32 bytes per voxel), optionally normalising by the summed visibility first (the view-sharded multi-GPU path)
+__global__ void volume_to_split_kernel(float* __restrict__ vol, const float* __restrict__ vis_sum, int D, int HW, size_t nvox) {
+    for (size_t vox = (size_t)blockIdx.x * blockDim.x + threadIdx.x; vox < nvox; vox += (size_t)gridDim.x * blockDim.x) {
+        float4* q = reinterpret_cast<float4*>(vol + vox * 8);
+        const float4 a = q[0], c = q[1];
+        float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        if (vis_sum != nullptr) {
+            const float den = vis_sum[(vox / ((size_t)D * HW)) * HW + vox % HW] + 1e-6f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = x[j] / den;
+        }
+        unsigned short hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = from_f32<uint16_t>(x[j]);
+            lo[j] = from_f32<uint16_t>(x[j] - to_f32(hi[j]));
+        }
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hw[j] = (unsigned)hi[2 * j] | ((unsigned)hi[2 * j + 1] << 16);
+            lw[j] = (unsigned)lo[2 * j] | ((unsigned)lo[2 * j + 1] << 16);
+        }
+        q[0] = make_float4(__builtin_bit_cast(float, hw[0]), __builtin_bit_cast(float, hw[1]), __builtin_bit_cast(float, hw[2]), __builtin_bit_cast(float, hw[3]));
+        q[1] = make_float4(__builtin_bit_cast(float, lw[0]), __builtin_bit_cast(float, lw[1]), __builtin_bit_cast(float, lw[2]), __builtin_bit_cast(float, lw[3]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a2/a3 standalone: warped [B,C,D,H,W] + proj_mask [B,D,H,W]                  warping.py:69-109
 // grid = (pixel blocks of 64, D-chunks, B); block = 64 px x 4 depth slots.
@@ -478,25 +507,21 @@ int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* ho
                         float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
 int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W, hipStream_t st);
 
-// wave-autonomous form (gather_wave_kernels.hip, round 3)
-bool gw_supported(int C, int G, int D, int H, int W);
-int gw_launch_entropy(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H,
-                      int W, int vb, int ve, hipStream_t st);
-int gw_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol,
-                        float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
-
-// Which form of the gather passes runs (A/B measurements): MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels,
-// =lds the round-2 workgroup-window kernels; anything else = the wave-autonomous kernels where supported (0 direct, 1 lds, 2 wave)
+// MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels (A/B measurements); anything else = LDS-staged where supported.
+// (Round 3 measured a third, wave-autonomous form - one private window per wave, no workgroup barriers, register prefetch of the
+// next window: parity green, 1.8-2.3x SLOWER than the workgroup-window kernels on the MI355X, profiles/r03_gather_wave_vs_lds.txt;
+// it lives in git history, commit b186996.)
 static int gather_impl(int C, int G, int D, int H, int W) {
     const char* e = getenv("MVS_GATHER_IMPL");
     if (e && e[0] == 'd') return 0;
-    if (!(e && e[0] == 'l') && gw_supported(C, G, D, H, W)) return 2;
     return gl_supported(C, G, D, H, W) ? 1 : 0;
 }
 
 }  // namespace mvs
 
 using namespace mvs;
+
+static int volume_to_split(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, hipStream_t st, const char* who);
 
 extern "C" int mvs_compose_homography(const float* proj, int B, int V, float* homography, void* stream) {
     if (!proj || !homography || B < 1 || V < 2) { set_error("mvs_compose_homography: bad arguments"); return MVS_ERR_ARG; }
@@ -552,7 +577,6 @@ extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int la
     rc = check_layout("mvs_warp_corr_entropy_fwd", layout, C, G, D, H, W);
     if (rc != MVS_OK) return rc;
     const int impl = gather_impl(C, G, D, H, W);
-    if (impl == 2) return gw_launch_entropy(features, dtype, layout, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
     if (layout == MVS_LAYOUT_OCTET_TILED || impl == 1)
         return gl_launch_entropy(features, dtype, layout, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
     switch (dtype) {
@@ -563,20 +587,28 @@ extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int la
 }
 
 extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, const float* vis,
-                                           float* volume_cl, float* vis_sum, int normalise, int B, int V, int C, int G, int D, int H,
-                                           int W, int view_begin, int view_end, void* stream) {
+                                           float* volume_cl, float* vis_sum, int normalise, int volume_format, int B, int V, int C, int G,
+                                           int D, int H, int W, int view_begin, int view_end, void* stream) {
     int rc = check_corr_args("mvs_warp_corr_aggregate_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, view_begin, view_end);
     if (rc != MVS_OK) return rc;
     if (!vis || !volume_cl) { set_error("mvs_warp_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
     if (!normalise && !vis_sum) { set_error("mvs_warp_corr_aggregate_fwd: partial mode needs vis_sum"); return MVS_ERR_ARG; }
+    if (volume_format != MVS_VOLUME_F32 && volume_format != MVS_VOLUME_SPLIT) { set_error("mvs_warp_corr_aggregate_fwd: unknown volume format %d", volume_format); return MVS_ERR_ARG; }
+    if (volume_format == MVS_VOLUME_SPLIT && (!normalise || G != 8)) {
+        set_error("mvs_warp_corr_aggregate_fwd: the split volume format holds the NORMALISED volume of 8 groups (partial sums stay fp32)");
+        return MVS_ERR_UNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
     rc = check_layout("mvs_warp_corr_aggregate_fwd", layout, C, G, D, H, W);
     if (rc != MVS_OK) return rc;
     const int impl = gather_impl(C, G, D, H, W);
-    if (impl == 2)
-        return gw_launch_aggregate(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, D, H, W, view_begin, view_end, st);
     if (layout == MVS_LAYOUT_OCTET_TILED || impl == 1)
-        return gl_launch_aggregate(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, D, H, W, view_begin, view_end, st);
+        return gl_launch_aggregate(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise | (volume_format << 1), B, V, C, D, H, W, view_begin, view_end, st);
+    if (volume_format == MVS_VOLUME_SPLIT) {                // shapes outside the LDS-staged fast path: fp32 volume, converted in place
+        rc = mvs_warp_corr_aggregate_fwd(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise, MVS_VOLUME_F32, B, V, C, G, D, H, W,
+                                         view_begin, view_end, stream);
+        return rc != MVS_OK ? rc : volume_to_split(volume_cl, nullptr, B, D, H, W, G, st, "mvs_warp_corr_aggregate_fwd");
+    }
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_F32, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_aggregate, MVS_DTYPE_BF16, features, homography, hyp, vis, volume_cl, vis_sum, normalise, B, V, C, G, D, H, W, view_begin, view_end, st);
@@ -584,8 +616,18 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int 
     }
 }
 
-extern "C" int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, void* stream) {
+static int volume_to_split(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, hipStream_t st, const char* who) {
+    if (G != 8) { set_error("%s: the split volume format needs 8 groups", who); return MVS_ERR_UNSUPPORTED; }
+    const size_t nvox = (size_t)B * D * H * W;
+    const unsigned grid = (unsigned)((nvox + 255) / 256 > 16384 ? 16384 : (nvox + 255) / 256);
+    hipLaunchKernelGGL(volume_to_split_kernel, dim3(grid), dim3(256), 0, st, volume_cl, vis_sum, D, H * W, nvox);
+    return check_launch("volume_to_split_kernel");
+}
+
+extern "C" int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, int volume_format, void* stream) {
     if (!volume_cl || !vis_sum || B < 1 || D < 1 || H < 1 || W < 1 || G < 1) { set_error("mvs_volume_normalise: bad arguments"); return MVS_ERR_ARG; }
+    if (volume_format == MVS_VOLUME_SPLIT) return volume_to_split(volume_cl, vis_sum, B, D, H, W, G, (hipStream_t)stream, "mvs_volume_normalise");
+    if (volume_format != MVS_VOLUME_F32) { set_error("mvs_volume_normalise: unknown volume format %d", volume_format); return MVS_ERR_ARG; }
     const size_t total = (size_t)B * D * H * W * G;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(volume_normalise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, volume_cl, vis_sum, D, H * W, G, total);

@@ -164,8 +164,9 @@ def vis_out(x_cl8: torch.Tensor, w4: torch.Tensor, b4: torch.Tensor, shape) -> t
 
 
 def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, vis: torch.Tensor,
-                        G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None):
-    """-> (volume_cl [B,D,H,W,G], vis_sum [B,H,W] or None).  `out` = preallocated (volume, vis_sum) to fill."""
+                        G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None, split: bool = False):
+    """-> (volume_cl [B,D,H,W,G], vis_sum [B,H,W] or None).  `out` = preallocated (volume, vis_sum) to fill.
+    split: leave the (normalised, G = 8) volume in the split activation format of the bf16x3 U-Net (to_split / from_split)."""
     B, V, Cc, H, W = features.shape
     D = hyp.shape[1]
     view_end = V if view_end is None else view_end
@@ -176,8 +177,8 @@ def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Ten
         vsum = None if normalise else torch.empty(B, H, W, dtype=torch.float32, device=features.device)
     ft, layout = _feat_ptr(features)
     check(lib().mvs_warp_corr_aggregate_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(vis), ptr(vol), ptr(vsum),
-                                            1 if normalise else 0, B, V, Cc, G, D, H, W, view_begin, view_end,
-                                            stream_of(ft)), "mvs_warp_corr_aggregate_fwd")
+                                            1 if normalise else 0, _lib.VOLUME_SPLIT if split else _lib.VOLUME_F32, B, V, Cc, G, D, H, W,
+                                            view_begin, view_end, stream_of(ft)), "mvs_warp_corr_aggregate_fwd")
     return vol, vsum
 
 
@@ -194,10 +195,29 @@ def warp_corr_aggregate_bwd(features: torch.Tensor, code: int, homography: torch
     return gfeat, gvis
 
 
-def volume_normalise_(vol_cl: torch.Tensor, vis_sum: torch.Tensor) -> torch.Tensor:
+def volume_normalise_(vol_cl: torch.Tensor, vis_sum: torch.Tensor, split: bool = False) -> torch.Tensor:
     B, D, H, W, G = vol_cl.shape
-    check(lib().mvs_volume_normalise(ptr(vol_cl), ptr(vis_sum), B, D, H, W, G, stream_of(vol_cl)), "mvs_volume_normalise")
+    check(lib().mvs_volume_normalise(ptr(vol_cl), ptr(vis_sum), B, D, H, W, G, _lib.VOLUME_SPLIT if split else _lib.VOLUME_F32,
+                                     stream_of(vol_cl)), "mvs_volume_normalise")
     return vol_cl
+
+
+def to_split(x_cl: torch.Tensor) -> torch.Tensor:
+    """fp32 channel-last [..., C] -> the split activation format of MVS_PREC_BF16X3_SPLIT, same shape and dtype (the bytes are, per
+    voxel, C / 8 octets of [hi x8 | lo x8] bf16 with hi = bf16(x), lo = bf16(x - hi)).  Plain torch ops: a test / tooling utility,
+    the product path never converts (the kernels' epilogues write the format)."""
+    C = x_cl.shape[-1]
+    hi = x_cl.to(torch.bfloat16)
+    lo = (x_cl - hi.float()).to(torch.bfloat16)
+    pair = torch.stack([hi.reshape(*x_cl.shape[:-1], C // 8, 8), lo.reshape(*x_cl.shape[:-1], C // 8, 8)], dim=-2)    # [..., C/8, 2, 8]
+    return pair.contiguous().view(torch.float32).reshape(x_cl.shape)
+
+
+def from_split(s_cl: torch.Tensor) -> torch.Tensor:
+    """Inverse of to_split up to the split's 2^-17 relative rounding: hi + lo as fp32."""
+    C = s_cl.shape[-1]
+    pair = s_cl.contiguous().view(torch.bfloat16).reshape(*s_cl.shape[:-1], C // 8, 2, 8).float()
+    return (pair[..., 0, :] + pair[..., 1, :]).reshape(s_cl.shape)
 
 
 # ---- a7-a9 --------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
-"""Per-stage HIP-event times of the two gather passes at the bench workload (cfg2): wave-autonomous (round 3, default) vs
-workgroup-window (round 2, MVS_GATHER_IMPL=lds) vs direct (round 1) kernels.  MVS_HIP_LIB selects a variant build.
-Usage (GPU box): python scripts/prof_gather.py [--views 5] [--reps 20] [--impls wave,lds]"""
+"""Per-stage HIP-event times of the two gather passes at the bench workload (cfg2): workgroup-window LDS kernels (default) vs
+direct (round 1, MVS_GATHER_IMPL=direct) kernels.  MVS_HIP_LIB selects a variant build.
+Usage (GPU box): python scripts/prof_gather.py [--views 5] [--reps 20] [--impls lds,direct]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -12,7 +12,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--height", type=int, default=1152)
 ap.add_argument("--width", type=int, default=1536)
 ap.add_argument("--feat-dtype", default="fp32")
-ap.add_argument("--impls", default="wave,lds")
+ap.add_argument("--impls", default="lds,direct")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 head = bench.build_head(dev)

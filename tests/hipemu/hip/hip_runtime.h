@@ -177,6 +177,7 @@ static inline int hipemu_readfirstlane(int v) {
     return all[0];
 }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
+typedef unsigned hipemu_u32x2_t __attribute__((ext_vector_type(2)));
 static inline int hipemu_readlane(int v, int src) {
     int all[64];
     hipemu::wave_gather(&v, all, sizeof(int));
@@ -184,6 +185,18 @@ static inline int hipemu_readlane(int v, int src) {
 }
 #define __builtin_amdgcn_readlane hipemu_readlane
 #define __builtin_amdgcn_fence(order, scope) ((void)0)      // the emulated lanes rendezvous in wave_barrier / __syncthreads
+
+// v_permlane16_swap: lanes 16-31 / 48-63 of the first operand <-> lanes 0-15 / 32-47 of the second; returns {new first, new second}
+static inline hipemu_u32x2_t hipemu_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+    struct AB { unsigned a, b; } mine{a, b}, all[64];
+    hipemu::wave_gather(&mine, all, sizeof(AB));
+    const int l = hipemu::lane_id();
+    hipemu_u32x2_t r;
+    r[0] = (l & 16) ? all[l - 16].b : a;
+    r[1] = (l & 16) ? b : all[l + 16].a;
+    return r;
+}
+#define __builtin_amdgcn_permlane16_swap hipemu_permlane16_swap
 
 // buffer descriptors (raw buffer loads): base + range; a dword whose offset lies beyond the range reads as zero
 struct __amdgpu_buffer_rsrc_t { const char* base; unsigned bytes; };

@@ -350,42 +350,9 @@ def case_gather_variants(device, quick=False):
         assert (cpu(both) - cpu(vol)).abs().max() <= 2e-6 * scale, (C, D, "partial sums")
 
 
-def gather_window_sizes(hom, hyp, H, W, nsw):
-    """Source-window sizes (positions) of the wave-autonomous gather kernels (csrc/gather_wave.h) per (view, chunk group, wave
-    tile), recomputed on the host: tile = PW x PH reference pixels x the 4 * nsw planes of a chunk group, window = bounding box of
-    the 2x2 tap blocks with its x origin / width rounded to 8 positions."""
-    NP = 64 // nsw
-    PW = 16 if NP >= 64 else (8 if NP >= 32 else 4)
-    PH = NP // PW
-    D = hyp.shape[1]
-    out = []
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    for v in range(hom.shape[1]):
-        h = hom[0, v]
-        q = h[:9].view(3, 3) @ torch.stack([xs.flatten(), ys.flatten(), torch.ones(H * W)])
-        for g0 in range(0, D, 4 * nsw):
-            d = hyp[0, g0:g0 + 4 * nsw].reshape(-1, H * W)
-            p = q[None] * d[:, None] + h[9:][None, :, None]
-            ix, iy = (p[:, 0] / (p[:, 2] + 1e-6)).view(-1, H, W), (p[:, 1] / (p[:, 2] + 1e-6)).view(-1, H, W)
-            ok = (ix > -1) & (ix < W) & (iy > -1) & (iy < H)
-            xb, yb = ix.floor().clamp(0, W - 2), iy.floor().clamp(0, H - 2)
-            for ty in range(0, H, PH):
-                for tx in range(0, W, PW):
-                    m = ok[:, ty:ty + PH, tx:tx + PW]
-                    if not bool(m.any()):
-                        out.append(0)
-                        continue
-                    xx, yy = xb[:, ty:ty + PH, tx:tx + PW][m], yb[:, ty:ty + PH, tx:tx + PW][m]
-                    wx0 = int(xx.min()) & ~7
-                    out.append(((int(xx.max()) + 2 - wx0 + 7) & ~7) * (int(yy.max()) + 2 - int(yy.min())))
-    return out
-
-
 def case_gather_windows(device):
-    """The three window regimes of the wave-autonomous gather kernels against the oracle in ONE launch each: windows of at most 256
-    positions (one staging round, prefetched), 257 .. 384 positions (a second, synchronous round), more than the 384-position
-    capacity (wave-uniform fallback to pair loads from global memory) and tiles with no tap inside the source image.  The
-    geometry (wide baseline, per-pixel hypothesis jitter) is checked on the host to really contain all of them."""
+    """Gather passes against the oracle on a wide-baseline rig with per-pixel hypothesis jitter: source windows from a few dozen to
+    several hundred positions in one launch, tiles whose taps all fall outside the source image, border-clamped 2x2 blocks."""
     g = torch.Generator().manual_seed(5)
     for C, D, H, W, amp in ((8, 4, 24, 64, 0.3), (16, 8, 24, 64, 0.1)):
         B, V, G = 1, 3, 8
@@ -394,10 +361,6 @@ def case_gather_windows(device):
         feats = torch.randn(B, V, C, H, W, generator=g)
         hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + amp * torch.rand(B, D, H, W, generator=g))).contiguous()
         hom = ops.compose_homography(dev(cams, device))
-        n = torch.tensor(gather_window_sizes(cpu(hom), hyp, H, W, {4: 1, 8: 2}[D]))
-        assert int((n == 0).sum()) > 0 and int(((n > 0) & (n <= 256)).sum()) > 0 and int(((n > 256) & (n <= 384)).sum()) > 0, n.tolist()
-        if D == 4:
-            assert int((n > 384).sum()) > 0, n.tolist()
         f, code = ops._feat(dev(feats, device))
         ent = cpu(ops.warp_corr_entropy(f, code, hom, dev(hyp, device), G))
         vis = torch.rand(B, V - 1, H, W, generator=g)
@@ -412,6 +375,68 @@ def case_gather_windows(device):
             vsum = vsum + vis[:, v - 1]
         expect = acc / (vsum[:, None, None] + 1e-6)
         assert (vol.permute(0, 4, 1, 2, 3) - expect).abs().max() <= 5e-5 * max(1.0, float(expect.abs().max())), (C, D, "volume")
+
+
+def case_split_format(device):
+    """The split activation format of the inference U-Net (MVS_PREC_BF16X3_SPLIT: per voxel C/8 octets of [hi x8 | lo x8] bf16):
+    every convolution / transposed convolution (with and without skip, both strides, the fused and the 3x3x3 head, the whole
+    U-Nets) fed with to_split(x) gives from_split(y) equal to the fp32-format path up to the split's 2^-17-class rounding, the
+    aggregate pass writes exactly to_split(volume), and mvs_volume_normalise converts in place."""
+    from mvsformerplusplus_amd import _lib
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 5, 7, 32, generator=g) * torch.logspace(-6, 3, 32)
+    s = ops.to_split(x)
+    assert s.shape == x.shape and s.dtype == torch.float32
+    assert (ops.from_split(s) - x).abs().max() <= 2.0 ** -16 * x.abs().max()
+    P1, P3 = _lib.PREC_BF16X3, _lib.PREC_BF16X3_SPLIT
+    for ci, co, stride in ((8, 16, (2, 2, 2)), (8, 16, (1, 2, 2)), (16, 16, (1, 1, 1)), (16, 32, (2, 2, 2)), (16, 32, (1, 2, 2)), (32, 32, (1, 1, 1)),
+                           (32, 64, (2, 2, 2)), (32, 64, (1, 2, 2)), (64, 64, (1, 1, 1))):
+        xx = torch.randn(2, 6, 10, 20, ci, generator=g)                     # ragged tiles: 10 x 20 is not a multiple of 4 x 16
+        w = torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1
+        wp = dev(packing.pack_conv_weights_bf16x3(w, packing.conv_chunk(ci, stride)), device)
+        b = dev(torch.randn(64, generator=g), device)
+        y1 = cpu(ops.conv3d_bn_relu(dev(xx, device), wp, b, co, 3, stride, True, P1))
+        y3 = ops.from_split(cpu(ops.conv3d_bn_relu(dev(ops.to_split(xx), device), wp, b, co, 3, stride, True, P3)))
+        assert (y1 - y3).abs().max() <= 2e-5 * max(1.0, float(y1.abs().max())), ("conv", ci, co, stride)
+    for ci, co, sd in ((64, 32, 2), (32, 16, 2), (16, 8, 2), (64, 32, 1), (32, 16, 1), (16, 8, 1)):
+        xx = torch.randn(2, 3, 6, 20, ci, generator=g)
+        w = torch.randn(ci, co, 3, 3, 3, generator=g) * 0.1
+        wp = dev(packing.pack_deconv_weights_bf16x3(w, sd), device)
+        b = dev(torch.randn(64, generator=g), device)
+        skip = torch.randn(2, 3 * sd, 12, 40, co, generator=g)
+        for sk in (None, skip):
+            y1 = cpu(ops.deconv3d_bn_relu_add(dev(xx, device), wp, b, co, sd, None if sk is None else dev(sk, device), P1))
+            y3 = ops.from_split(cpu(ops.deconv3d_bn_relu_add(dev(ops.to_split(xx), device), wp, b, co, sd, None if sk is None else dev(ops.to_split(sk), device), P3)))
+            assert (y1 - y3).abs().max() <= 2e-5 * max(1.0, float(y1.abs().max())), ("deconv", ci, co, sd, sk is not None)
+    # whole U-Nets incl. heads (CostRegNet: 3x3x3 head on the split features; CostRegNet3D: head fused into the last layer)
+    for cls, shape in ((M.CostRegNet, (1, 16, 16, 24)), (M.CostRegNet3D, (1, 4, 16, 24))):
+        reg = cls(8, 8)
+        reg.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(reg.state_dict()), 5))
+        reg = reg.eval().to(device)
+        vol = torch.randn(shape[0], *shape[1:], 8, generator=g) * 0.3
+        ws, bs, prob_w, prob_b = reg.packed_all(torch.device(device) if isinstance(device, str) else device, "bf16x3")
+        if reg.prob_ksize == 1:
+            l1 = cpu(ops.regnet_logits(reg.kind, dev(vol, device), ws, bs, prob_w, prob_b, P1))
+            l3 = cpu(ops.regnet_logits(reg.kind, dev(ops.to_split(vol), device), ws, bs, prob_w, prob_b, P3))
+        else:
+            l1 = cpu(ops.conv3d_logits(ops.regnet(reg.kind, dev(vol, device), ws, bs, P1), prob_w, prob_b, P1))
+            l3 = cpu(ops.conv3d_logits(ops.regnet(reg.kind, dev(ops.to_split(vol), device), ws, bs, P3), prob_w, prob_b, P3))
+        assert (l1 - l3).abs().max() <= 5e-5 * max(1.0, float(l1.abs().max())), cls.__name__
+    # the aggregate pass and the normaliser write the format themselves
+    B, V, C, D, H, W = 1, 3, 16, 8, 12, 24
+    cams = synth.make_cameras(V, H * 8, W * 8, baseline=60.0, rot_deg=2.0, seed=3, batch=B)
+    cams[:, :, 1, :2, :] /= 8
+    feats = torch.randn(B, V, C, H, W, generator=g)
+    hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.03 * torch.rand(B, D, H, W, generator=g))).contiguous()
+    f, code = ops._feat(dev(feats, device))
+    hom = ops.compose_homography(dev(cams, device))
+    vis = dev(torch.rand(B, V - 1, H, W, generator=g), device)
+    v32 = cpu(ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8)[0])
+    vs = cpu(ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, split=True)[0])
+    assert torch.equal(vs.view(torch.int32), ops.to_split(v32).view(torch.int32)), "aggregate: split volume"
+    part, vsum = ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, normalise=False)
+    vn = cpu(ops.volume_normalise_(part.clone(), vsum, split=True))
+    assert torch.equal(vn.view(torch.int32), ops.to_split(cpu(ops.volume_normalise_(part.clone(), vsum))).view(torch.int32)), "normalise: split volume"
 
 
 # ---------------------------------------------------------------- a16 cascade

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     from mvsformerplusplus_amd import build
     path = build.build()                       # hipcc cross-compiles gfx950 without a GPU
     lib = _lib.bind(path)                      # getattr() on every symbol; raises if one is missing
-    assert lib.mvs_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.mvs_abi_version() == _lib.ABI_VERSION == 6
     for name in header_symbols():
         assert hasattr(lib, name)
 
@@ -199,15 +199,31 @@ def test_device_guard_makes_the_tensor_device_current(monkeypatch):
     g = _lib._GuardedLib(fake)
     monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
     monkeypatch.setattr(torch.cuda, "device", fake_device)
-    del _lib._CALL_DEVICE[:]
-    _lib._CALL_DEVICE.extend([torch.device("cuda", 1), torch.device("cuda", 1)])
-    assert g.mvs_fake_fwd(1, 2) == 0 and entered == [torch.device("cuda", 1)] and not _lib._CALL_DEVICE
-    _lib._CALL_DEVICE.extend([torch.device("cuda", 0)])
-    g.mvs_fake_fwd(3)
+    rec = _lib._CALL_DEVICE.devs
+    # Python evaluates `g.mvs_x` (record cleared), then the arguments (ptr() records the tensors' devices), then calls
+    rec.append(torch.device("cuda", 1))                          # left behind by an argument list that raised half-way
+    call = g.mvs_fake_fwd
+    assert not rec, "fetching the entry point drops a stale record"
+    rec.extend([torch.device("cuda", 1), torch.device("cuda", 1)])
+    assert call(1, 2) == 0 and entered == [torch.device("cuda", 1)] and not rec
+    call = g.mvs_fake_fwd
+    rec.extend([torch.device("cuda", 0)])
+    call(3)
     assert entered == [torch.device("cuda", 1)], "no switch needed when the tensors live on the current device"
-    _lib._CALL_DEVICE.extend([torch.device("cuda", 0), torch.device("cuda", 1)])
+    call = g.mvs_fake_fwd
+    rec.extend([torch.device("cuda", 0), torch.device("cuda", 1)])
     with pytest.raises(_lib.MvsHipError):
-        g.mvs_fake_fwd(4)
+        call(4)
+    assert not rec
+    # the record is per thread (DataParallel replicas / autograd worker threads issue calls concurrently)
+    import threading
+    seen = []
+    rec.append(torch.device("cuda", 1))
+    t = threading.Thread(target=lambda: seen.append(list(_lib._CALL_DEVICE.devs)))
+    t.start()
+    t.join()
+    assert seen == [[]]
+    del rec[:]
     assert g.mvs_vis_workspace_bytes(1, 2, 3, 0) == 16          # size queries are not guarded
 
 

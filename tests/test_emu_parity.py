@@ -65,6 +65,10 @@ def test_gather_windows(emu):
     P.case_gather_windows(emu)
 
 
+def test_split_format(emu):
+    P.case_split_format(emu)
+
+
 def test_cascade_golden(emu):
     P.case_cascade_golden(emu)
 

@@ -80,6 +80,10 @@ def test_gather_windows():
     P.case_gather_windows(DEV)
 
 
+def test_split_format():
+    P.case_split_format(DEV)
+
+
 def test_aggregate_backward():
     P.case_aggregate_backward(DEV)
 
