@@ -60,11 +60,12 @@ def _timed(launches: List[Launch], kernel: str, stage: int, flops: float, nbytes
     return out
 
 
-def _regnet_layers(net, vol, stage, launches, precision, fused_head=False):
+def _regnet_layers(net, vol, stage, launches, precision, fused_head=False, split=False):
     """The nine U-Net launches of mvs_regnet_fwd, one C-ABI call each (same kernels, same order).  fused_head: the last layer
-    carries the 1x1x1 `prob` head (mvs_regnet_logits_fwd) and returns logits instead of features."""
+    carries the 1x1x1 `prob` head (mvs_regnet_logits_fwd) and returns logits instead of features.  split: the activations (`vol`
+    included) are in the split format of MVS_PREC_BF16X3_SPLIT, as in StageNet's inference path."""
     ws, bs, prob_w, prob_b = net.packed_all(vol.device, precision)
-    prec = _lib.PRECISIONS[precision]
+    prec = _lib.PREC_BF16X3_SPLIT if split else _lib.PRECISIONS[precision]
     three_d = net.kind == _lib.REG_COSTREGNET3D
     s2 = (1, 2, 2) if three_d else (2, 2, 2)
     sd = 1 if three_d else 2
@@ -177,7 +178,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
         vol = _timed(launches, gather_kernel_name("aggregate", code, C, D, W, isinstance(feats, ops.PackedFeatures)), s, corr_flops,
                      B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
-                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8)[0])
+                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8, split=net._split_activations())[0])
+        split = net._split_activations()
         if getattr(net.cost_reg, "kind", None) == "transformer":
             pos = None
             if head.use_pe3d:
@@ -192,17 +194,17 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             continue
         ks = net.cost_reg.prob_ksize
         if ks == 1 and net.conv_precision == "bf16x3" and net.fuse_prob_head:
-            logits = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, fused_head=True)
+            logits = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, fused_head=True, split=split)
             r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * (3 * D * HW + 2 * HW),
                         lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
             out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
             confs.append(r3[1])
             continue
-        feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision)
+        feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, split=split)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
         if ks == 3 and net.conv_precision == "bf16x3":
             logits = _timed(launches, "conv3d_mfma<8,1,k3,s111> prob head", s, 2.0 * B * D * HW * 8 * 27, 4.0 * B * (8 * D * HW + D * HW),
-                            lambda: ops.conv3d_logits(feat_cl, prob_w, prob_b, _lib.PRECISIONS[net.conv_precision]))
+                            lambda: ops.conv3d_logits(feat_cl, prob_w, prob_b, _lib.PREC_BF16X3_SPLIT if split else _lib.PRECISIONS[net.conv_precision]))
             r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * (3 * D * HW + 2 * HW),
                         lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
             out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
