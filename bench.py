@@ -65,28 +65,39 @@ def build_head(device, shipped=False):
 
 
 def cpu_baseline(head, feats, projs, dv, max_threads=None, shipped=False):
-    """The oracle (CPU restatement of the reference PyTorch path, fp32) on the host cores; second of two passes."""
+    """The oracle (CPU restatement of the reference PyTorch path, fp32) on the host cores, SURVEY.md section 8d: one warm-up pass
+    (the first call is slower), then the MEDIAN of three passes on 16 threads, and the median of three on 8 threads beside it (the
+    thread count of the in-container reference measurements)."""
     from oracle import ref_path as O
     # oneDNN convolutions on these shapes get SLOWER beyond a few dozen threads (256 threads: 171 s per pass on the
     # GPU box vs 11.5 s on 8 threads in the build container), so the baseline uses 16 threads and says so.
-    n = min(max_threads or 16, os.cpu_count() or 1)
-    torch.set_num_threads(n)
     sds = [{k: v.detach().cpu() for k, v in st.state_dict().items()} for st in head.fusions]
     f = {k: v.float().cpu() for k, v in feats.items()}
     p = {k: v.cpu() for k, v in projs.items()}
     d = dv.cpu()
-    times = []
-    out = None
-    with torch.no_grad():
-        for _ in range(2):
-            t0 = time.time()
-            out = O.cascade_forward(f, p, d, sds, ndepths=ARGS["ndepths"], depth_interals_ratio=ARGS["depth_interals_ratio"],
-                                    base_ch=ARGS["base_ch"], tmp=TMP, use_pe3d=shipped,
-                                    transformer_config=SHIPPED["transformer_config"] if shipped else None)
-            times.append(time.time() - t0)
-    return {"value": 1.0 / times[-1], "unit": "ref-views/s", "cores": n, "kind": "port",
-            "sample": "1 reference view of the bench workload (full 4-stage cascade, fp32), second of two passes; "
-                      "first pass %.1f s, timed pass %.1f s" % (times[0], times[-1])}, out
+
+    def passes(nthreads, count):
+        torch.set_num_threads(nthreads)
+        ts, o = [], None
+        with torch.no_grad():
+            for _ in range(count):
+                t0 = time.time()
+                o = O.cascade_forward(f, p, d, sds, ndepths=ARGS["ndepths"], depth_interals_ratio=ARGS["depth_interals_ratio"],
+                                      base_ch=ARGS["base_ch"], tmp=TMP, use_pe3d=shipped,
+                                      transformer_config=SHIPPED["transformer_config"] if shipped else None)
+                ts.append(time.time() - t0)
+        return ts, o
+
+    n = min(max_threads or 16, os.cpu_count() or 1)
+    t_main, out = passes(n, 4)                                   # pass 0 = warm-up
+    med = sorted(t_main[1:])[1]
+    res = {"value": 1.0 / med, "unit": "ref-views/s", "cores": n, "kind": "port",
+           "sample": "1 reference view of the bench workload (full 4-stage cascade, fp32) per pass; warm-up pass %.1f s, then the median of "
+                     "three passes: %s s" % (t_main[0], " / ".join("%.1f" % t for t in t_main[1:]))}
+    if n > 8:
+        t8, _ = passes(8, 3)
+        res["at_8_threads"] = {"value": 1.0 / sorted(t8)[1], "cores": 8, "passes_s": [round(t, 2) for t in t8]}
+    return res, out
 
 
 def main():
@@ -102,6 +113,10 @@ def main():
     ap.add_argument("--height", type=int, default=1152)
     ap.add_argument("--width", type=int, default=1536)
     ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1,
+                    help="reference views per forward call (the module API's batch axis B).  1 = the reference's own loop (test.py feeds one "
+                         "reference view per call); larger batches put B views into every launch (B x the workgroups per launch, 1 / B of the "
+                         "launches per view)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra `training_step` object (forward + backward of each cascade stage)")
     ap.add_argument("--no-profile", action="store_true")
@@ -147,7 +162,8 @@ def main():
     head = build_head(device, shipped=a.cost_reg == "shipped")
     fdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.feat_dtype]
     nsets = max(1, a.input_sets)
-    sets = [synth.make_cascade_inputs(a.height, a.width, a.views, seed=100 * rank + i, device=device, feat_dtype=fdt) for i in range(nsets)]
+    BATCH = max(1, a.batch)
+    sets = [synth.make_cascade_inputs(a.height, a.width, a.views, seed=100 * rank + i, device=device, feat_dtype=fdt, batch=BATCH) for i in range(nsets)]
     if a.feat_layout == "tiled":
         from mvsformerplusplus_amd import ops
         sets = [({k: ops.pack_features(v) for k, v in f.items()}, p, d) for f, p, d in sets]
@@ -176,7 +192,7 @@ def main():
             if streams is not None:
                 for st in streams:
                     st.wait_stream(torch.cuda.current_stream(device))
-            for j in range(first * R, (first + n_steps) * R):
+            for j in range(first * R // BATCH, (first + n_steps) * R // BATCH):       # one forward call = BATCH reference views
                 f, p, d = sets[j % nsets]
                 if streams is None:
                     o = head(f, p, d, tmp=TMP)
@@ -204,7 +220,7 @@ def main():
         for j in range(n_lat):
             head(*sets[j % nsets], tmp=TMP)
         torch.cuda.synchronize()
-        latency_ms = (time.perf_counter() - tl0) / n_lat * 1e3
+        latency_ms = (time.perf_counter() - tl0) / (n_lat * BATCH) * 1e3
         out = head(feats, projs, dv, tmp=TMP)
         torch.cuda.synchronize()
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -222,7 +238,9 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD if is_cfg2 else "%dx%d V=%d 4-stage cascade" % (a.height, a.width, a.views),
                    "height": a.height, "width": a.width, "views": a.views, "global_batch": world * R,
-                   "step": "one batch of %d reference views (batch 1 per forward call, like test.py), rotating over %d input sets" % (R, nsets),
+                   "step": "one batch of %d reference views (batch %d per forward call%s), rotating over %d input sets" %
+                           (R, BATCH, ", like test.py" if BATCH == 1 else "", nsets),
+                   "views_per_forward_call": BATCH,
                    "ref_views_per_step_per_gpu": R, "input_sets": nsets, "timed_seconds": elapsed,
                    "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams,
                    "features": "%s %s resident in HBM" % (a.feat_dtype, "octet-tiled [B,V,C/8,H,W,8]" if a.feat_layout == "tiled" else "planar [B,V,C,H,W]")},
@@ -237,7 +255,8 @@ def main():
                                 "note": "SURVEY.md section 8d layer-wise byte model (5.03 GB per reference view at cfg2) x ref-views/s / 8 TB/s"}
 
     result["config"]["cost_reg_type"] = SHIPPED["cost_reg_type"] if a.cost_reg == "shipped" else ["Normal"] * 4
-    result["config"]["conv_precision"] = ("%s MFMA contraction, fp32 activations and accumulation" % head.fusions[0].conv_precision)
+    result["config"]["conv_precision"] = ("%s MFMA contraction, fp32 accumulation; fp32-equivalent activations (between the U-Net layers stored as split "
+                                          "hi | lo bf16 pairs, the same 4 bytes per element)" % head.fusions[0].conv_precision)
 
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
     if not a.no_profile:
@@ -280,6 +299,40 @@ def main():
                                                    "ms_per_ref_view": gt / reps}
         result["kernels"] = {k: {"calls_per_ref_view": v["calls"] / reps, "ms_per_ref_view": v["ms"] / reps, "gbs": v["gbs"], "tflops": v["tflops"]}
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        # kernel FAMILIES: time, algorithmic work by SURVEY.md section 8d and the fraction of the family's own peak, so
+        # that the roofline picture does not hinge on which single symbol happens to be the largest
+        def fam(pred, bound):
+            ks = {k: v for k, v in agg.items() if pred(k)}
+            ms = sum(v["ms"] for v in ks.values()) / reps
+            if not ks or ms <= 0:
+                return None
+            if bound == "mfma":
+                work = sum(v["flops"] for v in ks.values()) / reps
+                ach = work / ms / 1e9                            # TFLOP/s
+                pk = 2500.0 / 3.0 if prec == "bf16x3" else profiling.PEAK_F32_MFMA_TFLOPS
+                return {"ms_per_ref_view": ms, "bound": "mfma", "algorithmic_gflop_per_ref_view": work / 1e9, "achieved_tflops": ach, "peak_tflops": pk,
+                        "frac": ach / pk, "launches_per_ref_view": sum(v["calls"] for v in ks.values()) / reps}
+            work = sum(v["bytes"] for v in ks.values()) / reps
+            ach = work / ms / 1e6                                # GB/s
+            return {"ms_per_ref_view": ms, "bound": "hbm", "algorithmic_mb_per_ref_view": work / 1e6, "achieved_gbs": ach, "peak_gbs": profiling.PEAK_HBM_GBS,
+                    "frac": ach / profiling.PEAK_HBM_GBS, "launches_per_ref_view": sum(v["calls"] for v in ks.values()) / reps}
+        is_gather = lambda k: k.startswith(("gl_", "warp_corr_"))
+        is_conv = lambda k: k.startswith(("conv3d_mfma", "deconv3d_mfma"))
+        is_vis = lambda k: k.startswith(("vis_",)) or k.startswith("conv3d_mfma<16,16,k1") or k.startswith("conv3d_mfma<16,8,k1")
+        families = {"gather": fam(is_gather, "hbm"), "visibility_cnn": fam(is_vis, "mfma"),
+                    "regulariser_convolutions": fam(lambda k: is_conv(k) and not is_vis(k), "mfma"),
+                    "heads_and_ranges": fam(lambda k: not (is_gather(k) or is_conv(k) or is_vis(k) or k.startswith(("tr_", "[bundle]"))), "hbm")}
+        if families["gather"] is not None and is_cfg2:
+            # the gather phase by SURVEY 8d's PATH count (features once, hypotheses once, volume once, entropy + visibility maps: 1.08 GB per
+            # reference view) beside the per-launch count above (features once PER PASS)
+            g = families["gather"]
+            g["by_path_count"] = {"algorithmic_mb_per_ref_view": 1080.0, "achieved_gbs": 1080.0 / g["ms_per_ref_view"], "frac": 1080.0 / g["ms_per_ref_view"] / profiling.PEAK_HBM_GBS}
+        if families["regulariser_convolutions"] is not None:
+            c = families["regulariser_convolutions"]
+            cb = sum(v["bytes"] for k, v in agg.items() if is_conv(k) and not is_vis(k)) / reps
+            c["hbm_view"] = {"algorithmic_mb_per_ref_view": cb / 1e6, "achieved_gbs": cb / c["ms_per_ref_view"] / 1e6,
+                             "frac": cb / c["ms_per_ref_view"] / 1e6 / profiling.PEAK_HBM_GBS}
+        result["families"] = {k: v for k, v in families.items() if v is not None}
         if a.profile_table and rank == 0:
             tot = sum(v["ms"] for v in agg.values()) / reps
             print("%-40s %6s %9s %9s %9s" % ("kernel", "calls", "ms/view", "GB/s", "TFLOP/s"), file=sys.stderr)

@@ -41,9 +41,6 @@
 #ifndef MVS_PERSIST_PFD
 #define MVS_PERSIST_PFD 1          // tiles the persistent forward convolution prefetches ahead (2: a second register set costs the first
 #endif                             // U-Net layer a resident block, 82 vs 75 us, and changes nothing elsewhere)
-#ifndef MVS_CONV_DMA
-#define MVS_CONV_DMA 1             // split format: LDS-DMA staged persistent kernel for the stride-1 16-channel-chunk layers
-#endif
 #ifndef MVS_XPASS_PREFETCH
 #define MVS_XPASS_PREFETCH 1       // loads of channel pass p + 1 issued before the contraction of pass p
 #endif
@@ -247,20 +244,13 @@ __device__ __forceinline__ void bf_conv_load_step(int g, const bf16x8* wq, const
 // one step ahead into two alternating register sets; weights (L2, several hundred cycles under load - more than the 48-384
 // MFMA cycles of a step) MVS_WPF steps ahead into MVS_WPF + 1 rotating sets.  sched_barrier keeps the requests above the
 // MFMAs they hide under.
-struct BfNoInject {
-    template <int T> __device__ __forceinline__ void step() const {}
-};
 template <class Cfg, int T>
 struct BfConvSteps {
     static constexpr int WPF = MVS_WPF, NW = WPF + 1;
-    // `inject.step<T>()` runs at the head of step T (the DMA-staged kernel requests one piece of the NEXT chunk per step there)
-    template <class Inject>
     static __device__ __forceinline__ void run(int g, const bf16x8* wq, const char* ldsb, int voxbase0, f32x4 (*acc)[Cfg::NREP],
-                                               bf16x8 (*ah)[Cfg::MREP], bf16x8 (*al)[Cfg::MREP], bf16x8* bh0, bf16x8* bl0, bf16x8* bh1, bf16x8* bl1,
-                                               const Inject& inject) {
+                                               bf16x8 (*ah)[Cfg::MREP], bf16x8 (*al)[Cfg::MREP], bf16x8* bh0, bf16x8* bl0, bf16x8* bh1, bf16x8* bl1) {
         constexpr int NSTEP = MVS_ABL == 6 ? 1 : BfConv<Cfg>::NSTEP;
         if constexpr (T < NSTEP) {
-            inject.template step<T>();
             if constexpr (T + WPF < NSTEP) bf_conv_load_w<Cfg, T + WPF>(wq, ah[(T + WPF) % NW], al[(T + WPF) % NW]);
             if constexpr (T + 1 < NSTEP) {
                 if constexpr ((T & 1) == 0) bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh1, bl1);
@@ -269,7 +259,7 @@ struct BfConvSteps {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah[T % NW], al[T % NW], bh0, bl0, acc);
             else bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah[T % NW], al[T % NW], bh1, bl1, acc);
-            BfConvSteps<Cfg, T + 1>::run(g, wq, ldsb, voxbase0, acc, ah, al, bh0, bl0, bh1, bl1, inject);
+            BfConvSteps<Cfg, T + 1>::run(g, wq, ldsb, voxbase0, acc, ah, al, bh0, bl0, bh1, bl1);
         }
     }
 };
@@ -284,13 +274,13 @@ __device__ __forceinline__ void bf_conv_preload_w(const bf16x8* wq, bf16x8 (*ah)
     }
 }
 
-template <class Cfg, class Inject = BfNoInject>
+template <class Cfg>
 __device__ __forceinline__ void bf_conv_contract(const bf16x8* wq, const char* ldsb, const int* voxbase, int g, f32x4 (*acc)[Cfg::NREP],
-                                                 bf16x8 (*ah)[Cfg::MREP], bf16x8 (*al)[Cfg::MREP], const Inject& inject = Inject()) {
+                                                 bf16x8 (*ah)[Cfg::MREP], bf16x8 (*al)[Cfg::MREP]) {
     constexpr int NREP = Cfg::NREP;
     bf16x8 bh0[NREP], bl0[NREP], bh1[NREP], bl1[NREP];
     bf_conv_load_x<Cfg, 0>(g, ldsb, voxbase[0], bh0, bl0);
-    BfConvSteps<Cfg, 0>::run(g, wq, ldsb, voxbase[0], acc, ah, al, bh0, bl0, bh1, bl1, inject);
+    BfConvSteps<Cfg, 0>::run(g, wq, ldsb, voxbase[0], acc, ah, al, bh0, bl0, bh1, bl1);
 }
 
 template <class Cfg, bool SPLIT>
@@ -416,165 +406,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// DMA-staged persistent form of the 16-channel-chunk layers (the stride-1 convolutions), split activation format only.
-//
-// Round 2's ablation: the memory phase of a tile (global loads -> registers -> split -> LDS) and its
-// contraction phase add up instead of overlapping, and moving the split to the producer (round 3, MVS_PREC_BF16X3_SPLIT) changed
-// nothing measurable - the LATENCY of the loads is what a tile waits for, not their VALU work.  With the activations pre-split
-// the staged image is a byte copy of HBM, so here it never touches a register: a workgroup walks a contiguous run of tiles and
-// keeps TWO chunk buffers (chunk = one tile x one 16-channel pass) in LDS; while chunk c is contracted, the 1-KiB pieces of chunk
-// c + 1 are requested with global_load_lds (LDS-DMA: 64 lanes x 16 bytes land at a wave-uniform base + 16 * lane; the per-lane
-// SOURCE address does the gather: lane -> (voxel 32 i + lane / 2, half lane & 1) of one octet plane, halo voxels outside the
-// volume read a zero line).  vmcnt retires in order and hipcc waits vmcnt(0) for an ordinary load while a DMA is in flight, so
-// a burst of DMA ahead of the contraction would stall its first weight wait for the whole burst: the pieces are requested ONE PER
-// CONTRACTION STEP, beside that step's weight loads (L2 requests of the same latency that the step waits for anyway).
-// One workgroup barrier per chunk.
-// ------------------------------------------------------------------------------------------------
-__device__ const float4 g_mvs_zero_line[4] = {};                 // 64 zero bytes: the DMA source of halo voxels outside the volume
-
-template <class Cfg>
-struct BfConvDma {
-    static_assert(BfConv<Cfg>::PLANES, "DMA staging: 16-channel chunks in the plane-split LDS image");
-    static constexpr int PLANE = BfConv<Cfg>::PLANE;
-    static constexpr int NI = (Cfg::NVOX * 2 + 63) / 64;         // DMA instructions per octet plane (32 voxels x [hi | lo] each)
-    static constexpr int NK = (2 * NI + 3) / 4;                  // ... per wave and chunk
-    static constexpr int CHUNK_BYTES = (2 * PLANE + 1023) / 1024 * 1024;
-    static constexpr size_t LDS_BYTES = (size_t)2 * CHUNK_BYTES;
-    static_assert(NK <= BfConv<Cfg>::NSTEP, "one DMA piece per contraction step");
-};
-
-template <class Cfg>
-struct BfDmaInject {
-    const char* const* src;       // this wave's NK source pointers of the next chunk (nullptr: nothing to request)
-    char* dst;                    // LDS base of the next chunk's buffer
-    int wave;
-    bool active;
-    template <int T> __device__ __forceinline__ void step() const {
-        if constexpr (T < BfConvDma<Cfg>::NK) {
-            constexpr int NI = BfConvDma<Cfg>::NI;
-            const int i = wave + 4 * T;                          // instruction index over both planes
-            if (active && i < 2 * NI) {
-                const int plane = i >= NI ? 1 : 0, ii = i - plane * NI;
-                if (src[T] != nullptr) MVS_GLOBAL_LOAD_LDS16(src[T], dst + plane * BfConvDma<Cfg>::PLANE + ii * 1024);
-            }
-        }
-    }
-};
-
-template <class Cfg, int T = 0>
-__device__ __forceinline__ void bf_dma_issue_all(const BfDmaInject<Cfg>& inj) {
-    if constexpr (T < BfConvDma<Cfg>::NK) {
-        inj.template step<T>();
-        bf_dma_issue_all<Cfg, T + 1>(inj);
-    }
-}
-
-template <class Cfg>
-__global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_dma_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
-                                                                     float* __restrict__ y, int D, int H, int W, int OD, int OH, int OW, int relu,
-                                                                     int tiles_x, int tiles_y, int ntiles) {
-    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, TD = Cfg::TD, TH = Cfg::TH, CH = Cfg::CH, NPASS = Cfg::NPASS;
-    constexpr int IH = Cfg::IH, IW = Cfg::IW, MREP = Cfg::MREP, NREP = Cfg::NREP, NVOX = Cfg::NVOX;
-    constexpr int NSTEP = BfConv<Cfg>::NSTEP, SB = BfConv<Cfg>::SB, NI = BfConvDma<Cfg>::NI, NK = BfConvDma<Cfg>::NK;
-    static_assert(Cfg::SD == 1 && Cfg::SH == 1 && Cfg::SW == 1, "stride-1 layers");
-    HIP_DYNAMIC_SHARED(float4, lds4)
-    char* lds = reinterpret_cast<char*>(lds4);
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, g = lane >> 4;
-    const int b = (int)blockIdx.y;
-    const int nblk = (int)gridDim.x, per = (ntiles + nblk - 1) / nblk;
-    const int t_begin = (int)xcd_remap(blockIdx.x, (unsigned)nblk) * per;
-    const int t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
-    if (t_begin >= t_end) return;
-    const int nchunk = (t_end - t_begin) * NPASS;
-
-    constexpr int MSPLIT = CfgSplit<Cfg>::MSPLIT, MREP_ALL = CfgSplit<Cfg>::MREP_ALL;
-    const int mb0 = (wave % MSPLIT) * MREP, rowgrp = wave / MSPLIT;
-    int voxbase[NREP];
-#pragma unroll
-    for (int nb = 0; nb < NREP; ++nb) {
-        const int nbg = rowgrp * NREP + nb;
-        const int oz = nbg / TH, oy = nbg % TH;
-        voxbase[nb] = ((oz * IH + oy) * IW + li) * SB;
-    }
-    const char* xb = reinterpret_cast<const char*>(x + (size_t)b * D * H * W * CIN);
-    const char* zero = reinterpret_cast<const char*>(g_mvs_zero_line);
-
-    // this wave's pieces: instruction i = wave + 4 k over both planes, lane -> voxel 32 ii + lane / 2 of the plane, half lane & 1
-    int pz[NK], py[NK], px[NK];                                   // tile-local halo coordinates, pz < 0: no such voxel (tail of a plane)
-    unsigned prel[NK];                                            // byte offset inside a voxel's channel run: octet plane and half
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int i = wave + 4 * k;
-        const int plane = i >= NI ? 1 : 0, ii = i - plane * NI;
-        const int vox = 32 * ii + (lane >> 1);
-        const int dx = vox % IW, t2 = vox / IW;
-        px[k] = dx; py[k] = t2 % IH; pz[k] = (i < 2 * NI && vox < NVOX) ? t2 / IH : -1;
-        prel[k] = (unsigned)(plane * 32 + (lane & 1) * 16);
-    }
-    // source pointers of chunk c (tile, pass) for this wave's pieces
-    auto sources = [&](int c, const char** src) {
-        const int tile = t_begin + c / NPASS, pass = c - (c / NPASS) * NPASS;
-        const int tx = tile % tiles_x, t1 = tile / tiles_x;
-        const int ty = t1 % tiles_y, tz = t1 / tiles_y;
-        const int iz0 = tz * TD - Cfg::PD, iy0 = ty * TH - 1, ix0 = tx * 16 - 1;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int z = iz0 + pz[k], yy = iy0 + py[k], xx = ix0 + px[k];
-            const bool ok = MVS_ABL != 1 && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            src[k] = pz[k] < 0 ? nullptr : (ok ? xb + ((((size_t)z * H + yy) * W + xx) * CIN + pass * CH) * 4 + prel[k] : zero + (lane & 1) * 16);
-        }
-    };
-    const char* src[NK];
-    // prologue: chunk 0, all pieces at once
-    sources(0, src);
-    {
-        BfDmaInject<Cfg> first{src, lds, wave, true};
-        bf_dma_issue_all<Cfg>(first);
-    }
-    float* yb = y + (size_t)b * OD * OH * OW * COUT;
-    f32x4 acc[MREP][NREP];
-    for (int c = 0; c < nchunk; ++c) {
-        const int tile = t_begin + c / NPASS, pass = c - (c / NPASS) * NPASS;
-        char* cur = lds + (c & 1) * BfConvDma<Cfg>::CHUNK_BYTES;
-        const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + ((size_t)pass * NSTEP * MREP_ALL + mb0) * 2 * 64 + lane;
-        bf16x8 ah[MVS_WPF + 1][MREP], al[MVS_WPF + 1][MREP];
-        bf_conv_preload_w<Cfg>(wq, ah, al);
-        MVS_WAIT_VMEM();                                         // this wave's pieces of chunk c have landed ...
-        __syncthreads();                                         // ... and everybody's; every wave has left chunk c - 1 (its buffer is free)
-        const bool more = c + 1 < nchunk;
-        if (more) sources(c + 1, src);
-        if (pass == 0) {
-#pragma unroll
-            for (int mb = 0; mb < MREP; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NREP; ++nb) acc[mb][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        BfDmaInject<Cfg> inject{src, lds + ((c + 1) & 1) * BfConvDma<Cfg>::CHUNK_BYTES, wave, more};
-        bf_conv_contract<Cfg>(wq, cur, voxbase, g, acc, ah, al, inject);
-        if (pass != NPASS - 1) continue;
-        const int tx = tile % tiles_x, t1 = tile / tiles_x;
-        const int ty = t1 % tiles_y, tz = t1 / tiles_y;
-        const int oz0 = tz * TD, oy0 = ty * TH, ox0 = tx * 16;
-#pragma unroll
-        for (int nb = 0; nb < NREP; ++nb) {
-            const int nbg = rowgrp * NREP + nb;
-            const int oz = oz0 + nbg / TH, oy = oy0 + nbg % TH, ox = ox0 + li;
-            const bool inside = oz < OD && oy < OH && ox < OW;
-            float* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
-#pragma unroll
-            for (int mb = 0; mb < MREP; ++mb) {
-                const int co = 16 * (mb0 + mb) + 4 * g;
-                const float4 bb = *reinterpret_cast<const float4*>(bias + (co < COUT ? co : 0));
-                float4 v = make_float4(acc[mb][nb][0] + bb.x, acc[mb][nb][1] + bb.y, acc[mb][nb][2] + bb.z, acc[mb][nb][3] + bb.w);
-                if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
-                split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
-            }
-        }
-    }
-}
+// (Round 3 also measured an LDS-DMA staged persistent form of the stride-1 layers for the split format - global_load_lds into two
+// chunk buffers, one DMA piece requested per contraction step, one barrier per chunk: parity green, but at the one workgroup per CU
+// its 84 KB of LDS allow it ran 1.2-1.8x SLOWER than the one-tile kernels below with their three co-resident workgroups
+// (profiles/r03_conv_dma_staging_ab.txt; the kernel lives in git history, commit "Experiment: LDS-DMA staged ...").  What hides
+// latency on this chip, for compiler-scheduled code, is co-resident workgroups, not depth of software pipelining in one wave.)
 
 // ------------------------------------------------------------------------------------------------
 // Persistent form for the layers whose whole packed weight set fits in registers (Cin = 8: 7 steps x 8 VGPRs).
@@ -1209,14 +1045,6 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
         return check_launch("conv3d_mfma_bf16x3_persist_kernel");
     }
     if (logits != nullptr) { set_error("conv3d(bf16x3): the planar single-channel output needs a persistent (Cin = 8) kernel"); return MVS_ERR_UNSUPPORTED; }
-    if constexpr (MVS_CONV_DMA && SPLIT && BfConv<Cfg>::PLANES && Cfg::KD == 3 && Cfg::SD == 1 && Cfg::SH == 1 && Cfg::SW == 1) {
-        constexpr size_t DLDS = BfConvDma<Cfg>::LDS_BYTES;
-        const int resident = resident_blocks(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_dma_kernel<Cfg>), DLDS);
-        if (resident < 1) { set_error("conv3d(bf16x3, dma): occupancy query failed"); return MVS_ERR_LAUNCH; }
-        const int nblk = ntiles < resident ? ntiles : resident;
-        hipLaunchKernelGGL((conv3d_mfma_bf16x3_dma_kernel<Cfg>), dim3(nblk, B), dim3(256), DLDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
-        return check_launch("conv3d_mfma_bf16x3_dma_kernel");
-    }
     if (LDS > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), dim3(ntiles, B), dim3(256), LDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);

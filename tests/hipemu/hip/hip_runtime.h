@@ -257,9 +257,6 @@ static inline int hipemu_any(int pred) {
 #define MVS_OPAQUE_SREG "r"
 #define MVS_NO_OPAQUE_VEC 1    // 128-bit bf16 vectors have no x86 asm register class; the laundering is a GPU register-allocation hint only
 
-// LDS-DMA (global_load_lds_dwordx4): the emulated copy lands at once; every fiber is one lane
-#define MVS_GLOBAL_LOAD_LDS16(gsrc, ldst) memcpy(static_cast<char*>(static_cast<void*>(ldst)) + 16 * hipemu::lane_id(), (gsrc), 16)
-#define MVS_WAIT_VMEM() ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 
