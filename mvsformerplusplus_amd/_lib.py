@@ -44,6 +44,8 @@ SIGNATURES = {
     "mvs_vis_out_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i] + [_i] * 9 + [_vp]),
     "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mvs_slab_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_slab_reduce": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),

@@ -185,10 +185,12 @@ class StageNet(nn.Module):
     def _buffer(self, name, shape, device, zero=False):
         """Persistent scratch per (name, shape): the sharded path allocates nothing in steady state.  One buffer per name is kept
         for each of the MAX_CACHED_SHAPES most recently used shapes (LRU)."""
-        key = (name, tuple(shape), device)
+        # per stream: two reference views in flight through the same module (separate streams) must not share scratch
+        stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        key = (name, tuple(shape), device, stream)
         buf = self._buffers_cache.pop(key, None)
         if buf is None:
-            same = [k for k in self._buffers_cache if k[0] == name and k[2] == device]
+            same = [k for k in self._buffers_cache if k[0] == name and k[2] == device and k[3] == stream]
             for k in same[: max(0, len(same) - (self.MAX_CACHED_SHAPES - 1))]:        # dicts keep insertion order: oldest first
                 del self._buffers_cache[k]
             buf = torch.empty(shape, dtype=torch.float32, device=device)
@@ -261,39 +263,37 @@ class StageNet(nn.Module):
         vol, vsum = self._partial_volume(feats, code, hom, hyp, G, vis_params, flat)
         a, b, ea, eb = plan[rank]
         rows = eb - ea
-        # ---- exchange: to rank j the rows [ea_j, eb_j) of this rank's partial (volume rows + vis_sum rows in one message) ----
-        ops_, sends, recvs = [], {}, {}
+        # ---- exchange: to rank j the rows [ea_j, eb_j) of this rank's partial (volume rows + vis_sum rows in one message).  ONE launch
+        #      packs the messages of all destinations (mvs_slab_pack), ONE launch sums the own slice and every received message in rank
+        #      order (mvs_slab_reduce): no staging copies of the own slab, no R - 1 add_ launches ----
+        p2p, sends, recvs = [], [None] * world, [None] * world
         for j in range(world):
             ja, jb, jea, jeb = plan[j]
-            if jb <= ja:
-                continue                                     # rank j owns no rows (more ranks than 8-row slabs)
-            n = B * D * (jeb - jea) * W * G + B * (jeb - jea) * W
-            if j == rank:
-                continue
-            sb = self._buffer("send%d" % j, (n,), dev)
-            sb[: n - B * (jeb - jea) * W].view(B, D, jeb - jea, W, G).copy_(vol[:, :, jea:jeb])
-            sb[n - B * (jeb - jea) * W:].view(B, jeb - jea, W).copy_(vsum[:, jea:jeb])
-            sends[j] = sb
-            ops_.append(dist.P2POp(dist.isend, sb, dist.get_global_rank(self.view_group, j), self.view_group))
+            if jb <= ja or j == rank:
+                continue                                     # rank j owns no rows (more ranks than 8-row slabs) / no message to self
+            sends[j] = self._buffer("send%d" % j, (B * D * (jeb - jea) * W * G + B * (jeb - jea) * W,), dev)
+        if any(b is not None for b in sends):
+            ops.slab_pack(vol, vsum, sends, [(pl[2], pl[3]) for pl in plan])
+        for j in range(world):
+            if sends[j] is not None:
+                p2p.append(dist.P2POp(dist.isend, sends[j], dist.get_global_rank(self.view_group, j), self.view_group))
         nmine = B * D * rows * W * G + B * rows * W
         if b > a:
             for j in range(world):
                 if j == rank:
                     continue
-                rb = self._buffer("recv%d" % j, (nmine,), dev)
-                recvs[j] = rb
-                ops_.append(dist.P2POp(dist.irecv, rb, dist.get_global_rank(self.view_group, j), self.view_group))
-        if ops_:
-            for w in dist.batch_isend_irecv(ops_):
+                recvs[j] = self._buffer("recv%d" % j, (nmine,), dev)
+                p2p.append(dist.P2POp(dist.irecv, recvs[j], dist.get_global_rank(self.view_group, j), self.view_group))
+        if p2p:
+            # Overlap comes from the caller keeping two or more reference views in flight per group on separate streams (bench.py issues
+            # them round-robin): the scratch buffers are per stream, the collectives of a view are enqueued behind its own launches
+            # only, and every rank issues the views in the same order.
+            for w in dist.batch_isend_irecv(p2p):
                 w.wait()
-        self.last_collective_bytes = sum(t.numel() for t in sends.values()) * 4
+        self.last_collective_bytes = sum(t.numel() for t in sends if t is not None) * 4
         out_rows = None
         if b > a:
-            acc = self._buffer("slab", (nmine,), dev)
-            acc[: nmine - B * rows * W].view(B, D, rows, W, G).copy_(vol[:, :, ea:eb])
-            acc[nmine - B * rows * W:].view(B, rows, W).copy_(vsum[:, ea:eb])
-            for j in sorted(recvs):                          # fixed rank order: every rank sums in the same order
-                acc.add_(recvs[j])
+            acc = ops.slab_reduce(vol, vsum, recvs, rank, self._buffer("slab", (nmine,), dev), ea, eb)
             svol = acc[: nmine - B * rows * W].view(B, D, rows, W, G)
             ssum = acc[nmine - B * rows * W:].view(B, rows, W)
             ops.volume_normalise_(svol, ssum, split=self._split_activations())

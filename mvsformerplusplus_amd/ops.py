@@ -202,6 +202,31 @@ def volume_normalise_(vol_cl: torch.Tensor, vis_sum: torch.Tensor, split: bool =
     return vol_cl
 
 
+def slab_pack(vol_cl: torch.Tensor, vis_sum: torch.Tensor, send_bufs, rows) -> None:
+    """One launch: send_bufs[j] (or None) <- rows[j] = [r0, r1) of the partial volume [B,D,H,W,8] followed by the same rows of the
+    partial visibility sum [B,H,W] (the messages of the slab exchange)."""
+    import ctypes as C
+    B, D, H, W, G = vol_cl.shape
+    n = len(send_bufs)
+    ptrs = (C.c_void_p * n)(*[None if b is None else ptr(b) for b in send_bufs])
+    r0 = (C.c_int * n)(*[int(r[0]) for r in rows])
+    r1 = (C.c_int * n)(*[int(r[1]) for r in rows])
+    check(lib().mvs_slab_pack(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), C.cast(r0, C.c_void_p), C.cast(r1, C.c_void_p), n, B, D, H, W,
+                              stream_of(vol_cl)), "mvs_slab_pack")
+
+
+def slab_reduce(vol_cl: torch.Tensor, vis_sum: torch.Tensor, recv_bufs, my_rank: int, out: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
+    """One launch: out <- sum over ranks, in rank order, of their partials of rows [r0, r1): the own slice read in place, the others
+    from recv_bufs[j] (None = rank j sent nothing)."""
+    import ctypes as C
+    B, D, H, W, G = vol_cl.shape
+    n = len(recv_bufs)
+    ptrs = (C.c_void_p * n)(*[None if b is None else ptr(b) for b in recv_bufs])
+    check(lib().mvs_slab_reduce(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), n, my_rank, ptr(out), r0, r1, B, D, H, W, stream_of(vol_cl)),
+          "mvs_slab_reduce")
+    return out
+
+
 def to_split(x_cl: torch.Tensor) -> torch.Tensor:
     """fp32 channel-last [..., C] -> the split activation format of MVS_PREC_BF16X3_SPLIT, same shape and dtype (the bytes are, per
     voxel, C / 8 octets of [hi x8 | lo x8] bf16 with hi = bf16(x), lo = bf16(x - hi)).  Plain torch ops: a test / tooling utility,

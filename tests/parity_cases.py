@@ -439,6 +439,35 @@ def case_split_format(device):
     assert torch.equal(vn.view(torch.int32), ops.to_split(cpu(ops.volume_normalise_(part.clone(), vsum))).view(torch.int32)), "normalise: split volume"
 
 
+def case_slab_exchange_kernels(device):
+    """mvs_slab_pack / mvs_slab_reduce (the slab exchange of the view-sharded latency mode) against torch slicing: message j = rows
+    [r0_j, r1_j) of the partial volume followed by the same rows of the partial visibility sum; the reduction adds the own slice and
+    the received messages in rank order (bit-identical to the sequential sum)."""
+    g = torch.Generator().manual_seed(9)
+    B, D, H, W, G, R = 2, 3, 24, 16, 8, 4
+    vol = torch.randn(B, D, H, W, G, generator=g)
+    vsum = torch.rand(B, H, W, generator=g)
+    rows = [(0, 10), (4, 18), (12, 24), (5, 5)]                      # rank 3 owns nothing
+    sends = [None if r1 <= r0 or j == 1 else torch.full((B * D * (r1 - r0) * W * G + B * (r1 - r0) * W,), float("nan")) for j, (r0, r1) in enumerate(rows)]
+    dsends = [None if t is None else dev(t, device) for t in sends]
+    ops.slab_pack(dev(vol, device), dev(vsum, device), dsends, rows)
+    for j, (r0, r1) in enumerate(rows):
+        if dsends[j] is None:
+            continue
+        want = torch.cat([vol[:, :, r0:r1].reshape(-1), vsum[:, r0:r1].reshape(-1)])
+        assert torch.equal(cpu(dsends[j]), want), j
+    my, (r0, r1) = 1, rows[1]
+    n = B * D * (r1 - r0) * W * G + B * (r1 - r0) * W
+    recvs = [None if j in (my, 3) else torch.randn(n, generator=g) for j in range(R)]
+    out = cpu(ops.slab_reduce(dev(vol, device), dev(vsum, device), [None if t is None else dev(t, device) for t in recvs], my,
+                              dev(torch.empty(n), device), r0, r1))
+    own = torch.cat([vol[:, :, r0:r1].reshape(-1), vsum[:, r0:r1].reshape(-1)])
+    want = torch.zeros(n)
+    for j in range(R):
+        want = want + (own if j == my else (recvs[j] if recvs[j] is not None else 0.0))
+    assert torch.equal(out, want)
+
+
 # ---------------------------------------------------------------- a16 cascade
 def case_cascade_golden(device):
     from mvsformerplusplus_amd.cascade import CascadeDepthHead

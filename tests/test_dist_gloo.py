@@ -160,6 +160,41 @@ def test_view_sharded_cascade_matches_single_process(world, V, mode):
         assert same, "ranks hold different results"
 
 
+def _two_views_worker(rank, world, port, emu_path, q):
+    """Two reference views through ONE view-sharded head back to back (the schedule of two views in flight per group: every rank
+    issues A, B, A): the persistent scratch of the slab exchange is reused across views, so A must come out the same both times,
+    B must not be disturbed by A's buffers, and the ranks must agree on all three."""
+    _setup(rank, world, port, emu_path)
+    from conftest import golden_weights, load_golden
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    fx = load_golden("f4_cascade.npz")
+    args = {"base_ch": [8] * 4, "depth_type": ["ce"] * 4, "ndepths": [32, 16, 8, 4], "depth_interals_ratio": [4.0, 2.67, 1.5, 1.0], "inverse_depth": True}
+    head = CascadeDepthHead(args)
+    for s in range(4):
+        head.fusions[s].load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
+    head.eval()
+    fa = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
+    projs = {"stage%d" % s: fx["proj%d" % s] for s in range(1, 5)}
+    g = torch.Generator().manual_seed(4)
+    fb = {k: v + 0.3 * torch.randn(v.shape, generator=g) for k, v in fa.items()}        # a second reference view: other features, same rig
+    with torch.no_grad():
+        single_b = head(fb, projs, fx["depth_values"])["refined_depth"]
+        head.set_view_group(dist.group.WORLD, shard_mode="slab")
+        a1 = head(fa, projs, fx["depth_values"])["refined_depth"].clone()
+        b1 = head(fb, projs, fx["depth_values"])["refined_depth"].clone()
+        a2 = head(fa, projs, fx["depth_values"])["refined_depth"].clone()
+    err = float(((single_b - b1).abs() / single_b.abs()).mean())
+    ok = torch.equal(a1, a2) and _agree(a1, world) and _agree(b1, world) and _agree(a2, world)
+    q.put((rank, err, ok))
+    dist.destroy_process_group()
+
+
+def test_two_views_in_flight_schedule_is_repeatable_and_rank_identical():
+    for rank, err, ok in _run(_two_views_worker, 2):
+        assert err <= 1e-4, "rank %d: second view's sharded depth differs from its single-process depth by %g" % (rank, err)
+        assert ok, "views issued back to back through one sharded head disturbed each other or the ranks disagree"
+
+
 def _syncbn_worker(rank, world, port, emu_path, q):
     """Training path under SyncBatchNorm: each rank holds one sample of a batch of two; the BatchNorm statistics (forward and
     backward sums) are all-reduced inside the native kernels' host code, so every rank's feature gradient equals the matching
