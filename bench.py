@@ -117,6 +117,9 @@ def main():
                     help="reference views per forward call (the module API's batch axis B).  1 = the reference's own loop (test.py feeds one "
                          "reference view per call); larger batches put B views into every launch (B x the workgroups per launch, 1 / B of the "
                          "launches per view)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay one captured hipGraph per (stream, input set) (CascadeDepthHead.capture) instead of issuing the ~67 launches of "
+                         "a reference view from Python: the same device work, one launch per view from the host's side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra `training_step` object (forward + backward of each cascade stage)")
     ap.add_argument("--no-profile", action="store_true")
@@ -186,6 +189,17 @@ def main():
             torch.cuda.synchronize()
         streams = [torch.cuda.Stream(device=device) for _ in range(a.streams)] if a.streams > 1 else None
 
+        graphs = {}
+        if a.graph:
+            for si in range(len(streams) if streams is not None else 1):
+                for k in range(nsets):
+                    if streams is None:
+                        graphs[(si, k)] = head.capture(*sets[k], tmp=TMP)
+                    else:
+                        with torch.cuda.stream(streams[si]):
+                            graphs[(si, k)] = head.capture(*sets[k], tmp=TMP)
+            torch.cuda.synchronize()
+
         def run(n_steps, first=0):
             """n_steps steps; step k = the R reference views k*R .. k*R+R-1, view j on input set j % nsets and stream j % nstreams."""
             o = None
@@ -195,10 +209,10 @@ def main():
             for j in range(first * R // BATCH, (first + n_steps) * R // BATCH):       # one forward call = BATCH reference views
                 f, p, d = sets[j % nsets]
                 if streams is None:
-                    o = head(f, p, d, tmp=TMP)
+                    o = graphs[(0, j % nsets)]() if a.graph else head(f, p, d, tmp=TMP)
                 else:
                     with torch.cuda.stream(streams[j % len(streams)]):
-                        o = head(f, p, d, tmp=TMP)
+                        o = graphs[(j % len(streams), j % nsets)]() if a.graph else head(f, p, d, tmp=TMP)
             if streams is not None:
                 for st in streams:
                     torch.cuda.current_stream(device).wait_stream(st)
@@ -240,7 +254,7 @@ def main():
                    "height": a.height, "width": a.width, "views": a.views, "global_batch": world * R,
                    "step": "one batch of %d reference views (batch %d per forward call%s), rotating over %d input sets" %
                            (R, BATCH, ", like test.py" if BATCH == 1 else "", nsets),
-                   "views_per_forward_call": BATCH,
+                   "views_per_forward_call": BATCH, "issue": "one hipGraph replay per reference view" if a.graph else "eager launches",
                    "ref_views_per_step_per_gpu": R, "input_sets": nsets, "timed_seconds": elapsed,
                    "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams,
                    "features": "%s %s resident in HBM" % (a.feat_dtype, "octet-tiled [B,V,C/8,H,W,8]" if a.feat_layout == "tiled" else "planar [B,V,C,H,W]")},

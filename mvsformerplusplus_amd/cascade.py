@@ -44,6 +44,13 @@ class CascadeDepthHead(nn.Module):
             f.view_group = group
             f.shard_mode = shard_mode
 
+    def capture(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
+                tmp: Sequence[float] = (5.0, 5.0, 5.0, 1.0)) -> "GraphedCascade":
+        """The cascade on these (fixed) input tensors as one replayable hipGraph: one launch per reference view from the host's side."""
+        if self.training or any(f.view_group is not None for f in self.fusions):
+            raise RuntimeError("capture: inference on one GPU only (train mode and view sharding issue host-side work per stage)")
+        return GraphedCascade(self, features, proj_matrices, depth_values, tmp)
+
     def forward(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
                 tmp: Sequence[float] = (5.0, 5.0, 5.0, 1.0)) -> Dict[str, torch.Tensor]:
         n = len(self.ndepths)
@@ -74,6 +81,34 @@ class CascadeDepthHead(nn.Module):
         outputs["refined_depth"] = stage_out["depth"]
         outputs["photometric_confidence"] = ops.confidence_average(confs, Hf, Wf)
         return outputs
+
+
+class GraphedCascade:
+    """One reference view's whole cascade (~67 launches) captured as ONE hipGraph (``CascadeDepthHead.capture``).
+
+    The graph reads the tensors it was captured on: a producer writes the next reference view's features / projection matrices /
+    depth values INTO ``features`` / ``proj_matrices`` / ``depth_values`` (``copy_`` or its own kernels, on the stream it will
+    replay on) and calls the object; the results appear in ``outputs`` (fixed buffers as well - consume or copy them before the next
+    replay).  Inference only; the captured launches are exactly the eager ones (every kernel of the path runs on the current stream,
+    allocates through the caching allocator only and never synchronises with the host)."""
+
+    def __init__(self, head: "CascadeDepthHead", features, proj_matrices, depth_values, tmp):
+        if not depth_values.is_cuda:
+            raise RuntimeError("hipGraph capture needs tensors on a ROCm device")
+        self.features, self.proj_matrices, self.depth_values = features, proj_matrices, depth_values
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=depth_values.device)
+            side.wait_stream(torch.cuda.current_stream(depth_values.device))
+            with torch.cuda.stream(side):                      # warm-up outside the capture: code objects, packed weights, allocator pools
+                head(features, proj_matrices, depth_values, tmp=tmp)
+            torch.cuda.current_stream(depth_values.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.outputs = head(features, proj_matrices, depth_values, tmp=tmp)
+
+    def __call__(self) -> Dict[str, torch.Tensor]:
+        self.graph.replay()
+        return self.outputs
 
 
 def patch_model(model: nn.Module) -> nn.Module:

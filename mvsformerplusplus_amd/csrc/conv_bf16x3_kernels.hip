@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     char* ldsb = reinterpret_cast<char*>(lds4);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
+    start_stagger(2048);
     int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
     const int b = (int)blockIdx.y;
     const int tx = tile % tiles_x;
@@ -572,7 +573,17 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
 template <class Cfg>
 struct BfDeconv {
     static constexpr int OPT = Cfg::CIN / 8;
-    static constexpr int SB = Cfg::S * 4;
+    // Round 3: the plane-split LDS image of the forward convolutions for the one-tile transposed convolutions too - one plane per
+    // channel octet, [voxel][hi x8 | lo x8] at 32 B per voxel, planes offset by 16 B modulo the 256-byte bank row.  The two lane
+    // groups that share a ds_read_b128 service group (g, g ^ 1) always read ADJACENT octets of one tap (OPT is 2, 4 or 8), i.e.
+    // addresses PLANE apart: 16 different bank slots.  (The interleaved (CIN + 4)-float voxel of rounds 1-2 2-way conflicted on
+    // every read: PMC SQ_LDS_BANK_CONFLICT = 46-50 % of the LDS cycles of the 32 -> 16 and 64 -> 32 layers, round-3 pass.)
+#ifndef MVS_DECONV_PLANES
+#define MVS_DECONV_PLANES 1
+#endif
+    static constexpr int SB = MVS_DECONV_PLANES ? 32 : Cfg::S * 4;
+    static constexpr int PLANE = MVS_DECONV_PLANES ? (Cfg::NVOX * 32 + 255) / 256 * 256 + 16 : 32;     // byte offset between octets
+    static constexpr size_t LDS_BYTES = MVS_DECONV_PLANES ? (size_t)OPT * PLANE : Cfg::LDS_BYTES;
 };
 
 template <class Cfg>
@@ -589,7 +600,7 @@ __device__ __forceinline__ void bf_deconv_load_step(int st, int ntap, int pd, in
     const int a_h = ti % nkh, a_d = ti / nkh;
     const int od = (SD == 2) ? (pd ? 1 - a_d : 0) : 1 - a_d;
     const int oh = ph ? 1 - a_h : 0, ow = pw ? 1 - a_w : 0;
-    const int ldsoff = ((od * Cfg::LH + oh) * Cfg::LW + ow) * BfDeconv<Cfg>::SB + oc * 32;
+    const int ldsoff = ((od * Cfg::LH + oh) * Cfg::LW + ow) * BfDeconv<Cfg>::SB + oc * BfDeconv<Cfg>::PLANE;
 #pragma unroll
     for (int mb = 0; mb < Cfg::MREP; ++mb) {
         if (MVS_ABL == 2 && st > 1) continue;
@@ -618,6 +629,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     char* ldsb = reinterpret_cast<char*>(lds4);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
+    start_stagger(2048);
     int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
     const int b = (int)blockIdx.y;
     const int tx = tile % tiles_x;
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             u = src[0];
             v = src[1];
         }
-        stage_to_lds<SPLIT>(ldsb + vox * SB + oc * 32, u, v);
+        stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfDeconv<Cfg>::PLANE, u, v);
     }
     __syncthreads();
 
@@ -1072,9 +1084,10 @@ static int launch_deconv_bf(const float* x, const void* wp, const float* bias, c
                            W, tx, ty, ntiles, relu);
         return check_launch("deconv3d_mfma_bf16x3_persist_kernel");
     }
-    if (Cfg::LDS_BYTES > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((deconv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), dim3(ntiles, B), dim3(256), Cfg::LDS_BYTES, st, x, wp, bias, skip, y, prob_w, prob_b,
+    constexpr size_t DLDS = BfDeconv<Cfg>::LDS_BYTES;
+    if (DLDS > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DLDS);
+    hipLaunchKernelGGL((deconv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), dim3(ntiles, B), dim3(256), DLDS, st, x, wp, bias, skip, y, prob_w, prob_b,
                        logits, D, H, W, tx, ty, ntiles, relu);
     return check_launch("deconv3d_mfma_bf16x3_kernel");
 }

@@ -70,9 +70,15 @@ struct DeconvCfg {
 #ifndef MVS_T3232_TD
 #define MVS_T3232_TD 4
 #endif
+#ifndef MVS_T1616_TH
+#define MVS_T1616_TH 4
+#endif
+#ifndef MVS_T3232_TH
+#define MVS_T3232_TH 4
+#endif
 #define MVS_CONV_TABLE(X)            \
-    X(16, 16, 3, 1, 1, 1, MVS_T1616_TD, 4, 16)  \
-    X(32, 32, 3, 1, 1, 1, MVS_T3232_TD, 4, 16)  \
+    X(16, 16, 3, 1, 1, 1, MVS_T1616_TD, MVS_T1616_TH, 16)  \
+    X(32, 32, 3, 1, 1, 1, MVS_T3232_TD, MVS_T3232_TH, 16)  \
     X(64, 64, 3, 1, 1, 1, MVS_T6464_TD, 4, 16)  \
     X(8, 16, 3, 1, 1, 1, MVS_HEAD_TD, MVS_HEAD_TH, 8)    \
     X(8, 16, 3, 2, 2, 2, 2, 2, 8)    \

@@ -212,6 +212,22 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
     return base + idx;
 }
 
+// Start stagger of the first generation of workgroups (experiment switch MVS_STAGGER = units of ~0.43 us per wave slot, 0 = off).
+// All workgroups of a launch start within a microsecond of each other and the co-resident ones of a CU then run their memory
+// phase and their contraction phase IN STEP - the phases add up instead of overlapping - and each
+// successor inherits its slot's timing.  Delaying the first workgroup of wave slot s of a SIMD by s units spreads the slots' phases.
+#ifndef MVS_STAGGER
+#define MVS_STAGGER 0
+#endif
+__device__ __forceinline__ void start_stagger(unsigned first_generation_blocks) {
+#if MVS_STAGGER > 0
+    if (blockIdx.x < first_generation_blocks) {
+        const unsigned slot = (unsigned)__builtin_amdgcn_s_getreg(6148) & 15u;      // HW_REG_HW_ID, WAVE_ID: this wave's slot in its SIMD
+        for (unsigned i = 0; i < slot * MVS_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);          // 16 x 64 cycles
+    }
+#endif
+}
+
 static inline unsigned ceil_div(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace mvs

@@ -16,3 +16,5 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA S
   tail -1 $OUT/p$i.log
 done
 cd $ROOT && python scripts/pmc_table.py gpurun_out/pmc_$TAG > gpurun_out/pmc_$TAG/table.txt 2>&1; wc -l gpurun_out/pmc_$TAG/table.txt
+python scripts/pmc_table_summary.py gpurun_out/pmc_$TAG/table.txt > gpurun_out/pmc_$TAG/summary.txt 2>&1; head -60 gpurun_out/pmc_$TAG/summary.txt
+rm -rf gpurun_out/pmc_$TAG/p[0-9]*          # the raw per-dispatch CSVs exceed what gpurun copies back

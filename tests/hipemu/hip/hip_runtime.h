@@ -258,6 +258,8 @@ static inline int hipemu_any(int pred) {
 #define MVS_NO_OPAQUE_VEC 1    // 128-bit bf16 vectors have no x86 asm register class; the laundering is a GPU register-allocation hint only
 
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_s_getreg(imm) 0
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 
 // ---- device math spellings used by the kernels ----

@@ -192,17 +192,18 @@ def test_cascade_hip_graph_capture():
         feats, projs, dv = synth.make_cascade_inputs(128, 192, 3, seed=3, device=DEV)
         with torch.no_grad():
             eager = head(feats, projs, dv)["refined_depth"].clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                head(feats, projs, dv)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                captured = head(feats, projs, dv)
-            graph.replay()
+            graphed = head.capture(feats, projs, dv)                # the product API: CascadeDepthHead.capture -> GraphedCascade
+            out = graphed()
             torch.cuda.synchronize()
-        assert torch.equal(captured["refined_depth"], eager)
+            assert torch.equal(out["refined_depth"], eager)
+            # a new reference view written into the captured input tensors, replayed: equals the eager result on the same data
+            f2, p2, d2 = synth.make_cascade_inputs(128, 192, 3, seed=4, device=DEV)
+            for k in feats:
+                feats[k].copy_(f2[k])
+                projs[k].copy_(p2[k])
+            out = graphed()
+            torch.cuda.synchronize()
+            assert torch.equal(out["refined_depth"], head(feats, projs, dv)["refined_depth"])
 
 
 def test_train_kernels():
