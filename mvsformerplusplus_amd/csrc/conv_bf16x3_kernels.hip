@@ -283,6 +283,97 @@ __device__ __forceinline__ void bf_conv_contract(const bf16x8* wq, const char* l
     BfConvSteps<Cfg, 0>::run(g, wq, ldsb, voxbase[0], acc, ah, al, bh0, bl0, bh1, bl1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weights through LDS, once per workgroup (round 3).  PMC on the round-2 kernels: the texture addresser is the busiest unit of the
+// MFMA convolutions (TA 53-60 % busy over a launch against MFMA 29-37 %, LDS 11-29 %) and two thirds of what it moves are packed
+// WEIGHTS - every wave fetched the whole step's A fragments itself, the four waves of a workgroup the same bytes four times
+// (16 -> 16: 112 KB of weight loads per tile against 41.5 KB of activations and 16 KB of stores).  Here the workgroup streams the
+// packed weights through a small LDS ring, WC contraction steps at a time: each thread copies ONE OR A FEW 16-byte pieces of chunk
+// c + 1 (global -> register before the MFMAs of chunk c, register -> LDS after them), one barrier per chunk, and every wave reads
+// its A fragments with conflict-free ds_read_b128 (lane-linear 16-byte slots).  TA traffic of a tile: weights once instead of once
+// per wave; the contraction issues no vector-memory instruction except the one prefetch per chunk.
+// ------------------------------------------------------------------------------------------------
+#ifndef MVS_WLDS
+#define MVS_WLDS 1
+#endif
+template <class Cfg>
+struct BfWlds {
+    static constexpr int MREP_ALL = CfgSplit<Cfg>::MREP_ALL;
+    static constexpr int NSTEP = BfConv<Cfg>::NSTEP;
+    // steps per chunk: 4 KB of packed weights (one 16-byte piece per thread) where that divides the pass, else one step
+    static constexpr int WC = (MREP_ALL == 1 && NSTEP % 2 == 0) ? 2 : 1;
+    static constexpr int CHUNK_BYTES = WC * MREP_ALL * 2048;
+    static constexpr int NPIECE = CHUNK_BYTES / 4096 > 0 ? CHUNK_BYTES / 4096 : 1;          // 16-byte pieces per thread and chunk
+    static constexpr int NCHUNK = NSTEP / WC;                                                 // per pass
+    static constexpr int RING_OFF = ((int)BfConv<Cfg>::LDS_BYTES + 255) / 256 * 256;
+    static constexpr size_t LDS_BYTES = (size_t)RING_OFF + 2 * CHUNK_BYTES;
+    // Measured (profiles/r03_conv_weights_via_lds_ab.txt): +4 % on the 16 -> 16 layer (one output block: all four waves fetched the SAME
+    // fragments, chunks of two steps).  With two or four output blocks the ring needs a barrier per step and, for 32 -> 32, costs the
+    // third resident workgroup: 32 -> 32 -22 %, 64 -> 64 -34 %, the strided layers -3 ... -11 %.  MVS_WLDS = 2 enables it everywhere.
+    static constexpr bool ENABLED = MVS_WLDS && !BfConv<Cfg>::PERSIST && NSTEP % WC == 0 && CHUNK_BYTES % 4096 == 0 && (MVS_WLDS > 1 || (MREP_ALL == 1 && WC == 2));
+};
+
+// global -> registers: this thread's pieces of global chunk `gc` (chunks are numbered through the passes: the packed weights are
+// contiguous in (pass, step)); beyond the last chunk nothing is loaded
+struct BfWPiece { float4 a, b; };                                  // this thread's one or two 16-byte pieces of a chunk (named members: no array)
+template <class Cfg>
+__device__ __forceinline__ void bf_wlds_fetch(const void* wp, int gc, int nchunk_total, int tid, BfWPiece& piece) {
+    using W = BfWlds<Cfg>;
+    static_assert(W::NPIECE <= 2, "at most two pieces per thread and chunk");
+    if (gc >= nchunk_total || (MVS_ABL == 2 && gc > 0)) return;
+    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wp) + (size_t)gc * W::CHUNK_BYTES);
+    piece.a = src[tid];
+    if constexpr (W::NPIECE > 1) piece.b = src[tid + 256];
+}
+template <class Cfg>
+__device__ __forceinline__ void bf_wlds_store(char* ring, int gc, int tid, const BfWPiece& piece) {
+    using W = BfWlds<Cfg>;
+    float4* dst = reinterpret_cast<float4*>(ring + (gc & 1) * W::CHUNK_BYTES);
+    dst[tid] = piece.a;
+    if constexpr (W::NPIECE > 1) dst[tid + 256] = piece.b;
+}
+
+// A fragments of local step T (compile-time) from the ring
+template <class Cfg, int T>
+__device__ __forceinline__ void bf_wlds_load_a(const char* ring, int gc, int mb0, int lane, bf16x8* ah, bf16x8* al) {
+    using W = BfWlds<Cfg>;
+    const char* base = ring + (gc & 1) * W::CHUNK_BYTES + ((T % W::WC) * W::MREP_ALL + mb0) * 2048 + lane * 16;
+#pragma unroll
+    for (int mb = 0; mb < Cfg::MREP; ++mb) {
+        ah[mb] = *reinterpret_cast<const bf16x8*>(base + mb * 2048);
+        al[mb] = *reinterpret_cast<const bf16x8*>(base + mb * 2048 + 1024);
+    }
+}
+
+// one pass: NSTEP steps in chunks of WC; `gc0` = global index of the pass's first chunk (its weights are in the ring and visible)
+template <class Cfg, int T>
+struct BfWldsSteps {
+    static __device__ __forceinline__ void run(int g, int lane, int tid, const void* wp, char* ring, int gc0, int nchunk_total, int mb0,
+                                               const char* ldsb, int voxbase0, f32x4 (*acc)[Cfg::NREP], BfWPiece& piece, bf16x8* bh0, bf16x8* bl0,
+                                               bf16x8* bh1, bf16x8* bl1) {
+        using W = BfWlds<Cfg>;
+        constexpr int NSTEP = MVS_ABL == 6 ? 1 : W::NSTEP;
+        if constexpr (T < NSTEP) {
+            const int gc = gc0 + T / W::WC;
+            if constexpr (T % W::WC == 0) bf_wlds_fetch<Cfg>(wp, gc + 1, nchunk_total, tid, piece);       // next chunk: in flight under this chunk's MFMAs
+            bf16x8 ah[Cfg::MREP], al[Cfg::MREP];
+            bf_wlds_load_a<Cfg, T>(ring, gc, mb0, lane, ah, al);
+            if constexpr (T + 1 < NSTEP) {
+                if constexpr ((T & 1) == 0) bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh1, bl1);
+                else bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh0, bl0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah, al, bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah, al, bh1, bl1, acc);
+            if constexpr (T % W::WC == W::WC - 1) {              // end of a chunk: hand the next one over
+                if (gc + 1 < nchunk_total) bf_wlds_store<Cfg>(ring, gc + 1, tid, piece);
+                __syncthreads();                                 // chunk gc + 1 visible; everybody has read chunk gc (its slot is free for gc + 2)
+            }
+            BfWldsSteps<Cfg, T + 1>::run(g, lane, tid, wp, ring, gc0, nchunk_total, mb0, ldsb, voxbase0, acc, piece, bh0, bl0, bh1, bl1);
+        }
+    }
+};
+
 template <class Cfg, bool SPLIT>
 __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
                                                                  float* __restrict__ y, int D, int H, int W, int OD, int OH, int OW,
@@ -354,12 +445,21 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         }
     };
     constexpr bool UNROLLED = BfConv<Cfg>::UNROLL_STAGE;
+    constexpr bool WLDS = BfWlds<Cfg>::ENABLED;
+    char* ring = ldsb + BfWlds<Cfg>::RING_OFF;
+    constexpr int nchunk_total = Cfg::NPASS * BfWlds<Cfg>::NCHUNK;
+    BfWPiece piece;
+    piece.a = piece.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (WLDS) {                                          // chunk 0 of pass 0: requested first, in the ring before the tile's barrier
+        bf_wlds_fetch<Cfg>(wp, 0, nchunk_total, tid, piece);
+    }
     if constexpr (UNROLLED) issue(0);
+    if constexpr (WLDS) bf_wlds_store<Cfg>(ring, 0, tid, piece);
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
         const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + ((size_t)pass * NSTEP * MREP_ALL + mb0) * 2 * 64 + lane;
         bf16x8 ah[MVS_WPF + 1][MREP], al[MVS_WPF + 1][MREP];
-        bf_conv_preload_w<Cfg>(wq, ah, al);
-        if (pass > 0) __syncthreads();
+        if constexpr (!WLDS) bf_conv_preload_w<Cfg>(wq, ah, al);
+        if (pass > 0 && !WLDS) __syncthreads();                   // (the weight ring's chunk barrier already separates the passes)
         if constexpr (UNROLLED) {
             commit();
         } else {
@@ -381,7 +481,13 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         }
         __syncthreads();
         if (UNROLLED && MVS_XPASS_PREFETCH && pass + 1 < Cfg::NPASS) issue(pass + 1);
-        bf_conv_contract<Cfg>(wq, ldsb, voxbase, g, acc, ah, al);
+        if constexpr (WLDS) {
+            bf16x8 bh0[NREP], bl0[NREP], bh1[NREP], bl1[NREP];
+            bf_conv_load_x<Cfg, 0>(g, ldsb, voxbase[0], bh0, bl0);
+            BfWldsSteps<Cfg, 0>::run(g, lane, tid, wp, ring, pass * BfWlds<Cfg>::NCHUNK, nchunk_total, mb0, ldsb, voxbase[0], acc, piece, bh0, bl0, bh1, bl1);
+        } else {
+            bf_conv_contract<Cfg>(wq, ldsb, voxbase, g, acc, ah, al);
+        }
         if (UNROLLED && !MVS_XPASS_PREFETCH && pass + 1 < Cfg::NPASS) issue(pass + 1);
     }
 
@@ -1057,9 +1163,10 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
         return check_launch("conv3d_mfma_bf16x3_persist_kernel");
     }
     if (logits != nullptr) { set_error("conv3d(bf16x3): the planar single-channel output needs a persistent (Cin = 8) kernel"); return MVS_ERR_UNSUPPORTED; }
-    if (LDS > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), dim3(ntiles, B), dim3(256), LDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
+    constexpr size_t TLDS = BfWlds<Cfg>::ENABLED ? BfWlds<Cfg>::LDS_BYTES : LDS;
+    if (TLDS > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TLDS);
+    hipLaunchKernelGGL((conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), dim3(ntiles, B), dim3(256), TLDS, st, x, wp, bias, y, D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
     return check_launch("conv3d_mfma_bf16x3_kernel");
 }
 
