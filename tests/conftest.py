@@ -19,9 +19,9 @@ def pytest_configure(config):
 
 
 def load_golden(name):
-    """-> dict of torch tensors / python scalars from tests/golden/<name>."""
+    """-> dict of torch tensors / python scalars from tests/golden/<name> (plus "__name__" = the file name)."""
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
-    out = {}
+    out = {"__name__": name}
     for k in z.files:
         a = z[k]
         if a.dtype.kind in "US":
@@ -33,12 +33,32 @@ def load_golden(name):
     return out
 
 
-def golden_weights(fx, prefix="w."):
-    """Rebuild the deterministic weights a fixture was generated with (manifest + seed stored in it)."""
+_WEIGHT_SUMS = None
+
+
+def golden_weights(fx, prefix="w.", name=None):
+    """Rebuild the deterministic weights a fixture was generated with (manifest + seed stored in it).  The fixtures do not carry the
+    weight arrays; so that they do not silently depend on the generator's reproducibility, the SHA-256 of every regenerated state
+    dict is pinned in tests/golden/weights_sha256.json (written when the fixtures were made): a torch RNG change fails HERE, loudly,
+    instead of as a numeric mismatch somewhere downstream.  `name` = the fixture file (checked when given)."""
+    import hashlib
     from mvsformerplusplus_amd import synth
+    global _WEIGHT_SUMS
+    name = name or fx.get("__name__")
     keys = fx[prefix + "keys"]
     shapes = [tuple(json.loads(s)) for s in fx[prefix + "shapes"]]
-    return synth.seeded_state_dict(dict(zip(keys, shapes)), int(fx[prefix + "seed"]))
+    sd = synth.seeded_state_dict(dict(zip(keys, shapes)), int(fx[prefix + "seed"]))
+    if name is not None:
+        if _WEIGHT_SUMS is None:
+            _WEIGHT_SUMS = json.load(open(os.path.join(GOLDEN, "weights_sha256.json")))
+        h = hashlib.sha256()
+        for k in sorted(sd):
+            h.update(k.encode())
+            h.update(sd[k].contiguous().numpy().tobytes())
+        want = _WEIGHT_SUMS[name + ":" + prefix]
+        assert h.hexdigest() == want, ("the regenerated weights of %s (%s) differ from the ones the fixture was generated with: "
+                                       "torch's CPU generator changed - regenerate the fixtures (tests/golden/make_golden.py)" % (name, prefix))
+    return sd
 
 
 def rel_l1(a, b):

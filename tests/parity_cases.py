@@ -5,6 +5,8 @@ tests/test_gpu_parity.py (-m gpu: the real libmvs_hip.so on an MI355X).  Every c
 Tolerances: depth within 1e-3 relative L1 is the north-star bar (BASELINE.json); the checks below are far tighter
 (fp32 MFMA is an exact fmaf chain, so differences are summation-order noise) and are written next to each assert.
 """
+import os
+
 import torch
 
 from conftest import golden_weights, load_golden, rel_l1
@@ -1059,6 +1061,69 @@ def case_regnet_train_native(device):
         for (n, b1), (_, b2) in zip(reg.named_buffers(), native.named_buffers()):
             if "running_" in n:
                 assert (cpu(b2) - b1).abs().max() <= 1e-4 * max(1.0, float(b1.abs().max())), n
+
+
+def case_train_midsize_vs_cpu_autograd(device):
+    """Train-mode forward + backward of one stage at 128 x 160, B = 2, V = 3 (a size where every U-Net level has thousands of voxels)
+    against PyTorch CPU autograd with NO library kernel in it (tests/train_torch_route.stage_forward_train_cpu: the oracle's
+    warping / correlation + the module's own layers), CostRegNet3D (D = 8) and CostRegNet (D = 16).  Loss to 1e-4; every gradient
+    tensor's cosine >= 0.999; per-tensor max-norm error <= max(1e-2, 10 x its own yardstick), the yardstick being what 3e-6-relative
+    noise on the CPU route's conv outputs does to the SAME tensor over three draws (a ReLU unit within the forward's rounding of zero
+    flips with it: the measured size of a flip, not a guess); median <= max(1e-3, 3 x the yardstick's median)."""
+    import copy
+    from train_torch_route import stage_forward_train_cpu
+    for D, C, stage in ((8, 16, 2), (16, 32, 1)):
+        B, V, H, W = 2, 3, 128, 160
+        net = StageNet(dict(ARGS), D, stage)
+        net.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(net.state_dict()), 77 + D), strict=True)
+        net.train()
+        cams = synth.make_cameras(V, H, W, baseline=30.0, rot_deg=1.0, seed=D, batch=B)
+        g = torch.Generator().manual_seed(D)
+        feats = synth.make_features(cams, C, H, W, dmin=480.0, dmax=880.0, seed=D)
+        hyp = ((1.0 / torch.linspace(1 / 900.0, 1 / 430.0, D))[None, :, None, None] * (1 + 0.02 * torch.rand(B, D, H, W, generator=g))).contiguous()
+        R = torch.randn(B, D, H, W, generator=g)
+
+        def run(m, fn):
+            m.zero_grad()
+            f = feats.clone().requires_grad_(True)
+            out = fn(m, f)
+            loss = (out["prob_volume"] * R).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
+            loss.backward()
+            return float(loss), f.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}
+        l_ref, gf_ref, gp_ref = run(copy.deepcopy(net), lambda m, f: stage_forward_train_cpu(m, f, cams, hyp, 1.0))
+        yard = {}
+        for draw in range(3):
+            noisy = copy.deepcopy(net)
+            gen = torch.Generator().manual_seed(500 + draw)
+            for mod in list(noisy.cost_reg.modules()) + list(noisy.vis.modules()):
+                if isinstance(mod, (torch.nn.Conv3d, torch.nn.ConvTranspose3d, torch.nn.Conv2d)):
+                    mod.register_forward_hook(lambda m_, i_, o_, gen=gen: o_ + 3e-6 * float(o_.abs().max()) * torch.randn(o_.shape, generator=gen))
+            _, _, gp_n = run(noisy, lambda m, f: stage_forward_train_cpu(m, f, cams, hyp, 1.0))
+            for n in gp_n:
+                yard[n] = max(yard.get(n, 0.0), float((gp_n[n] - gp_ref[n]).abs().max() / gp_ref[n].abs().max().clamp_min(1e-20)))
+        dnet = copy.deepcopy(net).to(device)
+        dfeat = dev(feats, device).requires_grad_(True)
+        out = dnet(dfeat, dev(cams, device), dev(hyp, device), 1.0)
+        loss = (out["prob_volume"] * dev(R, device)).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()
+        loss.backward()
+        assert abs(float(loss) - l_ref) <= 1e-4 * max(1.0, abs(l_ref)), (D, float(loss), l_ref)
+        cos = lambda a, b: float(torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
+        errs = [float((cpu(dfeat.grad) - gf_ref).abs().max() / gf_ref.abs().max())]
+        assert cos(cpu(dfeat.grad), gf_ref) >= 0.999, (D, "features")
+        top = max(float(v.abs().max()) for v in gp_ref.values())
+        for n, p in dnet.named_parameters():
+            ref = gp_ref[n]
+            if float(ref.abs().max()) <= 1e-6 * top:
+                continue                                                  # analytically-zero gradients hold noise on both sides
+            e = float((cpu(p.grad) - ref).abs().max() / ref.abs().max())
+            errs.append(e)
+            assert cos(cpu(p.grad), ref) >= 0.999, (D, n, cos(cpu(p.grad), ref))
+            assert e <= max(1e-2, 10.0 * yard.get(n, 0.0)), (D, n, e, yard.get(n))
+        ymed = sorted(yard.values())[len(yard) // 2]
+        if os.environ.get("MVS_TEST_VERBOSE"):
+            print("D=%d loss %.6f / %.6f  median err %.2e worst %.2e | yardstick median %.2e worst %.2e" %
+                  (D, float(loss), l_ref, sorted(errs)[len(errs) // 2], max(errs), ymed, max(yard.values())))
+        assert sorted(errs)[len(errs) // 2] <= max(1e-3, 3.0 * ymed), (D, sorted(errs)[len(errs) // 2], ymed)
 
 
 def case_train_backward_transformer_golden(device):

@@ -101,6 +101,10 @@ def test_train_path_properties():
     P.case_train_path_properties(DEV)
 
 
+def test_train_midsize_vs_cpu_autograd():
+    P.case_train_midsize_vs_cpu_autograd(DEV)
+
+
 def test_cascade_golden():
     P.case_cascade_golden(DEV)
 

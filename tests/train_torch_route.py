@@ -61,3 +61,24 @@ def stage_forward_train_torch(net, features, proj_matrices, depth_values, tmp, p
     else:
         pre = regnet_forward_torch(net.cost_reg, volume).squeeze(1)
     return T.stage_head_train(net, pre, depth_values, tmp)
+
+
+def stage_forward_train_cpu(net, features, proj_matrices, depth_values, tmp):
+    """The same stage ENTIRELY on PyTorch CPU autograd - no library kernel anywhere: warping / correlation / entropy from the oracle's
+    differentiable restatement (oracle/ref_path.py: F.grid_sample under no_grad for the grid, entropy from sim.detach(), as the
+    reference), the module's own Conv / BatchNorm layers in train mode, the shared autograd head.  `net` and all tensors on the CPU."""
+    from oracle import ref_path as O
+    B, V, C, H, W = features.shape
+    G = net.in_channels
+    ref_p = O.compose_proj(proj_matrices[:, 0])
+    vol_sum, vis_sum = 0.0, 0.0
+    for v in range(1, V):
+        warped, _ = O.homo_warping_3D_with_mask(features[:, v], O.compose_proj(proj_matrices[:, v]), ref_p, depth_values)
+        ip = O.group_correlation(features[:, 0], warped, G)                              # [B,G,D,H,W]
+        ent = O.entropy_of_similarity(ip.detach())                                       # cost_volume.py:90-92
+        vis = vis_forward_torch(net.vis, ent)                                            # [B,1,H,W]
+        vol_sum = vol_sum + ip * vis.unsqueeze(1)
+        vis_sum = vis_sum + vis
+    volume = vol_sum / (vis_sum.unsqueeze(1) + 1e-6)
+    pre = regnet_forward_torch(net.cost_reg, volume).squeeze(1)
+    return T.stage_head_train(net, pre, depth_values, tmp)
