@@ -19,6 +19,7 @@
 #include <utility>
 
 #include "conv_cfg.h"
+#include "split_format.h"
 
 // ---- experiment switches -------------------------------------------------------------------------------------------
 // The defaults ARE the shipped configuration; scripts/conv_ablate.py builds variants of this file with other values to measure
@@ -46,80 +47,6 @@
 #endif
 
 namespace mvs {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& hi, bf16x8& lo) {
-    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];                 // round to nearest even (v_cvt_pk_bf16_f32)
-        hi[j] = h;
-        lo[j] = (__bf16)(x[j] - (float)h);
-    }
-}
-
-// ---- the split activation format (MVS_PREC_BF16X3_SPLIT) ---------------------------------------------------------------
-// Between the layers of the inference U-Net the activations live in HBM ALREADY SPLIT: channel-last, per voxel C / 8 octets of
-// [hi x8 | lo x8] bf16 = the same 4 bytes per element as fp32.  The producing epilogue splits each value once; the consumers'
-// staging is a plain copy of 32-byte runs into the LDS image (round 2 split every staged element - halo voxels included, 2.5x
-// the tile for the 4x4x16 stride-1 tile - on the consumer side: ~45 VALU per 8 channels in the memory phase of every tile).
-// An accumulator lane holds 4 consecutive channels of a voxel = one QUAD of an octet; its partner 16 lanes up holds the other
-// quad of the same octet and voxel.  v_permlane16_swap exchanges the halves so that the even lane row owns hi x8 and the odd row
-// lo x8 of the octet: one 16-byte store per lane, 32 contiguous bytes per lane pair.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned pack_bf16x2(__bf16 a, __bf16 b) {
-    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
-__device__ __forceinline__ float bf16_lo_f32(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi_f32(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-
-// store the channel quad `v` of this lane (quad g & 1 of the octet at `octet`) - EVERY lane of the wave must call (lane exchange);
-// `guard` = the voxel exists
-__device__ __forceinline__ void split_store_quad(float* octet, int g, const float4& v, bool guard) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    __bf16 h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = (__bf16)x[j];
-        l[j] = (__bf16)(x[j] - (float)h[j]);
-    }
-    unsigned h0 = pack_bf16x2(h[0], h[1]), h1 = pack_bf16x2(h[2], h[3]), l0 = pack_bf16x2(l[0], l[1]), l1 = pack_bf16x2(l[2], l[3]);
-    // rows 1, 3 of the first operand <-> rows 0, 2 of the second: even rows end up with {own hi, partner's hi}, odd rows with
-    // {partner's lo, own lo}
-    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false);
-    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
-    if (guard) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(octet) + (g & 1) * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
-}
-
-// the fp32 values of channel quad q of the octet at `octet` (skip connections): raw = {hi, hi, lo, lo} dwords
-__device__ __forceinline__ float4 split_raw_quad(const float* octet, int q) {
-    const u32x2 h = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(octet) + q * 8);
-    const u32x2 l = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(octet) + 16 + q * 8);
-    // (scalars first: __builtin_bit_cast applied directly to an ext-vector ELEMENT expression yields element 0 with this clang)
-    const unsigned h0 = h[0], h1 = h[1], l0 = l[0], l1 = l[1];
-    return make_float4(__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1), __builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1));
-}
-__device__ __forceinline__ float4 split_join_quad(const float4& raw) {
-    const unsigned h0 = __builtin_bit_cast(unsigned, raw.x), h1 = __builtin_bit_cast(unsigned, raw.y);
-    const unsigned l0 = __builtin_bit_cast(unsigned, raw.z), l1 = __builtin_bit_cast(unsigned, raw.w);
-    return make_float4(bf16_lo_f32(h0) + bf16_lo_f32(l0), bf16_hi_f32(h0) + bf16_hi_f32(l0), bf16_lo_f32(h1) + bf16_lo_f32(l1), bf16_hi_f32(h1) + bf16_hi_f32(l1));
-}
-// staged 32-byte run (one voxel x one octet) -> the LDS image [hi x8 | lo x8]
-template <bool SPLIT>
-__device__ __forceinline__ void stage_to_lds(char* dst, const float4& u, const float4& v) {
-    if (SPLIT) {
-        *reinterpret_cast<float4*>(dst) = u;
-        *reinterpret_cast<float4*>(dst + 16) = v;
-    } else {
-        bf16x8 hi, lo;
-        split8(u, v, hi, lo);
-        *reinterpret_cast<bf16x8*>(dst) = hi;
-        *reinterpret_cast<bf16x8*>(dst + 16) = lo;
-    }
-}
 
 // three-term split product, term-outer so that consecutive MFMAs hit different accumulators
 template <int MREP, int NREP>
@@ -188,6 +115,54 @@ struct BfConv {
     static_assert(Cfg::CH % 8 == 0 && OPT <= 2, "split-bf16 path stages one or two octets per pass");
 };
 
+// ------------------------------------------------------------------------------------------------
+// Tile walk of the staging loops (round 3).  ISA census of the 16 -> 16 tile kernel: ~63 VALU instructions per staged 32-byte run
+// - voxel index -> (dz, dy, dx) by constant division, six range compares, a 64-bit address, eight selects that zero the
+// out-of-volume runs - i.e. 380 of the 700 VALU instructions a wave issues per tile, and on this chip VALU and MFMA issue do not
+// overlap (scripts/ubench/overlap.hip: MFMA || VALU on one SIMD takes the SUM of the two).  A work-item's runs are 256 / OPT
+// voxels apart: the walk advances (dz, dy, dx) by compile-time steps with at most one carry each and the byte offset by three
+// wave-uniform constants; out-of-volume runs are fetched through a buffer descriptor at an out-of-range offset (the hardware
+// returns zeros: no select on the data).  Offsets are 32-bit: one batch item of the input must stay below 2 GB (dispatch checks).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned BF_OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bf_buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + (unsigned)imm), 0, 0));
+}
+
+// IW x IH x (any depth) tile of voxels, OPT runs (channel octets) per voxel; run e = tid + 256 it  <->  voxel e / OPT, octet e % OPT
+template <int IW, int IH, int OPT>
+struct BfTileWalk {
+    static constexpr int STEPV = 256 / OPT;
+    static constexpr int SDZ = STEPV / (IH * IW), SDY = (STEPV % (IH * IW)) / IW, SDX = STEPV % IW;
+    int dx, dy, dz;
+    unsigned off;                                     // byte offset of voxel (z0 + dz, y0 + dy, x0 + dx), octet oc, in the batch item
+    unsigned c0, c1, c2;                              // wave-uniform offset steps: one `it`, the x carry, the y carry
+    // vstride = bytes per voxel (CIN * 4), chan0 = byte offset of the pass's first channel
+    __device__ __forceinline__ BfTileWalk(int tid, int z0, int y0, int x0, int H, int W, unsigned vstride, unsigned chan0) {
+        const int vox = tid / OPT, oc = tid % OPT;
+        dx = vox % IW;
+        const int t2 = vox / IW;
+        dy = t2 % IH;
+        dz = t2 / IH;
+        off = (unsigned)(((z0 + dz) * H + (y0 + dy)) * W + (x0 + dx)) * vstride + chan0 + (unsigned)oc * 32u;   // wraps for out-of-volume voxels: never used then
+        c0 = (unsigned)((SDZ * H + SDY) * W + SDX) * vstride;
+        c1 = (unsigned)(W - IW) * vstride;
+        c2 = (unsigned)((H - IH) * W) * vstride;
+    }
+    __device__ __forceinline__ void advance() {
+        dx += SDX; dy += SDY; dz += SDZ; off += c0;
+        if (dx >= IW) { dx -= IW; dy += 1; off += c1; }
+        if (dy >= IH) { dy -= IH; dz += 1; off += c2; }
+    }
+    __device__ __forceinline__ bool inside(int z0, int y0, int x0, int D, int H, int W) const {
+        return (unsigned)(z0 + dz) < (unsigned)D && (unsigned)(y0 + dy) < (unsigned)H && (unsigned)(x0 + dx) < (unsigned)W;
+    }
+};
+
 // LDS byte offset of channel octet o = tap * OPT + oc of a staged tile (compile-time for a compile-time o)
 template <class Cfg>
 __device__ __forceinline__ constexpr int bf_tap_offset(int o) {
@@ -220,10 +195,18 @@ __device__ __forceinline__ void bf_conv_load_x(int g, const char* ldsb, int voxb
     constexpr int ROWB = Cfg::SH * Cfg::IW * BfConv<Cfg>::SB;             // bytes between consecutive output rows in the tile
     constexpr int c0 = bf_tap_offset<Cfg>(4 * T), c1 = bf_tap_offset<Cfg>(4 * T + 1), c2 = bf_tap_offset<Cfg>(4 * T + 2),
                   c3 = bf_tap_offset<Cfg>(4 * T + 3);
-    int sel = c0;
-    sel = g == 1 ? c1 : sel;
-    sel = g == 2 ? c2 : sel;
-    sel = g == 3 ? c3 : sel;
+    int sel;
+    if constexpr (BfConv<Cfg>::PLANES) {
+        // two octets per tap: groups 0 / 1 = the two octet planes of tap 2T, groups 2 / 3 of tap 2T + 1 - one select, and the plane
+        // term is the same in every step (the compiler keeps voxbase0 + plane in one register)
+        static_assert(c1 == c0 + BfConv<Cfg>::PLANE && c3 == c2 + BfConv<Cfg>::PLANE, "octet planes of one tap");
+        sel = ((g & 2) ? c2 : c0) + (g & 1) * BfConv<Cfg>::PLANE;
+    } else {
+        sel = c0;
+        sel = g == 1 ? c1 : sel;
+        sel = g == 2 ? c2 : sel;
+        sel = g == 3 ? c3 : sel;
+    }
     const char* p = ldsb + voxbase0 + sel;
 #pragma unroll
     for (int nb = 0; nb < Cfg::NREP; ++nb) {
@@ -386,6 +369,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     start_stagger(2048);
+    prio_kernel_begin();
     int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
     const int b = (int)blockIdx.y;
     const int tx = tile % tiles_x;
@@ -418,21 +402,16 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     // p + 1 are issued before the contraction of pass p.
     constexpr int NITEM = Cfg::NVOX * OPT, NIT = (NITEM + 255) / 256;
     float4 su[NIT], sv[NIT];
+    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
     auto issue = [&](int pass) {
+        BfTileWalk<IW, IH, OPT> wk(tid, iz0, iy0, ix0, H, W, CIN * 4, (unsigned)(pass * CH * 4));
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int e = tid + it * 256;
-            const int vox = e / OPT, oc = e - vox * OPT;
-            const int dx = vox % IW;
-            const int t2 = vox / IW;
-            const int dy = t2 % IH, dz = t2 / IH;
-            const int z = iz0 + dz, yy = iy0 + dy, xx = ix0 + dx;
-            const bool ok = MVS_ABL != 1 && e < NITEM && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const size_t off = ok ? (((size_t)z * H + yy) * W + xx) * CIN + pass * CH + oc * 8 : 0;
-            const float4* src = reinterpret_cast<const float4*>(xb + off);
-            const float4 u = src[0], v = src[1];
-            su[it] = ok ? u : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sv[it] = ok ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (it > 0) wk.advance();
+            const bool ok = MVS_ABL != 1 && (it * 256 + 255 < NITEM || tid + it * 256 < NITEM) && wk.inside(iz0, iy0, ix0, D, H, W);
+            const unsigned voff = ok ? wk.off : BF_OOB;                     // out of the volume (or of the tile): zeros from the descriptor's range check
+            su[it] = bf_buf_load16(xrs, voff, 0);
+            sv[it] = bf_buf_load16(xrs, voff, 16);
         }
     };
     auto commit = [&]() {
@@ -463,24 +442,21 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         if constexpr (UNROLLED) {
             commit();
         } else {
+            BfTileWalk<IW, IH, OPT> wk(tid, iz0, iy0, ix0, H, W, CIN * 4, (unsigned)(pass * CH * 4));
+            int ldso = (tid / OPT) * SB + (tid % OPT) * BfConv<Cfg>::PLANE;
 #pragma unroll 1
             for (int e = tid; e < NITEM; e += 256) {
-                const int vox = e / OPT, oc = e - vox * OPT;
-                const int dx = vox % IW;
-                const int t2 = vox / IW;
-                const int dy = t2 % IH, dz = t2 / IH;
-                const int z = iz0 + dz, yy = iy0 + dy, xx = ix0 + dx;
-                float4 u = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v = u;
-                if (MVS_ABL != 1 && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                    const float4* src = reinterpret_cast<const float4*>(xb + (((size_t)z * H + yy) * W + xx) * CIN + pass * CH + oc * 8);
-                    u = src[0];
-                    v = src[1];
-                }
-                stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, u, v);
+                const bool ok = MVS_ABL != 1 && wk.inside(iz0, iy0, ix0, D, H, W);
+                const unsigned voff = ok ? wk.off : BF_OOB;
+                const float4 u = bf_buf_load16(xrs, voff, 0), v = bf_buf_load16(xrs, voff, 16);
+                stage_to_lds<SPLIT>(ldsb + ldso, u, v);
+                wk.advance();
+                ldso += (256 / OPT) * SB;
             }
         }
         __syncthreads();
         if (UNROLLED && MVS_XPASS_PREFETCH && pass + 1 < Cfg::NPASS) issue(pass + 1);
+        prio_contract_begin();
         if constexpr (WLDS) {
             bf16x8 bh0[NREP], bl0[NREP], bh1[NREP], bl1[NREP];
             bf_conv_load_x<Cfg, 0>(g, ldsb, voxbase[0], bh0, bl0);
@@ -488,6 +464,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         } else {
             bf_conv_contract<Cfg>(wq, ldsb, voxbase, g, acc, ah, al);
         }
+        prio_contract_end();
         if (UNROLLED && !MVS_XPASS_PREFETCH && pass + 1 < Cfg::NPASS) issue(pass + 1);
     }
 
@@ -593,25 +570,20 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
     constexpr int NITEM = Cfg::NVOX * OPT, NIT = (NITEM + 255) / 256;
     // MVS_PERSIST_PFD register sets: the loads of tile t + PFD are issued while tile t is contracted
     float4 su0[NIT], sv0[NIT], su1[NIT], sv1[NIT];
+    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
     auto issue = [&](int tile, float4* su, float4* sv) {
         const int tx = tile % tiles_x;
         const int t1 = tile / tiles_x;
         const int ty = t1 % tiles_y, tz = t1 / tiles_y;
         const int iz0 = tz * TD * SD - Cfg::PD, iy0 = ty * TH * SH - 1, ix0 = tx * 16 * SW - 1;
+        BfTileWalk<IW, IH, OPT> wk(tid, iz0, iy0, ix0, H, W, CIN * 4, 0u);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int e = tid + it * 256;
-            const int vox = e / OPT, oc = e - vox * OPT;
-            const int dx = vox % IW;
-            const int t2 = vox / IW;
-            const int dy = t2 % IH, dz = t2 / IH;
-            const int z = iz0 + dz, yy = iy0 + dy, xx = ix0 + dx;
-            const bool ok = MVS_ABL != 1 && e < NITEM && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const size_t off = ok ? (((size_t)z * H + yy) * W + xx) * CIN + oc * 8 : 0;
-            const float4* src = reinterpret_cast<const float4*>(xb + off);
-            const float4 u = src[0], v = src[1];
-            su[it] = ok ? u : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sv[it] = ok ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (it > 0) wk.advance();
+            const bool ok = MVS_ABL != 1 && (it * 256 + 255 < NITEM || tid + it * 256 < NITEM) && wk.inside(iz0, iy0, ix0, D, H, W);
+            const unsigned voff = ok ? wk.off : BF_OOB;
+            su[it] = bf_buf_load16(xrs, voff, 0);
+            sv[it] = bf_buf_load16(xrs, voff, 16);
         }
     };
     auto process = [&](int tile, float4* su, float4* sv) {
@@ -736,6 +708,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     start_stagger(2048);
+    prio_kernel_begin();
     int tile = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
     const int b = (int)blockIdx.y;
     const int tx = tile % tiles_x;
@@ -745,19 +718,18 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     const int OD = D * SD, OH = 2 * H, OW = 2 * W;
 
     const float* xb = x + (size_t)b * D * H * W * CIN;
-    for (int e = tid; e < Cfg::NVOX * OPT; e += 256) {
-        const int vox = e / OPT, oc = e - vox * OPT;
-        const int dx = vox % LW;
-        const int t2 = vox / LW;
-        const int dy = t2 % LH, dz = t2 / LH;
-        const int z = mz0 - Cfg::ZO + dz, yy = my0 + dy, xx = mx0 + dx;
-        float4 u = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v = u;
-        if (MVS_ABL != 1 && z >= 0 && z < D && yy < H && xx < W) {
-            const float4* src = reinterpret_cast<const float4*>(xb + (((size_t)z * H + yy) * W + xx) * CIN + oc * 8);
-            u = src[0];
-            v = src[1];
+    {
+        const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
+        BfTileWalk<LW, LH, OPT> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * 4, 0u);
+        int ldso = (tid / OPT) * SB + (tid % OPT) * BfDeconv<Cfg>::PLANE;
+        for (int e = tid; e < Cfg::NVOX * OPT; e += 256) {
+            const bool ok = MVS_ABL != 1 && wk.inside(mz0 - Cfg::ZO, my0, mx0, D, H, W);
+            const unsigned voff = ok ? wk.off : BF_OOB;
+            const float4 u = bf_buf_load16(xrs, voff, 0), v = bf_buf_load16(xrs, voff, 16);
+            stage_to_lds<SPLIT>(ldsb + ldso, u, v);
+            wk.advance();
+            ldso += (256 / OPT) * SB;
         }
-        stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfDeconv<Cfg>::PLANE, u, v);
     }
     __syncthreads();
 
@@ -816,6 +788,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
         const int ntap = ((SD == 2) ? (pd ? 2 : 1) : 3) * (ph ? 2 : 1) * (pw ? 2 : 1);
         const int nst = MVS_ABL == 6 ? 1 : (ntap * OPT + 3) / 4;
         bf16x8 ah0[MREP], al0[MREP], bh0[NREP], bl0[NREP], ah1[MREP], al1[MREP], bh1[NREP], bl1[NREP];
+        prio_contract_begin();
         bf_deconv_load_step<Cfg>(0, ntap, pd, ph, pw, g, wq, ldsb, voxbase, ah0, al0, bh0, bl0);
 #pragma unroll 1
         for (int st = 0; st + 1 < nst; st += 2) {
@@ -827,6 +800,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
             bf_mfma_step<MREP, NREP>(ah1, al1, bh1, bl1, acc);
         }
         if (nst & 1) bf_mfma_step<MREP, NREP>(ah0, al0, bh0, bl0, acc);
+        prio_contract_end();
         wq += (size_t)nst * MREP_ALL * 2 * 64;
 
 #pragma unroll
@@ -1006,25 +980,20 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
 
     constexpr int NITEM = Cfg::NVOX * OPT, NITX = (NITEM + 255) / 256;
     float4 su[NITX], sv[NITX];
+    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
     auto issue_x = [&](int tile) {
         const int tx = tile % tiles_x;
         const int t1 = tile / tiles_x;
         const int ty = t1 % tiles_y, tz = t1 / tiles_y;
         const int mz0 = tz * TDM, my0 = ty * THM, mx0 = tx * 16;
+        BfTileWalk<LW, LH, OPT> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * 4, 0u);
 #pragma unroll
         for (int it = 0; it < NITX; ++it) {
-            const int e = tid + it * 256;
-            const int vox = e / OPT, oc = e - vox * OPT;
-            const int dx = vox % LW;
-            const int t2 = vox / LW;
-            const int dy = t2 % LH, dz = t2 / LH;
-            const int z = mz0 - Cfg::ZO + dz, yy = my0 + dy, xx = mx0 + dx;
-            const bool ok = MVS_ABL != 1 && e < NITEM && z >= 0 && z < D && yy < H && xx < W;
-            const size_t off = ok ? (((size_t)z * H + yy) * W + xx) * CIN + oc * 8 : 0;
-            const float4* src = reinterpret_cast<const float4*>(xb + off);
-            const float4 u = src[0], v = src[1];
-            su[it] = ok ? u : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sv[it] = ok ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (it > 0) wk.advance();
+            const bool ok = MVS_ABL != 1 && (it * 256 + 255 < NITEM || tid + it * 256 < NITEM) && wk.inside(mz0 - Cfg::ZO, my0, mx0, D, H, W);
+            const unsigned voff = ok ? wk.off : BF_OOB;
+            su[it] = bf_buf_load16(xrs, voff, 0);
+            sv[it] = bf_buf_load16(xrs, voff, 16);
         }
     };
     float4 skp[NIT][NREP];
@@ -1201,6 +1170,7 @@ static int launch_deconv_bf(const float* x, const void* wp, const float* bias, c
 
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
                            int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits, int split) {
+    if (logits == nullptr && conv3d_march_usable(Cin, Cout, kd, sd, sh, sw, D, H, W, split)) return conv3d_march_bf16x3(x, wp, bias, y, B, D, H, W, relu, st);
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW) {                    \
         typedef typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type K;              \

@@ -228,6 +228,31 @@ __device__ __forceinline__ void start_stagger(unsigned first_generation_blocks) 
 #endif
 }
 
+// Wave priority around the contraction phase of the one-tile MFMA kernels (experiment switch MVS_PRIO: 0 off, 1 contraction
+// waves high, 2 staging / epilogue waves high).  Co-resident workgroups of a CU are at different phases; the arbiter picks by priority.
+#ifndef MVS_PRIO
+#define MVS_PRIO 0
+#endif
+__device__ __forceinline__ void prio_kernel_begin() {
+#if MVS_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+__device__ __forceinline__ void prio_contract_begin() {
+#if MVS_PRIO == 1
+    __builtin_amdgcn_s_setprio(3);
+#elif MVS_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+__device__ __forceinline__ void prio_contract_end() {
+#if MVS_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#elif MVS_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 static inline unsigned ceil_div(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace mvs

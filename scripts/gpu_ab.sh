@@ -12,7 +12,7 @@ for lib in mvsformerplusplus_amd/csrc/libmvs_hip.so mvsformerplusplus_amd/csrc/l
     tag=$(basename $lib .so)
     echo "== bench: $tag =="
     MVS_HIP_LIB=$PWD/$lib timeout 600 python bench.py --steps 10 --warmup 3 --profile-table --no-cpu-baseline --no-train-leg ${BENCH_ARGS:-} > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err
-    grep -v "amdgpu.ids" $OUT/bench_$tag.err | grep -E "conv|deconv|sum of|kernel  " | head -${TABLE_ROWS:-30}
+    grep -v "amdgpu.ids" $OUT/bench_$tag.err | grep -E "${TABLE_GREP:-conv|deconv|sum of|kernel  }" | head -${TABLE_ROWS:-30}
     python - "$OUT/bench_$tag.json" <<'PY'
 import json, sys
 try:
