@@ -490,6 +490,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     }
 }
 
+// (Round 3 measured a row-marching form of the 16 -> 16 layer - a workgroup owns 4 z-planes x 30 columns and walks along y, every
+// LDS operand read feeds all three kh taps (three rotating accumulator sets), all packed weights in 120 VGPRs, the next row's loads in
+// flight under the MFMAs: parity green, dense MFMA stream, 8-15 % SLOWER than the tile kernel below; its ablation and the pipe-overlap
+// microbenchmark it led to are in profiles/r03_conv_march_ab.txt, the kernel in git history, commit dc3a8dc.)
 // (Round 3 also measured an LDS-DMA staged persistent form of the stride-1 layers for the split format - global_load_lds into two
 // chunk buffers, one DMA piece requested per contraction step, one barrier per chunk: parity green, but at the one workgroup per CU
 // its 84 KB of LDS allow it ran 1.2-1.8x SLOWER than the one-tile kernels below with their three co-resident workgroups
@@ -1170,7 +1174,6 @@ static int launch_deconv_bf(const float* x, const void* wp, const float* bias, c
 
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
                            int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits, int split) {
-    if (logits == nullptr && conv3d_march_usable(Cin, Cout, kd, sd, sh, sw, D, H, W, split)) return conv3d_march_bf16x3(x, wp, bias, y, B, D, H, W, relu, st);
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW) {                    \
         typedef typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type K;              \

@@ -108,9 +108,6 @@ struct DeconvCfg {
 // split != 0: x, y (and skip) are in the split activation format of MVS_PREC_BF16X3_SPLIT (conv_bf16x3_kernels.hip)
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
                            int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits = nullptr, int split = 0);
-// row-marching form of the 16 -> 16 stride-1 layer in the split activation format (conv_march_kernels.hip); reads the same packed weights
-bool conv3d_march_usable(int Cin, int Cout, int kd, int sd, int sh, int sw, int D, int H, int W, int split);
-int conv3d_march_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int D, int H, int W, int relu, hipStream_t st);
 int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                              const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st);
 // prob_w / prob_b / logits != NULL (Cout == 8 only): the 1x1x1 `prob` head is applied in the epilogue and the planar logits

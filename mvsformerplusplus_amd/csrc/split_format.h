@@ -1,5 +1,5 @@
-// The split activation format (MVS_PREC_BF16X3_SPLIT) and the hi / lo split helpers shared by the split-bf16 convolution kernels
-// (conv_bf16x3_kernels.hip: tile kernels, conv_march_kernels.hip: row-marching kernels).
+// The split activation format (MVS_PREC_BF16X3_SPLIT) and the hi / lo split helpers of the split-bf16 convolution kernels
+// (conv_bf16x3_kernels.hip).
 #pragma once
 #include "mvs_common.h"
 

@@ -1,5 +1,6 @@
-"""One U-Net layer on its own, tile kernel against the row-marching kernel (same library, MVS_MARCH_MIN_VOXELS switched in-process):
-16 -> 16 stride 1 in the split activation format at the cfg2 stage-4 / stage-3 / stage-2 shapes.  HIP-event timing, interleaved A/B."""
+"""One U-Net layer on its own at the cfg2 stage shapes: 16 -> 16 stride 1 in the split activation format, HIP-event timing, best of three
+interleaved runs.  MVS_HIP_LIB selects a variant library (A/B of kernel changes: profiles/r03_conv_march_ab.txt was measured with this script,
+its second row then timed the row-marching kernel of commit dc3a8dc through MVS_MARCH_MIN_VOXELS)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +16,7 @@ for shape in ((1, 4, 576, 768), (1, 8, 288, 384), (1, 8, 144, 192), (1, 16, 72, 
     x = ops.to_split(torch.randn(*shape, 16, generator=g)).to(dev)
     res = {}
     for rep in range(3):
-        for name, thr in (("tile", "1000000000"), ("march", "0")):
+        for name, thr in (("tile", "1000000000"),):
             os.environ["MVS_MARCH_MIN_VOXELS"] = thr
             for _ in range(3):
                 y = ops.conv3d_bn_relu(x, wp, bias, 16, 3, (1, 1, 1), True, P3)

@@ -441,39 +441,6 @@ def case_split_format(device):
     assert torch.equal(vn.view(torch.int32), ops.to_split(cpu(ops.volume_normalise_(part.clone(), vsum))).view(torch.int32)), "normalise: split volume"
 
 
-def case_conv_march(device):
-    """Row-marching form of the 16 -> 16 stride-1 layer (csrc/conv_march_kernels.hip; chosen above MVS_MARCH_MIN_VOXELS voxels):
-    against torch's fp32 conv3d and against the tile kernel on the same split-format input.  Shapes: D = 4 (one z tile, both halo
-    planes are padding), D = 6 / 9 (two / three z tiles, the last ragged), W below / not a multiple of 30 columns, H giving one and
-    several y segments, relu on and off, batch 2."""
-    import os
-    import torch.nn.functional as F
-    from mvsformerplusplus_amd import _lib
-    g = torch.Generator().manual_seed(33)
-    P3 = _lib.PREC_BF16X3_SPLIT
-    old = os.environ.get("MVS_MARCH_MIN_VOXELS")
-    try:
-        for (B, D, H, W), relu in (((2, 4, 9, 20), True), ((1, 6, 37, 75), True), ((1, 9, 5, 31), False), ((1, 4, 70, 64), True)):
-            xx = torch.randn(B, D, H, W, 16, generator=g)
-            w = torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1
-            bias = torch.randn(64, generator=g)
-            wp = dev(packing.pack_conv_weights_bf16x3(w, packing.conv_chunk(16, (1, 1, 1))), device)
-            ref = F.conv3d(xx.permute(0, 4, 1, 2, 3).double(), w.double(), bias[:16].double(), padding=1)
-            ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 4, 1).float()
-            os.environ["MVS_MARCH_MIN_VOXELS"] = "1000000000"
-            yt = ops.from_split(cpu(ops.conv3d_bn_relu(dev(ops.to_split(xx), device), wp, dev(bias, device), 16, 3, (1, 1, 1), relu, P3)))
-            os.environ["MVS_MARCH_MIN_VOXELS"] = "0"
-            ym = ops.from_split(cpu(ops.conv3d_bn_relu(dev(ops.to_split(xx), device), wp, dev(bias, device), 16, 3, (1, 1, 1), relu, P3)))
-            scale = max(1.0, float(ref.abs().max()))
-            assert (yt - ref).abs().max() <= 2e-5 * scale, ("tile", B, D, H, W)
-            assert (ym - ref).abs().max() <= 2e-5 * scale, ("march", B, D, H, W, float((ym - ref).abs().max()))
-    finally:
-        if old is None:
-            os.environ.pop("MVS_MARCH_MIN_VOXELS", None)
-        else:
-            os.environ["MVS_MARCH_MIN_VOXELS"] = old
-
-
 def case_slab_exchange_kernels(device):
     """mvs_slab_pack / mvs_slab_reduce (the slab exchange of the view-sharded latency mode) against torch slicing: message j = rows
     [r0_j, r1_j) of the partial volume followed by the same rows of the partial visibility sum; the reduction adds the own slice and

@@ -69,10 +69,6 @@ def test_split_format(emu):
     P.case_split_format(emu)
 
 
-def test_conv_march(emu):
-    P.case_conv_march(emu)
-
-
 def test_slab_exchange_kernels(emu):
     P.case_slab_exchange_kernels(emu)
 

@@ -84,10 +84,6 @@ def test_split_format():
     P.case_split_format(DEV)
 
 
-def test_conv_march():
-    P.case_conv_march(DEV)
-
-
 def test_slab_exchange_kernels():
     P.case_slab_exchange_kernels(DEV)
 
