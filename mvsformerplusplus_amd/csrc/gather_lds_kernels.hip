@@ -28,9 +28,6 @@ namespace mvs {
 #ifndef MVS_GL_CAP
 #define MVS_GL_CAP 1024
 #endif
-#ifndef MVS_GPRIO
-#define MVS_GPRIO 0                // experiment: wave priority 1 = window staging high, 2 = tap gather high
-#endif
 constexpr int GL_CAP = MVS_GL_CAP;   // window capacity in source positions: LDS = 2 quads * GL_CAP * 16 B = 32 KiB
 constexpr int GL_XALIGN = 8;       // window x origin / width granularity in pixels (32 B of fp32, 16 B of bf16)
 constexpr int GL_DCH = 4;          // depth planes per work-item
@@ -112,11 +109,6 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rf[c] = rf_in[c];
             }
-#if MVS_GPRIO == 1
-            __builtin_amdgcn_s_setprio(3);
-#elif MVS_GPRIO == 2
-            __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll 1
             for (int i = tid; i < n; i += 256) {
                 const int row = (int)(((float)i + 0.5f) * inv_ww);
@@ -127,11 +119,6 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 win[GL_CAP + i] = f32x4{v[4], v[5], v[6], v[7]};
             }
             __syncthreads();                                    // (B) window of octet o is in LDS
-#if MVS_GPRIO == 1
-            __builtin_amdgcn_s_setprio(0);
-#elif MVS_GPRIO == 2
-            __builtin_amdgcn_s_setprio(3);
-#endif
             if (active) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rf[c] *= wscale;
