@@ -14,9 +14,9 @@ What is native and what is not, stated plainly:
   the strided convolution), WEIGHT gradients on an fp32-MFMA kernel (``mvs_conv3d_wgrad``), batch-statistics BatchNorm + ReLU +
   skip forward and backward on ``mvs_bn_*`` (sums in double, SyncBatchNorm's all-reduce of the sums included); on one rank each
   block is ONE C call per direction (``mvs_train_block_fwd`` / ``_bwd`` chain pack, convolution, statistics, finalize, normalise /
-  reduce, apply, weight gradient, pack, data gradient on the stream).  Activations are
-  kept (pre-BatchNorm convolution outputs and block outputs) instead of being recomputed under ``torch.utils.checkpoint``
-  (module.py:393-396): at training sizes they are tens of MB per stage;
+  reduce, apply, weight gradient, pack, data gradient on the stream).  Activations (pre-BatchNorm convolution outputs and
+  block outputs) are kept while small and RECOMPUTED in the backward pass above 512 MB, or when ``reg.recompute_in_backward`` says
+  so - the reference always runs its regularisers under ``torch.utils.checkpoint`` (module.py:393-396, 488-492);
 * the visibility CNN's three Conv2d + BatchNorm2d + ReLU blocks (``VisTrain``: the same kernels on D = 1 volumes, BatchNorm per
   source view like the reference's per-view calls) and CostRegNet's 3x3x3 `prob` (``Prob3Train``) are native as well;
 * still PyTorch-ROCm autograd, all of it element-wise or tiny: the visibility CNN's 1x1 Conv2d + sigmoid, CostRegNet3D's 1x1x1 `prob`,
@@ -200,18 +200,49 @@ class RegNetTrain(torch.autograd.Function):
     NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")
     SKIP = {6: 3, 7: 1, 8: -1}                       # block index -> index of the block whose output is added (-1: the input volume)
 
+    # Activations: kept by default while they are small, RECOMPUTED in the backward pass above `RECOMPUTE_ABOVE_BYTES` - the
+    # reference always runs its regularisers under torch.utils.checkpoint (module.py:393-396, 488-492: only the input volume survives
+    # the forward, the backward re-runs forward_once).  `reg.recompute_in_backward = True / False` overrides the size rule.  In
+    # recompute mode the forward saves the input volume, the parameters and each BatchNorm's batch statistics ([C] vectors); the
+    # backward re-runs convolution + normalise with THOSE statistics (the kernels are deterministic: the regenerated activations are
+    # bit-identical, so are the gradients) - one extra U-Net forward without the statistics passes.
+    RECOMPUTE_ABOVE_BYTES = 512 << 20
+
+    @staticmethod
+    def kept_bytes(reg, shape) -> int:
+        """Bytes of the activations the keep-everything mode holds between forward and backward: every block's pre-BatchNorm output z
+        and every block's output y except the last (which is the result)."""
+        B, D, H, W = shape[:4]
+        dims, total = {0: (D, H, W)}, 0
+        for i, name in enumerate(RegNetTrain.NAMES):
+            conv, _, transposed = _block_parts(getattr(reg, name))
+            d, h, w = dims[i]
+            dims[i + 1] = ops._out_dims(transposed, 3, _stride3(conv), d, h, w)
+            od, oh, ow = dims[i + 1]
+            total += (2 if i + 1 < len(RegNetTrain.NAMES) else 1) * 4 * B * od * oh * ow * conv.out_channels
+        return total
+
+    @staticmethod
+    def _wants_recompute(reg, shape) -> bool:
+        flag = getattr(reg, "recompute_in_backward", None)
+        return bool(flag) if flag is not None else RegNetTrain.kept_bytes(reg, shape) > RegNetTrain.RECOMPUTE_ABOVE_BYTES
+
     @staticmethod
     def forward(ctx, volume_cl, reg, *params):
         x = ops._f32c(volume_cl.detach())
         wsp = ops.TrainWorkspace(x.device)
         zero_bias = wsp.zero_bias
-        blocks, acts, saved = [], [x], []
+        recompute = RegNetTrain._wants_recompute(reg, x.shape)
+        skip_sources = {k + 1 for k in RegNetTrain.SKIP.values()}              # activation indices a later block adds
+        last_use = {k + 1: i for i, k in RegNetTrain.SKIP.items()}
+        blocks, acts, saved = [], {0: x}, []
+        n = len(RegNetTrain.NAMES)
         for i, name in enumerate(RegNetTrain.NAMES):
             conv, bn, transposed = _block_parts(getattr(reg, name))
             w = params[3 * i].detach().float()
             gamma, beta = params[3 * i + 1].detach().float().contiguous(), params[3 * i + 2].detach().float().contiguous()
             stride = _stride3(conv)
-            a_in = acts[-1]
+            a_in = acts[i]
             skip_idx = RegNetTrain.SKIP.get(i)
             skip = None if skip_idx is None else acts[skip_idx + 1]
             if _fast_bn(bn):
@@ -219,18 +250,37 @@ class RegNetTrain(torch.autograd.Function):
                     bn.num_batches_tracked += 1
                 z, stats, y = ops.train_block_fwd(wsp, a_in, w, transposed, 3, stride, gamma, beta, bn.eps, bn.running_mean, bn.running_var,
                                                   bn.momentum, skip)
-                acts.append(y)
+                acts[i + 1] = y
                 blocks.append((transposed, stride, True, 0.0, (False, None), bn))
-                saved += [a_in, z, stats, stats, w, gamma, beta]
-                continue
-            z = _conv_fwd(a_in, w, stride, transposed, zero_bias)
-            st = _BnState(bn, z)
-            acts.append(ops.bn_relu_apply(z, st.mean, st.invstd, gamma, beta, skip, relu=True))
-            blocks.append((transposed, stride, st.batch, st.count, (st.sync, st.group), st))
-            saved += [a_in, z, st.mean, st.invstd, w, gamma, beta]
-        ctx.blocks = blocks
-        ctx.save_for_backward(*saved)
-        return acts[-1]
+                saved += ([stats, stats, w, gamma, beta] if recompute else [a_in, z, stats, stats, w, gamma, beta])
+            else:
+                z = _conv_fwd(a_in, w, stride, transposed, zero_bias)
+                st = _BnState(bn, z)
+                acts[i + 1] = ops.bn_relu_apply(z, st.mean, st.invstd, gamma, beta, skip, relu=True)
+                blocks.append((transposed, stride, st.batch, st.count, (st.sync, st.group), st))
+                saved += ([st.mean, st.invstd, w, gamma, beta] if recompute else [a_in, z, st.mean, st.invstd, w, gamma, beta])
+            if recompute:                                # drop what no later block reads: the forward's live set stays a few tensors
+                del z, a_in
+                for k in [k for k in acts if k <= i and k != 0 and not (k in skip_sources and last_use[k] > i)]:
+                    del acts[k]
+        ctx.blocks, ctx.recompute = blocks, recompute
+        ctx.save_for_backward(*(([x] if recompute else []) + saved))
+        return acts[n]
+
+    @staticmethod
+    def _regenerate(S, blocks, zero_bias):
+        """Recompute mode: the forward again from the saved input volume with the saved batch statistics -> the (a_in, z, ...) rows the
+        backward reads.  Statistics rows: one-call blocks saved [3, 1, C] (mean, var, invstd), granular blocks mean and invstd."""
+        acts, rows = {0: S[0]}, []
+        for i, (transposed, stride, _, _, _, bn_state) in enumerate(blocks):
+            s0, s1, w, gamma, beta = S[1 + 5 * i: 6 + 5 * i]
+            mean, invstd = (s0, s1) if isinstance(bn_state, _BnState) else (s0[0].contiguous(), s0[2].contiguous())
+            skip_idx = RegNetTrain.SKIP.get(i)
+            skip = None if skip_idx is None else acts[skip_idx + 1]
+            z = _conv_fwd(acts[i], w, stride, transposed, zero_bias)
+            acts[i + 1] = ops.bn_relu_apply(z, mean, invstd, gamma, beta, skip, relu=True)
+            rows += [acts[i], z, s0, s1, w, gamma, beta]
+        return rows
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -241,6 +291,8 @@ class RegNetTrain(torch.autograd.Function):
         pending[n] = ops._f32c(grad_out)
         wsp = ops.TrainWorkspace(grad_out.device)
         zero_bias = wsp.zero_bias
+        if ctx.recompute:
+            S = RegNetTrain._regenerate(S, ctx.blocks, zero_bias)
         for i in range(n - 1, -1, -1):
             transposed, stride, batch, count, group, bn_state = ctx.blocks[i]
             a_in, z, mean, invstd, w, gamma, beta = S[7 * i:7 * i + 7]
@@ -256,17 +308,19 @@ class RegNetTrain(torch.autograd.Function):
                 grads[3 * i], grads[3 * i + 1], grads[3 * i + 2], da = ops.train_block_bwd(
                     wsp, g, a_in, z, mean, w, transposed, 3, stride, gamma, beta, bn.running_mean, bn.running_var, bn.momentum)
                 pending[i] = da if i not in pending else pending[i] + da
-                continue
-            bn_state.update_running_stats()              # the reference's checkpoint recomputation (see _BnState)
-            sums = ops.bn_relu_bwd_reduce(g, z, mean, invstd, gamma, beta, relu=True)
-            grads[3 * i + 2] = sums[: sums.numel() // 2].float()                     # d beta (this rank's voxels; DDP averages)
-            grads[3 * i + 1] = sums[sums.numel() // 2:].float()                      # d gamma
-            if group[0]:
-                sums = sums.clone()
-                torch.distributed.all_reduce(sums, group=group[1])
-            dz = ops.bn_relu_bwd_apply(g, z, mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
-            grads[3 * i], da = _conv_bwd(a_in, dz, w, stride, transposed, zero_bias)
-            pending[i] = da if i not in pending else pending[i] + da
+            else:
+                bn_state.update_running_stats()          # the reference's checkpoint recomputation (see _BnState)
+                sums = ops.bn_relu_bwd_reduce(g, z, mean, invstd, gamma, beta, relu=True)
+                grads[3 * i + 2] = sums[: sums.numel() // 2].float()                 # d beta (this rank's voxels; DDP averages)
+                grads[3 * i + 1] = sums[sums.numel() // 2:].float()                  # d gamma
+                if group[0]:
+                    sums = sums.clone()
+                    torch.distributed.all_reduce(sums, group=group[1])
+                dz = ops.bn_relu_bwd_apply(g, z, mean, invstd, gamma, beta, sums, count, relu=True, use_batch_stats=batch)
+                grads[3 * i], da = _conv_bwd(a_in, dz, w, stride, transposed, zero_bias)
+                pending[i] = da if i not in pending else pending[i] + da
+            if ctx.recompute:
+                S[7 * i] = S[7 * i + 1] = None           # this block's regenerated activations are done with
         return (pending[0], None) + tuple(grads)
 
 

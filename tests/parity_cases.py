@@ -1063,6 +1063,47 @@ def case_regnet_train_native(device):
                 assert (cpu(b2) - b1).abs().max() <= 1e-4 * max(1.0, float(b1.abs().max())), n
 
 
+def case_regnet_train_recompute(device):
+    """checkpoint-style recomputation in the native U-Net (module.py:393-396, 488-492: the reference runs forward_once under
+    torch.utils.checkpoint): with `recompute_in_backward = True` the forward keeps the input volume, the parameters and [C]-sized
+    statistics only, the backward regenerates the activations with the saved statistics - output, every gradient, the running
+    statistics and num_batches_tracked (two momentum steps per iteration) are BIT-IDENTICAL to the keep-everything mode, and the
+    tensors held between forward and backward shrink to the input volume + weights.  The size rule picks the mode when the flag is unset."""
+    import copy
+    from mvsformerplusplus_amd import training as T
+    for cls, shape, granular in ((M.CostRegNet3D, (2, 4, 16, 24), False), (M.CostRegNet, (1, 16, 16, 24), False), (M.CostRegNet3D, (1, 4, 16, 24), True)):
+        reg = cls(8, 8)
+        reg.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(reg.state_dict()), 3))
+        reg.train()
+        if granular:                                      # cumulative-average BatchNorm: the granular (not one-call) block path
+            for m in reg.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                    m.momentum = None
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(shape[0], *shape[1:], 8, generator=g) * 0.3
+        wgt = torch.randn(shape[0], *shape[1:], 8, generator=g)
+        res = {}
+        for mode in (False, True):
+            net = copy.deepcopy(reg).to(device)
+            net.recompute_in_backward = mode
+            xb = dev(x, device).requires_grad_(True)
+            fb = T.regnet_forward_native(net, xb)
+            held = sum(t.numel() * t.element_size() for t in {id(t): t for t in fb.grad_fn.saved_tensors}.values())
+            (fb * dev(wgt, device)).sum().backward()
+            res[mode] = (cpu(fb.detach()), cpu(xb.grad), [cpu(p.grad) for p in net.parameters() if p.grad is not None], [cpu(b.float()) for b in net.buffers()], held)
+        keep, rec = res[False], res[True]
+        assert torch.equal(keep[0], rec[0]) and torch.equal(keep[1], rec[1]), cls.__name__
+        assert all(torch.equal(a, b) for a, b in zip(keep[2], rec[2])), cls.__name__ + ": parameter gradients"
+        assert all(torch.equal(a, b) for a, b in zip(keep[3], rec[3])), cls.__name__ + ": running statistics / num_batches_tracked"
+        vol_bytes = x.numel() * 4
+        par_bytes = sum(p.numel() * 4 for n, p in reg.named_parameters() if not n.startswith("prob"))
+        assert rec[4] <= vol_bytes + par_bytes + (64 << 10), (cls.__name__, rec[4], vol_bytes, par_bytes)     # input volume + parameters + [C] statistics
+        est = T.RegNetTrain.kept_bytes(reg, x.shape)
+        assert abs((keep[4] - rec[4]) - est) <= 0.15 * est, (cls.__name__, keep[4], rec[4], est)               # the activations are what went away
+    reg = M.CostRegNet3D(8, 8)
+    assert not T.RegNetTrain._wants_recompute(reg, (2, 4, 512, 640)) and T.RegNetTrain._wants_recompute(reg, (2, 4, 1152, 1536))
+
+
 def case_train_midsize_vs_cpu_autograd(device):
     """Train-mode forward + backward of one stage at 128 x 160, B = 2, V = 3 (a size where every U-Net level has thousands of voxels)
     against PyTorch CPU autograd with NO library kernel in it (tests/train_torch_route.stage_forward_train_cpu: the oracle's

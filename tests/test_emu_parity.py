@@ -119,6 +119,10 @@ def test_train_kernels(emu):
     P.case_train_kernels(emu)
 
 
+def test_regnet_train_recompute(emu):
+    P.case_regnet_train_recompute(emu)
+
+
 def test_regnet_train_native(emu):
     P.case_regnet_train_native(emu)
 

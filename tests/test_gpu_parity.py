@@ -218,6 +218,10 @@ def test_regnet_train_native():
     P.case_regnet_train_native(DEV)
 
 
+def test_regnet_train_recompute():
+    P.case_regnet_train_recompute(DEV)
+
+
 def test_train_backward_transformer_golden():
     P.case_train_backward_transformer_golden(DEV)
 
