@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 6
+#define MVS_ABI_VERSION 7
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -317,6 +317,12 @@ int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, void* k, void*
  * precision MVS_PREC_BF16X3 or MVS_PREC_BF16P                                                                       */
 int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt, float* out, int B, int n, int heads,
                          int precision, void* stream);
+/* Backward of the attention core (training path; the reference differentiates scaled_dot_product_attention / flash-attn,
+ * dino/layers/attention.py:141-170): qkv [B,n,3,heads,16] fp32 = the projection's plain output (q | k | v), o [B,n,heads*16] the
+ * forward result, d_o its gradient -> d_qkv [B,n,3,heads,16] (dq | dk | dv).  fp32 throughout, two launches, no atomics.
+ * lse_ws / dsum_ws: B*heads*n floats each (log-sum-exp and sum_c d_o*o per query row, produced by the first launch).            */
+int mvs_tr_attention_bwd(const float* qkv, const float* o, const float* d_o, float* d_qkv, float* lse_ws, float* dsum_ws,
+                         int B, int n, int heads, float softmax_scale, void* stream);
 
 /* `up` = ConvTranspose3d(64, 8, kernel = stride = (rd,rh,rw)) + bias + LayerNorm3D(8, eps 1e-6), then `prob` =
  * Conv3d(8, 1, 1) + bias (module.py:621-626, 643-644): tokens [B,n,64] -> logits [B,D,H,W].

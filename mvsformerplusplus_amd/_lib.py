@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
@@ -82,6 +82,7 @@ SIGNATURES = {
     "mvs_tr_attention_operand_bytes": (_sz, [_i, _i, _i]),
     "mvs_tr_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "mvs_tr_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_tr_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mvs_tr_up_prob_fwd": (_i, [_vp] * 8 + [_i] * 8 + [_vp]),
     "mvs_fusion_campack_floats": (_sz, []),
     "mvs_fusion_prepare_cams": (_i, [_vp, _i, _vp, _vp]),

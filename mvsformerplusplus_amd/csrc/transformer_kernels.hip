@@ -654,3 +654,122 @@ extern "C" int mvs_tr_up_prob_fwd(const float* tokens, const void* w_packed, con
     a.n = (D / rd) * a.Ht * a.Wt; a.N = 8 * rd * rh * rw;
     return launch_gemm<64, PRO_TOKENS, EPI_UP>(a, B, (hipStream_t)stream, "tr_gemm_kernel<up>");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the attention core (training path; the reference differentiates
+// F.scaled_dot_product_attention / flash-attn, dino/layers/attention.py:141-170):
+//     o = softmax(scale * q k^T) v      ->      dq, dk, dv   from   d_o
+// with  p_ij = exp(s_ij - lse_i),  D_i = sum_c d_o[i][c] o[i][c],  ds_ij = p_ij (d_o_i . v_j - D_i):
+//     dq_i = scale * sum_j ds_ij k_j        dk_j = scale * sum_i ds_ij q_i        dv_j = sum_i p_ij d_o_i
+// fp32 throughout (the reference's flash-attn backward keeps q, k, v, p in bf16).  Two launches, no atomics, deterministic:
+//   pass Q: one work-item per QUERY row walks all keys twice (log-sum-exp, then dq); writes lse (base 2) and D for pass K
+//   pass K: one work-item per KEY row walks all queries; dk and dv
+// The row a work-item walks over is the same for the whole wave: its 16 + 16 floats arrive through scalar loads (one
+// s_load_dwordx16 each) and enter the v_fma as SGPR operands - per (query, key) pair ~50 VALU instructions on registers, no LDS.
+// Training token counts are a few thousand (DTU 512 x 640, D = 32 -> 2560 tokens): 0.3 ms per launch; at cfg2's 27 648 tokens ~7 ms.
+// qkv is the projection's plain output [B][n][3][heads][16] (q | k | v), o / d_o are [B][n][heads*16], d_qkv has qkv's layout.
+// ------------------------------------------------------------------------------------------------
+constexpr float kLog2e = 1.4426950408889634f;
+
+__global__ __launch_bounds__(256) void tr_attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
+                                                            float* __restrict__ d_qkv, float* __restrict__ lse2, float* __restrict__ dsum, int n,
+                                                            int heads, float scale) {
+    const int b = (int)blockIdx.z, h = (int)blockIdx.y;
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const bool valid = i < n;
+    const int ii = valid ? i : n - 1;
+    const int RS = 3 * heads * 16, OS = heads * 16;
+    const float* base = qkv + (size_t)b * n * RS;
+    const float* qrow = base + (size_t)ii * RS + h * 16;
+    const float* orow = o + ((size_t)b * n + ii) * OS + h * 16;
+    const float* grow = d_o + ((size_t)b * n + ii) * OS + h * 16;
+    float qs[16], g[16], Dq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        qs[c] = qrow[c] * (scale * kLog2e);                        // scores in base 2
+        g[c] = grow[c];
+        Dq += g[c] * orow[c];
+    }
+    const float* kbase = base + OS + h * 16;                        // key j at kbase + j * RS, value j at kbase + OS + j * RS
+    float m = -INFINITY, l = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float* kj = kbase + (size_t)j * RS;
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += qs[c] * kj[c];
+        const float mn = fmaxf(m, s);
+        l = l * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(s - mn);
+        m = mn;
+    }
+    const float L = m + __builtin_amdgcn_logf(l);                  // log2 of the row's sum of 2^s
+    float dq[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dq[c] = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float* kj = kbase + (size_t)j * RS;
+        const float* vj = kj + OS;
+        float s = 0.0f, dp = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { s += qs[c] * kj[c]; dp += g[c] * vj[c]; }
+        const float ds = __builtin_amdgcn_exp2f(s - L) * (dp - Dq);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dq[c] += ds * kj[c];
+    }
+    if (valid) {
+        float* dst = d_qkv + ((size_t)b * n + i) * RS + h * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c] = dq[c] * scale;
+        lse2[((size_t)b * heads + h) * n + i] = L;
+        dsum[((size_t)b * heads + h) * n + i] = Dq;
+    }
+}
+
+__global__ __launch_bounds__(256) void tr_attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o, const float* __restrict__ lse2,
+                                                             const float* __restrict__ dsum, float* __restrict__ d_qkv, int n, int heads, float scale) {
+    const int b = (int)blockIdx.z, h = (int)blockIdx.y;
+    const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const bool valid = j < n;
+    const int jj = valid ? j : n - 1;
+    const int RS = 3 * heads * 16, OS = heads * 16;
+    const float* base = qkv + (size_t)b * n * RS;
+    const float* krow = base + (size_t)jj * RS + OS + h * 16;
+    float ks[16], v[16], dk[16], dv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        ks[c] = krow[c] * (scale * kLog2e);
+        v[c] = krow[OS + c];
+        dk[c] = 0.0f;
+        dv[c] = 0.0f;
+    }
+    const float* qbase = base + h * 16;                             // query i at qbase + i * RS
+    const float* gbase = d_o + (size_t)b * n * OS + h * 16;
+    const float* Lr = lse2 + ((size_t)b * heads + h) * n;
+    const float* Dr = dsum + ((size_t)b * heads + h) * n;
+    for (int i = 0; i < n; ++i) {
+        const float* qi = qbase + (size_t)i * RS;
+        const float* gi = gbase + (size_t)i * OS;
+        float s = 0.0f, dp = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { s += qi[c] * ks[c]; dp += gi[c] * v[c]; }
+        const float p = __builtin_amdgcn_exp2f(s - Lr[i]);
+        const float ds = p * (dp - Dr[i]);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { dv[c] += p * gi[c]; dk[c] += ds * qi[c]; }
+    }
+    if (valid) {
+        float* dst = d_qkv + ((size_t)b * n + j) * RS + OS + h * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { dst[c] = dk[c] * scale; dst[OS + c] = dv[c]; }
+    }
+}
+
+extern "C" int mvs_tr_attention_bwd(const float* qkv, const float* o, const float* d_o, float* d_qkv, float* lse_ws, float* dsum_ws, int B, int n,
+                                    int heads, float softmax_scale, void* stream) {
+    if (!qkv || !o || !d_o || !d_qkv || !lse_ws || !dsum_ws || B < 1 || n < 1 || heads < 1) { set_error("mvs_tr_attention_bwd: bad arguments"); return MVS_ERR_ARG; }
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(tr_attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, o, d_o, d_qkv, lse_ws, dsum_ws, n, heads, softmax_scale);
+    int rc = check_launch("tr_attn_bwd_q_kernel");
+    if (rc != MVS_OK) return rc;
+    hipLaunchKernelGGL(tr_attn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, d_o, lse_ws, dsum_ws, d_qkv, n, heads, softmax_scale);
+    return check_launch("tr_attn_bwd_kv_kernel");
+}

@@ -556,6 +556,17 @@ def tr_attention(x: torch.Tensor, wqkv_packed, heads: int, softmax_scale: float,
     return out
 
 
+def tr_attention_bwd(qkv: torch.Tensor, o: torch.Tensor, d_o: torch.Tensor, heads: int, softmax_scale: float) -> torch.Tensor:
+    """Backward of softmax(scale q k^T) v: qkv [B,n,3*heads*16] (the projection's plain output), o / d_o [B,n,heads*16] -> d_qkv like qkv."""
+    B, n, _ = qkv.shape
+    qkv, o, d_o = _f32c(qkv), _f32c(o), _f32c(d_o)
+    d_qkv = torch.empty_like(qkv)
+    ws = torch.empty(2, B * heads * n, dtype=torch.float32, device=qkv.device)
+    check(lib().mvs_tr_attention_bwd(ptr(qkv), ptr(o), ptr(d_o), ptr(d_qkv), ptr(ws[0]), ptr(ws[1]), B, n, heads, float(softmax_scale),
+                                     stream_of(qkv)), "mvs_tr_attention_bwd")
+    return d_qkv
+
+
 def tr_up_prob(tokens: torch.Tensor, w_packed, up_bias, ln_w, ln_b, prob_w, prob_b, dhw, rate, precision: int) -> torch.Tensor:
     B = tokens.shape[0]
     D, H, W = dhw

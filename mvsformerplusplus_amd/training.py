@@ -27,9 +27,11 @@ What is native and what is not, stated plainly:
 
 The reference differentiates neither the sampling grid (built under ``torch.no_grad()``, warping.py:80) nor the entropy
 (``sim_vol.detach()``, cost_volume.py:90); this path follows it: no gradient reaches the depth hypotheses, the cameras or - via
-the entropy - the features.  The transformer regulariser of the shipped stage 1 trains through PyTorch autograd ops
-(``transformer_forward_torch``: token GEMMs, scaled-dot-product attention, LayerNorms on the module's own parameters) between the
-native cost volume and head; a hand-written attention backward is not built.
+the entropy - the features.  The transformer regulariser of the shipped stage 1 (``transformer_forward_torch``): each of its six
+blocks is one autograd node (``TransformerBlockTrain``) whose forward is the inference path's five launches and whose backward is
+hand-written - the attention core on ``mvs_tr_attention_bwd`` (fp32, no [n, n] tensor), the linears' gradients as plain GEMMs
+(rocBLAS), LayerNorm / GELU / residual-scale gradients as tensor expressions, the FFN hidden layer and the pre-LayerNorm sums
+recomputed; patch embedding / expansion with their LayerNorm3D and `prob` stay PyTorch-ROCm autograd ops.
 """
 from __future__ import annotations
 
@@ -457,10 +459,104 @@ def _layer_norm_channels(x: torch.Tensor, ln) -> torch.Tensor:
     return ln.weight.view(1, -1, 1, 1, 1) * (xc * torch.rsqrt(xc.pow(2).mean(1, keepdim=True) + ln.eps)) + ln.bias.view(1, -1, 1, 1, 1)
 
 
+class AttentionTrain(torch.autograd.Function):
+    """a [B,n,64] = proj-less attention of one block: softmax(scale q k^T) v over all tokens, q | k | v = t W_qkv^T (no bias,
+    attention.py:76-101, 141-170).  Forward = the inference kernels (mvs_tr_qkv_fwd + mvs_tr_attention_fwd: split-bf16 operands,
+    flash attention on the MFMA k axis); backward = the library's attention backward (mvs_tr_attention_bwd: fp32, two launches, no
+    atomics) between two plain GEMMs - q | k | v are re-projected from the saved tokens (nothing [n, n]-sized or per-key is kept
+    between forward and backward), d_t = d_qkv W_qkv, d_W = d_qkv^T t."""
+
+    @staticmethod
+    def forward(ctx, t, w_qkv, heads, scale):
+        tt = ops._f32c(t.detach())
+        w = w_qkv.detach().float()
+        a = ops.tr_attention(tt, packing.pack_linear_bf16x3(w), heads, scale, _lib.PREC_BF16X3)   # packed on the weight's device (torch ops)
+        ctx.save_for_backward(tt, w, a)
+        ctx.heads, ctx.scale = heads, scale
+        return a
+
+    @staticmethod
+    def backward(ctx, d_a):
+        t, w, a = ctx.saved_tensors
+        B, n, C = t.shape
+        qkv = (t.reshape(B * n, C) @ w.t()).reshape(B, n, 3 * C)                   # [.., (q | k | v), heads, 16]
+        d_qkv = ops.tr_attention_bwd(qkv, a, ops._f32c(d_a), ctx.heads, ctx.scale)
+        d2 = d_qkv.reshape(B * n, 3 * C)
+        return (d2 @ w).reshape(B, n, C), d2.t() @ t.reshape(B * n, C), None, None
+
+
+def _layer_norm_bwd(d_y, u, w, eps):
+    """Backward of y = LayerNorm(u) over the last axis (weight w): -> (d_u, d_w, d_b)."""
+    mu = u.mean(-1, keepdim=True)
+    xc = u - mu
+    rstd = torch.rsqrt(xc.pow(2).mean(-1, keepdim=True) + eps)
+    xh = xc * rstd
+    dxh = d_y * w
+    d_u = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+    red = tuple(range(d_y.dim() - 1))
+    return d_u, (d_y * xh).sum(red), d_y.sum(red)
+
+
+class TransformerBlockTrain(torch.autograd.Function):
+    """One post-norm block (module.py:535-583: t1 = LN1(t + g1 proj(attn(t))), t2 = LN2(t1 + g2 W2 gelu(W1 t1))) with a hand-written
+    backward.  Forward = the five launches of the inference path (qkv + flash attention, proj + residual + LayerNorm, linear1 + GELU,
+    linear2 + residual + LayerNorm on the split-bf16 kernels); kept for the backward: the block input, the attention output and t1 -
+    the 4x wider FFN hidden layer and both pre-LayerNorm sums are recomputed.  Backward: the attention core on
+    ``mvs_tr_attention_bwd``; the linears' data / weight gradients are plain GEMMs (rocBLAS through torch.mm), LayerNorm / GELU /
+    residual-scale gradients element-wise tensor expressions - no autograd graph, no [n, n] tensor."""
+
+    @staticmethod
+    def forward(ctx, t, heads, scale, w_qkv, w_proj, b_proj, g1, n1w, n1b, eps1, w1, b1, w2, b2, g2, n2w, n2b, eps2):
+        f = lambda p: p.detach().float().contiguous()
+        pk = lambda w: packing.pack_linear_bf16x3(f(w))
+        prec = _lib.PREC_BF16X3
+        t0 = ops._f32c(t.detach())
+        a = ops.tr_attention(t0, pk(w_qkv), heads, scale, prec)
+        t1 = ops.tr_linear(a, pk(w_proj), f(b_proj), _lib.TR_EPI_RES_LN, 64, prec, residual=t0, gamma=f(g1).reshape(1), ln_w=f(n1w), ln_b=f(n1b), ln_eps=eps1)
+        hdn = ops.tr_linear(t1, pk(w1), f(b1), _lib.TR_EPI_GELU, w1.shape[0], prec)
+        t2 = ops.tr_linear(hdn, pk(w2), f(b2), _lib.TR_EPI_RES_LN, 64, prec, residual=t1, gamma=f(g2).reshape(1), ln_w=f(n2w), ln_b=f(n2b), ln_eps=eps2)
+        ctx.save_for_backward(t0, a, t1, f(w_qkv), f(w_proj), f(b_proj), f(g1), f(n1w), f(w1), f(b1), f(w2), f(b2), f(g2), f(n2w))
+        ctx.heads, ctx.scale, ctx.eps = heads, scale, (eps1, eps2)
+        return t2
+
+    @staticmethod
+    def backward(ctx, d_t2):
+        t0, a, t1, w_qkv, w_proj, b_proj, g1, n1w, w1, b1, w2, b2, g2, n2w = ctx.saved_tensors
+        B, n, C = t0.shape
+        flat = lambda x: x.reshape(B * n, -1)
+        d_t2 = ops._f32c(d_t2)
+        # ---- FFN half: recompute pre-GELU, hidden, the scaled branch and the pre-LayerNorm sum
+        pre = flat(t1) @ w1.t() + b1
+        hdn = F.gelu(pre)
+        y2 = hdn @ w2.t() + b2
+        d_u2, d_n2w, d_n2b = _layer_norm_bwd(flat(d_t2), flat(t1) + g2 * y2, n2w, ctx.eps[1])
+        d_g2 = (d_u2 * y2).sum()
+        d_y2 = g2 * d_u2
+        d_w2, d_b2 = d_y2.t() @ hdn, d_y2.sum(0)
+        d_pre = (d_y2 @ w2) * (0.5 * (1.0 + torch.erf(pre * 0.7071067811865476)) + pre * torch.exp(-0.5 * pre * pre) * 0.3989422804014327)
+        d_w1, d_b1 = d_pre.t() @ flat(t1), d_pre.sum(0)
+        d_t1 = d_u2 + d_pre @ w1
+        # ---- attention half
+        yp = flat(a) @ w_proj.t() + b_proj
+        d_u1, d_n1w, d_n1b = _layer_norm_bwd(d_t1, flat(t0) + g1 * yp, n1w, ctx.eps[0])
+        d_g1 = (d_u1 * yp).sum()
+        d_yp = g1 * d_u1
+        d_wp, d_bp = d_yp.t() @ flat(a), d_yp.sum(0)
+        d_a = (d_yp @ w_proj).reshape(B, n, C)
+        qkv = (flat(t0) @ w_qkv.t()).reshape(B, n, 3 * C)
+        d_qkv = flat(ops.tr_attention_bwd(qkv, a, d_a, ctx.heads, ctx.scale))
+        d_t0 = (d_u1 + d_qkv @ w_qkv).reshape(B, n, C)
+        d_wqkv = d_qkv.t() @ flat(t0)
+        return (d_t0, None, None, d_wqkv, d_wp, d_bp, d_g1.reshape(g1.shape), d_n1w, d_n1b, None, d_w1, d_b1, d_w2, d_b2, d_g2.reshape(g2.shape),
+                d_n2w, d_n2b, None)
+
+
 def transformer_forward_torch(reg, x: torch.Tensor, position3d) -> torch.Tensor:
-    """PureTransformerCostReg.forward (module.py:629-646, blocks :569-581, attention dino/layers/attention.py:76-101,141-170) as
-    PyTorch autograd ops on the module's own parameters - the training form of the shipped stage 1 (the inference form is the
-    HIP path of csrc/transformer_kernels.hip; a hand-written attention backward is not built)."""
+    """PureTransformerCostReg.forward (module.py:629-646, blocks :569-581, attention dino/layers/attention.py:76-101,141-170), the
+    training form of the shipped stage 1: every transformer block runs forward on the inference path's kernels and backward through
+    the hand-written ``TransformerBlockTrain`` (attention backward on the library's kernel, linears as plain GEMMs, LayerNorm / GELU
+    gradients as tensor expressions); the two ends - position-encoding projection + patch embedding + LayerNorm3D, and patch
+    expansion + LayerNorm3D + `prob` - are PyTorch-ROCm autograd ops on the module's own parameters."""
     import math
     if reg.training and (reg.drop or reg.attn_drop):
         raise NotImplementedError("dropout inside the transformer regulariser (drop / attn_drop != 0) is not used by the shipped config")
@@ -475,10 +571,15 @@ def transformer_forward_torch(reg, x: torch.Tensor, position3d) -> torch.Tensor:
     if reg.softmax_scale == "entropy_invariance":
         scale *= math.log(N, reg.train_avg_length)
     for blk in reg.attention_layers:
-        q, k, v = blk.attn.qkv(t).reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
-        a = F.scaled_dot_product_attention(q, k, v, scale=scale).transpose(1, 2).reshape(B, N, C)
-        t = blk.norm1(t + blk.gamma1 * blk.attn.proj(a))
-        t = blk.norm2(t + blk.gamma2 * blk.ffn.linear2(F.gelu(blk.ffn.linear1(t))))
+        if C == 64 and heads == 4 and blk.attn.proj.bias is not None and blk.ffn.linear1.bias is not None and blk.ffn.linear2.bias is not None:
+            t = TransformerBlockTrain.apply(t, heads, scale, blk.attn.qkv.weight, blk.attn.proj.weight, blk.attn.proj.bias, blk.gamma1,
+                                            blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, blk.ffn.linear1.weight, blk.ffn.linear1.bias,
+                                            blk.ffn.linear2.weight, blk.ffn.linear2.bias, blk.gamma2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            continue
+        a = AttentionTrain.apply(t, blk.attn.qkv.weight, heads, scale)               # bias-free variants: attention core native, the rest autograd ops
+        proj, l1, l2 = blk.attn.proj, blk.ffn.linear1, blk.ffn.linear2
+        t = blk.norm1(t + blk.gamma1 * proj(a))
+        t = blk.norm2(t + blk.gamma2 * l2(F.gelu(l1(t))))
     x = t.reshape(B, h, w, d, C).permute(0, 4, 3, 1, 2)
     return reg.prob(_layer_norm_channels(reg.up[0](x), reg.up[1]))
 

@@ -1104,6 +1104,76 @@ def case_regnet_train_recompute(device):
     assert not T.RegNetTrain._wants_recompute(reg, (2, 4, 512, 640)) and T.RegNetTrain._wants_recompute(reg, (2, 4, 1152, 1536))
 
 
+def case_attention_backward(device):
+    """mvs_tr_attention_bwd and the AttentionTrain autograd node (native qkv + flash-attention forward, native backward) against
+    float64 autograd through F.scaled_dot_product_attention: token counts that are not multiples of the block (200, 333), batch 2,
+    the entropy-invariance scale, and a peaky case (large scores: the log-sum-exp path)."""
+    import math
+    import torch.nn.functional as F
+    from mvsformerplusplus_amd import training as T
+    g = torch.Generator().manual_seed(12)
+    for B, n, gain in ((2, 200, 1.0), (1, 333, 6.0)):
+        heads, C = 4, 64
+        t = torch.randn(B, n, C, generator=g)
+        w = torch.randn(3 * C, C, generator=g) * (gain / math.sqrt(C))
+        R = torch.randn(B, n, C, generator=g)
+        scale = (C // heads) ** -0.5 * math.log(n, 1500.0)
+        t64, w64 = t.double().requires_grad_(True), w.double().requires_grad_(True)
+        q, k, v = (t64 @ w64.t()).reshape(B, n, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+        a64 = F.scaled_dot_product_attention(q, k, v, scale=scale).transpose(1, 2).reshape(B, n, C)
+        (a64 * R.double()).sum().backward()
+        # the raw entry point on the float64 route's own q | k | v and output
+        qkv32 = (t64 @ w64.t()).detach().float()
+        d_qkv = cpu(ops.tr_attention_bwd(dev(qkv32, device), dev(a64.detach().float(), device), dev(R, device), heads, scale))
+        d_t = (d_qkv.reshape(B * n, 3 * C).double() @ w64.detach()).reshape(B, n, C)
+        assert (d_t - t64.grad).abs().max() <= 2e-5 * float(t64.grad.abs().max()), (n, "mvs_tr_attention_bwd")
+        # the autograd node end to end (forward on the split-bf16 kernels)
+        tn, wn = dev(t, device).requires_grad_(True), dev(w, device).requires_grad_(True)
+        an = T.AttentionTrain.apply(tn, wn, heads, scale)
+        assert (cpu(an) - a64.detach().float()).abs().max() <= 2e-4 * float(a64.abs().max()), n
+        (an * dev(R, device)).sum().backward()
+        for name, got, ref in (("d_t", cpu(tn.grad), t64.grad), ("d_W", cpu(wn.grad), w64.grad)):
+            assert (got - ref.float()).abs().max() <= 5e-4 * float(ref.abs().max()), (n, name, float((got - ref.float()).abs().max() / ref.abs().max()))
+
+
+def case_transformer_block_backward(device):
+    """TransformerBlockTrain (native forward, hand-written backward: module.py:535-583) against float64 autograd through the block's
+    own parameters: output, the token gradient and all 13 parameter gradients."""
+    import copy, math
+    import torch.nn.functional as F
+    from mvsformerplusplus_amd import training as T
+    g = torch.Generator().manual_seed(5)
+    B, n, C, heads = 2, 150, 64, 4
+    blk = M.FlashAttnBlock(C, num_heads=heads, mlp_ratio=4)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() == 0 else 1.0 / math.sqrt(p.shape[-1]) if p.dim() == 2 else 0.3))
+        blk.gamma1.fill_(0.7); blk.gamma2.fill_(1.3)
+        blk.norm1.weight.add_(1.0); blk.norm2.weight.add_(1.0)
+    t = torch.randn(B, n, C, generator=g)
+    R = torch.randn(B, n, C, generator=g)
+    scale = (C // heads) ** -0.5
+    ref = copy.deepcopy(blk).double()
+    t64 = t.double().requires_grad_(True)
+    q, k, v = ref.attn.qkv(t64).reshape(B, n, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    a = F.scaled_dot_product_attention(q, k, v, scale=scale).transpose(1, 2).reshape(B, n, C)
+    u = ref.norm1(t64 + ref.gamma1 * ref.attn.proj(a))
+    y64 = ref.norm2(u + ref.gamma2 * ref.ffn.linear2(F.gelu(ref.ffn.linear1(u))))
+    (y64 * R.double()).sum().backward()
+    nat = copy.deepcopy(blk).to(device)
+    tn = dev(t, device).requires_grad_(True)
+    yn = T.TransformerBlockTrain.apply(tn, heads, scale, nat.attn.qkv.weight, nat.attn.proj.weight, nat.attn.proj.bias, nat.gamma1,
+                                       nat.norm1.weight, nat.norm1.bias, nat.norm1.eps, nat.ffn.linear1.weight, nat.ffn.linear1.bias,
+                                       nat.ffn.linear2.weight, nat.ffn.linear2.bias, nat.gamma2, nat.norm2.weight, nat.norm2.bias, nat.norm2.eps)
+    assert (cpu(yn) - y64.detach().float()).abs().max() <= 2e-4 * float(y64.abs().max())
+    (yn * dev(R, device)).sum().backward()
+    errs = {"d_t": float((cpu(tn.grad) - t64.grad.float()).abs().max() / t64.grad.abs().max())}
+    for (name, p), (_, q64) in zip(nat.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, name
+        errs[name] = float((cpu(p.grad) - q64.grad.float()).abs().max() / q64.grad.abs().max().clamp_min(1e-12))
+    assert max(errs.values()) <= 1e-3, errs
+
+
 def case_train_midsize_vs_cpu_autograd(device):
     """Train-mode forward + backward of one stage at 128 x 160, B = 2, V = 3 (a size where every U-Net level has thousands of voxels)
     against PyTorch CPU autograd with NO library kernel in it (tests/train_torch_route.stage_forward_train_cpu: the oracle's

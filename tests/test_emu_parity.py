@@ -119,6 +119,14 @@ def test_train_kernels(emu):
     P.case_train_kernels(emu)
 
 
+def test_attention_backward(emu):
+    P.case_attention_backward(emu)
+
+
+def test_transformer_block_backward(emu):
+    P.case_transformer_block_backward(emu)
+
+
 def test_regnet_train_recompute(emu):
     P.case_regnet_train_recompute(emu)
 

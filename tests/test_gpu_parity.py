@@ -218,6 +218,14 @@ def test_regnet_train_native():
     P.case_regnet_train_native(DEV)
 
 
+def test_attention_backward():
+    P.case_attention_backward(DEV)
+
+
+def test_transformer_block_backward():
+    P.case_transformer_block_backward(DEV)
+
+
 def test_regnet_train_recompute():
     P.case_regnet_train_recompute(DEV)
 
