@@ -1066,8 +1066,9 @@ def case_regnet_train_native(device):
 def case_regnet_train_recompute(device):
     """checkpoint-style recomputation in the native U-Net (module.py:393-396, 488-492: the reference runs forward_once under
     torch.utils.checkpoint): with `recompute_in_backward = True` the forward keeps the input volume, the parameters and [C]-sized
-    statistics only, the backward regenerates the activations with the saved statistics - output, every gradient, the running
-    statistics and num_batches_tracked (two momentum steps per iteration) are BIT-IDENTICAL to the keep-everything mode, and the
+    statistics only, the backward regenerates the activations with the saved statistics - the output is BIT-IDENTICAL to the
+    keep-everything mode, every gradient, the running statistics and num_batches_tracked (two momentum steps per iteration) equal it
+    to the run-to-run spread of the weight-gradient kernel's atomics (exactly, on the sequential emulator), and the
     tensors held between forward and backward shrink to the input volume + weights.  The size rule picks the mode when the flag is unset."""
     import copy
     from mvsformerplusplus_amd import training as T
@@ -1092,9 +1093,12 @@ def case_regnet_train_recompute(device):
             (fb * dev(wgt, device)).sum().backward()
             res[mode] = (cpu(fb.detach()), cpu(xb.grad), [cpu(p.grad) for p in net.parameters() if p.grad is not None], [cpu(b.float()) for b in net.buffers()], held)
         keep, rec = res[False], res[True]
-        assert torch.equal(keep[0], rec[0]) and torch.equal(keep[1], rec[1]), cls.__name__
-        assert all(torch.equal(a, b) for a, b in zip(keep[2], rec[2])), cls.__name__ + ": parameter gradients"
-        assert all(torch.equal(a, b) for a, b in zip(keep[3], rec[3])), cls.__name__ + ": running statistics / num_batches_tracked"
+        # the regenerated activations are bit-identical (deterministic convolutions, saved statistics): so is the output; gradients pass
+        # through the weight-gradient kernel's same-address fp32 atomics, whose order differs from launch to launch on the GPU
+        close = lambda a, b: torch.equal(a, b) or float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30)
+        assert torch.equal(keep[0], rec[0]) and close(keep[1], rec[1]), cls.__name__
+        assert all(close(a, b) for a, b in zip(keep[2], rec[2])), cls.__name__ + ": parameter gradients"
+        assert all(close(a, b) for a, b in zip(keep[3], rec[3])), cls.__name__ + ": running statistics / num_batches_tracked"
         vol_bytes = x.numel() * 4
         par_bytes = sum(p.numel() * 4 for n, p in reg.named_parameters() if not n.startswith("prob"))
         assert rec[4] <= vol_bytes + par_bytes + (64 << 10), (cls.__name__, rec[4], vol_bytes, par_bytes)     # input volume + parameters + [C] statistics
