@@ -54,10 +54,13 @@ SHIPPED = {"cost_reg_type": ["PureTransformerCostReg", "Normal", "Normal", "Norm
                                    "softmax_scale": "entropy_invariance", "train_avg_length": 12185, "use_pe_proj": True}]}
 
 
-def build_head(device, shipped=False):
+def build_head(device, shipped=False, conv_precision=None):
     from mvsformerplusplus_amd import synth
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
-    head = CascadeDepthHead(json.loads(json.dumps(dict(ARGS, **SHIPPED))) if shipped else dict(ARGS))
+    args = json.loads(json.dumps(dict(ARGS, **SHIPPED))) if shipped else dict(ARGS)
+    if conv_precision:
+        args["conv_precision"] = conv_precision
+    head = CascadeDepthHead(args)
     for i, st in enumerate(head.fusions):
         st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 100 + i), strict=True)
         st.return_prob_volumes = True       # reference-faithful outputs (a12): prob_volume / prob_volume_pre are written
@@ -136,6 +139,8 @@ def main():
                          "layout [B,V,C/8,H,W,8] (SURVEY.md section 8f #4) as a producer-side emitter would hand it over - packed once, "
                          "outside the timed region")
     ap.add_argument("--view-sharded-timeout", type=int, default=240, help="N > 1: seconds the extra view-sharded latency leg may take")
+    ap.add_argument("--conv-precision", choices=["bf16x3", "f16x2", "fp32"], default=None,
+                    help="contraction / activation format of the 3-D regularisers (default: the package default, module.DEFAULT_PRECISION)")
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
                     help="normal: all-'Normal' regularisers (Track R headline); shipped: stage-1 transformer + PE3D as in the shipped config")
     a = ap.parse_args()
@@ -162,7 +167,7 @@ def main():
             dist.init_process_group(backend)
 
     from mvsformerplusplus_amd import profiling, synth
-    head = build_head(device, shipped=a.cost_reg == "shipped")
+    head = build_head(device, shipped=a.cost_reg == "shipped", conv_precision=a.conv_precision)
     fdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.feat_dtype]
     nsets = max(1, a.input_sets)
     BATCH = max(1, a.batch)
@@ -269,8 +274,16 @@ def main():
                                 "note": "SURVEY.md section 8d layer-wise byte model (5.03 GB per reference view at cfg2) x ref-views/s / 8 TB/s"}
 
     result["config"]["cost_reg_type"] = SHIPPED["cost_reg_type"] if a.cost_reg == "shipped" else ["Normal"] * 4
-    result["config"]["conv_precision"] = ("%s MFMA contraction, fp32 accumulation; fp32-equivalent activations (between the U-Net layers stored as split "
-                                          "hi | lo bf16 pairs, the same 4 bytes per element)" % head.fusions[0].conv_precision)
+    prec0 = head.fusions[0].conv_precision
+    result["config"]["conv_precision"] = {
+        "bf16x3": "bf16x3 MFMA contraction, fp32 accumulation; fp32-equivalent activations (between the U-Net layers stored as split hi | lo bf16 pairs, "
+                  "the same 4 bytes per element)",
+        "f16x2": "f16x2: U-Net activations (cost volume included) stored as fp16, weights as fp16 hi + lo, two MFMA terms per product on "
+                 "v_mfma_f32_16x16x32_f16, fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the "
+                 "regulariser under bf16 autocast, test.py:250)",
+        "fp32": "fp32-exact MFMA contraction"}[prec0]
+    if prec0 == "f16x2":
+        result["dtype"] = "f32 (fp16 storage of the regulariser's activations)"
 
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
     if not a.no_profile:
@@ -289,9 +302,11 @@ def main():
         if not mfma:
             peak, note = profiling.PEAK_HBM_GBS, ("algorithmic HBM bytes per launch (SURVEY.md section 8d: every feature map once + hypotheses once + "
                                                   "outputs once) / HIP-event launch time on the launch stream")
-        elif prec == "bf16x3":
+        elif prec == "bf16x3" or dom_name.startswith("vis_cnn"):
             # every algorithmic product is three bf16 MFMA products: peak for algorithmic FLOPs = dense bf16 peak / 3
             peak, note = 2500.0 / 3.0, "3-term split-bf16 contraction on v_mfma_f32_16x16x32_bf16: dense bf16 peak 2500 TFLOP/s / 3 passes"
+        elif prec == "f16x2":
+            peak, note = 2500.0 / 2.0, "2-term fp16 contraction (w_hi.x + w_lo.x) on v_mfma_f32_16x16x32_f16: dense fp16 peak 2500 TFLOP/s / 2 passes"
         else:
             peak, note = profiling.PEAK_F32_MFMA_TFLOPS, "fp32-exact contraction on v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense peak)"
         traffic = None
@@ -315,7 +330,7 @@ def main():
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         # kernel FAMILIES: time, algorithmic work by SURVEY.md section 8d and the fraction of the family's own peak, so
         # that the roofline picture does not hinge on which single symbol happens to be the largest
-        def fam(pred, bound):
+        def fam(pred, bound, fam_prec=None):
             ks = {k: v for k, v in agg.items() if pred(k)}
             ms = sum(v["ms"] for v in ks.values()) / reps
             if not ks or ms <= 0:
@@ -323,7 +338,8 @@ def main():
             if bound == "mfma":
                 work = sum(v["flops"] for v in ks.values()) / reps
                 ach = work / ms / 1e9                            # TFLOP/s
-                pk = 2500.0 / 3.0 if prec == "bf16x3" else profiling.PEAK_F32_MFMA_TFLOPS
+                fp = fam_prec or prec
+                pk = 2500.0 / 3.0 if fp == "bf16x3" else (2500.0 / 2.0 if fp == "f16x2" else profiling.PEAK_F32_MFMA_TFLOPS)
                 return {"ms_per_ref_view": ms, "bound": "mfma", "algorithmic_gflop_per_ref_view": work / 1e9, "achieved_tflops": ach, "peak_tflops": pk,
                         "frac": ach / pk, "launches_per_ref_view": sum(v["calls"] for v in ks.values()) / reps}
             work = sum(v["bytes"] for v in ks.values()) / reps
@@ -333,7 +349,7 @@ def main():
         is_gather = lambda k: k.startswith(("gl_", "warp_corr_"))
         is_conv = lambda k: k.startswith(("conv3d_mfma", "deconv3d_mfma"))
         is_vis = lambda k: k.startswith(("vis_",)) or k.startswith("conv3d_mfma<16,16,k1") or k.startswith("conv3d_mfma<16,8,k1")
-        families = {"gather": fam(is_gather, "hbm"), "visibility_cnn": fam(is_vis, "mfma"),
+        families = {"gather": fam(is_gather, "hbm"), "visibility_cnn": fam(is_vis, "mfma", "bf16x3" if prec == "f16x2" else None),
                     "regulariser_convolutions": fam(lambda k: is_conv(k) and not is_vis(k), "mfma"),
                     "heads_and_ranges": fam(lambda k: not (is_gather(k) or is_conv(k) or is_vis(k) or k.startswith(("tr_", "[bundle]"))), "hbm")}
         if families["gather"] is not None and is_cfg2:

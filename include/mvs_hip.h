@@ -52,11 +52,17 @@ enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
  *                    lo = bf16(x - hi); the same 4 bytes per element as fp32, element type still declared float).  The producing
  *                    epilogue splits once, the consumers' staging is a copy.  Logits stay planar fp32.  The inference U-Net runs in
  *                    this form (mvs_regnet_fwd / mvs_regnet_logits_fwd / mvs_conv3d_logits_fwd and the single layers accept it);
- *                    the training path and the fp32-contraction path keep fp32 activations.                                       */
-enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2, MVS_PREC_BF16X3_SPLIT = 3 };
-/* format of the cost volume mvs_warp_corr_aggregate_fwd / mvs_volume_normalise leave behind: fp32 [B,D,H,W,8] or the split activation
- * format of MVS_PREC_BF16X3_SPLIT (normalised volumes of 8 groups only; partial sums are always fp32) */
-enum { MVS_VOLUME_F32 = 0, MVS_VOLUME_SPLIT = 1 };
+ *                    the training path and the fp32-contraction path keep fp32 activations.
+ *   MVS_PREC_F16X2   fp16 ACTIVATIONS: every x_cl / skip_cl / y_cl / feat_cl / volume_cl of the call is channel-last _Float16 (declared
+ *                    float*; 2 bytes per element), weights packed as fp16 hi + lo, two MFMA terms w_hi.x + w_lo.x on
+ *                    v_mfma_f32_16x16x32_f16, fp32 accumulation, fp32 logits.  Final depth vs the fp32 oracle: 5.5e-5 relative L1 on plain
+ *                    inputs, 4.2e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers under bf16
+ *                    autocast (test.py:250).  Values beyond +-65504 overflow: the aggregate pass clamps the volume it writes.           */
+enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2, MVS_PREC_BF16X3_SPLIT = 3, MVS_PREC_F16X2 = 4 };
+/* format of the cost volume mvs_warp_corr_aggregate_fwd / mvs_volume_normalise leave behind: fp32 [B,D,H,W,8], the split activation
+ * format of MVS_PREC_BF16X3_SPLIT, or fp16 [B,D,H,W,8] for MVS_PREC_F16X2 (aggregate only; normalised volumes of 8 groups only;
+ * partial sums are always fp32) */
+enum { MVS_VOLUME_F32 = 0, MVS_VOLUME_SPLIT = 1, MVS_VOLUME_F16 = 2 };
 /* epilogues of mvs_tr_linear_fwd */
 enum { MVS_TR_EPI_BIAS = 0, MVS_TR_EPI_GELU = 1, MVS_TR_EPI_RES_LN = 2 };
 
@@ -128,6 +134,12 @@ int mvs_slab_reduce(const float* volume_cl, const float* vis_sum, float* const* 
                     int row_begin, int row_end, int B, int D, int H, int W, void* stream);
 /* volume_cl /= (vis_sum + 1e-6) in place; volume_format = MVS_VOLUME_SPLIT additionally converts it to the split format */
 int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, int volume_format, void* stream);
+/* fp32 volume [B,D,H,W,8] (vis_sum != NULL: divided by vis_sum + 1e-6 first) -> fp16 [B,D,H,W,8] in a separate buffer, clamped to the
+ * fp16 range: the cost volume of the MVS_PREC_F16X2 U-Net where the aggregate pass could not write it directly (view-sharded
+ * multi-GPU partial sums; shapes outside the LDS-staged gather)                                                                */
+/* 1 when the two gather passes take the LDS-staged kernels for this shape (the only ones that write MVS_VOLUME_SPLIT / _F16 directly) */
+int mvs_gather_is_lds_staged(int layout, int C, int G, int D, int H, int W);
+int mvs_volume_to_f16(const float* volume_cl, const float* vis_sum, void* out_f16, int B, int D, int H, int W, int G, void* stream);
 
 /* ---- section 8f #2 (first slice): backward of mvs_warp_corr_aggregate_fwd(normalise = 1) ----------------------------
  * The gradient the reference's autograd produces for cost_volume.py:74-101: the sampling grid is built under torch.no_grad()

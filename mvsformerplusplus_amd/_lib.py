@@ -23,9 +23,9 @@ DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 LAYOUT_PLANAR, LAYOUT_OCTET_TILED = 0, 1
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
-PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT = 0, 1, 2, 3
-PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
-VOLUME_F32, VOLUME_SPLIT = 0, 1
+PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT, PREC_F16X2 = 0, 1, 2, 3, 4
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f16x2": PREC_F16X2}
+VOLUME_F32, VOLUME_SPLIT, VOLUME_F16 = 0, 1, 2
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -44,6 +44,8 @@ SIGNATURES = {
     "mvs_vis_out_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvs_warp_corr_aggregate_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i] + [_i] * 9 + [_vp]),
     "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mvs_volume_to_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_gather_is_lds_staged": (_i, [_i, _i, _i, _i, _i, _i]),
     "mvs_slab_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_slab_reduce": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),

@@ -48,9 +48,50 @@
 
 namespace mvs {
 
-// three-term split product, term-outer so that consecutive MFMAs hit different accumulators
-template <int MREP, int NREP>
+// ---- fp16 activation format (MVS_PREC_F16X2, round 3) ------------------------------------------------------------------
+// Activations in HBM and LDS as fp16 (11 significant bits; channel-last, 16 bytes per voxel and channel octet), weights as fp16 hi + lo
+// (22 bits), TWO MFMA terms  w_hi . x + w_lo . x  on v_mfma_f32_16x16x32_f16, fp32 accumulation.  Against the split-bf16 form: 2 instead of
+// 3 MFMAs per product, half the LDS operand reads, half the HBM bytes of every U-Net tensor.  Error budget measured on the oracle with the
+// activations rounded to fp16 at every layer input (scripts/study_activation_precision.py): final depth 5.5e-5 relative L1 on the plain
+// sets, 4.2e-4 on the x30-logits stress set (bar 1e-3; plain bf16 activations: 4.5e-4 / 3.0e-3).  The reference's own GPU path runs
+// these layers under bf16 autocast (test.py:250).  A tile configuration opts in by deriving from F16Cfg.
+template <class Base>
+struct F16Cfg : Base { static constexpr int ACT_F16 = 1; };
+template <class Cfg, class = void> struct CfgFmt { static constexpr bool F16 = false; };
+template <class Cfg> struct CfgFmt<Cfg, decltype((void)Cfg::ACT_F16)> { static constexpr bool F16 = true; };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 quad -> 4 halves, saturated to the fp16 range (an overflow would turn into inf and poison every later layer)
+__device__ __forceinline__ f16x4 f16_pack4(const float4& v) {
+    const float m = 65504.0f;
+    return f16x4{(_Float16)__builtin_amdgcn_fmed3f(v.x, -m, m), (_Float16)__builtin_amdgcn_fmed3f(v.y, -m, m),
+                 (_Float16)__builtin_amdgcn_fmed3f(v.z, -m, m), (_Float16)__builtin_amdgcn_fmed3f(v.w, -m, m)};
+}
+
+// a channel quad kept raw as 4 halves in the first two dwords of a float4 (skip connections of the fp16 format) -> fp32
+__device__ __forceinline__ float4 f16_quad_to_f32(const float4& raw) {
+    const float lo = raw.x, hi = raw.y;
+    const f16x4 h = __builtin_bit_cast(f16x4, make_float2(lo, hi));
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+
+// three-term split product, term-outer so that consecutive MFMAs hit different accumulators (F16: the two-term fp16 form, bl unused)
+template <int MREP, int NREP, bool F16 = false>
 __device__ __forceinline__ void bf_mfma_step(const bf16x8* ah, const bf16x8* al, const bf16x8* bh, const bf16x8* bl, f32x4 (*acc)[NREP]) {
+    if constexpr (F16) {
+#pragma unroll
+        for (int mb = 0; mb < MREP; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NREP; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[mb]), __builtin_bit_cast(f16x8, bh[nb]), acc[mb][nb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MREP; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NREP; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[mb]), __builtin_bit_cast(f16x8, bh[nb]), acc[mb][nb], 0, 0, 0);
+        return;
+    }
 #if MVS_ABL == 4
 #pragma unroll
     for (int mb = 0; mb < MREP; ++mb)
@@ -104,9 +145,14 @@ struct BfConv {
     // then hit 16 different bank slots.  (Round 1 interleaved both octets in an 80-byte voxel: every read 2-way conflicted, PMC
     // SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles, and the tile was 25 % larger.)
     static constexpr bool PLANES = OPT == 2;
-    static constexpr int SB = PLANES ? 32 : Cfg::S * 4;                  // bytes per voxel (within a plane)
-    static constexpr int PLANE = PLANES ? (Cfg::NVOX * 32 + 255) / 256 * 256 + 16 : 32;    // byte offset of octet 1
-    static constexpr size_t LDS_BYTES = PLANES ? (size_t)2 * PLANE : Cfg::LDS_BYTES;
+    // fp16 activations: 16 B per voxel and octet; consecutive voxels fill the 256-byte bank row, the second octet plane sits half a
+    // bank row further (8 voxels of octet 0 + 8 of octet 1 per ds_read_b128 group)
+    static constexpr bool F16 = CfgFmt<Cfg>::F16;
+    static constexpr int RUNB = F16 ? 16 : 32;                           // bytes of one staged run (voxel x octet) in the LDS image
+    static constexpr int SB = F16 ? 16 : (PLANES ? 32 : Cfg::S * 4);     // bytes per voxel (within a plane)
+    static constexpr int PLANE = F16 ? (Cfg::NVOX * 16 + 255) / 256 * 256 + 128
+                                     : (PLANES ? (Cfg::NVOX * 32 + 255) / 256 * 256 + 16 : 32);    // byte offset of octet 1
+    static constexpr size_t LDS_BYTES = F16 ? (size_t)OPT * PLANE : (PLANES ? (size_t)2 * PLANE : Cfg::LDS_BYTES);
     // persistent, weights-in-registers form (below): one pass whose packed weights take at most 64 VGPRs
     static constexpr bool PERSIST = MVS_PERSIST && Cfg::CIN == 8 && Cfg::NPASS == 1 && NSTEP * Cfg::MREP * 8 <= 64;
     // staging of the one-tile-per-block kernel: all loads of a pass issued back to back (registers: 8 per 256 voxel-octets of the
@@ -134,7 +180,7 @@ __device__ __forceinline__ float4 bf_buf_load16(__amdgpu_buffer_rsrc_t rs, unsig
 }
 
 // IW x IH x (any depth) tile of voxels, OPT runs (channel octets) per voxel; run e = tid + 256 it  <->  voxel e / OPT, octet e % OPT
-template <int IW, int IH, int OPT>
+template <int IW, int IH, int OPT, int RUNB = 32>
 struct BfTileWalk {
     static constexpr int STEPV = 256 / OPT;
     static constexpr int SDZ = STEPV / (IH * IW), SDY = (STEPV % (IH * IW)) / IW, SDX = STEPV % IW;
@@ -148,7 +194,7 @@ struct BfTileWalk {
         const int t2 = vox / IW;
         dy = t2 % IH;
         dz = t2 / IH;
-        off = (unsigned)(((z0 + dz) * H + (y0 + dy)) * W + (x0 + dx)) * vstride + chan0 + (unsigned)oc * 32u;   // wraps for out-of-volume voxels: never used then
+        off = (unsigned)(((z0 + dz) * H + (y0 + dy)) * W + (x0 + dx)) * vstride + chan0 + (unsigned)oc * (unsigned)RUNB;   // wraps for out-of-volume voxels: never used then
         c0 = (unsigned)((SDZ * H + SDY) * W + SDX) * vstride;
         c1 = (unsigned)(W - IW) * vstride;
         c2 = (unsigned)((H - IH) * W) * vstride;
@@ -212,7 +258,7 @@ __device__ __forceinline__ void bf_conv_load_x(int g, const char* ldsb, int voxb
     for (int nb = 0; nb < Cfg::NREP; ++nb) {
         if (MVS_ABL == 3 && T > 1) continue;
         bh[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB);
-        bl[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB + 16);
+        if constexpr (!BfConv<Cfg>::F16) bl[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB + 16);
     }
 }
 
@@ -240,8 +286,8 @@ struct BfConvSteps {
                 else bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah[T % NW], al[T % NW], bh0, bl0, acc);
-            else bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah[T % NW], al[T % NW], bh1, bl1, acc);
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah[T % NW], al[T % NW], bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah[T % NW], al[T % NW], bh1, bl1, acc);
             BfConvSteps<Cfg, T + 1>::run(g, wq, ldsb, voxbase0, acc, ah, al, bh0, bl0, bh1, bl1);
         }
     }
@@ -346,8 +392,8 @@ struct BfWldsSteps {
                 else bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah, al, bh0, bl0, acc);
-            else bf_mfma_step<Cfg::MREP, Cfg::NREP>(ah, al, bh1, bl1, acc);
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah, al, bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah, al, bh1, bl1, acc);
             if constexpr (T % W::WC == W::WC - 1) {              // end of a chunk: hand the next one over
                 if (gc + 1 < nchunk_total) bf_wlds_store<Cfg>(ring, gc + 1, tid, piece);
                 __syncthreads();                                 // chunk gc + 1 visible; everybody has read chunk gc (its slot is free for gc + 2)
@@ -394,7 +440,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         voxbase[nb] = (((oz * SD) * IH + oy * SH) * IW + li * SW) * SB;
     }
 
-    const float* xb = x + (size_t)b * D * H * W * CIN;
+    constexpr bool F16 = BfConv<Cfg>::F16;                           // fp16 activations in and out (x, y are then _Float16 tensors)
+    constexpr int EB = F16 ? 2 : 4, RUNB = BfConv<Cfg>::RUNB;          // bytes per element in HBM, per staged run
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)b * D * H * W * CIN * EB;
     // ---- stage + split: 8 channels of one voxel per work-item and iteration.  All loads of a pass are issued back to back
     // (unconditional, from a clamped address: no branch between them) before the first one is consumed - the rolled
     // load -> wait -> split -> write loop of round 1 exposed one memory latency per iteration (ablation: 40-55 % of the
@@ -402,16 +450,16 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     // p + 1 are issued before the contraction of pass p.
     constexpr int NITEM = Cfg::NVOX * OPT, NIT = (NITEM + 255) / 256;
     float4 su[NIT], sv[NIT];
-    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
+    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
     auto issue = [&](int pass) {
-        BfTileWalk<IW, IH, OPT> wk(tid, iz0, iy0, ix0, H, W, CIN * 4, (unsigned)(pass * CH * 4));
+        BfTileWalk<IW, IH, OPT, RUNB> wk(tid, iz0, iy0, ix0, H, W, CIN * EB, (unsigned)(pass * CH * EB));
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it > 0) wk.advance();
             const bool ok = MVS_ABL != 1 && (it * 256 + 255 < NITEM || tid + it * 256 < NITEM) && wk.inside(iz0, iy0, ix0, D, H, W);
             const unsigned voff = ok ? wk.off : BF_OOB;                     // out of the volume (or of the tile): zeros from the descriptor's range check
             su[it] = bf_buf_load16(xrs, voff, 0);
-            sv[it] = bf_buf_load16(xrs, voff, 16);
+            if constexpr (!F16) sv[it] = bf_buf_load16(xrs, voff, 16);
         }
     };
     auto commit = [&]() {
@@ -420,7 +468,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
             const int e = tid + it * 256;
             if (e >= NITEM) break;
             const int vox = e / OPT, oc = e - vox * OPT;
-            stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, su[it], sv[it]);
+            if constexpr (F16) *reinterpret_cast<float4*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE) = su[it];
+            else stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, su[it], sv[it]);
         }
     };
     constexpr bool UNROLLED = BfConv<Cfg>::UNROLL_STAGE;
@@ -442,14 +491,19 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         if constexpr (UNROLLED) {
             commit();
         } else {
-            BfTileWalk<IW, IH, OPT> wk(tid, iz0, iy0, ix0, H, W, CIN * 4, (unsigned)(pass * CH * 4));
+            BfTileWalk<IW, IH, OPT, RUNB> wk(tid, iz0, iy0, ix0, H, W, CIN * EB, (unsigned)(pass * CH * EB));
             int ldso = (tid / OPT) * SB + (tid % OPT) * BfConv<Cfg>::PLANE;
 #pragma unroll 1
             for (int e = tid; e < NITEM; e += 256) {
                 const bool ok = MVS_ABL != 1 && wk.inside(iz0, iy0, ix0, D, H, W);
                 const unsigned voff = ok ? wk.off : BF_OOB;
-                const float4 u = bf_buf_load16(xrs, voff, 0), v = bf_buf_load16(xrs, voff, 16);
-                stage_to_lds<SPLIT>(ldsb + ldso, u, v);
+                const float4 u = bf_buf_load16(xrs, voff, 0);
+                if constexpr (F16) {
+                    *reinterpret_cast<float4*>(ldsb + ldso) = u;
+                } else {
+                    const float4 v = bf_buf_load16(xrs, voff, 16);
+                    stage_to_lds<SPLIT>(ldsb + ldso, u, v);
+                }
                 wk.advance();
                 ldso += (256 / OPT) * SB;
             }
@@ -468,14 +522,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         if (UNROLLED && !MVS_XPASS_PREFETCH && pass + 1 < Cfg::NPASS) issue(pass + 1);
     }
 
-    float* yb = y + (size_t)b * OD * OH * OW * COUT;
+    float* yb = reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (size_t)b * OD * OH * OW * COUT * EB);
 #pragma unroll
     for (int nb = 0; nb < NREP; ++nb) {
         const int nbg = rowgrp * NREP + nb;
         const int oz = oz0 + nbg / TH, oy = oy0 + nbg % TH, ox = ox0 + li;
         const bool inside = oz < OD && oy < OH && ox < OW;
         if (!SPLIT && !inside) continue;                                   // split stores exchange lanes: every lane takes part
-        float* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
+        float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(yb) + (((size_t)oz * OH + oy) * OW + ox) * COUT * EB);
 #pragma unroll
         for (int mb = 0; mb < MREP; ++mb) {
             const int co = 16 * (mb0 + mb) + 4 * g;
@@ -484,7 +538,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
             float4 v = make_float4(acc[mb][nb][0] + bb.x, acc[mb][nb][1] + bb.y, acc[mb][nb][2] + bb.z, acc[mb][nb][3] + bb.w);
             if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
             if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-            if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
+            if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(o) + co) = f16_pack4(v);
+            else if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
             else *reinterpret_cast<float4*>(o + co) = v;
         }
     }
@@ -522,8 +577,8 @@ struct BfConvStepsWreg {
                 else bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP>(wh[T], wl[T], bh0, bl0, acc);
-            else bf_mfma_step<Cfg::MREP, Cfg::NREP>(wh[T], wl[T], bh1, bl1, acc);
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(wh[T], wl[T], bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(wh[T], wl[T], bh1, bl1, acc);
             BfConvStepsWreg<Cfg, T + 1>::run(g, wh, wl, ldsb, voxbase0, acc, bh0, bl0, bh1, bl1);
         }
     }
@@ -568,26 +623,28 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
         const int oz = nbg / TH, oy = nbg % TH;
         voxbase[nb] = (((oz * SD) * IH + oy * SH) * IW + li * SW) * SB;
     }
-    const float* xb = x + (size_t)b * D * H * W * CIN;
-    float* yb = y ? y + (size_t)b * OD * OH * OW * COUT : nullptr;
+    constexpr bool F16 = BfConv<Cfg>::F16;                           // fp16 activations in and out
+    constexpr int EB = F16 ? 2 : 4, RUNB = BfConv<Cfg>::RUNB;
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)b * D * H * W * CIN * EB;
+    char* yb = y ? reinterpret_cast<char*>(y) + (size_t)b * OD * OH * OW * COUT * EB : nullptr;
 
     constexpr int NITEM = Cfg::NVOX * OPT, NIT = (NITEM + 255) / 256;
     // MVS_PERSIST_PFD register sets: the loads of tile t + PFD are issued while tile t is contracted
     float4 su0[NIT], sv0[NIT], su1[NIT], sv1[NIT];
-    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
+    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
     auto issue = [&](int tile, float4* su, float4* sv) {
         const int tx = tile % tiles_x;
         const int t1 = tile / tiles_x;
         const int ty = t1 % tiles_y, tz = t1 / tiles_y;
         const int iz0 = tz * TD * SD - Cfg::PD, iy0 = ty * TH * SH - 1, ix0 = tx * 16 * SW - 1;
-        BfTileWalk<IW, IH, OPT> wk(tid, iz0, iy0, ix0, H, W, CIN * 4, 0u);
+        BfTileWalk<IW, IH, OPT, RUNB> wk(tid, iz0, iy0, ix0, H, W, CIN * EB, 0u);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it > 0) wk.advance();
             const bool ok = MVS_ABL != 1 && (it * 256 + 255 < NITEM || tid + it * 256 < NITEM) && wk.inside(iz0, iy0, ix0, D, H, W);
             const unsigned voff = ok ? wk.off : BF_OOB;
             su[it] = bf_buf_load16(xrs, voff, 0);
-            sv[it] = bf_buf_load16(xrs, voff, 16);
+            if constexpr (!F16) sv[it] = bf_buf_load16(xrs, voff, 16);
         }
     };
     auto process = [&](int tile, float4* su, float4* sv) {
@@ -596,7 +653,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
             const int e = tid + it * 256;
             if (e >= NITEM) break;
             const int vox = e / OPT, oc = e - vox * OPT;
-            stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, su[it], sv[it]);
+            if constexpr (F16) *reinterpret_cast<float4*>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE) = su[it];
+            else stage_to_lds<SPLIT>(ldsb + vox * SB + oc * BfConv<Cfg>::PLANE, su[it], sv[it]);
         }
         __syncthreads();
         if (tile + MVS_PERSIST_PFD < t_end) issue(tile + MVS_PERSIST_PFD, su, sv);
@@ -627,7 +685,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
                 if (g == 0 && !(MVS_ABL == 5 && acc[0][nb][0] != 12345.678f)) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = acc[0][nb][0] + bb[0].x;
                 continue;
             }
-            float* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
+            float* o = reinterpret_cast<float*>(yb + (((size_t)oz * OH + oy) * OW + ox) * COUT * EB);
 #pragma unroll
             for (int mb = 0; mb < MREP; ++mb) {
                 const int co = 16 * mb + 4 * g;
@@ -635,7 +693,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
                 float4 v = make_float4(acc[mb][nb][0] + bb[mb].x, acc[mb][nb][1] + bb[mb].y, acc[mb][nb][2] + bb[mb].z, acc[mb][nb][3] + bb[mb].w);
                 if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
                 if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-                if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
+                if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(o) + co) = f16_pack4(v);
+                else if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
                 else *reinterpret_cast<float4*>(o + co) = v;
             }
         }
@@ -663,9 +722,13 @@ struct BfDeconv {
 #ifndef MVS_DECONV_PLANES
 #define MVS_DECONV_PLANES 1
 #endif
-    static constexpr int SB = MVS_DECONV_PLANES ? 32 : Cfg::S * 4;
-    static constexpr int PLANE = MVS_DECONV_PLANES ? (Cfg::NVOX * 32 + 255) / 256 * 256 + 16 : 32;     // byte offset between octets
-    static constexpr size_t LDS_BYTES = MVS_DECONV_PLANES ? (size_t)OPT * PLANE : Cfg::LDS_BYTES;
+    // fp16 activations (F16Cfg): 16 B per voxel and octet, planes half a bank row apart (as BfConv)
+    static constexpr bool F16 = CfgFmt<Cfg>::F16;
+    static constexpr int RUNB = F16 ? 16 : 32;
+    static constexpr int SB = F16 ? 16 : (MVS_DECONV_PLANES ? 32 : Cfg::S * 4);
+    static constexpr int PLANE = F16 ? (Cfg::NVOX * 16 + 255) / 256 * 256 + 128
+                                     : (MVS_DECONV_PLANES ? (Cfg::NVOX * 32 + 255) / 256 * 256 + 16 : 32);     // byte offset between octets
+    static constexpr size_t LDS_BYTES = (F16 || MVS_DECONV_PLANES) ? (size_t)OPT * PLANE : Cfg::LDS_BYTES;
 };
 
 template <class Cfg>
@@ -693,7 +756,7 @@ __device__ __forceinline__ void bf_deconv_load_step(int st, int ntap, int pd, in
     for (int nb = 0; nb < Cfg::NREP; ++nb) {
         if (MVS_ABL == 3 && st > 1) continue;
         bh[nb] = *reinterpret_cast<const bf16x8*>(ldsb + voxbase[nb] + ldsoff);
-        bl[nb] = *reinterpret_cast<const bf16x8*>(ldsb + voxbase[nb] + ldsoff + 16);
+        if constexpr (!BfDeconv<Cfg>::F16) bl[nb] = *reinterpret_cast<const bf16x8*>(ldsb + voxbase[nb] + ldsoff + 16);
     }
 }
 
@@ -721,16 +784,23 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     const int mz0 = tz * TDM, my0 = ty * THM, mx0 = tx * 16;
     const int OD = D * SD, OH = 2 * H, OW = 2 * W;
 
-    const float* xb = x + (size_t)b * D * H * W * CIN;
+    constexpr bool F16 = BfDeconv<Cfg>::F16;                         // fp16 activations: x, skip, y are _Float16 tensors
+    constexpr int EB = F16 ? 2 : 4, RUNB = BfDeconv<Cfg>::RUNB;
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)b * D * H * W * CIN * EB;
     {
-        const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
-        BfTileWalk<LW, LH, OPT> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * 4, 0u);
+        const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
+        BfTileWalk<LW, LH, OPT, RUNB> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * EB, 0u);
         int ldso = (tid / OPT) * SB + (tid % OPT) * BfDeconv<Cfg>::PLANE;
         for (int e = tid; e < Cfg::NVOX * OPT; e += 256) {
             const bool ok = MVS_ABL != 1 && wk.inside(mz0 - Cfg::ZO, my0, mx0, D, H, W);
             const unsigned voff = ok ? wk.off : BF_OOB;
-            const float4 u = bf_buf_load16(xrs, voff, 0), v = bf_buf_load16(xrs, voff, 16);
-            stage_to_lds<SPLIT>(ldsb + ldso, u, v);
+            const float4 u = bf_buf_load16(xrs, voff, 0);
+            if constexpr (F16) {
+                *reinterpret_cast<float4*>(ldsb + ldso) = u;
+            } else {
+                const float4 v = bf_buf_load16(xrs, voff, 16);
+                stage_to_lds<SPLIT>(ldsb + ldso, u, v);
+            }
             wk.advance();
             ldso += (256 / OPT) * SB;
         }
@@ -746,8 +816,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
         const int mz = nbg / THM, my = nbg % THM;
         voxbase[nb] = (((mz + Cfg::ZO) * LH + my) * LW + li) * SB;
     }
-    float* yb = y + (size_t)b * OD * OH * OW * COUT;
-    const float* sb = skip ? skip + (size_t)b * OD * OH * OW * COUT : nullptr;
+    float* yb = reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (size_t)b * OD * OH * OW * COUT * EB);
+    const float* sb = skip ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(skip) + (size_t)b * OD * OH * OW * COUT * EB) : nullptr;
     const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + (size_t)mb0 * 2 * 64 + lane;          // advanced class by class
 
     // COUT == 8: the two x-parity classes of a (pd, ph) pair ride in one MFMA (rows 0-7: pw = 0, rows 8-15: pw = 1, tap set
@@ -773,7 +843,14 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
 #pragma unroll
                 for (int mb = 0; mb < MREP; ++mb) {
                     const int co = PAIR ? 4 * (g & 1) : 16 * (mb0 + mb) + 4 * g;
-                    const float* sv = sb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
+                    const size_t sidx = (((size_t)oz * OH + oy) * OW + ox) * COUT;
+                    const float* sv = sb + sidx;
+                    if constexpr (F16) {                             // 4 halves: kept raw in the first two dwords
+                        const float2 raw = !(inside && co < COUT) ? make_float2(0.0f, 0.0f)
+                                                                  : *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(sb) + sidx + co);
+                        skp[it][nb][mb] = make_float4(raw.x, raw.y, 0.0f, 0.0f);
+                        continue;
+                    }
                     skp[it][nb][mb] = !(inside && co < COUT) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f)
                                       : SPLIT ? split_raw_quad(sv + (co & ~7), (co >> 2) & 1) : *reinterpret_cast<const float4*>(sv + co);
                 }
@@ -798,12 +875,12 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
         for (int st = 0; st + 1 < nst; st += 2) {
             bf_deconv_load_step<Cfg>(st + 1, ntap, pd, ph, pw, g, wq, ldsb, voxbase, ah1, al1, bh1, bl1);
             __builtin_amdgcn_sched_barrier(0);
-            bf_mfma_step<MREP, NREP>(ah0, al0, bh0, bl0, acc);
+            bf_mfma_step<MREP, NREP, F16>(ah0, al0, bh0, bl0, acc);
             bf_deconv_load_step<Cfg>(st + 2 < nst ? st + 2 : nst - 1, ntap, pd, ph, pw, g, wq, ldsb, voxbase, ah0, al0, bh0, bl0);
             __builtin_amdgcn_sched_barrier(0);
-            bf_mfma_step<MREP, NREP>(ah1, al1, bh1, bl1, acc);
+            bf_mfma_step<MREP, NREP, F16>(ah1, al1, bh1, bl1, acc);
         }
-        if (nst & 1) bf_mfma_step<MREP, NREP>(ah0, al0, bh0, bl0, acc);
+        if (nst & 1) bf_mfma_step<MREP, NREP, F16>(ah0, al0, bh0, bl0, acc);
         prio_contract_end();
         wq += (size_t)nst * MREP_ALL * 2 * 64;
 
@@ -821,7 +898,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 float4 v = make_float4(fmaxf(acc[0][nb][0] + bb.x, lo_clamp), fmaxf(acc[0][nb][1] + bb.y, lo_clamp), fmaxf(acc[0][nb][2] + bb.z, lo_clamp),
                                        fmaxf(acc[0][nb][3] + bb.w, lo_clamp));
                 if (sb && inside) {
-                    const float4 sk = SPLIT ? split_join_quad(skp[it][nb][0]) : skp[it][nb][0];
+                    const float4 sk = F16 ? f16_quad_to_f32(skp[it][nb][0]) : SPLIT ? split_join_quad(skp[it][nb][0]) : skp[it][nb][0];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 if (prob_w != nullptr) {
@@ -834,6 +911,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                     part += v.w * pw4.w;
                     part += __shfl_xor(part, 16);
                     if ((g & 1) == 0 && inside && !(MVS_ABL == 5 && part != 12345.678f)) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = part + prob_b[0];
+                } else if (F16) {
+                    if (inside) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + off) = f16_pack4(v);
                 } else if (SPLIT) {
                     split_store_quad(yb + off - co, g, v, inside);
                 } else {
@@ -851,11 +930,12 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                 float4 v = make_float4(fmaxf(acc[mb][nb][0] + bb.x, lo_clamp), fmaxf(acc[mb][nb][1] + bb.y, lo_clamp),
                                        fmaxf(acc[mb][nb][2] + bb.z, lo_clamp), fmaxf(acc[mb][nb][3] + bb.w, lo_clamp));
                 if (sb) {
-                    const float4 sk = SPLIT ? split_join_quad(skp[it][nb][mb]) : skp[it][nb][mb];
+                    const float4 sk = F16 ? f16_quad_to_f32(skp[it][nb][mb]) : SPLIT ? split_join_quad(skp[it][nb][mb]) : skp[it][nb][mb];
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-                if (SPLIT) split_store_quad(yb + off + (co & ~7), g, v, inside && co < COUT);
+                if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + off + co) = f16_pack4(v);
+                else if (SPLIT) split_store_quad(yb + off + (co & ~7), g, v, inside && co < COUT);
                 else *reinterpret_cast<float4*>(yb + off + co) = v;
             }
         }
@@ -873,8 +953,9 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
 // ------------------------------------------------------------------------------------------------
 template <class Cfg>
 struct BfDeconvP {
-    static constexpr int OPT = 2, SB = 32;
-    static constexpr int PLANE = (Cfg::NVOX * 32 + 255) / 256 * 256 + 16;
+    static constexpr bool F16 = CfgFmt<Cfg>::F16;                                  // fp16 activations: 16 B per voxel and octet
+    static constexpr int OPT = 2, SB = F16 ? 16 : 32, RUNB = SB;
+    static constexpr int PLANE = F16 ? (Cfg::NVOX * 16 + 255) / 256 * 256 + 128 : (Cfg::NVOX * 32 + 255) / 256 * 256 + 16;
     static constexpr int XBYTES = (2 * PLANE + 255) / 256 * 256;
     static constexpr int NIT = (Cfg::SD == 2 ? 2 : 1) * 2;                         // (pd, ph) pairs; both x parities ride in one MFMA
     static constexpr int ntap(int it) { return ((Cfg::SD == 2) ? ((it >> 1) ? 2 : 1) : 3) * ((it & 1) ? 2 : 1) * 2; }
@@ -918,7 +999,7 @@ __device__ __forceinline__ void bfd_load_step(int g, int lane, const char* ldsx,
 #pragma unroll
     for (int nb = 0; nb < Cfg::NREP; ++nb) {
         bh[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB);
-        bl[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB + 16);
+        if constexpr (!P::F16) bl[nb] = *reinterpret_cast<const bf16x8*>(p + nb * ROWB + 16);
     }
 }
 
@@ -933,8 +1014,8 @@ struct BfDeconvSteps {
                 else bfd_load_step<Cfg, IT, T + 1>(g, lane, ldsx, ldsw, voxbase0, a0[0], a0[1], bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<1, Cfg::NREP>(&a0[0], &a0[1], bh0, bl0, acc);
-            else bf_mfma_step<1, Cfg::NREP>(&a1[0], &a1[1], bh1, bl1, acc);
+            if constexpr ((T & 1) == 0) bf_mfma_step<1, Cfg::NREP, CfgFmt<Cfg>::F16>(&a0[0], &a0[1], bh0, bl0, acc);
+            else bf_mfma_step<1, Cfg::NREP, CfgFmt<Cfg>::F16>(&a1[0], &a1[1], bh1, bl1, acc);
             BfDeconvSteps<Cfg, IT, T + 1>::run(g, lane, ldsx, ldsw, voxbase0, acc, a0, bh0, bl0, a1, bh1, bl1);
         }
     }
@@ -965,9 +1046,11 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
     // packed weights of all classes -> LDS, once per block
     for (int e = tid; e < P::WBYTES / 16; e += 256) reinterpret_cast<float4*>(ldsw)[e] = reinterpret_cast<const float4*>(wp)[e];
 
-    const float* xb = x + (size_t)b * D * H * W * CIN;
-    float* yb = y ? y + (size_t)b * OD * OH * OW * COUT : nullptr;
-    const float* sb = skip ? skip + (size_t)b * OD * OH * OW * COUT : nullptr;
+    constexpr bool F16 = P::F16;                                     // fp16 activations: x, skip, y are _Float16 tensors
+    constexpr int EB = F16 ? 2 : 4;
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)b * D * H * W * CIN * EB;
+    float* yb = y ? reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (size_t)b * OD * OH * OW * COUT * EB) : nullptr;
+    const float* sb = skip ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(skip) + (size_t)b * OD * OH * OW * COUT * EB) : nullptr;
     const int co = 4 * (g & 1);                                             // lane groups 0/1: channels 0-3 / 4-7 of output voxel 2mx; 2/3: of 2mx + 1
     const float4 bb = *reinterpret_cast<const float4*>(bias + co);
     const bool head = prob_w != nullptr;
@@ -984,20 +1067,20 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
 
     constexpr int NITEM = Cfg::NVOX * OPT, NITX = (NITEM + 255) / 256;
     float4 su[NITX], sv[NITX];
-    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4));
+    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
     auto issue_x = [&](int tile) {
         const int tx = tile % tiles_x;
         const int t1 = tile / tiles_x;
         const int ty = t1 % tiles_y, tz = t1 / tiles_y;
         const int mz0 = tz * TDM, my0 = ty * THM, mx0 = tx * 16;
-        BfTileWalk<LW, LH, OPT> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * 4, 0u);
+        BfTileWalk<LW, LH, OPT, P::RUNB> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * EB, 0u);
 #pragma unroll
         for (int it = 0; it < NITX; ++it) {
             if (it > 0) wk.advance();
             const bool ok = MVS_ABL != 1 && (it * 256 + 255 < NITEM || tid + it * 256 < NITEM) && wk.inside(mz0 - Cfg::ZO, my0, mx0, D, H, W);
             const unsigned voff = ok ? wk.off : BF_OOB;
             su[it] = bf_buf_load16(xrs, voff, 0);
-            sv[it] = bf_buf_load16(xrs, voff, 16);
+            if constexpr (!F16) sv[it] = bf_buf_load16(xrs, voff, 16);
         }
     };
     float4 skp[NIT][NREP];
@@ -1016,6 +1099,11 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                 const bool inside = mz < D && my < H && mx < W;
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1);
                 const size_t vbase = inside ? (((size_t)oz * OH + oy) * OW + ox) * COUT : 0;
+                if constexpr (F16) {                                 // 4 halves, raw in the first two dwords
+                    const float2 raw = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(sb) + vbase + co);
+                    skp[it][nb] = inside ? make_float4(raw.x, raw.y, 0.0f, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    continue;
+                }
                 const float4 sk = SPLIT ? split_raw_quad(sb + vbase, co >> 2) : *reinterpret_cast<const float4*>(sb + vbase + co);
                 skp[it][nb] = inside ? sk : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
@@ -1029,7 +1117,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
             const int e = tid + it * 256;
             if (e >= NITEM) break;
             const int vox = e / OPT, oc = e - vox * OPT;
-            stage_to_lds<SPLIT>(ldsx + vox * SB + oc * P::PLANE, su[it], sv[it]);
+            if constexpr (F16) *reinterpret_cast<float4*>(ldsx + vox * SB + oc * P::PLANE) = su[it];
+            else stage_to_lds<SPLIT>(ldsx + vox * SB + oc * P::PLANE, su[it], sv[it]);
         }
         __syncthreads();
         if (tile + 1 < t_end) issue_x(tile + 1);
@@ -1070,7 +1159,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                 const int oz = mz * SD + pd, oy = 2 * my + ph, ox = 2 * mx + (g >> 1);
                 float4 v = outv[it][nb];
                 if (sb) {
-                    const float4 sk = SPLIT ? split_join_quad(skp[it][nb]) : skp[it][nb];      // an all-zero raw quad joins to zero
+                    const float4 sk = F16 ? f16_quad_to_f32(skp[it][nb]) : SPLIT ? split_join_quad(skp[it][nb]) : skp[it][nb];      // an all-zero raw quad joins to zero
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 if (head) {
@@ -1081,6 +1170,9 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                     part += __shfl_xor(part, 16);                            // the voxel's other four channels (every lane takes part)
                     if ((g & 1) == 0 && inside && !(MVS_ABL == 5 && part != 12345.678f))
                         logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = part + pb;
+                } else if (F16) {
+                    if (inside) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + (((size_t)oz * OH + oy) * OW + ox) * COUT + co) =
+                        f16_pack4(v);
                 } else if (SPLIT) {
                     split_store_quad(yb + (((size_t)oz * OH + oy) * OW + ox) * COUT, g, v, inside);
                 } else if (inside && !(MVS_ABL == 5 && v.x != 12345.678f)) {
@@ -1177,6 +1269,7 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW) {                    \
         typedef typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type K;              \
+        if (split == 2) return launch_conv_bf<F16Cfg<K>, false>(x, wp, bias, y, B, D, H, W, relu, st, logits);   \
         return split ? launch_conv_bf<K, true>(x, wp, bias, y, B, D, H, W, relu, st, logits)          \
                      : launch_conv_bf<K, false>(x, wp, bias, y, B, D, H, W, relu, st, logits);        \
     }
@@ -1192,6 +1285,7 @@ int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, 
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
     if (Cin == CI && Cout == CO && sd == SD) {                                                          \
         typedef typename BfDeconvSplitOf<DeconvCfg<CI, CO, SD, TDM, THM>>::type K;                      \
+        if (split == 2) return launch_deconv_bf<F16Cfg<K>, false>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);      \
         return split ? launch_deconv_bf<K, true>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu)    \
                      : launch_deconv_bf<K, false>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);  \
     }

@@ -336,8 +336,9 @@ static int launch_deconv(const float* x, const float* wp, const float* bias, con
 
 int conv3d_dispatch(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
                     int sd, int sh, int sw, int relu, int prec, hipStream_t st) {
-    if (prec == MVS_PREC_BF16X3 || prec == MVS_PREC_BF16X3_SPLIT)
-        return conv3d_dispatch_bf16x3(x, wp, bias, y, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, st, nullptr, prec == MVS_PREC_BF16X3_SPLIT);
+    if (prec == MVS_PREC_BF16X3 || prec == MVS_PREC_BF16X3_SPLIT || prec == MVS_PREC_F16X2)
+        return conv3d_dispatch_bf16x3(x, wp, bias, y, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, st, nullptr,
+                                      prec == MVS_PREC_F16X2 ? 2 : (prec == MVS_PREC_BF16X3_SPLIT ? 1 : 0));
     if (prec != MVS_PREC_FP32) { set_error("conv3d: unknown precision %d", prec); return MVS_ERR_ARG; }
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW)                      \
@@ -351,8 +352,9 @@ int conv3d_dispatch(const float* x, const void* wp, const float* bias, float* y,
 int deconv3d_dispatch(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout, int D,
                       int H, int W, int sd, int prec, hipStream_t st, const float* prob_w = nullptr, const float* prob_b = nullptr,
                       float* logits = nullptr) {
-    if (prec == MVS_PREC_BF16X3 || prec == MVS_PREC_BF16X3_SPLIT)
-        return deconv3d_dispatch_bf16x3(x, wp, bias, skip, y, B, Cin, Cout, D, H, W, sd, st, prob_w, prob_b, logits, 1, prec == MVS_PREC_BF16X3_SPLIT);
+    if (prec == MVS_PREC_BF16X3 || prec == MVS_PREC_BF16X3_SPLIT || prec == MVS_PREC_F16X2)
+        return deconv3d_dispatch_bf16x3(x, wp, bias, skip, y, B, Cin, Cout, D, H, W, sd, st, prob_w, prob_b, logits, 1,
+                                        prec == MVS_PREC_F16X2 ? 2 : (prec == MVS_PREC_BF16X3_SPLIT ? 1 : 0));
     if (prob_w != nullptr) { set_error("deconv3d: the fused prob head exists for the bf16x3 contraction only"); return MVS_ERR_UNSUPPORTED; }
     if (prec != MVS_PREC_FP32) { set_error("deconv3d: unknown precision %d", prec); return MVS_ERR_ARG; }
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
@@ -384,8 +386,9 @@ extern "C" int mvs_deconv3d_linear_fwd(const float* x_cl, const void* w_packed, 
 extern "C" int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* bias, float* logits, int B, int D, int H, int W,
                                      int precision, void* stream) {
     if (!x_cl || !w_packed || !bias || !logits || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_conv3d_logits_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (precision != MVS_PREC_BF16X3 && precision != MVS_PREC_BF16X3_SPLIT) { set_error("mvs_conv3d_logits_fwd: only MVS_PREC_BF16X3 / _SPLIT (use mvs_prob_regress_fwd for the exact-fp32 head)"); return MVS_ERR_UNSUPPORTED; }
-    return conv3d_dispatch_bf16x3(x_cl, w_packed, bias, nullptr, B, 8, 16, D, H, W, 3, 1, 1, 1, 0, (hipStream_t)stream, logits, precision == MVS_PREC_BF16X3_SPLIT);
+    if (precision != MVS_PREC_BF16X3 && precision != MVS_PREC_BF16X3_SPLIT && precision != MVS_PREC_F16X2) { set_error("mvs_conv3d_logits_fwd: only MVS_PREC_BF16X3 / _SPLIT / MVS_PREC_F16X2 (use mvs_prob_regress_fwd for the exact-fp32 head)"); return MVS_ERR_UNSUPPORTED; }
+    return conv3d_dispatch_bf16x3(x_cl, w_packed, bias, nullptr, B, 8, 16, D, H, W, 3, 1, 1, 1, 0, (hipStream_t)stream, logits,
+                                  precision == MVS_PREC_F16X2 ? 2 : (precision == MVS_PREC_BF16X3_SPLIT ? 1 : 0));
 }
 
 extern "C" int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const void* w_packed, const float* bias, const float* skip_cl, float* y_cl,
@@ -506,7 +509,7 @@ extern "C" int mvs_regnet_logits_fwd(int kind, const float* volume_cl, const voi
                                      const float* prob_w, const float* prob_b, float* logits, void* workspace, size_t workspace_bytes, int B,
                                      int D, int H, int W, int precision, void* stream) {
     if (!prob_w || !prob_b || !logits) { set_error("mvs_regnet_logits_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (precision != MVS_PREC_BF16X3 && precision != MVS_PREC_BF16X3_SPLIT) { set_error("mvs_regnet_logits_fwd: the fused 1x1x1 head exists for MVS_PREC_BF16X3 / _SPLIT only"); return MVS_ERR_UNSUPPORTED; }
+    if (precision != MVS_PREC_BF16X3 && precision != MVS_PREC_BF16X3_SPLIT && precision != MVS_PREC_F16X2) { set_error("mvs_regnet_logits_fwd: the fused 1x1x1 head exists for MVS_PREC_BF16X3 / _SPLIT / MVS_PREC_F16X2 only"); return MVS_ERR_UNSUPPORTED; }
     return regnet_run(kind, volume_cl, w_packed, bias, nullptr, prob_w, prob_b, logits, workspace, workspace_bytes, B, D, H, W, precision, stream,
                       "mvs_regnet_logits_fwd");
 }

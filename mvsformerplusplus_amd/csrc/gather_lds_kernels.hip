@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     if (vis_sum != nullptr && it == 0 && t.slot == 0 && t.valid) vis_sum[(size_t)b * HW + t.pc] = vsum;
     const float rdenom = (normalise & 1) ? 1.0f / (vsum + 1e-6f) : 1.0f;                          // cost_volume.py:101
     const bool split_out = (normalise & 2) != 0;                 // volume in the split activation format of the bf16x3 U-Net
+    const bool f16_out = (normalise & 4) != 0;                   // volume as fp16 [D,HW,8] (MVS_PREC_F16X2 U-Net), clamped to the fp16 range
     const float inv_cpg = 1.0f / (float)NOCT;
     float rf0[8];                                               // C = 8: the pixel's reference features, once per block
     if (NOCT == 1) gl_load8<TILED, T>(ref, HW, t.pc, rf0);
@@ -358,6 +359,14 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
             float r[8];
 #pragma unroll
             for (int g = 0; g < 8; ++g) r[g] = acc[g * GL_DCH + dd] * rdenom;
+            if (f16_out) {
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                h8 hv;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f);
+                *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(vol) + ((size_t)b * D * HW + (size_t)(unsigned)(d0 + dd) * HW + t.pc) * 8) = hv;
+                continue;
+            }
             f32x4* o = reinterpret_cast<f32x4*>(vb + ((size_t)(unsigned)(d0 + dd) * HW + t.pc) * 8);
             if (split_out) {                                    // [hi x8 | lo x8] bf16: the same 32 bytes (conv_bf16x3_kernels.hip)
                 unsigned hw[4], lw[4];

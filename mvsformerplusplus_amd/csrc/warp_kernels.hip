@@ -382,6 +382,22 @@ __global__ void volume_normalise_kernel(float* __restrict__ vol, const float* __
     }
 }
 
+// fp32 channel-last volume [.., 8] -> fp16 [.., 8] in a SEPARATE buffer (MVS_PREC_F16X2 U-Net), optionally normalising by the summed
+// visibility first; clamped to the fp16 range.  Out of place: a compacting in-place conversion would race between work-items.
+__global__ void volume_to_f16_kernel(const float* __restrict__ vol, const float* __restrict__ vis_sum, _Float16* __restrict__ out, int D, int HW, size_t nvox) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    for (size_t vox = (size_t)blockIdx.x * blockDim.x + threadIdx.x; vox < nvox; vox += (size_t)gridDim.x * blockDim.x) {
+        const float4* q = reinterpret_cast<const float4*>(vol + vox * 8);
+        const float4 a = q[0], c = q[1];
+        float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        const float den = vis_sum != nullptr ? vis_sum[(vox / ((size_t)D * HW)) * HW + vox % HW] + 1e-6f : 1.0f;
+        h8 hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)fminf(fmaxf(vis_sum != nullptr ? x[j] / den : x[j], -65504.0f), 65504.0f);
+        *reinterpret_cast<h8*>(out + vox * 8) = hv;
+    }
+}
+
 // fp32 channel-last volume [.., 8] -> the split activation format of MVS_PREC_BF16X3_SPLIT (per voxel [hi x8 | lo x8] bf16), in
 // place (same 32 bytes per voxel), optionally normalising by the summed visibility first (the view-sharded multi-GPU path)
 __global__ void volume_to_split_kernel(float* __restrict__ vol, const float* __restrict__ vis_sum, int D, int HW, size_t nvox) {
@@ -641,9 +657,9 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int 
     if (rc != MVS_OK) return rc;
     if (!vis || !volume_cl) { set_error("mvs_warp_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
     if (!normalise && !vis_sum) { set_error("mvs_warp_corr_aggregate_fwd: partial mode needs vis_sum"); return MVS_ERR_ARG; }
-    if (volume_format != MVS_VOLUME_F32 && volume_format != MVS_VOLUME_SPLIT) { set_error("mvs_warp_corr_aggregate_fwd: unknown volume format %d", volume_format); return MVS_ERR_ARG; }
-    if (volume_format == MVS_VOLUME_SPLIT && (!normalise || G != 8)) {
-        set_error("mvs_warp_corr_aggregate_fwd: the split volume format holds the NORMALISED volume of 8 groups (partial sums stay fp32)");
+    if (volume_format != MVS_VOLUME_F32 && volume_format != MVS_VOLUME_SPLIT && volume_format != MVS_VOLUME_F16) { set_error("mvs_warp_corr_aggregate_fwd: unknown volume format %d", volume_format); return MVS_ERR_ARG; }
+    if (volume_format != MVS_VOLUME_F32 && (!normalise || G != 8)) {
+        set_error("mvs_warp_corr_aggregate_fwd: the split / fp16 volume formats hold the NORMALISED volume of 8 groups (partial sums stay fp32)");
         return MVS_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -652,6 +668,11 @@ extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int 
     const int impl = gather_impl(C, G, D, H, W);
     if (layout == MVS_LAYOUT_OCTET_TILED || impl == 1)
         return gl_launch_aggregate(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise | (volume_format << 1), B, V, C, D, H, W, view_begin, view_end, st);
+    if (volume_format == MVS_VOLUME_F16) {
+        set_error("mvs_warp_corr_aggregate_fwd: the fp16 volume is written by the LDS-staged gather only (C in {8,16,32,64}, W %% 8 == 0); "
+                  "for other shapes aggregate in MVS_VOLUME_F32 and convert with mvs_volume_to_f16");
+        return MVS_ERR_UNSUPPORTED;
+    }
     if (volume_format == MVS_VOLUME_SPLIT) {                // shapes outside the LDS-staged fast path: fp32 volume, converted in place
         rc = mvs_warp_corr_aggregate_fwd(features, dtype, layout, homography, hyp, vis, volume_cl, vis_sum, normalise, MVS_VOLUME_F32, B, V, C, G, D, H, W,
                                          view_begin, view_end, stream);
@@ -709,6 +730,19 @@ extern "C" int mvs_slab_reduce(const float* volume_cl, const float* vis_sum, flo
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, volume_cl, vis_sum, m, my_rank, slab_out, row_begin, row_end, B, D, H,
                        W);
     return check_launch("slab_reduce_kernel");
+}
+
+extern "C" int mvs_gather_is_lds_staged(int layout, int C, int G, int D, int H, int W) {
+    return (layout == MVS_LAYOUT_OCTET_TILED || gather_impl(C, G, D, H, W) == 1) ? 1 : 0;
+}
+
+extern "C" int mvs_volume_to_f16(const float* volume_cl, const float* vis_sum, void* out_f16, int B, int D, int H, int W, int G, void* stream) {
+    if (!volume_cl || !out_f16 || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_volume_to_f16: bad arguments"); return MVS_ERR_ARG; }
+    if (G != 8) { set_error("mvs_volume_to_f16: the fp16 volume format needs 8 groups"); return MVS_ERR_UNSUPPORTED; }
+    const size_t nvox = (size_t)B * D * H * W;
+    const unsigned grid = (unsigned)((nvox + 255) / 256 > 16384 ? 16384 : (nvox + 255) / 256);
+    hipLaunchKernelGGL(volume_to_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, volume_cl, vis_sum, static_cast<_Float16*>(out_f16), D, H * W, nvox);
+    return check_launch("volume_to_f16_kernel");
 }
 
 extern "C" int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, int volume_format, void* stream) {

@@ -164,20 +164,22 @@ def vis_out(x_cl8: torch.Tensor, w4: torch.Tensor, b4: torch.Tensor, shape) -> t
 
 
 def warp_corr_aggregate(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, vis: torch.Tensor,
-                        G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None, split: bool = False):
+                        G: int, normalise: bool = True, view_begin: int = 1, view_end: Optional[int] = None, out=None, split: bool = False,
+                        f16: bool = False):
     """-> (volume_cl [B,D,H,W,G], vis_sum [B,H,W] or None).  `out` = preallocated (volume, vis_sum) to fill.
-    split: leave the (normalised, G = 8) volume in the split activation format of the bf16x3 U-Net (to_split / from_split)."""
+    split: leave the (normalised, G = 8) volume in the split activation format of the bf16x3 U-Net (to_split / from_split);
+    f16: write it as fp16 (the cost volume of the MVS_PREC_F16X2 U-Net; LDS-staged gather shapes only)."""
     B, V, Cc, H, W = features.shape
     D = hyp.shape[1]
     view_end = V if view_end is None else view_end
     if out is not None:
         vol, vsum = out
     else:
-        vol = torch.empty(B, D, H, W, G, dtype=torch.float32, device=features.device)
+        vol = torch.empty(B, D, H, W, G, dtype=torch.float16 if f16 else torch.float32, device=features.device)
         vsum = None if normalise else torch.empty(B, H, W, dtype=torch.float32, device=features.device)
     ft, layout = _feat_ptr(features)
     check(lib().mvs_warp_corr_aggregate_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(vis), ptr(vol), ptr(vsum),
-                                            1 if normalise else 0, _lib.VOLUME_SPLIT if split else _lib.VOLUME_F32, B, V, Cc, G, D, H, W,
+                                            1 if normalise else 0, _lib.VOLUME_F16 if f16 else (_lib.VOLUME_SPLIT if split else _lib.VOLUME_F32), B, V, Cc, G, D, H, W,
                                             view_begin, view_end, stream_of(ft)), "mvs_warp_corr_aggregate_fwd")
     return vol, vsum
 
@@ -200,6 +202,21 @@ def volume_normalise_(vol_cl: torch.Tensor, vis_sum: torch.Tensor, split: bool =
     check(lib().mvs_volume_normalise(ptr(vol_cl), ptr(vis_sum), B, D, H, W, G, _lib.VOLUME_SPLIT if split else _lib.VOLUME_F32,
                                      stream_of(vol_cl)), "mvs_volume_normalise")
     return vol_cl
+
+
+def gather_is_lds_staged(features, G: int, hyp: torch.Tensor) -> bool:
+    """Do the gather passes take the LDS-staged kernels for this call (they alone write the split / fp16 volume directly)?"""
+    B, V, Cc, H, W = features.shape
+    _, layout = _feat_ptr(features)
+    return bool(lib().mvs_gather_is_lds_staged(layout, Cc, G, hyp.shape[1], H, W))
+
+
+def volume_to_f16(vol_cl: torch.Tensor, vis_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 volume [B,D,H,W,8] (divided by vis_sum + 1e-6 first when given) -> fp16 in a new buffer, clamped to the fp16 range."""
+    B, D, H, W, G = vol_cl.shape
+    out = torch.empty(B, D, H, W, G, dtype=torch.float16, device=vol_cl.device)
+    check(lib().mvs_volume_to_f16(ptr(vol_cl), ptr(vis_sum), ptr(out), B, D, H, W, G, stream_of(vol_cl)), "mvs_volume_to_f16")
+    return out
 
 
 def slab_pack(vol_cl: torch.Tensor, vis_sum: torch.Tensor, send_bufs, rows) -> None:
@@ -246,13 +263,21 @@ def from_split(s_cl: torch.Tensor) -> torch.Tensor:
 
 
 # ---- a7-a9 --------------------------------------------------------------------------------------
+def _act_dtype(x_cl: torch.Tensor, precision: int):
+    """Element type of the activation tensors of a call: fp16 for MVS_PREC_F16X2, fp32 (plain or split pairs) otherwise."""
+    want = torch.float16 if precision == _lib.PREC_F16X2 else torch.float32
+    if x_cl.dtype != want:
+        raise _lib.MvsHipError("precision %d takes %s activations, got %s" % (precision, want, x_cl.dtype))
+    return want
+
+
 def conv3d_bn_relu(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, kd: int,
                    stride: Tuple[int, int, int], relu: bool = True, precision: int = 0) -> torch.Tensor:
     B, D, H, W, cin = x_cl.shape
     sd, sh, sw = stride
     pd = kd // 2
     od, oh, ow = (D + 2 * pd - kd) // sd + 1, (H - 1) // sh + 1, (W - 1) // sw + 1
-    y = torch.empty(B, od, oh, ow, cout, dtype=torch.float32, device=x_cl.device)
+    y = torch.empty(B, od, oh, ow, cout, dtype=_act_dtype(x_cl, precision), device=x_cl.device)
     check(lib().mvs_conv3d_bn_relu_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(y), B, cin, cout, D, H, W, kd, sd, sh, sw,
                                        1 if relu else 0, precision, stream_of(x_cl)), "mvs_conv3d_bn_relu_fwd")
     return y
@@ -261,9 +286,9 @@ def conv3d_bn_relu(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tenso
 def deconv3d_bn_relu_add(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, sd: int,
                          skip_cl: Optional[torch.Tensor] = None, precision: int = 0) -> torch.Tensor:
     B, D, H, W, cin = x_cl.shape
-    y = torch.empty(B, D * sd, 2 * H, 2 * W, cout, dtype=torch.float32, device=x_cl.device)
+    y = torch.empty(B, D * sd, 2 * H, 2 * W, cout, dtype=_act_dtype(x_cl, precision), device=x_cl.device)
     if skip_cl is not None:
-        assert tuple(skip_cl.shape) == tuple(y.shape), "skip tensor shape mismatch"
+        assert tuple(skip_cl.shape) == tuple(y.shape) and skip_cl.dtype == y.dtype, "skip tensor shape / dtype mismatch"
     check(lib().mvs_deconv3d_bn_relu_add_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(skip_cl), ptr(y), B, cin, cout, D, H, W,
                                              sd, precision, stream_of(x_cl)), "mvs_deconv3d_bn_relu_add_fwd")
     return y

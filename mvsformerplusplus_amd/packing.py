@@ -72,6 +72,25 @@ def _split_bf16(x: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo])
 
 
+def _split_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [...] -> fp16 [2, ...] with x ~= hi + lo (22 significant bits; lo flushes below 6e-8): operands of the f16x2 kernels,
+    viewed as bf16 so that the packers below stay dtype-agnostic (2-byte elements, bit pattern preserved)."""
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    return torch.stack([hi, lo]).view(torch.bfloat16)
+
+
+def f16x2(packer, *args):
+    """Run one of the pack_*_bf16x3 functions with the fp16 hi + lo split instead of the bf16 one (MVS_PREC_F16X2)."""
+    global _split_bf16
+    keep = _split_bf16
+    _split_bf16 = _split_f16
+    try:
+        return packer(*args)
+    finally:
+        _split_bf16 = keep
+
+
 def pack_conv_weights_bf16x3(w: torch.Tensor, ch: int) -> torch.Tensor:
     """w [Cout, Cin, kd, 3, 3] (BN folded) -> bf16 1-D tensor for ``conv3d_mfma_bf16x3_kernel``:
 

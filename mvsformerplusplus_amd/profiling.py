@@ -160,10 +160,10 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, isinstance(feats, ops.PackedFeatures)), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
                      lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
         vp = net._vis_params(feats.device)
-        prec = _lib.PRECISIONS[net.conv_precision]
+        prec = _lib.PRECISIONS[net._vis_precision()]
         N = B * (V - 1)
         vis_flops = 2.0 * N * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8)
-        if net.conv_precision == "bf16x3":
+        if net._vis_precision() == "bf16x3":
             # one row-streaming launch; algorithmic traffic = entropy in + visibility out
             vis = _timed(launches, "vis_cnn_kernel", s, vis_flops, 4.0 * N * HW * 2, lambda: ops.vis_weight(ent, vp, prec))
         else:
@@ -178,7 +178,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
         vol = _timed(launches, gather_kernel_name("aggregate", code, C, D, W, isinstance(feats, ops.PackedFeatures)), s, corr_flops,
                      B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
-                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8, split=net._split_activations())[0])
+                     lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8, split=net._split_activations(), f16=net._f16_activations())[0])
         split = net._split_activations()
         if getattr(net.cost_reg, "kind", None) == "transformer":
             pos = None
@@ -193,7 +193,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             confs.append(r3[1])
             continue
         ks = net.cost_reg.prob_ksize
-        if ks == 1 and net.conv_precision == "bf16x3" and net.fuse_prob_head:
+        if ks == 1 and net.conv_precision in ("bf16x3", "f16x2") and net.fuse_prob_head:
             logits = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, fused_head=True, split=split)
             r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * (3 * D * HW + 2 * HW),
                         lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
@@ -202,7 +202,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             continue
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, split=split)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
-        if ks == 3 and net.conv_precision == "bf16x3":
+        if ks == 3 and net.conv_precision in ("bf16x3", "f16x2"):
             logits = _timed(launches, "conv3d_mfma<8,1,k3,s111> prob head", s, 2.0 * B * D * HW * 8 * 27, 4.0 * B * (8 * D * HW + D * HW),
                             lambda: ops.conv3d_logits(feat_cl, prob_w, prob_b, _lib.PREC_BF16X3_SPLIT if split else _lib.PRECISIONS[net.conv_precision]))
             r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * (3 * D * HW + 2 * HW),

@@ -171,6 +171,25 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
 
+// v_mfma_f32_16x16x32_f16: the same lane maps with fp16 operands (products of two fp16 values are exact in fp32)
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c, int, int, int) {
+    struct AB { hipemu_f16x8 a, b; } mine{a, b}, all[64];
+    hipemu::wave_gather(&mine, all, sizeof(AB));
+    const int l = hipemu::lane_id(), col = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < 8; ++j) acc += (float)all[row + 16 * k].a[j] * (float)all[col + 16 * k].b[j];
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_f32_16x16x32_f16
+static inline float hipemu_fmed3f(float a, float b, float c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
+#define __builtin_amdgcn_fmed3f hipemu_fmed3f
+
 static inline int hipemu_readfirstlane(int v) {
     int all[64];
     hipemu::wave_gather(&v, all, sizeof(int));

@@ -441,6 +441,72 @@ def case_split_format(device):
     assert torch.equal(vn.view(torch.int32), ops.to_split(cpu(ops.volume_normalise_(part.clone(), vsum))).view(torch.int32)), "normalise: split volume"
 
 
+def case_f16_layers(device):
+    """MVS_PREC_F16X2 (fp16 activations, fp16 hi + lo weights, two MFMA terms): every convolution of the U-Nets against torch's float64
+    conv on the SAME fp16-rounded input - what remains is the fp32 accumulation order and the rounding of the fp16 result (2^-11)."""
+    import torch.nn.functional as F
+    from mvsformerplusplus_amd import _lib
+    g = torch.Generator().manual_seed(41)
+    P4 = _lib.PREC_F16X2
+    for ci, co, stride in F16_CONVS:
+        xx = (torch.randn(2, 6, 10, 20, ci, generator=g)).half()
+        w = torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1
+        bias = torch.randn(64, generator=g)
+        wp = dev(packing.f16x2(packing.pack_conv_weights_bf16x3, w, packing.conv_chunk(ci, stride)), device)
+        ref = F.relu(F.conv3d(xx.permute(0, 4, 1, 2, 3).double(), w.double(), bias[:co].double(), stride=stride, padding=1)).permute(0, 2, 3, 4, 1)
+        y = cpu(ops.conv3d_bn_relu(dev(xx, device), wp, dev(bias, device), co, 3, stride, True, P4))
+        assert y.dtype == torch.float16 and y.shape == ref.shape
+        assert (y.double() - ref).abs().max() <= 1.5e-3 * max(1.0, float(ref.abs().max())), ("conv", ci, co, stride, float((y.double() - ref).abs().max()))
+    for ci, co, sd in ((64, 32, 2), (32, 16, 2), (16, 8, 2), (64, 32, 1), (32, 16, 1), (16, 8, 1)):
+        xx = torch.randn(2, 3, 6, 20, ci, generator=g).half()
+        w = torch.randn(ci, co, 3, 3, 3, generator=g) * 0.1
+        bias = torch.randn(64, generator=g)
+        wp = dev(packing.f16x2(packing.pack_deconv_weights_bf16x3, w, sd), device)
+        skip = torch.randn(2, 3 * sd, 12, 40, co, generator=g).half()
+        for sk in (None, skip):
+            ref = F.relu(F.conv_transpose3d(xx.permute(0, 4, 1, 2, 3).double(), w.double(), bias[:co].double(), stride=(sd, 2, 2), padding=1,
+                                            output_padding=(sd - 1, 1, 1))).permute(0, 2, 3, 4, 1)
+            if sk is not None:
+                ref = ref + sk.double()
+            y = cpu(ops.deconv3d_bn_relu_add(dev(xx, device), wp, dev(bias, device), co, sd, None if sk is None else dev(sk, device), P4))
+            assert y.dtype == torch.float16
+            assert (y.double() - ref).abs().max() <= 1.5e-3 * max(1.0, float(ref.abs().max())), ("deconv", ci, co, sd, sk is not None)
+    # Cin = 8 layers (persistent kernels) and the two heads
+    for stride in ((2, 2, 2), (1, 2, 2)):
+        xx = torch.randn(2, 6, 10, 24, 8, generator=g).half()
+        w = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.1
+        bias = torch.randn(64, generator=g)
+        wp = dev(packing.f16x2(packing.pack_conv_weights_bf16x3, w, packing.conv_chunk(8, stride)), device)
+        ref = F.relu(F.conv3d(xx.permute(0, 4, 1, 2, 3).double(), w.double(), bias[:16].double(), stride=stride, padding=1)).permute(0, 2, 3, 4, 1)
+        y = cpu(ops.conv3d_bn_relu(dev(xx, device), wp, dev(bias, device), 16, 3, stride, True, P4))
+        assert (y.double() - ref).abs().max() <= 1.5e-3 * max(1.0, float(ref.abs().max())), ("conv 8->16", stride)
+
+
+def case_f16_cascade(device):
+    """conv_precision = "f16x2" end to end (fp16 cost volume from the aggregate pass, fp16 U-Net tensors, both heads) against the
+    reference-generated cascade golden F4 and, per stage, the golden stage outputs: the north-star bar is 1e-3 relative L1 on depth;
+    measured ~5e-5 on plain inputs (scripts/study_activation_precision.py predicts 5.5e-5 plain, 4.2e-4 on the x30 stress set)."""
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    fx = load_golden("f4_cascade.npz")
+    args = {"base_ch": [8] * 4, "depth_type": ["ce"] * 4, "ndepths": [32, 16, 8, 4], "depth_interals_ratio": [4.0, 2.67, 1.5, 1.0], "inverse_depth": True,
+            "conv_precision": "f16x2"}
+    head = CascadeDepthHead(args)
+    for s in range(4):
+        head.fusions[s].load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
+        assert head.fusions[s].conv_precision == "f16x2"
+    head = head.eval().to(device)
+    feats = {"stage%d" % s: dev(fx["features%d" % s], device) for s in range(1, 5)}
+    projs = {"stage%d" % s: dev(fx["proj%d" % s], device) for s in range(1, 5)}
+    with torch.no_grad():
+        out = head(feats, projs, dev(fx["depth_values"], device))
+    r = rel_l1(cpu(out["refined_depth"]), fx["refined_depth"])
+    assert r <= 3e-4, "f16x2 cascade: refined depth rel-L1 %g vs the reference's golden" % r
+    return r
+
+
+F16_CONVS = ((16, 16, (1, 1, 1)), (32, 32, (1, 1, 1)), (64, 64, (1, 1, 1)), (16, 32, (2, 2, 2)), (16, 32, (1, 2, 2)), (32, 64, (2, 2, 2)), (32, 64, (1, 2, 2)))
+
+
 def case_slab_exchange_kernels(device):
     """mvs_slab_pack / mvs_slab_reduce (the slab exchange of the view-sharded latency mode) against torch slicing: message j = rows
     [r0_j, r1_j) of the partial volume followed by the same rows of the partial visibility sum; the reduction adds the own slice and
@@ -498,9 +564,11 @@ def case_cascade_golden(device):
 
 
 # ---------------------------------------------------------------- larger sizes (GPU only)
-def _seeded_head(device, seed=11, peaky=False):
+def _seeded_head(device, seed=11, peaky=False, conv_precision=None):
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
     args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True)
+    if conv_precision:
+        args["conv_precision"] = conv_precision
     head = CascadeDepthHead(args)
     for i, st in enumerate(head.fusions):
         sd = synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), seed + i)
@@ -510,8 +578,10 @@ def _seeded_head(device, seed=11, peaky=False):
     return head.eval().to(device), args
 
 
-def case_cascade_vs_oracle(device, H, W, V, peaky=False, **inputs):
-    head, args = _seeded_head(device, peaky=peaky)
+def case_cascade_vs_oracle(device, H, W, V, peaky=False, conv_precision=None, **inputs):
+    """conv_precision "f16x2" (the product default): the same 1e-3 depth bar; the confidence (max softmax probability - not part of
+    the north-star bar) is allowed 1e-2 mean absolute error on the x30-logits stress set (bf16x3: 1e-3)."""
+    head, args = _seeded_head(device, peaky=peaky, conv_precision=conv_precision)
     feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=2, rot_deg=1.0, **inputs)
     sds = [{k: v.cpu() for k, v in st.state_dict().items()} for st in head.fusions]
     with torch.no_grad():
@@ -526,7 +596,7 @@ def case_cascade_vs_oracle(device, H, W, V, peaky=False, **inputs):
     # confidence = max softmax probability: with x30 logits a near-tie between two planes turns a 1e-5 logit difference
     # into a visible probability difference at isolated pixels, so the check is on the mean (the max is only reported)
     dconf = (cpu(out["photometric_confidence"]) - ref["photometric_confidence"]).abs()
-    assert float(dconf.mean()) <= 1e-3, "confidence mean abs error %g" % float(dconf.mean())
+    assert float(dconf.mean()) <= (1e-2 if conv_precision == "f16x2" else 1e-3), "confidence mean abs error %g" % float(dconf.mean())
     return r
 
 
@@ -637,9 +707,9 @@ def case_baseline_cfg_wide_range(device, name):
     return case_cascade_vs_oracle_finite(device, c["small"][0], c["small"][1], c["V"], **inputs)
 
 
-def case_cfg2_fullsize_vs_oracle(device):
+def case_cfg2_fullsize_vs_oracle(device, conv_precision=None):
     """BASELINE configs[1] at its FULL size (1152x1536, V = 5, ndepths 32/16/8/4) against the oracle: the north-star bar itself."""
-    return case_cascade_vs_oracle(device, 1152, 1536, 5)
+    return case_cascade_vs_oracle(device, 1152, 1536, 5, conv_precision=conv_precision)
 
 
 def case_baseline_cfg_full(device, name):

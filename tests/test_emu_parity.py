@@ -69,6 +69,14 @@ def test_split_format(emu):
     P.case_split_format(emu)
 
 
+def test_f16_layers(emu):
+    P.case_f16_layers(emu)
+
+
+def test_f16_cascade(emu):
+    P.case_f16_cascade(emu)
+
+
 def test_slab_exchange_kernels(emu):
     P.case_slab_exchange_kernels(emu)
 

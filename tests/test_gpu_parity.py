@@ -84,6 +84,14 @@ def test_split_format():
     P.case_split_format(DEV)
 
 
+def test_f16_layers():
+    P.case_f16_layers(DEV)
+
+
+def test_f16_cascade():
+    P.case_f16_cascade(DEV)
+
+
 def test_slab_exchange_kernels():
     P.case_slab_exchange_kernels(DEV)
 
@@ -142,6 +150,19 @@ def test_baseline_cfgs_small_vs_oracle(name):
 def test_baseline_cfgs_wide_range_vs_oracle(name):
     """cfg4 / cfg5 on the literal 0.5 .. 10 hypothesis range, compared where the reference's own hypotheses stay finite."""
     P.case_baseline_cfg_wide_range(DEV, name)
+
+
+def test_cfg2_fullsize_vs_oracle_f16():
+    """The same with the PRODUCT DEFAULT regulariser format ("f16x2": fp16 activations, 2-term fp16 contraction)."""
+    r = P.case_cfg2_fullsize_vs_oracle(DEV, conv_precision="f16x2")
+    assert r <= 3e-4, r                      # measured ~5e-5; the bar is 1e-3
+
+
+def test_cascade_midsize_vs_oracle_f16():
+    """384x512, V=5, peaky logits (prob weights x30) in the product default format: inside the 1e-3 bar (predicted 4e-4 by
+    scripts/study_activation_precision.py), and the plain set a decade below."""
+    P.case_cascade_vs_oracle(DEV, 384, 512, 5, peaky=True, conv_precision="f16x2")
+    assert P.case_cascade_vs_oracle(DEV, 384, 512, 5, peaky=False, conv_precision="f16x2") <= 2e-4
 
 
 def test_cfg2_fullsize_vs_oracle():
