@@ -302,7 +302,7 @@ def main():
         if not mfma:
             peak, note = profiling.PEAK_HBM_GBS, ("algorithmic HBM bytes per launch (SURVEY.md section 8d: every feature map once + hypotheses once + "
                                                   "outputs once) / HIP-event launch time on the launch stream")
-        elif prec == "bf16x3" or dom_name.startswith("vis_cnn"):
+        elif prec == "bf16x3":
             # every algorithmic product is three bf16 MFMA products: peak for algorithmic FLOPs = dense bf16 peak / 3
             peak, note = 2500.0 / 3.0, "3-term split-bf16 contraction on v_mfma_f32_16x16x32_bf16: dense bf16 peak 2500 TFLOP/s / 3 passes"
         elif prec == "f16x2":
@@ -349,7 +349,7 @@ def main():
         is_gather = lambda k: k.startswith(("gl_", "warp_corr_"))
         is_conv = lambda k: k.startswith(("conv3d_mfma", "deconv3d_mfma"))
         is_vis = lambda k: k.startswith(("vis_",)) or k.startswith("conv3d_mfma<16,16,k1") or k.startswith("conv3d_mfma<16,8,k1")
-        families = {"gather": fam(is_gather, "hbm"), "visibility_cnn": fam(is_vis, "mfma", "bf16x3" if prec == "f16x2" else None),
+        families = {"gather": fam(is_gather, "hbm"), "visibility_cnn": fam(is_vis, "mfma"),
                     "regulariser_convolutions": fam(lambda k: is_conv(k) and not is_vis(k), "mfma"),
                     "heads_and_ranges": fam(lambda k: not (is_gather(k) or is_conv(k) or is_vis(k) or k.startswith(("tr_", "[bundle]"))), "hbm")}
         if families["gather"] is not None and is_cfg2:

@@ -81,7 +81,10 @@ class StageNet(nn.Module):
     # ---- packed parameters ----
     def _vis_params(self, device):
         prec = self._vis_precision()
-        pack = packing.pack_conv_weights_bf16x3 if prec == "bf16x3" else packing.pack_conv_weights
+        if prec == "f16x2":
+            pack = lambda w, ch: packing.f16x2(packing.pack_conv_weights_bf16x3, w, ch)
+        else:
+            pack = packing.pack_conv_weights_bf16x3 if prec == "bf16x3" else packing.pack_conv_weights
         precision_code(prec)
 
         def build(dev):
@@ -99,8 +102,9 @@ class StageNet(nn.Module):
         return self._vis_cache.get(self.vis, build, prec)
 
     def _vis_precision(self) -> str:
-        """The visibility CNN keeps its activations on chip: "f16x2" (a storage format of the U-Net's tensors) runs it as "bf16x3"."""
-        return "bf16x3" if self.conv_precision == "f16x2" else self.conv_precision
+        """Contraction of the visibility CNN's two MFMA layers (its activations stay on chip): the stage's conv_precision - "f16x2" runs
+        the fp16 two-term form with fp16 rings."""
+        return self.conv_precision
 
     def _f16_activations(self) -> bool:
         """conv_precision "f16x2": the U-Net's tensors - cost volume included - are fp16 in HBM (MVS_PREC_F16X2); the transformer

@@ -109,7 +109,7 @@ struct DeconvCfg {
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
                            int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits = nullptr, int split = 0);
 int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
-                             const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st);
+                             const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st, int f16 = 0);
 // prob_w / prob_b / logits != NULL (Cout == 8 only): the 1x1x1 `prob` head is applied in the epilogue and the planar logits
 // [B,OD,OH,OW] are written instead of y
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,

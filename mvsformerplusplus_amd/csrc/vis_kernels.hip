@@ -28,16 +28,24 @@ typedef __bf16 vs_bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int VS_TW = 60;                 // output columns per strip
 constexpr int VS_P = 64;                  // columns per ring row
-constexpr int VS_POSB = 32;               // bytes per (position, octet): hi x8 | lo x8
 constexpr int VS_RING = 4;                // ring rows
-// one octet plane, sized = 16 (mod 256) bytes: the octet-1 lanes of a ds_read_b128 group then sit one 16-byte bank slot
-// away from the octet-0 lanes (which cover the even slots with their 32-byte position stride)
-constexpr int VS_PLANE = ((VS_RING * VS_P + 2) * VS_POSB + 255) / 256 * 256 + 16;
-constexpr int VS_LAYER = 2 * VS_PLANE;
 constexpr int VS_SH_MAX = 64;             // output rows per block (segment height) at most
 constexpr int VS_EP = VS_P + 2;           // entropy tile pitch: image columns x0 - 3 .. x0 + 62
 constexpr int VS_ENT_BYTES = (VS_SH_MAX + 6) * VS_EP * 4;
-constexpr int VS_LDS = 2 * VS_LAYER + VS_ENT_BYTES;
+// F16 = false: split bf16 rings ([hi x8 | lo x8] = 32 B per position and octet, three MFMA terms); F16 = true (MVS_PREC_F16X2): fp16
+// rings (16 B per position and octet), weights fp16 hi + lo, two MFMA terms - 20 instead of 30 MFMAs and 10 instead of 20 operand
+// reads per row and wave
+template <bool F16>
+struct VsL {
+    static constexpr int POSB = F16 ? 16 : 32;                 // bytes per (position, octet)
+    // one octet plane; the octet-1 lanes of a ds_read_b128 group sit beside the octet-0 lanes in the 256-byte bank row: 16 B away for
+    // the 32-byte positions (which cover the even 16-byte slots), 128 B away for the 16-byte positions (which cover the first half)
+    static constexpr int PLANE = ((VS_RING * VS_P + 2) * POSB + 255) / 256 * 256 + (F16 ? 128 : 16);
+    static constexpr int LAYER = 2 * PLANE;
+    static constexpr int LDS = 2 * LAYER + VS_ENT_BYTES;
+};
+typedef _Float16 vs_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vs_f16x4 __attribute__((ext_vector_type(4)));
 
 #ifndef MVS_OPAQUE_VEC
 #define MVS_OPAQUE_VEC "v"
@@ -54,36 +62,51 @@ __device__ __forceinline__ void vs_split4(const float* v, vs_bf16x4& hi, vs_bf16
 
 // B-operand offset of contraction step t: lane group g>>1 picks the first or second tap of the step (two taps x 16 channels =
 // 32 k-values).  SLOT0 = ring slot of tap row kh = 0 (compile-time: the row loop dispatches on i & 3).
-template <int SLOT0>
+template <int SLOT0, int POSB>
 __device__ __forceinline__ int vs_step_off(int laneoff, int tapsel, int t) {
     const int tapA = 2 * t, tapB = 2 * t + 1 < 9 ? 2 * t + 1 : 8;              // tap 9 does not exist: zero weights, any finite data
-    const int offA = (((SLOT0 + tapA / 3) & (VS_RING - 1)) * VS_P + tapA % 3) * VS_POSB;
-    const int offB = (((SLOT0 + tapB / 3) & (VS_RING - 1)) * VS_P + tapB % 3) * VS_POSB;
+    const int offA = (((SLOT0 + tapA / 3) & (VS_RING - 1)) * VS_P + tapA % 3) * POSB;
+    const int offB = (((SLOT0 + tapB / 3) & (VS_RING - 1)) * VS_P + tapB % 3) * POSB;
     return laneoff + (tapsel ? offB : offA);
 }
 
 struct VsOperand { vs_bf16x8 h, l; };
+template <bool F16>
 __device__ __forceinline__ VsOperand vs_load(const char* p) {
     VsOperand o;
     o.h = *reinterpret_cast<const vs_bf16x8*>(p);
-    o.l = *reinterpret_cast<const vs_bf16x8*>(p + 16);
+    if constexpr (!F16) o.l = *reinterpret_cast<const vs_bf16x8*>(p + 16);
+    else o.l = o.h;
     return o;
+}
+
+// one contraction step of one layer: the split-bf16 three-term product or the fp16 two-term product (weights hi + lo)
+template <bool F16>
+__device__ __forceinline__ f32x4 vs_mfma_lo(const vs_bf16x8& wl, const VsOperand& x, f32x4 a) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vs_f16x8, wl), __builtin_bit_cast(vs_f16x8, x.h), a, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, x.h, a, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 vs_mfma_hi(const vs_bf16x8& wh, const VsOperand& x, f32x4 a) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vs_f16x8, wh), __builtin_bit_cast(vs_f16x8, x.h), a, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, x.h, a, 0, 0, 0);
 }
 
 // one MFMA layer row: 5 contraction steps, three split-bf16 terms on three accumulators, the operand reads of step t+1 issued
 // before the MFMAs of step t
-template <int SLOT0>
+template <int SLOT0, bool F16>
 __device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, const vs_bf16x8* wh, const vs_bf16x8* wl) {
+    constexpr int POSB = VsL<F16>::POSB;
     f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0;
-    VsOperand cur = vs_load(lds_layer + vs_step_off<SLOT0>(laneoff, tapsel, 0));
+    VsOperand cur = vs_load<F16>(lds_layer + vs_step_off<SLOT0, POSB>(laneoff, tapsel, 0));
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         VsOperand nxt = cur;
-        if (t < 4) nxt = vs_load(lds_layer + vs_step_off<SLOT0>(laneoff, tapsel, t + 1));
+        if (t < 4) nxt = vs_load<F16>(lds_layer + vs_step_off<SLOT0, POSB>(laneoff, tapsel, t + 1));
         __builtin_amdgcn_sched_barrier(0);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t], cur.h, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], cur.l, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], cur.h, a2, 0, 0, 0);
+        a0 = vs_mfma_lo<F16>(wl[t], cur, a0);
+        if constexpr (!F16) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], cur.l, a1, 0, 0, 0);
+        a2 = vs_mfma_hi<F16>(wh[t], cur, a2);
         cur = nxt;
     }
     return a0 + a1 + a2;
@@ -92,26 +115,29 @@ __device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff
 // both MFMA layers of one iteration interleaved (layer 2 reads ring 1, layer 3 reads ring 2: independent): four operand
 // reads in flight under six MFMAs; one accumulator per layer - the two chains alternate, so a chain's next link is issued two
 // MFMAs (32 cycles) after the previous one
-template <int SLOT2, int SLOT3>
+template <int SLOT2, int SLOT3, bool F16>
 __device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* lds2, int laneoff, int tapsel, const vs_bf16x8* w2h,
                                                   const vs_bf16x8* w2l, const vs_bf16x8* w3h, const vs_bf16x8* w3l, f32x4& out2, f32x4& out3) {
+    constexpr int POSB = VsL<F16>::POSB;
     f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, c = a;
-    VsOperand cb = vs_load(lds1 + vs_step_off<SLOT2>(laneoff, tapsel, 0));
-    VsOperand cc = vs_load(lds2 + vs_step_off<SLOT3>(laneoff, tapsel, 0));
+    VsOperand cb = vs_load<F16>(lds1 + vs_step_off<SLOT2, POSB>(laneoff, tapsel, 0));
+    VsOperand cc = vs_load<F16>(lds2 + vs_step_off<SLOT3, POSB>(laneoff, tapsel, 0));
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         VsOperand nb = cb, nc = cc;
         if (t < 4) {
-            nb = vs_load(lds1 + vs_step_off<SLOT2>(laneoff, tapsel, t + 1));
-            nc = vs_load(lds2 + vs_step_off<SLOT3>(laneoff, tapsel, t + 1));
+            nb = vs_load<F16>(lds1 + vs_step_off<SLOT2, POSB>(laneoff, tapsel, t + 1));
+            nc = vs_load<F16>(lds2 + vs_step_off<SLOT3, POSB>(laneoff, tapsel, t + 1));
         }
         __builtin_amdgcn_sched_barrier(0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[t], cb.h, a, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3l[t], cc.h, c, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t], cb.l, a, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[t], cc.l, c, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t], cb.h, a, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[t], cc.h, c, 0, 0, 0);
+        a = vs_mfma_lo<F16>(w2l[t], cb, a);
+        c = vs_mfma_lo<F16>(w3l[t], cc, c);
+        if constexpr (!F16) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t], cb.l, a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[t], cc.l, c, 0, 0, 0);
+        }
+        a = vs_mfma_hi<F16>(w2h[t], cb, a);
+        c = vs_mfma_hi<F16>(w3h[t], cc, c);
         cb = nb;
         cc = nc;
     }
@@ -122,12 +148,14 @@ __device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* 
 template <int V> struct VsInt { static constexpr int value = V; };
 
 // grid = (strips, row segments, N)
+template <bool F16>
 __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ ent, const float* __restrict__ w1 /*[9][16]*/,
                                                       const float* __restrict__ b1, const void* __restrict__ wp2, const float* __restrict__ b2,
                                                       const void* __restrict__ wp3, const float* __restrict__ b3, const float* __restrict__ w4,
                                                       const float* __restrict__ b4, float* __restrict__ vis, int H, int W, int SH) {
     HIP_DYNAMIC_SHARED(float4, lds4)
     char* lds1 = reinterpret_cast<char*>(lds4);
+    constexpr int VS_POSB = VsL<F16>::POSB, VS_PLANE = VsL<F16>::PLANE, VS_LAYER = VsL<F16>::LAYER;
     char* lds2 = lds1 + VS_LAYER;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     __syncthreads();
     const int colmaskA = xa >= 0 && xa < W;
     // per-lane LDS offsets
-    const int wrA = (wave >> 1) * VS_PLANE + lane * VS_POSB + (wave & 1) * 8;                     // stage A store (octet wave>>1, quad wave&1)
+    const int wrA = (wave >> 1) * VS_PLANE + lane * VS_POSB + (wave & 1) * 8;                     // stage A store (octet wave>>1, quad wave&1: 8 bytes of hi [, 8 of lo at + 16])
     const int laneoff = (g & 1) * VS_PLANE + (16 * wave + li) * VS_POSB;                          // MFMA B-operand reads
     const int wrB = (g >> 1) * VS_PLANE + (16 * wave + li) * VS_POSB + (g & 1) * 8;               // stage B store
     const int tapsel = g >> 1;
@@ -215,30 +243,38 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             const bool in = colmaskA && i >= 0 && i < H;
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = in ? fmaxf(a[r], 0.0f) : 0.0f;
-            vs_bf16x4 hi, lo;
-            vs_split4(a, hi, lo);
             char* p = lds1 + wrA + PH * (VS_P * VS_POSB);
-            *reinterpret_cast<vs_bf16x4*>(p) = hi;
-            *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
+            if constexpr (F16) {
+                *reinterpret_cast<vs_f16x4*>(p) = vs_f16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
+            } else {
+                vs_bf16x4 hi, lo;
+                vs_split4(a, hi, lo);
+                *reinterpret_cast<vs_bf16x4*>(p) = hi;
+                *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
+            }
         }
         // ---- B: layer-2 row i-2 from layer-1 rows i-3 .. i-1;  C: layer-3 row i-4 from layer-2 rows i-5 .. i-3 ----
         const int yb = i - 2, yc = i - 4;
         const bool doB = yb >= r0 - 1 && yb <= r1, doC = yc >= r0;
         constexpr int S2 = (PH + 1) & 3, S3 = (PH + 3) & 3;          // slots of rows i-3 and i-5
         f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc3 = acc2;
-        if (doB && doC) vs_two_layer_rows<S2, S3>(lds1, lds2, laneoff, tapsel, w2h, w2l, w3h, w3l, acc2, acc3);
-        else if (doB) acc2 = vs_layer_row<S2>(lds1, laneoff, tapsel, w2h, w2l);
-        else if (doC) acc3 = vs_layer_row<S3>(lds2, laneoff, tapsel, w3h, w3l);
+        if (doB && doC) vs_two_layer_rows<S2, S3, F16>(lds1, lds2, laneoff, tapsel, w2h, w2l, w3h, w3l, acc2, acc3);
+        else if (doB) acc2 = vs_layer_row<S2, F16>(lds1, laneoff, tapsel, w2h, w2l);
+        else if (doC) acc3 = vs_layer_row<S3, F16>(lds2, laneoff, tapsel, w3h, w3l);
         if (doB) {
             const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc2[r] + b2v[r], 0.0f) : 0.0f;
-            vs_bf16x4 hi, lo;
-            vs_split4(v, hi, lo);
             char* p = lds2 + wrB + ((PH + 2) & 3) * (VS_P * VS_POSB);          // row i-2
-            *reinterpret_cast<vs_bf16x4*>(p) = hi;
-            *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
+            if constexpr (F16) {
+                *reinterpret_cast<vs_f16x4*>(p) = vs_f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            } else {
+                vs_bf16x4 hi, lo;
+                vs_split4(v, hi, lo);
+                *reinterpret_cast<vs_bf16x4*>(p) = hi;
+                *reinterpret_cast<vs_bf16x4*>(p + 16) = lo;
+            }
         }
         if (doC) {                                                  // 1x1 + sigmoid
             float part = 0.0f;
@@ -262,8 +298,10 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     }
 }
 
-int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
-                             const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st) {
+template <bool F16>
+static int vis_weight_stream_t(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                               const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st) {
+    constexpr int VS_LDS = VsL<F16>::LDS;
     const int strips = (int)ceil_div(W, VS_TW);
     // segment height: a block's run time is ~ (SH + 6) row iterations (6 warm-up rows) and the launch takes ceil(blocks / resident
     // blocks) of those back to back - pick the segment count that minimises that product (3 blocks per CU fit: 52 KB LDS, 152 VGPRs)
@@ -277,9 +315,16 @@ int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float*
         if (best < 0 || cost < best) { best = cost; segs = (int)ceil_div(H, sh); SH = sh; }
     }
     if (VS_LDS > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS);
-    hipLaunchKernelGGL(vis_cnn_kernel, dim3(strips, segs, N), dim3(256), VS_LDS, st, entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, H, W, SH);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS);
+    hipLaunchKernelGGL((vis_cnn_kernel<F16>), dim3(strips, segs, N), dim3(256), VS_LDS, st, entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, H, W, SH);
     return check_launch("vis_cnn_kernel");
+}
+
+// f16: the fp16 two-term form (MVS_PREC_F16X2: rings in fp16, w2 / w3 packed as fp16 hi + lo)
+int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                             const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st, int f16) {
+    return f16 ? vis_weight_stream_t<true>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st)
+               : vis_weight_stream_t<false>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
 }
 
 }  // namespace mvs

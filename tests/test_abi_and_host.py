@@ -33,7 +33,7 @@ def test_product_default_precision():
     finally:
         cost_volume.STAGE_DEFAULT_PRECISION = keep
     net = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "f16x2"}, 4, 3)
-    assert net._f16_activations() and not net._split_activations() and net._vis_precision() == "bf16x3"
+    assert net._f16_activations() and not net._split_activations() and net._vis_precision() == "f16x2"
 
 
 def test_header_matches_binding_table():
