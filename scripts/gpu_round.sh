@@ -29,6 +29,10 @@ import json
 r = json.loads(open('gpurun_out/bench_shipped.json').read().strip().splitlines()[-1])
 print('shipped', {k: r[k] for k in ('value', 'ms_per_ref_view') if k in r}, 'parity', r.get('parity'))
 PY
+echo "== bench, fp32-equivalent regulariser format (--conv-precision bf16x3: split bf16 pairs, three MFMA terms) =="
+timeout 600 python bench.py --steps 10 --warmup 3 --profile-table --no-train-leg --no-cpu-baseline --conv-precision bf16x3 > $OUT/bench_bf16x3.json 2> $OUT/bench_bf16x3.err
+python -c "
+import json; r = json.loads(open('gpurun_out/bench_bf16x3.json').read().strip().splitlines()[-1]); print('bf16x3', r['value'], r['ms_per_ref_view'], r['latency']['single_stream_ms_per_ref_view'])"
 echo "== bench, bf16 features in the octet-tiled hand-off layout =="
 timeout 600 python bench.py --steps 6 --warmup 2 --no-profile --no-cpu-baseline --feat-layout tiled --feat-dtype bf16 > $OUT/bench_tiled_bf16.json 2>/dev/null
 python -c "
@@ -71,6 +75,8 @@ cp $OUT/bench.json $OUT/profiles_$TAG/${TAG}_bench_1gpu.json
 cp $OUT/bench_shipped.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_shipped.json
 cp $OUT/bench_n2.json $OUT/profiles_$TAG/${TAG}_bench_n2_flow_check_one_gpu_gloo.json
 cp $OUT/bench_tiled_bf16.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_tiled_bf16.json
+cp $OUT/bench_bf16x3.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_bf16x3.json
+grep -v "amdgpu.ids" $OUT/bench_bf16x3.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_bf16x3.txt
 grep -v "amdgpu.ids" $OUT/bench.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table.txt
 grep -v "amdgpu.ids" $OUT/bench_shipped.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_shipped.txt
 rm -rf $OUT/prof_$TAG $OUT/prof1_$TAG $OUT/pmc_$TAG
