@@ -1264,8 +1264,17 @@ static int launch_deconv_bf(const float* x, const void* wp, const float* bias, c
     return check_launch("deconv3d_mfma_bf16x3_kernel");
 }
 
+// the staging loops address one batch item of the input through 32-bit byte offsets and a buffer descriptor
+static bool bf_input_fits(const char* who, int Cin, int D, int H, int W, int split) {
+    const long long bytes = (long long)D * H * W * Cin * (split == 2 ? 2 : 4);
+    if (bytes < (1LL << 31)) return true;
+    set_error("%s: one batch item of the input is %lld bytes; the MFMA convolutions address it with 32-bit offsets (< 2 GB)", who, bytes);
+    return false;
+}
+
 int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
                            int kd, int sd, int sh, int sw, int relu, hipStream_t st, float* logits, int split) {
+    if (!bf_input_fits("conv3d(mfma)", Cin, D, H, W, split)) return MVS_ERR_UNSUPPORTED;
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW) {                    \
         typedef typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type K;              \
@@ -1282,6 +1291,7 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
 int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout,
                              int D, int H, int W, int sd, hipStream_t st, const float* prob_w, const float* prob_b, float* logits, int relu, int split) {
     if (prob_w != nullptr && Cout != 8) { set_error("deconv3d(bf16x3): the fused prob head needs Cout == 8"); return MVS_ERR_UNSUPPORTED; }
+    if (!bf_input_fits("deconv3d(mfma)", Cin, D, H, W, split)) return MVS_ERR_UNSUPPORTED;
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
     if (Cin == CI && Cout == CO && sd == SD) {                                                          \
         typedef typename BfDeconvSplitOf<DeconvCfg<CI, CO, SD, TDM, THM>>::type K;                      \

@@ -81,17 +81,11 @@ def _split_f16(x: torch.Tensor) -> torch.Tensor:
 
 
 def f16x2(packer, *args):
-    """Run one of the pack_*_bf16x3 functions with the fp16 hi + lo split instead of the bf16 one (MVS_PREC_F16X2)."""
-    global _split_bf16
-    keep = _split_bf16
-    _split_bf16 = _split_f16
-    try:
-        return packer(*args)
-    finally:
-        _split_bf16 = keep
+    """One of the pack_*_bf16x3 functions with the fp16 hi + lo split instead of the bf16 one (the weights of MVS_PREC_F16X2)."""
+    return packer(*args, split=_split_f16)
 
 
-def pack_conv_weights_bf16x3(w: torch.Tensor, ch: int) -> torch.Tensor:
+def pack_conv_weights_bf16x3(w: torch.Tensor, ch: int, split=None) -> torch.Tensor:
     """w [Cout, Cin, kd, 3, 3] (BN folded) -> bf16 1-D tensor for ``conv3d_mfma_bf16x3_kernel``:
 
         packed[pass][step][mb][hi|lo][lane = g*16 + j][e] = W'[16*mb + j][pass*CH + 8*oc + e][tap],
@@ -109,10 +103,10 @@ def pack_conv_weights_bf16x3(w: torch.Tensor, ch: int) -> torch.Tensor:
     full = torch.zeros(npass, nstep * 4, mrep * 16, 8, dtype=torch.float32, device=w.device)
     full[:, :noct, :cout] = wt
     full = full.reshape(npass, nstep, 4, mrep, 16, 8).permute(0, 1, 3, 2, 4, 5)                              # [pass, step, mb, g, j, e]
-    return _split_bf16(full).permute(1, 2, 3, 0, 4, 5, 6).contiguous().reshape(-1)                           # [pass, step, mb, 2, g, j, e]
+    return (split or _split_bf16)(full).permute(1, 2, 3, 0, 4, 5, 6).contiguous().reshape(-1)                           # [pass, step, mb, 2, g, j, e]
 
 
-def pack_linear_bf16x3(w: torch.Tensor) -> torch.Tensor:
+def pack_linear_bf16x3(w: torch.Tensor, split=None) -> torch.Tensor:
     """w [N, K] (y = x @ w.T; N % 16 == 0, K % 32 == 0) -> bf16 1-D tensor for ``tr_gemm_kernel``:
 
         packed[step][mb][hi|lo][lane = g*16 + j][e] = w[16*mb + j][32*step + 8*g + e]
@@ -120,7 +114,7 @@ def pack_linear_bf16x3(w: torch.Tensor) -> torch.Tensor:
     n, k = w.shape
     assert n % 16 == 0 and k % 32 == 0, (n, k)
     full = w.float().reshape(n // 16, 16, k // 32, 4, 8).permute(2, 0, 3, 1, 4)                                # [step, mb, g, j, e]
-    return _split_bf16(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1)                                # [step, mb, 2, g, j, e]
+    return (split or _split_bf16)(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1)                                # [step, mb, 2, g, j, e]
 
 
 def patch_embed_matrix(w: torch.Tensor) -> torch.Tensor:
@@ -148,7 +142,7 @@ def deconv_class_taps(sd: int):
     return out
 
 
-def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
+def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int, split=None) -> torch.Tensor:
     """w [Cin, Cout, 3, 3, 3] (BN folded over Cout) -> bf16 1-D tensor for ``deconv3d_mfma_bf16x3_kernel``: per parity
     class, packed[step][mb][hi|lo][lane = g*16 + j][e] = Wt'[8*oc + e][16*mb + j][taps[ti]], (ti, oc) = divmod(4*step + g, Cin/8)."""
     cin, cout = w.shape[:2]
@@ -174,7 +168,7 @@ def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
                 if kw == 2:                                                                       # input mx: pw = 0 uses kw = 1 of the same (kd, kh)
                     full[ti * opt:(ti + 1) * opt, 0:8] = wf[:, :, :, t1 - 1].permute(0, 2, 1)
             full = full.reshape(nst, 4, 1, 16, 8).permute(0, 2, 1, 3, 4)
-            chunks.append(_split_bf16(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1))
+            chunks.append((split or _split_bf16)(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1))
         return torch.cat(chunks)
     for taps in deconv_class_taps(sd):
         noct = len(taps) * opt
@@ -183,7 +177,7 @@ def pack_deconv_weights_bf16x3(w: torch.Tensor, sd: int) -> torch.Tensor:
         full = torch.zeros(nst * 4, mrep * 16, 8, dtype=torch.float32, device=w.device)
         full[:noct, :cout] = sel
         full = full.reshape(nst, 4, mrep, 16, 8).permute(0, 2, 1, 3, 4)             # [step, mb, g, j, e]
-        chunks.append(_split_bf16(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1))   # [step, mb, 2, g, j, e]
+        chunks.append((split or _split_bf16)(full).permute(1, 2, 0, 3, 4, 5).contiguous().reshape(-1))   # [step, mb, 2, g, j, e]
     return torch.cat(chunks)
 
 
