@@ -13,6 +13,10 @@
 //     [voxel][octet of 8 channels][hi x8 | lo x8] (same bytes per voxel as fp32)
 //   * weights are split on the host (packing.pack_conv_weights_bf16x3) in per-lane MFMA operand order
 //   * one contraction step = 32 k-values = 4 channel octets; lane group g = lane>>4 owns octet 4*step + g
+//
+// Three activation formats share these kernels (C ABI precision codes): MVS_PREC_BF16X3 (fp32 tensors, split while staging),
+// MVS_PREC_BF16X3_SPLIT (tensors stored as hi | lo bf16 pairs: template parameter SPLIT) and MVS_PREC_F16X2 (fp16 tensors, fp16 hi + lo
+// weights, two MFMA terms: tile configurations wrapped in F16Cfg, below) - the product default at inference.
 #include <map>
 #include <mutex>
 #include <type_traits>
