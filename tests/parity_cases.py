@@ -629,8 +629,8 @@ def case_cascade_vs_oracle_finite(device, H, W, V, **inputs):
     return rel, frac
 
 
-def case_cascade_fullsize_properties(device, H=1152, W=1536, V=5, **inputs):
-    head, args = _seeded_head(device)
+def case_cascade_fullsize_properties(device, H=1152, W=1536, V=5, conv_precision=None, **inputs):
+    head, args = _seeded_head(device, conv_precision=conv_precision)
     feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=0, device=device, **inputs)
     with torch.no_grad():
         a = head(feats, projs, dv)
@@ -693,9 +693,9 @@ def case_baseline_cfg1(device):
     return r
 
 
-def case_baseline_cfg_small(device, name):
+def case_baseline_cfg_small(device, name, conv_precision=None):
     c = BASELINE_CFGS[name]
-    return case_cascade_vs_oracle(device, c["small"][0], c["small"][1], c["V"], **c["inputs"])
+    return case_cascade_vs_oracle(device, c["small"][0], c["small"][1], c["V"], conv_precision=conv_precision, **c["inputs"])
 
 
 def case_baseline_cfg_wide_range(device, name):
@@ -761,12 +761,17 @@ def case_stage_transformer_golden(device):
     assert rel_l1(cpu(out["depth"]), fx["depth"]) <= 1e-5
 
 
-def case_cascade_shipped_golden(device):
-    """Shipped regulariser mix (stage-1 transformer + Frustoconical PE, CostRegNet / CostRegNet3D after it) on the f4 inputs."""
+def case_cascade_shipped_golden(device, conv_precision=None):
+    """Shipped regulariser mix (stage-1 transformer + Frustoconical PE, CostRegNet / CostRegNet3D after it) on the f4 inputs.
+    conv_precision "f16x2" (product default): the three U-Net stages and all four visibility CNNs in the fp16 form; 3e-4 instead of 1e-4."""
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
     fx, f4 = load_golden("f9_cascade_shipped.npz"), load_golden("f4_cascade.npz")
     args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True, use_pe3d=True,
                 cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(fx)])
+    tol = 1e-4
+    if conv_precision:
+        args["conv_precision"] = conv_precision
+        tol = 3e-4
     head = CascadeDepthHead(args)
     for s, stn in enumerate(head.fusions):
         stn.load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
@@ -776,9 +781,9 @@ def case_cascade_shipped_golden(device):
     with torch.no_grad():
         out = head(feats, projs, dev(f4["depth_values"], device))
     for s in range(1, 5):
-        assert rel_l1(cpu(out["stage%d" % s]["depth"]), fx["depth%d" % s]) <= 1e-4, s
-    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= 1e-4
-    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-3
+        assert rel_l1(cpu(out["stage%d" % s]["depth"]), fx["depth%d" % s]) <= tol, s
+    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= tol
+    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= (1e-3 if conv_precision is None else 2e-2)
 
 
 def case_attention_stress(device, n=200, gain=2.0, bf16p=False):

@@ -73,6 +73,10 @@ def test_f16_layers(emu):
     P.case_f16_layers(emu)
 
 
+def test_cascade_shipped_golden_f16(emu):
+    P.case_cascade_shipped_golden(emu, conv_precision="f16x2")
+
+
 def test_f16_cascade(emu):
     P.case_f16_cascade(emu)
 

@@ -152,6 +152,21 @@ def test_baseline_cfgs_wide_range_vs_oracle(name):
     P.case_baseline_cfg_wide_range(DEV, name)
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
+def test_baseline_cfgs_small_vs_oracle_f16(name):
+    """BASELINE configs[2..4] at a reduced image size in the product default regulariser format."""
+    P.case_baseline_cfg_small(DEV, name, conv_precision="f16x2")
+
+
+def test_cascade_shipped_golden_f16():
+    P.case_cascade_shipped_golden(DEV, conv_precision="f16x2")
+
+
+def test_cascade_fullsize_properties_f16():
+    """Determinism, ranges, softmax sums, hypothesis ordering and view-order invariance at 1152x1536 in the product default format."""
+    P.case_cascade_fullsize_properties(DEV, conv_precision="f16x2")
+
+
 def test_cfg2_fullsize_vs_oracle_f16():
     """The same with the PRODUCT DEFAULT regulariser format ("f16x2": fp16 activations, 2-term fp16 contraction)."""
     r = P.case_cfg2_fullsize_vs_oracle(DEV, conv_precision="f16x2")
