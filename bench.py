@@ -15,6 +15,11 @@ Workload = BASELINE.json configs[1]: 1152x1536, V=5, numdepth 192 (-> cascade nd
 fp32 features, all-"Normal" regularisers, synthetic features / cameras and seeded random weights with randomised BatchNorm
 statistics (no dataset or checkpoint exists offline).
 
+Arithmetic: warp, correlation, visibility, heads and every accumulation in fp32; the 3-D regularisers in the PRODUCT DEFAULT format
+"f16x2" (cost_volume.STAGE_DEFAULT_PRECISION: fp16 activation tensors, fp16 hi + lo weights, two MFMA terms per product) - wider than
+the bf16 autocast the reference's own GPU path runs these layers under (test.py:250); `--conv-precision bf16x3` selects the
+fp32-equivalent mode of rounds 1-2.  `parity` = this run's refined depth against the fp32 CPU oracle on the same inputs (bar 1e-3).
+
 The reference views of a step are issued round-robin on `--streams` HIP streams (default 3): views are independent, so the small
 latency-bound launches of one view's coarse stages overlap the large launches of another's fine stages; the single-stream
 figure (one view at a time, the reference's loop) is reported in `latency`, the per-kernel profile behind `roofline` is
