@@ -482,6 +482,32 @@ def case_f16_layers(device):
         assert (y.double() - ref).abs().max() <= 1.5e-3 * max(1.0, float(ref.abs().max())), ("conv 8->16", stride)
 
 
+def case_f16_saturation(device):
+    """fp16 stores saturate instead of overflowing: a layer whose outputs exceed 65504 writes +-65504 (finite), and the aggregate pass
+    clamps the cost volume it writes (features scaled until the correlations leave the fp16 range)."""
+    from mvsformerplusplus_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    xx = (torch.rand(1, 4, 8, 16, 16, generator=g) * 200.0 + 100.0).half()
+    w = torch.ones(16, 16, 3, 3, 3) * 2.0                                                   # every output ~ 27 * 16 * 2 * 200 >> 65504
+    wp = dev(packing.f16x2(packing.pack_conv_weights_bf16x3, w, packing.conv_chunk(16, (1, 1, 1))), device)
+    y = cpu(ops.conv3d_bn_relu(dev(xx, device), wp, dev(torch.zeros(64), device), 16, 3, (1, 1, 1), True, _lib.PREC_F16X2))
+    assert torch.isfinite(y).all() and float(y.max()) == 65504.0
+    B, V, C, D, H, W = 1, 3, 8, 4, 8, 32
+    cams = synth.make_cameras(V, H * 8, W * 8, baseline=30.0, seed=1, batch=B)
+    cams[:, :, 1, :2, :] /= 8
+    feats = torch.randn(B, V, C, H, W, generator=g) * 400.0
+    hyp = (torch.linspace(800, 500, D)[None, :, None, None] * torch.ones(B, D, H, W)).contiguous()
+    f, code = ops._feat(dev(feats, device))
+    hom = ops.compose_homography(dev(cams, device))
+    vis = dev(torch.ones(B, V - 1, H, W), device)
+    v32 = cpu(ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8)[0])
+    v16 = cpu(ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, f16=True)[0])
+    assert float(v32.abs().max()) > 65504.0, "the case must leave the fp16 range"
+    assert v16.dtype == torch.float16 and torch.isfinite(v16).all()
+    assert torch.equal(v16, v32.clamp(-65504.0, 65504.0).half())
+    assert torch.equal(cpu(ops.volume_to_f16(dev(v32, device))), v16)
+
+
 def case_f16_cascade(device):
     """conv_precision = "f16x2" end to end (fp16 cost volume from the aggregate pass, fp16 U-Net tensors, both heads) against the
     reference-generated cascade golden F4 and, per stage, the golden stage outputs: the north-star bar is 1e-3 relative L1 on depth;

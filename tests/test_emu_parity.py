@@ -77,6 +77,10 @@ def test_cascade_shipped_golden_f16(emu):
     P.case_cascade_shipped_golden(emu, conv_precision="f16x2")
 
 
+def test_f16_saturation(emu):
+    P.case_f16_saturation(emu)
+
+
 def test_f16_cascade(emu):
     P.case_f16_cascade(emu)
 

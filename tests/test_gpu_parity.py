@@ -88,6 +88,10 @@ def test_f16_layers():
     P.case_f16_layers(DEV)
 
 
+def test_f16_saturation():
+    P.case_f16_saturation(DEV)
+
+
 def test_f16_cascade():
     P.case_f16_cascade(DEV)
 
