@@ -3,7 +3,7 @@
 # Usage: gpurun --timeout 1800 -- 'bash scripts/gpu_round.sh <tag>'
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r02}
+ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r03}
 mkdir -p $OUT
 export PYTHONDONTWRITEBYTECODE=1
 echo "== pytest -m gpu =="
