@@ -527,6 +527,13 @@ def case_f16_cascade(device):
         out = head(feats, projs, dev(fx["depth_values"], device))
     r = rel_l1(cpu(out["refined_depth"]), fx["refined_depth"])
     assert r <= 3e-4, "f16x2 cascade: refined depth rel-L1 %g vs the reference's golden" % r
+    # the A/B switch fuse_prob_head = False (standalone fp32 head on the fp16 features) gives the same stage result up to the
+    # fp16 rounding of the 8-channel features the fused head never stores
+    for st in head.fusions:
+        st.fuse_prob_head = False
+    with torch.no_grad():
+        out2 = head(feats, projs, dev(fx["depth_values"], device))
+    assert rel_l1(cpu(out2["refined_depth"]), cpu(out["refined_depth"])) <= 3e-4
     return r
 
 
