@@ -3,7 +3,7 @@
 # Usage: gpurun --timeout 1800 -- 'bash scripts/gpu_round.sh <tag>'
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r03}
+ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r04}
 mkdir -p $OUT
 export PYTHONDONTWRITEBYTECODE=1
 echo "== pytest -m gpu =="
@@ -56,8 +56,8 @@ tail -2 $ROOT/$OUT/rocprof.log
 # (what bench.py's HIP-event table and its `roofline` object measure); with 3 streams co-running kernels stretch each other
 timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --streams 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof1.log 2>&1
 echo "== PMC: HBM traffic of every kernel (separate passes) =="
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile > $ROOT/$OUT/pmc_f.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile > $ROOT/$OUT/pmc_w.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_f.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_w.log 2>&1
 cd $ROOT
 mkdir -p $OUT/profiles_$TAG
 python scripts/pmc_traffic.py $OUT/pmc_$TAG $OUT/profiles_$TAG/pmc_traffic.json $OUT/profiles_$TAG/${TAG}_pmc_fetch_write_raw.json

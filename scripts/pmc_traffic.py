@@ -40,6 +40,14 @@ for k in sorted(set(f) | set(w)):
     rawd[k] = {"calls": max(fc, wc), "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa}
     short = re.sub(r"<.*$", "", k) if k.startswith("warp_corr") or k.startswith("weighted") else k
     res[short] = {"hbm_bytes_per_launch": (2 * fa + wa) * 1024, "fetch_size_kb": fa, "write_size_kb": wa, "launches_sampled": max(fc, wc)}
+# whole path: every library kernel of the run / the reference views of the run (confidence_average_kernel runs once per view)
+views = max(f.get("confidence_average_kernel", [0])[0], w.get("confidence_average_kernel", [0])[0])
+if views:
+    tot = sum((2 * f.get(k, [0, 0.0])[1] / max(f.get(k, [1])[0], 1) * max(f.get(k, [0])[0], w.get(k, [0])[0]) +
+               w.get(k, [0, 0.0])[1] / max(w.get(k, [1])[0], 1) * max(f.get(k, [0])[0], w.get(k, [0])[0])) * 1024 for k in rawd
+              if not any(t in k for t in ("bn_", "wgrad", "pack_", "_bwd", "train")))
+    res["_whole_path"] = {"ref_views_in_run": views, "hbm_bytes_per_ref_view": tot / views,
+                          "note": "sum over every library kernel launch of the PMC run of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / reference views in the run"}
 json.dump(res, open(out, "w"), indent=1)
 json.dump(rawd, open(raw, "w"), indent=1)
 print("wrote", out, raw, len(res) - 1, "kernels")
