@@ -17,13 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 LAYOUT_PLANAR, LAYOUT_OCTET_TILED = 0, 1
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
-PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT, PREC_F16X2 = 0, 1, 2, 3, 4
+PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT, PREC_F16X2, PREC_F16 = 0, 1, 2, 3, 4, 5
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f16x2": PREC_F16X2}
 VOLUME_F32, VOLUME_SPLIT, VOLUME_F16 = 0, 1, 2
 
@@ -82,7 +82,7 @@ SIGNATURES = {
     "mvs_tr_embed_fwd": (_i, [_vp] * 9 + [_i] * 8 + [_vp]),
     "mvs_tr_linear_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_tr_attention_operand_bytes": (_sz, [_i, _i, _i]),
-    "mvs_tr_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
+    "mvs_tr_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
     "mvs_tr_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_tr_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mvs_tr_up_prob_fwd": (_i, [_vp] * 8 + [_i] * 8 + [_vp]),

@@ -20,6 +20,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # accumulators must live in VGPRs (the default AGPR form costs a v_accvgpr move per value and direction); no NaN can
 # occur in the softmax (masked scores are -inf, never inf - inf), which lets max chains fold into v_max3_f32.
 FILE_FLAGS = {"transformer_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"],
+              # attention_f16_kernels: as above; -fno-slp-vectorize keeps the row-sum adds single instructions (MI355X_MICROARCH.md: packed f32 VALU
+              # beside MFMAs costs more than the two scalar ops it replaces)
+              "attention_f16_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans", "-fno-slp-vectorize"],
               # vis_kernels: every MFMA result of the row-streaming CNN goes straight into a VALU epilogue (bias, ReLU, bf16 split, 1x1 +
               # sigmoid): VGPR accumulators save 40 v_accvgpr moves per row and wave (18 % of the kernel's non-MFMA VALU instructions)
               "vis_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}

@@ -14,6 +14,15 @@
 
 #include "../../include/mvs_hip.h"
 
+// LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane from a per-lane global address to (wave-uniform LDS base) + 16 * lane; no VGPRs,
+// no ds_write.  Completion is tracked by vmcnt (MVS_WAIT_VMEM) and needs a barrier before other waves read.  The host emulator of the
+// tests defines its own (synchronous) forms first.
+#ifndef MVS_GLOBAL_LOAD_LDS16
+#define MVS_GLOBAL_LOAD_LDS16(gsrc, ldst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
+#define MVS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 namespace mvs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -16,7 +16,10 @@
 //                         (k_hi + k_lo).(q_hi + q_lo); p.v is the usual three-term split.  Scores leave the matrix core in
 //                         exactly the per-lane order the p.v product wants them in, so P never moves between lanes.
 //   * pos3d_*             normalised frustum coordinates of every hypothesis voxel (two-pass min/max + write).
+#include <stdlib.h>
+
 #include "mvs_common.h"
+#include "attention_f16.h"
 
 namespace mvs {
 
@@ -43,7 +46,7 @@ __device__ __forceinline__ float wave_sum_groups(float v) {      // sum over the
 }  // namespace
 
 enum { PRO_TOKENS = 0, PRO_PATCH = 1 };
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES_LN = 2, EPI_LN = 3, EPI_QKV = 4, EPI_UP = 5 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES_LN = 2, EPI_LN = 3, EPI_QKV = 4, EPI_UP = 5, EPI_QKV16 = 6 };
 
 struct TrArgs {
     const float* x;          // PRO_TOKENS: [B, n, K] token rows;  PRO_PATCH: cost volume [B, D, H, W, 8] channel-last
@@ -61,6 +64,9 @@ struct TrArgs {
     __bf16* q;               // EPI_QKV: [B, heads, npad, 32] = [hi16 | lo16], pre-multiplied by qscale
     __bf16* k;               //          [B, heads, npad, 32]
     __bf16* vt;              //          [B, heads, 2 (hi, lo), 16, npad]
+    _Float16* q16;           // EPI_QKV16 (attention_f16_kernels.hip): Q [B, heads, npad, 16], pre-multiplied by qscale
+    _Float16* k16;           //            KP [B, heads, npad/16, 4, 16, 4]: dims 4g..4g+3 of key 16 tile + j at [tile][g][j]
+    _Float16* v16;           //            VP [B, heads, npad/32, 4, 16, 8]: v[key 32 step + 16 (e >> 2) + 4g + (e & 3)][d] at [step][g][d][e]
     float qscale;
     int heads, npad;
     const float* prob_w;     // EPI_UP: prob.weight [8], prob.bias [1]
@@ -247,6 +253,31 @@ __global__ __launch_bounds__(256) void tr_gemm_kernel(const TrArgs a) {
                         a.vt[((hb * 2 + 0) * 16 + 4 * g + r) * (size_t)a.npad + tok] = hi[r];
                         a.vt[((hb * 2 + 1) * 16 + 4 * g + r) * (size_t)a.npad + tok] = lo[r];
                     }
+                }
+            }
+        } else if (EPI == EPI_QKV16) {
+            // the fp16 operands of tr_attention_f16_kernel; the lane holds dims 4g..4g+3 of (which, head) for token j.  Values are clamped to
+            // the fp16 range (|x| <= 65504); rows >= n of the padded buffers receive zeros like EPI_QKV.
+            typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int tile = mc + mb, which = tile / a.heads, hh = tile - which * a.heads;
+                const size_t hb = (size_t)b * a.heads + hh;
+                f16x4_t hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = which == 0 ? acc[mb][r] * a.qscale : acc[mb][r];
+                    hv[r] = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
+                }
+                if (which == 0) {
+                    *reinterpret_cast<f16x4_t*>(a.q16 + (hb * a.npad + tok) * 16 + 4 * g) = hv;
+                } else if (which == 1) {
+                    *reinterpret_cast<f16x4_t*>(a.k16 + ((hb * (a.npad >> 4) + (tok >> 4)) * 4 + g) * 64 + (tok & 15) * 4) = hv;
+                } else {
+                    const int kk = tok & 31, e = 4 * (kk >> 4) + (kk & 3), gk = (kk & 15) >> 2;
+                    _Float16* dst = a.v16 + ((hb * (a.npad >> 5) + (tok >> 5)) * 4 + gk) * 128 + e;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(4 * g + r) * 8] = hv[r];
                 }
             }
         } else if (EPI == EPI_UP) {
@@ -524,7 +555,7 @@ static int launch_gemm(const TrArgs& a, int B, hipStream_t st, const char* what)
     const size_t lds = (size_t)64 * (K * 4 + 16) + (PRO == PRO_PATCH ? 192 * sizeof(float) : 0);
     if (lds > 64 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&tr_gemm_kernel<K, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int tiles = EPI == EPI_QKV ? a.npad / 64 : (a.n + 63) / 64;
+    const int tiles = (EPI == EPI_QKV || EPI == EPI_QKV16) ? a.npad / 64 : (a.n + 63) / 64;
     hipLaunchKernelGGL((tr_gemm_kernel<K, PRO, EPI>), dim3(tiles, B), dim3(256), lds, st, a);
     return check_launch(what);
 }
@@ -608,25 +639,43 @@ extern "C" int mvs_tr_linear_fwd(const float* x, const void* w_packed, const flo
 }
 
 extern "C" size_t mvs_tr_attention_operand_bytes(int B, int n, int heads) {
-    const size_t npad = ((size_t)n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT);
-    return (size_t)B * heads * npad * 32 * 2;            // each of q, k, vt: 32 bf16 per (head, token)
+    // enough for either operand format: [hi16 | lo16] bf16 rows padded to 64 tokens, or 16 fp16 per row padded to kAttnPad tokens
+    const size_t npad = ((size_t)n + kAttnPad - 1) / kAttnPad * kAttnPad;
+    return (size_t)B * heads * npad * 32 * 2;            // each of q, k, vt
 }
 
 extern "C" int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, void* k, void* vt, float softmax_scale, int B, int n,
-                              int heads, int precision, void* stream) {
+                              int heads, int precision, int operand_format, void* stream) {
     if (!x || !w_packed || !q || !k || !vt || B < 1 || n < 1) { set_error("mvs_tr_qkv_fwd: bad arguments"); return MVS_ERR_ARG; }
     if (!only_bf16x3(precision, "mvs_tr_qkv_fwd")) return MVS_ERR_UNSUPPORTED;
     if (heads != 4) { set_error("mvs_tr_qkv_fwd: built for 4 heads of 16 channels (shipped transformer_config), got %d heads", heads); return MVS_ERR_UNSUPPORTED; }
     TrArgs a = {};
-    a.x = x; a.w = w_packed; a.q = static_cast<__bf16*>(q); a.k = static_cast<__bf16*>(k); a.vt = static_cast<__bf16*>(vt);
+    a.x = x; a.w = w_packed;
     a.qscale = softmax_scale * 1.44269504088896340736f;    // scores in base 2
-    a.heads = heads; a.npad = (n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT); a.n = n; a.N = 3 * 16 * heads;
+    a.heads = heads; a.n = n; a.N = 3 * 16 * heads;
+    if (operand_format == MVS_PREC_F16) {
+        a.q16 = static_cast<_Float16*>(q); a.k16 = static_cast<_Float16*>(k); a.v16 = static_cast<_Float16*>(vt);
+        a.npad = (n + kAttnPad - 1) / kAttnPad * kAttnPad;
+        // the GEMM runs over all npad rows: rows >= n are staged as zeros and written as zeros (no bias)
+        return launch_gemm<64, PRO_TOKENS, EPI_QKV16>(a, B, (hipStream_t)stream, "tr_gemm_kernel<qkv16>");
+    }
+    if (operand_format != MVS_PREC_BF16X3 && operand_format != MVS_PREC_BF16P) {
+        set_error("mvs_tr_qkv_fwd: operand_format must be MVS_PREC_BF16X3 (split-bf16 operands) or MVS_PREC_F16, got %d", operand_format);
+        return MVS_ERR_UNSUPPORTED;
+    }
+    a.q = static_cast<__bf16*>(q); a.k = static_cast<__bf16*>(k); a.vt = static_cast<__bf16*>(vt);
+    a.npad = (n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT);
     return launch_gemm<64, PRO_TOKENS, EPI_QKV>(a, B, (hipStream_t)stream, "tr_gemm_kernel<qkv>");
 }
 
 extern "C" int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt, float* out, int B, int n, int heads, int precision,
                                     void* stream) {
     if (!q || !k || !vt || !out || B < 1 || n < 1 || heads < 1) { set_error("mvs_tr_attention_fwd: bad arguments"); return MVS_ERR_ARG; }
+    if (precision == MVS_PREC_F16) {
+        const char* ev = getenv("MVS_ATTN_VARIANT");                       // measurement / test switch (tile shapes of the same algorithm)
+        const int variant = ev ? atoi(ev) : 0;
+        return launch_attention_f16(q, k, vt, out, B, n, heads, variant, (hipStream_t)stream);
+    }
     if (precision != MVS_PREC_BF16P && !only_bf16x3(precision, "mvs_tr_attention_fwd")) return MVS_ERR_UNSUPPORTED;
     const int npad = (n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT);
     const dim3 grid(npad / (64 * kAttnQT), heads, B);

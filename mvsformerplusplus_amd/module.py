@@ -396,14 +396,24 @@ class PureTransformerCostReg(nn.Module):
         self.up = nn.Sequential(nn.ConvTranspose3d(mid_channel, base_channel, kernel_size=down_rate, stride=down_rate),
                                 LayerNorm3D(base_channel, eps=1e-6))
         self.prob = nn.Conv3d(base_channel, 1, 1, stride=1, padding=0)
-        # "bf16x3": probabilities enter p.v as hi + lo (fp32-equivalent); "bf16p": as one bf16 term - what the reference's
-        # flash-attn does for q, k, v and p alike; -17 % attention time, depth parity unchanged at 1e-6
-        self.attention_precision = kwargs.get("attention_precision", "bf16x3")
+        # Attention core (the token GEMMs around it stay split-bf16):
+        #   "f16"     (default, round 4) q, k, v and the probabilities as ONE fp16 term, fp32 softmax statistics / accumulation - the form of
+        #             the reference's own GPU path (flash-attn on bf16 operands, attention.py:141-170) with 3 more significant bits; refined
+        #             depth 8e-7 relative L1 from the fp32 oracle (x30-logits stress set 3.5e-5), scripts/study_attention_precision.py
+        #   "bf16x3"  fp32-equivalent: four-term scores, three-term p.v (rounds 1-3)
+        #   "bf16p"   the latter with one-term bf16 probabilities
+        self.attention_precision = kwargs.get("attention_precision", "f16")
         self._cache = _PackedCache()
 
     @property
     def rate(self):
         return _triple(self.down_rate)
+
+    def attention_code(self) -> int:
+        try:
+            return {"f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "bf16p": _lib.PREC_BF16P}[self.attention_precision]
+        except KeyError:
+            raise ValueError("attention_precision must be 'f16', 'bf16x3' or 'bf16p', got %r" % (self.attention_precision,))
 
     def _build(self, dev):
         import math
@@ -441,8 +451,7 @@ class PureTransformerCostReg(nn.Module):
         if self.softmax_scale == "entropy_invariance":
             scale *= math.log(n, self.train_avg_length)                                       # attention.py:82-83 / 158-161
         for L in P["layers"]:
-            a = ops.tr_attention(x, L["qkv"], self.num_heads, scale, prec,
-                                 _lib.PREC_BF16P if self.attention_precision == "bf16p" else None)
+            a = ops.tr_attention(x, L["qkv"], self.num_heads, scale, prec, self.attention_code())
             x = ops.tr_linear(a, L["proj"], L["proj_b"], _lib.TR_EPI_RES_LN, 64, prec, residual=x, gamma=L["g1"],
                               ln_w=L["n1"][0], ln_b=L["n1"][1], ln_eps=L["n1"][2])
             hdn = ops.tr_linear(x, L["l1"], L["l1_b"], _lib.TR_EPI_GELU, L["l1_b"].numel(), prec)

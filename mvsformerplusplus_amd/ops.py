@@ -568,15 +568,16 @@ def tr_linear(x: torch.Tensor, w_packed, bias, epilogue: int, N: int, precision:
 
 def tr_attention(x: torch.Tensor, wqkv_packed, heads: int, softmax_scale: float, precision: int, attn_precision: Optional[int] = None) -> torch.Tensor:
     """x [B,n,64] -> softmax(q k^T * scale) v for all heads, [B,n,64] (qkv projection + flash attention, two launches).
-    ``attn_precision`` (default = precision) may be PREC_BF16P: bf16 probabilities in the p.v product."""
+    ``attn_precision`` (default = precision): PREC_F16 = one fp16 term per operand like the reference's flash-attn (the module's
+    default), PREC_BF16X3 = fp32-equivalent split-bf16 products, PREC_BF16P = the latter with bf16 probabilities in p.v."""
     B, n, Cc = x.shape
+    ap = precision if attn_precision is None else attn_precision
     nb = lib().mvs_tr_attention_operand_bytes(B, n, heads)
     buf = torch.empty(3, nb // 2, dtype=torch.bfloat16, device=x.device)
     check(lib().mvs_tr_qkv_fwd(ptr(x), ptr(wqkv_packed), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), float(softmax_scale), B, n, heads,
-                               precision, stream_of(x)), "mvs_tr_qkv_fwd")
+                               precision, ap, stream_of(x)), "mvs_tr_qkv_fwd")
     out = torch.empty(B, n, Cc, dtype=torch.float32, device=x.device)
-    check(lib().mvs_tr_attention_fwd(ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(out), B, n, heads,
-                                     precision if attn_precision is None else attn_precision, stream_of(x)),
+    check(lib().mvs_tr_attention_fwd(ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(out), B, n, heads, ap, stream_of(x)),
           "mvs_tr_attention_fwd")
     return out
 

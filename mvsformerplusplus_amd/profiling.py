@@ -157,8 +157,7 @@ def _transformer_layers(net, vol, pos, stage, launches):
         scale *= math.log(n, net.train_avg_length)
     for L in P["layers"]:
         a = _timed(launches, "[bundle] tr_gemm<qkv>+tr_attention", stage, 2.0 * T * 64 * 192 + 4.0 * B * n * n * 64,
-                   4.0 * T * (64 + 64) + 2.0 * T * 192 * 2, lambda: ops.tr_attention(x, L["qkv"], net.num_heads, scale, prec,
-                                                                               _lib.PREC_BF16P if net.attention_precision == "bf16p" else None))
+                   4.0 * T * (64 + 64) + 2.0 * T * 192 * 2, lambda: ops.tr_attention(x, L["qkv"], net.num_heads, scale, prec, net.attention_code()))
         x = _timed(launches, "tr_gemm<res_ln,64>", stage, 2.0 * T * 64 * 64, 4.0 * T * 64 * 3,
                    lambda: ops.tr_linear(a, L["proj"], L["proj_b"], _lib.TR_EPI_RES_LN, 64, prec, residual=x, gamma=L["g1"],
                                          ln_w=L["n1"][0], ln_b=L["n1"][1], ln_eps=L["n1"][2]))

@@ -187,6 +187,22 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_f16(hipemu_f16x8 a, hipemu_f
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_f32_16x16x32_f16
+// v_mfma_f32_16x16x16_f16 (the K = 16 form): lane l supplies A[i=l&15][k=4*(l>>4)+j], B[k=4*(l>>4)+j][col=l&15], j<4; D as 16x16 above.
+typedef _Float16 hipemu_f16x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x16f16(hipemu_f16x4 a, hipemu_f16x4 b, hipemu_f32x4 c, int, int, int) {
+    struct AB { hipemu_f16x4 a, b; } mine{a, b}, all[64];
+    hipemu::wave_gather(&mine, all, sizeof(AB));
+    const int l = hipemu::lane_id(), col = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < 4; ++j) acc += (float)all[row + 16 * k].a[j] * (float)all[col + 16 * k].b[j];
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16f16 hipemu_mfma_f32_16x16x16f16
 static inline float hipemu_fmed3f(float a, float b, float c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 #define __builtin_amdgcn_fmed3f hipemu_fmed3f
 
@@ -276,6 +292,9 @@ static inline int hipemu_any(int pred) {
 #define MVS_OPAQUE_SREG "r"
 #define MVS_NO_OPAQUE_VEC 1    // 128-bit bf16 vectors have no x86 asm register class; the laundering is a GPU register-allocation hint only
 
+// LDS-DMA (global_load_lds_dwordx4): the emulated copy lands at once; every fiber is one lane
+#define MVS_GLOBAL_LOAD_LDS16(gsrc, ldst) memcpy(static_cast<char*>(static_cast<void*>(ldst)) + 16 * hipemu::lane_id(), (gsrc), 16)
+#define MVS_WAIT_VMEM() ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_getreg(imm) 0
 #define __builtin_amdgcn_s_sleep(n) ((void)0)

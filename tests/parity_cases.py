@@ -756,12 +756,17 @@ def _tcfg(fx):
     return json.loads(fx["cfg"])
 
 
-def case_transformer_golden(device):
-    """PureTransformerCostReg alone + get_position_3d against fixture f7 (generated from the reference)."""
+def case_transformer_golden(device, attention_precision=None):
+    """PureTransformerCostReg alone + get_position_3d against fixture f7 (generated from the reference).  attention_precision None = the
+    module default ("f16": one fp16 term per attention operand, like the reference's flash-attn path but 3 bits wider): logits within 1e-3;
+    "bf16x3" = the fp32-equivalent attention: 2e-4."""
     from mvsformerplusplus_amd import PureTransformerCostReg, get_position_3d
     fx = load_golden("f7_transformer.npz")
     cfg = _tcfg(fx)
+    if attention_precision:
+        cfg["attention_precision"] = attention_precision
     net = PureTransformerCostReg(8, **cfg)
+    assert net.attention_precision == (attention_precision or "f16")
     net.load_state_dict(golden_weights(fx), strict=True)
     net = net.eval().to(device)
     dv = fx["depth_values"]
@@ -774,33 +779,42 @@ def case_transformer_golden(device):
         assert torch.equal(cpu(pos2), cpu(pos)), "reusing the measured range must reproduce the positions"
         y = cpu(net(dev(fx["x"], device), dev(fx["position3d"], device)))
         y0 = cpu(net(dev(fx["x"], device), None))
-    tol = 2e-4 * max(1.0, float(fx["y"].abs().max()))
+    tol = (2e-4 if net.attention_precision == "bf16x3" else 1e-3) * max(1.0, float(fx["y"].abs().max()))
     assert y.shape == fx["y"].shape
     assert (y - fx["y"]).abs().max() <= tol, float((y - fx["y"]).abs().max())
     assert (y0 - fx["y_nope"]).abs().max() <= tol, float((y0 - fx["y_nope"]).abs().max())
+    return float((y - fx["y"]).abs().max())
 
 
-def case_stage_transformer_golden(device):
+def case_stage_transformer_golden(device, attention_precision=None):
     from mvsformerplusplus_amd.cost_volume import StageNet
     fx = load_golden("f8_stage_transformer.npz")
-    args = dict(ARGS, cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(fx)])
+    tc = _tcfg(fx)
+    if attention_precision:
+        tc["attention_precision"] = attention_precision
+    args = dict(ARGS, cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[tc])
     st = StageNet(args, 32, 0)
     st.load_state_dict(golden_weights(fx), strict=True)
     st = st.eval().to(device)
     with torch.no_grad():
         out = st(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), tmp=5.0, position3d=dev(fx["position3d"], device))
-    assert (cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max() <= 1e-3
-    assert (cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max() <= 1e-4
-    assert rel_l1(cpu(out["depth"]), fx["depth"]) <= 1e-5
+    exact = st.cost_reg.attention_precision == "bf16x3"
+    assert (cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max() <= (1e-3 if exact else 3e-3)
+    assert (cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max() <= (1e-4 if exact else 5e-4)
+    assert rel_l1(cpu(out["depth"]), fx["depth"]) <= (1e-5 if exact else 5e-5)
 
 
-def case_cascade_shipped_golden(device, conv_precision=None):
+def case_cascade_shipped_golden(device, conv_precision=None, attention_precision=None):
     """Shipped regulariser mix (stage-1 transformer + Frustoconical PE, CostRegNet / CostRegNet3D after it) on the f4 inputs.
-    conv_precision "f16x2" (product default): the three U-Net stages and all four visibility CNNs in the fp16 form; 3e-4 instead of 1e-4."""
+    conv_precision "f16x2" (product default): the three U-Net stages and all four visibility CNNs in the fp16 form; 3e-4 instead of 1e-4.
+    attention_precision None = the module default ("f16")."""
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
     fx, f4 = load_golden("f9_cascade_shipped.npz"), load_golden("f4_cascade.npz")
+    tc = _tcfg(fx)
+    if attention_precision:
+        tc["attention_precision"] = attention_precision
     args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True, use_pe3d=True,
-                cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[_tcfg(fx)])
+                cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[tc])
     tol = 1e-4
     if conv_precision:
         args["conv_precision"] = conv_precision
@@ -819,26 +833,33 @@ def case_cascade_shipped_golden(device, conv_precision=None):
     assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= (1e-3 if conv_precision is None else 2e-2)
 
 
-def case_attention_stress(device, n=200, gain=2.0, bf16p=False):
-    """Flash attention alone against float64 softmax attention: token count not a multiple of the 64-key block (masked tail),
-    scores large and growing along the key axis so that the lazily raised running maximum must rescale in later blocks."""
+def case_attention_stress(device, n=200, gain=2.0, bf16p=False, mode=None):
+    """Flash attention alone against float64 softmax attention: token count not a multiple of the key block (masked tail),
+    scores large and growing along the key axis so that the lazily raised running maximum must rescale in later blocks.
+    mode: "f16" (the module default: one fp16 term per operand, csrc/attention_f16_kernels.hip), "bf16p", or None = "bf16x3"."""
     from mvsformerplusplus_amd import _lib, ops, packing
+    mode = mode or ("bf16p" if bf16p else "bf16x3")
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, n, 64, generator=g)
     x = x * torch.linspace(0.2, 1.0, n).reshape(1, n, 1) * gain         # later keys carry larger scores
     w = torch.randn(192, 64, generator=g) * 0.125
     scale = 0.25 * 1.07
-    got = cpu(ops.tr_attention(dev(x, device), dev(packing.pack_linear_bf16x3(w), device), 4, scale, _lib.PREC_BF16X3,
-                               _lib.PREC_BF16P if bf16p else None))
+    code = {"f16": _lib.PREC_F16, "bf16p": _lib.PREC_BF16P, "bf16x3": None}[mode]
+    got = cpu(ops.tr_attention(dev(x, device), dev(packing.pack_linear_bf16x3(w), device), 4, scale, _lib.PREC_BF16X3, code))
     qkv = (x.double() @ w.double().t()).reshape(2, n, 3, 4, 16).permute(2, 0, 3, 1, 4)
     att = torch.softmax(qkv[0] @ qkv[1].transpose(-2, -1) * scale, -1) @ qkv[2]
     ref = att.transpose(1, 2).reshape(2, n, 64).float()
-    assert float((qkv[0] @ qkv[1].transpose(-2, -1)).abs().max() * scale * 1.4427) > 3 * 8.0, "the case must exceed the lazy threshold"
+    smax = float((qkv[0] @ qkv[1].transpose(-2, -1)).abs().max() * scale * 1.4427)
+    assert smax > 3 * 8.0, "the case must exceed the lazy threshold"
     # the split-bf16 score product carries ~2^-17 relative error, i.e. an ABSOLUTE error proportional to the score in
     # the exponent: measured relative output error ~ 5e-7 * max|score in log2 units| (1.6e-4 at 308, 2.8e-5 at 34)
     err = float((got - ref).abs().max())
-    # bf16 probabilities (MVS_PREC_BF16P): 2^-9 relative rounding per probability, unbiased
-    assert err <= (4e-3 if bf16p else 1e-4) * max(1.0, float(ref.abs().max())), err
+    # bf16 probabilities (MVS_PREC_BF16P): 2^-9 relative rounding per probability, unbiased.
+    # fp16 operands (MVS_PREC_F16): q and k carry 2^-12 relative rounding each, i.e. an absolute score error ~ 2^-12 |score| / 2 in the
+    # exponent (this stress set reaches scores of several hundred in log2 units - far beyond the O(10) of the real network, where the
+    # error is 1e-4 of the logits, scripts/study_attention_precision.py), plus 2^-12 per probability and value
+    tol = {"bf16x3": 1e-4, "bf16p": 4e-3, "f16": 1e-3 + 1.5e-4 * smax}[mode]
+    assert err <= tol * max(1.0, float(ref.abs().max())), (err, smax)
     return err
 
 

@@ -93,12 +93,14 @@ def test_cascade_golden(emu):
     P.case_cascade_golden(emu)
 
 
-def test_transformer_golden(emu):
-    P.case_transformer_golden(emu)
+@pytest.mark.parametrize("attn", [None, "bf16x3"])
+def test_transformer_golden(emu, attn):
+    P.case_transformer_golden(emu, attn)
 
 
-def test_stage_transformer_golden(emu):
-    P.case_stage_transformer_golden(emu)
+@pytest.mark.parametrize("attn", [None, "bf16x3"])
+def test_stage_transformer_golden(emu, attn):
+    P.case_stage_transformer_golden(emu, attn)
 
 
 def test_cascade_shipped_golden(emu):
@@ -107,6 +109,13 @@ def test_cascade_shipped_golden(emu):
 
 def test_attention_stress(emu):
     P.case_attention_stress(emu)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
+def test_attention_stress_f16(emu, variant, monkeypatch):
+    """The fp16 flash attention (module default) incl. its tile-shape variants: masked tail, rescales far into the key stream."""
+    monkeypatch.setenv("MVS_ATTN_VARIANT", str(variant))
+    P.case_attention_stress(emu, n=300 if variant else 200, mode="f16")
 
 
 def test_fusion_golden(emu):

@@ -195,13 +195,16 @@ def test_baseline_cfgs_fullsize_properties(name):
     P.case_baseline_cfg_full(DEV, name)
 
 
-def test_transformer_golden():
-    """SURVEY.md section 8f #1: PureTransformerCostReg + get_position_3d vs fixture f7 (from the reference)."""
-    P.case_transformer_golden(DEV)
+@pytest.mark.parametrize("attn", [None, "bf16x3"])
+def test_transformer_golden(attn):
+    """PureTransformerCostReg + get_position_3d vs fixture f7 (from the reference); None = the default attention
+    precision ("f16"), "bf16x3" = the fp32-equivalent attention of rounds 1-3."""
+    P.case_transformer_golden(DEV, attn)
 
 
-def test_stage_transformer_golden():
-    P.case_stage_transformer_golden(DEV)
+@pytest.mark.parametrize("attn", [None, "bf16x3"])
+def test_stage_transformer_golden(attn):
+    P.case_stage_transformer_golden(DEV, attn)
 
 
 def test_cascade_shipped_golden():
@@ -213,6 +216,12 @@ def test_cascade_shipped_golden():
 def test_attention_stress(n):
     """Masked key tail + running-maximum rescales far into the key stream, vs float64 softmax attention."""
     P.case_attention_stress(DEV, n=n)
+
+
+@pytest.mark.parametrize("n", [200, 4099])
+def test_attention_stress_f16(n):
+    """The same for the module default: one fp16 term per attention operand (csrc/attention_f16_kernels.hip)."""
+    P.case_attention_stress(DEV, n=n, mode="f16")
 
 
 def test_fusion_golden():
