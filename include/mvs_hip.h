@@ -58,7 +58,7 @@ enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
  *                    v_mfma_f32_16x16x32_f16, fp32 accumulation, fp32 logits.  Final depth vs the fp32 oracle: 5.5e-5 relative L1 on plain
  *                    inputs, 4.2e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers under bf16
  *                    autocast (test.py:250).  Values beyond +-65504 overflow: the aggregate pass clamps the volume it writes.           */
-enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2, MVS_PREC_BF16X3_SPLIT = 3, MVS_PREC_F16X2 = 4, MVS_PREC_F16 = 5 };
+enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2, MVS_PREC_BF16X3_SPLIT = 3, MVS_PREC_F16X2 = 4, MVS_PREC_ATTN16 = 5 };
 /* format of the cost volume mvs_warp_corr_aggregate_fwd / mvs_volume_normalise leave behind: fp32 [B,D,H,W,8], the split activation
  * format of MVS_PREC_BF16X3_SPLIT, or fp16 [B,D,H,W,8] for MVS_PREC_F16X2 (aggregate only; normalised volumes of 8 groups only;
  * partial sums are always fp32) */
@@ -323,17 +323,18 @@ int mvs_tr_linear_fwd(const float* x, const void* w_packed, const float* bias, i
  * `precision` = contraction of the projection itself (MVS_PREC_BF16X3); `operand_format` = what the attention kernel will read:
  *   MVS_PREC_BF16X3 (or _BF16P)  q, k as [B,heads,npad,32] bf16 = [hi16 | lo16], v transposed as [B,heads,2,16,npad] bf16, npad = n
  *                                rounded up to 64 (rounds 1-3: fp32-equivalent attention)
- *   MVS_PREC_F16                 ONE fp16 term per operand like the reference's flash-attn (dino/layers/attention.py:141-170 runs q, k, v,
- *                                p in bf16): q [B,heads,npad,16]; k as score-MFMA operand tiles [B,heads,npad/16,4,16,4]; v as p.v-MFMA
- *                                operand tiles [B,heads,npad/32,4,16,8] in the key order the scores leave the matrix core in
- *                                (csrc/attention_f16_kernels.hip); npad = n rounded up to 256; values clamped to +-65504
+ *   MVS_PREC_ATTN16              ONE 16-bit term per operand like the reference's flash-attn (dino/layers/attention.py:141-170 runs q, k, v,
+ *                                p in bf16): q, k fp16 (clamped to +-65504), v bf16 (the probabilities are bf16 in the kernel); q
+ *                                [B,heads,npad,16]; k as score-MFMA operand tiles [B,heads,npad/32,4,16,2,4]; v as p.v-MFMA operand tiles
+ *                                [B,heads,npad/32,4,16,8] in the key order the scores leave the matrix core in
+ *                                (csrc/attention_f16_kernels.hip); npad = n rounded up to 256
  * Each buffer holds mvs_tr_attention_operand_bytes(B, n, heads) bytes (enough for either format).                              */
 size_t mvs_tr_attention_operand_bytes(int B, int n, int heads);
 int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, void* k, void* vt, float softmax_scale, int B, int n,
                    int heads, int precision, int operand_format, void* stream);
 /* softmax(q k^T) v over all n tokens -> out [B,n,heads*16] (scaled_dot_product_attention, attention.py:96);
  * precision = the operand format of mvs_tr_qkv_fwd: MVS_PREC_BF16X3 (four-term scores, three-term p.v), MVS_PREC_BF16P (the same with
- * one-term probabilities) or MVS_PREC_F16 (fp16 operands, one MFMA term, fp32 softmax statistics and accumulation)              */
+ * one-term probabilities) or MVS_PREC_ATTN16 (fp16 q / k, bf16 p / v, one MFMA term, fp32 softmax statistics and accumulation)              */
 int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt, float* out, int B, int n, int heads,
                          int precision, void* stream);
 /* Backward of the attention core (training path; the reference differentiates scaled_dot_product_attention / flash-attn,

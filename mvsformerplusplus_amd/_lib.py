@@ -23,7 +23,7 @@ DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 LAYOUT_PLANAR, LAYOUT_OCTET_TILED = 0, 1
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
-PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT, PREC_F16X2, PREC_F16 = 0, 1, 2, 3, 4, 5
+PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT, PREC_F16X2, PREC_ATTN16 = 0, 1, 2, 3, 4, 5
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f16x2": PREC_F16X2}
 VOLUME_F32, VOLUME_SPLIT, VOLUME_F16 = 0, 1, 2
 

@@ -38,7 +38,7 @@ def shard_views(n_src: int, world: int, rank: int):
 # ~5e-5 relative L1 on plain inputs, 4e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers
 # under bf16 autocast (test.py:250).  "bf16x3" = fp32-equivalent activations (split bf16 pairs, three terms; 1e-6 from the oracle),
 # "fp32" = exact.  args["conv_precision"] overrides it per head.  Training always runs the bf16x3 kernels on fp32 activations.
-STAGE_DEFAULT_PRECISION = "f16x2"
+STAGE_DEFAULT_PRECISION = DEFAULT_PRECISION      # one constant (module.DEFAULT_PRECISION): "f16x2"
 
 
 class StageNet(nn.Module):

@@ -64,9 +64,9 @@ struct TrArgs {
     __bf16* q;               // EPI_QKV: [B, heads, npad, 32] = [hi16 | lo16], pre-multiplied by qscale
     __bf16* k;               //          [B, heads, npad, 32]
     __bf16* vt;              //          [B, heads, 2 (hi, lo), 16, npad]
-    _Float16* q16;           // EPI_QKV16 (attention_f16_kernels.hip): Q [B, heads, npad, 16], pre-multiplied by qscale
-    _Float16* k16;           //            KP [B, heads, npad/16, 4, 16, 4]: dims 4g..4g+3 of key 16 tile + j at [tile][g][j]
-    _Float16* v16;           //            VP [B, heads, npad/32, 4, 16, 8]: v[key 32 step + 16 (e >> 2) + 4g + (e & 3)][d] at [step][g][d][e]
+    _Float16* q16;           // EPI_QKV16 (attention_f16_kernels.hip): Q [B, heads, npad, 16] fp16, pre-multiplied by qscale
+    _Float16* k16;           //            KP [B, heads, npad/32, 4, 16, 2, 4] fp16: dims 4g..4g+3 of key 32 step + 16 t + j at [step][g][j][t]
+    __bf16* v16;             //            VP [B, heads, npad/32, 4, 16, 8] bf16: v[key 32 step + 16 (e >> 2) + 4g + (e & 3)][d] at [step][g][d][e]
     float qscale;
     int heads, npad;
     const float* prob_w;     // EPI_UP: prob.weight [8], prob.bias [1]
@@ -256,28 +256,27 @@ __global__ __launch_bounds__(256) void tr_gemm_kernel(const TrArgs a) {
                 }
             }
         } else if (EPI == EPI_QKV16) {
-            // the fp16 operands of tr_attention_f16_kernel; the lane holds dims 4g..4g+3 of (which, head) for token j.  Values are clamped to
-            // the fp16 range (|x| <= 65504); rows >= n of the padded buffers receive zeros like EPI_QKV.
+            // the 16-bit operands of tr_attention16_kernel; the lane holds dims 4g..4g+3 of (which, head) for token j.  q and k are fp16,
+            // clamped to the fp16 range (|x| <= 65504); v is bf16; rows >= n of the padded buffers receive zeros like EPI_QKV.
             typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const int tile = mc + mb, which = tile / a.heads, hh = tile - which * a.heads;
                 const size_t hb = (size_t)b * a.heads + hh;
-                f16x4_t hv;
+                if (which < 2) {
+                    f16x4_t hv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = which == 0 ? acc[mb][r] * a.qscale : acc[mb][r];
-                    hv[r] = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
-                }
-                if (which == 0) {
-                    *reinterpret_cast<f16x4_t*>(a.q16 + (hb * a.npad + tok) * 16 + 4 * g) = hv;
-                } else if (which == 1) {
-                    *reinterpret_cast<f16x4_t*>(a.k16 + ((hb * (a.npad >> 4) + (tok >> 4)) * 4 + g) * 64 + (tok & 15) * 4) = hv;
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = which == 0 ? acc[mb][r] * a.qscale : acc[mb][r];
+                        hv[r] = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
+                    }
+                    if (which == 0) *reinterpret_cast<f16x4_t*>(a.q16 + (hb * a.npad + tok) * 16 + 4 * g) = hv;
+                    else *reinterpret_cast<f16x4_t*>(a.k16 + (((hb * (a.npad >> 5) + (tok >> 5)) * 4 + g) * 16 + (tok & 15)) * 8 + ((tok >> 4) & 1) * 4) = hv;
                 } else {
                     const int kk = tok & 31, e = 4 * (kk >> 4) + (kk & 3), gk = (kk & 15) >> 2;
-                    _Float16* dst = a.v16 + ((hb * (a.npad >> 5) + (tok >> 5)) * 4 + gk) * 128 + e;
+                    __bf16* dst = a.v16 + ((hb * (a.npad >> 5) + (tok >> 5)) * 4 + gk) * 128 + e;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[(4 * g + r) * 8] = hv[r];
+                    for (int r = 0; r < 4; ++r) dst[(4 * g + r) * 8] = (__bf16)acc[mb][r];
                 }
             }
         } else if (EPI == EPI_UP) {
@@ -653,14 +652,14 @@ extern "C" int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, voi
     a.x = x; a.w = w_packed;
     a.qscale = softmax_scale * 1.44269504088896340736f;    // scores in base 2
     a.heads = heads; a.n = n; a.N = 3 * 16 * heads;
-    if (operand_format == MVS_PREC_F16) {
-        a.q16 = static_cast<_Float16*>(q); a.k16 = static_cast<_Float16*>(k); a.v16 = static_cast<_Float16*>(vt);
+    if (operand_format == MVS_PREC_ATTN16) {
+        a.q16 = static_cast<_Float16*>(q); a.k16 = static_cast<_Float16*>(k); a.v16 = static_cast<__bf16*>(vt);
         a.npad = (n + kAttnPad - 1) / kAttnPad * kAttnPad;
         // the GEMM runs over all npad rows: rows >= n are staged as zeros and written as zeros (no bias)
         return launch_gemm<64, PRO_TOKENS, EPI_QKV16>(a, B, (hipStream_t)stream, "tr_gemm_kernel<qkv16>");
     }
     if (operand_format != MVS_PREC_BF16X3 && operand_format != MVS_PREC_BF16P) {
-        set_error("mvs_tr_qkv_fwd: operand_format must be MVS_PREC_BF16X3 (split-bf16 operands) or MVS_PREC_F16, got %d", operand_format);
+        set_error("mvs_tr_qkv_fwd: operand_format must be MVS_PREC_BF16X3 (split-bf16 operands) or MVS_PREC_ATTN16, got %d", operand_format);
         return MVS_ERR_UNSUPPORTED;
     }
     a.q = static_cast<__bf16*>(q); a.k = static_cast<__bf16*>(k); a.vt = static_cast<__bf16*>(vt);
@@ -671,10 +670,10 @@ extern "C" int mvs_tr_qkv_fwd(const float* x, const void* w_packed, void* q, voi
 extern "C" int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt, float* out, int B, int n, int heads, int precision,
                                     void* stream) {
     if (!q || !k || !vt || !out || B < 1 || n < 1 || heads < 1) { set_error("mvs_tr_attention_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (precision == MVS_PREC_F16) {
+    if (precision == MVS_PREC_ATTN16) {
         const char* ev = getenv("MVS_ATTN_VARIANT");                       // measurement / test switch (tile shapes of the same algorithm)
         const int variant = ev ? atoi(ev) : 0;
-        return launch_attention_f16(q, k, vt, out, B, n, heads, variant, (hipStream_t)stream);
+        return launch_attention16(q, k, vt, out, B, n, heads, variant, (hipStream_t)stream);
     }
     if (precision != MVS_PREC_BF16P && !only_bf16x3(precision, "mvs_tr_attention_fwd")) return MVS_ERR_UNSUPPORTED;
     const int npad = (n + 64 * kAttnQT - 1) / (64 * kAttnQT) * (64 * kAttnQT);

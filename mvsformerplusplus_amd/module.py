@@ -10,8 +10,10 @@ checkpoint loads with ``strict=True`` (SURVEY.md section 8b state-dict contract)
     depth_regression, conf_regression, init_range, init_inverse_range, schedule_inverse_range, schedule_range
 
 The torch sub-modules are parameter containers only: every forward runs hand-written HIP kernels through
-``ops`` (implicit-GEMM MFMA convs with BatchNorm folded at eval time).  Training-mode BatchNorm and backward
-are not part of this round and raise instead of silently falling back.
+``ops`` (implicit-GEMM MFMA convs with BatchNorm folded at eval time).  Training mode (batch-statistics BatchNorm, backward:
+SURVEY.md section 8f #2) runs through ``training.py``'s autograd Functions over the library's training kernels when a StageNet /
+CascadeDepthHead is in ``.train()`` mode; the standalone layer wrappers of this file are inference forms and raise for train-mode
+BatchNorm or tensors that require grad instead of silently falling back.
 """
 from __future__ import annotations
 
@@ -25,15 +27,25 @@ from . import _lib, ops, packing
 
 def _bn_dict(bn: nn.Module) -> Dict[str, torch.Tensor]:
     if bn.training:
-        raise NotImplementedError("train-mode BatchNorm (batch statistics) is not implemented in the HIP path yet "
-                                  "(SURVEY.md section 8f #2); call .eval() on the BatchNorm layers")
+        raise NotImplementedError("train-mode BatchNorm (batch statistics) of a standalone layer: the native training path (training.py, SURVEY.md "
+                                  "section 8f #2) is entered through StageNet / CascadeDepthHead in .train() mode; call .eval() for this inference form")
     return {"weight": bn.weight.detach().cpu(), "bias": bn.bias.detach().cpu(),
             "running_mean": bn.running_mean.detach().cpu(), "running_var": bn.running_var.detach().cpu(), "eps": float(bn.eps)}
 
 
-# contraction of the MFMA convolutions: "bf16x3" (3-term split bf16, fp32-equivalent activations), "f16x2" (fp16 activations, fp16
-# hi + lo weights, 2 terms: 1.3x faster, depth 5e-5 / 4e-4 from the fp32 oracle on plain / stress inputs) or "fp32" (exact)
-DEFAULT_PRECISION = "bf16x3"
+# THE default contraction / activation format of the 3-D regularisers at inference (one constant: cost_volume.STAGE_DEFAULT_PRECISION is
+# this value): "f16x2" - fp16 activation tensors, fp16 hi + lo weights, two MFMA terms per product, fp32 accumulation; depth 5e-5 / 4e-4
+# from the fp32 oracle on plain / x30-logits stress inputs (bar 1e-3); the reference's own GPU path runs these layers under bf16 autocast
+# (test.py:250).  "bf16x3" = 3-term split bf16, fp32-equivalent activations (1e-6 from the oracle); "fp32" = exact.
+DEFAULT_PRECISION = "f16x2"
+
+
+def _to_act(x_cl: torch.Tensor, precision: str) -> torch.Tensor:
+    """fp32 channel-last tensor -> the activation dtype of `precision` (API edge of the standalone layer wrappers): fp16, clamped to the
+    fp16 range, for "f16x2"."""
+    if precision == "f16x2" and x_cl.dtype == torch.float32:
+        return x_cl.clamp(-65504.0, 65504.0).to(torch.float16)
+    return x_cl
 
 
 def _mfma_pack(precision, packer, *args):
@@ -79,8 +91,8 @@ class _PackedCache:
 
 def _no_grad_path(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("backward through the HIP hot path is not implemented yet (SURVEY.md section 8f #2); "
-                                  "run under torch.no_grad()")
+        raise NotImplementedError("this standalone wrapper is the inference form; gradients flow through StageNet / CascadeDepthHead "
+                                  "(training.py, SURVEY.md section 8f #2) - run it under torch.no_grad()")
 
 
 # --------------------------------------------------------------------------------------------------
@@ -126,7 +138,8 @@ class Conv3d(nn.Module):
 
     def forward(self, x):
         _no_grad_path(x)
-        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x), getattr(self, "conv_precision", DEFAULT_PRECISION)))
+        prec = getattr(self, "conv_precision", DEFAULT_PRECISION)
+        return ops.cl_to_ncdhw(self.forward_cl(_to_act(ops.ncdhw_to_cl(x), prec), prec).float())
 
 
 class Deconv3d(nn.Module):
@@ -153,7 +166,8 @@ class Deconv3d(nn.Module):
 
     def forward(self, x):
         _no_grad_path(x)
-        return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x), None, getattr(self, "conv_precision", DEFAULT_PRECISION)))
+        prec = getattr(self, "conv_precision", DEFAULT_PRECISION)
+        return ops.cl_to_ncdhw(self.forward_cl(_to_act(ops.ncdhw_to_cl(x), prec), None, prec).float())
 
 
 def _deconv_sd(conv: nn.ConvTranspose3d) -> int:
@@ -235,9 +249,12 @@ class _RegNetBase(nn.Module):
         return self._cache.get(self, lambda dev: self._build(dev, precision), precision)
 
     def forward_cl(self, volume_cl: torch.Tensor, precision=None) -> torch.Tensor:
-        """[B,D,H,W,8] channel-last cost volume -> [B,D,H,W,8] features that feed `prob`."""
+        """[B,D,H,W,8] channel-last cost volume -> [B,D,H,W,8] features that feed `prob`.  With precision "f16x2" the U-Net's tensors are
+        fp16: an fp32 volume is converted on the way in (clamped to the fp16 range, ops.volume_to_f16) and the features come back fp16."""
         precision = precision or self.conv_precision
         ws, bs, _, _ = self.packed_all(volume_cl.device, precision)
+        if precision == "f16x2" and volume_cl.dtype == torch.float32:
+            volume_cl = ops.volume_to_f16(volume_cl)
         return ops.regnet(self.kind, volume_cl, ws, bs, precision_code(precision))
 
     def forward(self, x, *kwargs):
@@ -249,6 +266,8 @@ class _RegNetBase(nn.Module):
         B, D, H, W, _ = feat.shape
         if self.prob_ksize == 3 and self.conv_precision in ("bf16x3", "f16x2"):
             return ops.conv3d_logits(feat, prob_w, prob_b, precision_code(self.conv_precision)).unsqueeze(1)
+        if feat.dtype != torch.float32:
+            feat = feat.float()                         # the standalone 1x1x1 head reads fp32
         dummy_hyp = torch.ones(B, D, H, W, dtype=torch.float32, device=x.device)
         _, _, _, pre = ops.prob_regress(feat, prob_w, prob_b, self.prob_ksize, dummy_hyp, 1.0, _lib.HEAD_CE_EVAL, 0, True)
         return pre.unsqueeze(1)
@@ -397,12 +416,13 @@ class PureTransformerCostReg(nn.Module):
                                 LayerNorm3D(base_channel, eps=1e-6))
         self.prob = nn.Conv3d(base_channel, 1, 1, stride=1, padding=0)
         # Attention core (the token GEMMs around it stay split-bf16):
-        #   "f16"     (default, round 4) q, k, v and the probabilities as ONE fp16 term, fp32 softmax statistics / accumulation - the form of
-        #             the reference's own GPU path (flash-attn on bf16 operands, attention.py:141-170) with 3 more significant bits; refined
-        #             depth 8e-7 relative L1 from the fp32 oracle (x30-logits stress set 3.5e-5), scripts/study_attention_precision.py
+        #   "attn16"  (default, round 4) ONE 16-bit term per operand, the form of the reference's own GPU path (flash-attn on bf16 q, k, v, p,
+        #             attention.py:141-170): q, k fp16 (3 more bits than the reference where the error enters the exponent), p, v bf16, fp32
+        #             softmax statistics and accumulation; refined depth 7e-6 .. 9e-6 relative L1 from the fp32 oracle, 2.5e-4 .. 2.8e-4 on the
+        #             x30-logits stress set (all-bf16 like the reference: 1.3e-5 / 4.2e-4), scripts/study_attention_precision.py
         #   "bf16x3"  fp32-equivalent: four-term scores, three-term p.v (rounds 1-3)
         #   "bf16p"   the latter with one-term bf16 probabilities
-        self.attention_precision = kwargs.get("attention_precision", "f16")
+        self.attention_precision = kwargs.get("attention_precision", "attn16")
         self._cache = _PackedCache()
 
     @property
@@ -411,9 +431,9 @@ class PureTransformerCostReg(nn.Module):
 
     def attention_code(self) -> int:
         try:
-            return {"f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "bf16p": _lib.PREC_BF16P}[self.attention_precision]
+            return {"attn16": _lib.PREC_ATTN16, "bf16x3": _lib.PREC_BF16X3, "bf16p": _lib.PREC_BF16P}[self.attention_precision]
         except KeyError:
-            raise ValueError("attention_precision must be 'f16', 'bf16x3' or 'bf16p', got %r" % (self.attention_precision,))
+            raise ValueError("attention_precision must be 'attn16', 'bf16x3' or 'bf16p', got %r" % (self.attention_precision,))
 
     def _build(self, dev):
         import math

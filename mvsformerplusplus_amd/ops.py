@@ -298,6 +298,8 @@ def deconv3d_prob(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor
                   prob_b: torch.Tensor, precision: int) -> torch.Tensor:
     """Last U-Net layer (Cout = 8) + skip + 1x1x1 `prob` in one launch -> logits [B, D*sd, 2H, 2W]."""
     B, D, H, W, cin = x_cl.shape
+    _act_dtype(x_cl, precision)
+    _act_dtype(skip_cl, precision)
     logits = torch.empty(B, D * sd, 2 * H, 2 * W, dtype=torch.float32, device=x_cl.device)
     check(lib().mvs_deconv3d_prob_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(skip_cl), ptr(prob_w), ptr(prob_b), ptr(logits), B, cin, D, H, W,
                                       sd, precision, stream_of(x_cl)), "mvs_deconv3d_prob_fwd")
@@ -462,6 +464,7 @@ def conv3d_logits(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor
     """CostRegNet's 3x3x3 `prob` head on the MFMA path: x_cl [B,D,H,W,8] -> logits [B,D,H,W]."""
     B, D, H, W, c = x_cl.shape
     assert c == 8
+    _act_dtype(x_cl, precision)
     logits = torch.empty(B, D, H, W, dtype=torch.float32, device=x_cl.device)
     check(lib().mvs_conv3d_logits_fwd(ptr(x_cl), ptr(w_packed), ptr(bias), ptr(logits), B, D, H, W, precision, stream_of(x_cl)),
           "mvs_conv3d_logits_fwd")
@@ -477,6 +480,7 @@ def regnet(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.Tensor],
     """Whole U-Net up to (not including) `prob`: volume_cl [B,D,H,W,8] -> feat_cl [B,D,H,W,8]."""
     B, D, H, W, c = volume_cl.shape
     assert c == 8 and len(w_packed) == 9 and len(bias) == 9
+    _act_dtype(volume_cl, precision)
     out = torch.empty_like(volume_cl)
     nbytes = lib().mvs_regnet_workspace_bytes(kind, B, D, H, W)
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=volume_cl.device)
@@ -491,6 +495,7 @@ def regnet_logits(kind: int, volume_cl: torch.Tensor, w_packed: Sequence[torch.T
     """U-Net + fused 1x1x1 `prob` head: volume_cl [B,D,H,W,8] -> logits [B,D,H,W] (the feature volume stays on chip)."""
     B, D, H, W, c = volume_cl.shape
     assert c == 8 and len(w_packed) == 9 and len(bias) == 9
+    _act_dtype(volume_cl, precision)
     logits = torch.empty(B, D, H, W, dtype=torch.float32, device=volume_cl.device)
     nbytes = lib().mvs_regnet_workspace_bytes(kind, B, D, H, W)
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=volume_cl.device)
@@ -568,7 +573,7 @@ def tr_linear(x: torch.Tensor, w_packed, bias, epilogue: int, N: int, precision:
 
 def tr_attention(x: torch.Tensor, wqkv_packed, heads: int, softmax_scale: float, precision: int, attn_precision: Optional[int] = None) -> torch.Tensor:
     """x [B,n,64] -> softmax(q k^T * scale) v for all heads, [B,n,64] (qkv projection + flash attention, two launches).
-    ``attn_precision`` (default = precision): PREC_F16 = one fp16 term per operand like the reference's flash-attn (the module's
+    ``attn_precision`` (default = precision): PREC_ATTN16 = one fp16 term per operand like the reference's flash-attn (the module's
     default), PREC_BF16X3 = fp32-equivalent split-bf16 products, PREC_BF16P = the latter with bf16 probabilities in p.v."""
     B, n, Cc = x.shape
     ap = precision if attn_precision is None else attn_precision

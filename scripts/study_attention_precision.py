@@ -61,7 +61,8 @@ def state_dicts(peaky, seed=11):
     return sds
 
 
-MODES = [("fp32 q,k / bf16 p,v (round 3 'bf16p')", "fp32", "bf16", False), ("bf16 q,k,p,v (reference flash-attn)", "bf16", "bf16", False),
+MODES = [("fp16 q,k / bf16 p,v (round 4 default)", "fp16", "bf16", False), ("fp16 q,k / bf16 p,v, lazy max", "fp16", "bf16", True),
+         ("fp32 q,k / bf16 p,v (round 3 'bf16p')", "fp32", "bf16", False), ("bf16 q,k,p,v (reference flash-attn)", "bf16", "bf16", False),
          ("bf16 q,k,p,v, lazy max", "bf16", "bf16", True), ("fp16 q,k,p,v", "fp16", "fp16", False), ("fp16 q,k,p,v, lazy max", "fp16", "fp16", True)]
 for peaky in (False, True):
     sds = state_dicts(peaky)

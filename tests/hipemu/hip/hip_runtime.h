@@ -203,6 +203,14 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x16f16(hipemu_f16x4 a, hipemu_f1
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x16f16 hipemu_mfma_f32_16x16x16f16
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {a (bytes 4..7), b (bytes 0..3)} (selectors 0..7 only)
+static inline unsigned hipemu_perm(unsigned a, unsigned b, unsigned sel) {
+    const unsigned long long src = ((unsigned long long)a << 32) | b;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((src >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+}
+#define __builtin_amdgcn_perm hipemu_perm
 static inline float hipemu_fmed3f(float a, float b, float c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 #define __builtin_amdgcn_fmed3f hipemu_fmed3f
 

@@ -19,19 +19,16 @@ def header_symbols():
 
 
 def test_product_default_precision():
-    """The product's default regulariser format is "f16x2" (the test session pins the older cases to "bf16x3", conftest.py); an explicit
-    conv_precision wins; training accepts an f16x2 stage (it runs the bf16x3 kernels on fp32 activations)."""
+    """The product's default regulariser format is "f16x2" - ONE constant for stages, standalone regularisers and layer wrappers, and
+    the test session does not override it; an explicit conv_precision wins; training accepts an f16x2 stage (it runs the bf16x3 kernels
+    on fp32 activations)."""
     import conftest
-    from mvsformerplusplus_amd import cost_volume
+    from mvsformerplusplus_amd import cost_volume, module
     from mvsformerplusplus_amd.cost_volume import StageNet
-    assert conftest.PRODUCT_DEFAULT_PRECISION == "f16x2"
-    keep = cost_volume.STAGE_DEFAULT_PRECISION
-    try:
-        cost_volume.STAGE_DEFAULT_PRECISION = conftest.PRODUCT_DEFAULT_PRECISION
-        assert StageNet({"base_ch": 8, "depth_type": "ce"}, 4, 3).conv_precision == "f16x2"
-        assert StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "bf16x3"}, 4, 3).conv_precision == "bf16x3"
-    finally:
-        cost_volume.STAGE_DEFAULT_PRECISION = keep
+    assert conftest.PRODUCT_DEFAULT_PRECISION == cost_volume.STAGE_DEFAULT_PRECISION == module.DEFAULT_PRECISION == "f16x2"
+    assert StageNet({"base_ch": 8, "depth_type": "ce"}, 4, 3).conv_precision == "f16x2"
+    assert module.CostRegNet3D(8, 8).conv_precision == "f16x2"
+    assert StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "bf16x3"}, 4, 3).conv_precision == "bf16x3"
     net = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "f16x2"}, 4, 3)
     assert net._f16_activations() and not net._split_activations() and net._vis_precision() == "f16x2"
 

@@ -30,7 +30,7 @@ def _setup(rank, world, port, emu_path):
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import conftest  # noqa: F401  (the worker is a fresh process: pins the legacy cases to the fp32-equivalent mode, as in the parent)
+    import conftest  # noqa: F401
     from mvsformerplusplus_amd import _lib
     _lib._LIB = _lib.bind(emu_path)
     _lib._REQUIRE_DEVICE = False

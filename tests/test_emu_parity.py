@@ -111,11 +111,15 @@ def test_attention_stress(emu):
     P.case_attention_stress(emu)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 80])
 def test_attention_stress_f16(emu, variant, monkeypatch):
-    """The fp16 flash attention (module default) incl. its tile-shape variants: masked tail, rescales far into the key stream."""
+    """The 16-bit flash attention (module default) incl. its tile-shape variants: masked tail, rescales far into the key stream."""
     monkeypatch.setenv("MVS_ATTN_VARIANT", str(variant))
-    P.case_attention_stress(emu, n=300 if variant else 200, mode="f16")
+    P.case_attention_stress(emu, n=300 if variant else 200, mode="attn16")
+
+
+def test_attention_overflow(emu):
+    P.case_attention_overflow(emu)
 
 
 def test_fusion_golden(emu):

@@ -198,7 +198,7 @@ def test_baseline_cfgs_fullsize_properties(name):
 @pytest.mark.parametrize("attn", [None, "bf16x3"])
 def test_transformer_golden(attn):
     """PureTransformerCostReg + get_position_3d vs fixture f7 (from the reference); None = the default attention
-    precision ("f16"), "bf16x3" = the fp32-equivalent attention of rounds 1-3."""
+    precision ("attn16"), "bf16x3" = the fp32-equivalent attention of rounds 1-3."""
     P.case_transformer_golden(DEV, attn)
 
 
@@ -220,8 +220,14 @@ def test_attention_stress(n):
 
 @pytest.mark.parametrize("n", [200, 4099])
 def test_attention_stress_f16(n):
-    """The same for the module default: one fp16 term per attention operand (csrc/attention_f16_kernels.hip)."""
-    P.case_attention_stress(DEV, n=n, mode="f16")
+    """The same for the module default: fp16 q / k, bf16 p / v (csrc/attention_f16_kernels.hip)."""
+    P.case_attention_stress(DEV, n=n, mode="attn16")
+
+
+def test_attention_overflow():
+    """The 16-bit attention's SAFE path: a score jump that overflows fp32 inside a key block (csrc/attention_f16_kernels.hip)."""
+    P.case_attention_overflow(DEV)
+    P.case_attention_overflow(DEV, n=4099)
 
 
 def test_fusion_golden():
