@@ -67,6 +67,13 @@ enum { MVS_VOLUME_F32 = 0, MVS_VOLUME_SPLIT = 1, MVS_VOLUME_F16 = 2 };
 enum { MVS_TR_EPI_BIAS = 0, MVS_TR_EPI_GELU = 1, MVS_TR_EPI_RES_LN = 2 };
 
 int mvs_abi_version(void);
+
+/* fp16 activation format (MVS_PREC_F16X2): every store of an activation tensor clamps to +-65504.  A clamp that really fired means the
+ * default format degraded a value the fp32-equivalent format (MVS_PREC_BF16X3) would have kept.  Returns the number of work-items, summed
+ * over all launches on the CURRENT device since the last reset, that stored at least one value beyond the fp16 range (cost volume writes
+ * of mvs_warp_corr_aggregate_fwd / mvs_volume_to_f16, every convolution / transposed-convolution epilogue); reset != 0 clears it.
+ * Synchronises the device (a device-to-host copy of three counters): call it between batches, not per launch.                        */
+unsigned long long mvs_f16_saturation_count(int reset);
 const char* mvs_last_error(void);
 
 /* ---- a1 + warping.py:80-82 ---------------------------------------------------------------------

@@ -32,6 +32,7 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> (restype, argtypes); mirrors include/mvs_hip.h one to one
 SIGNATURES = {
     "mvs_abi_version": (_i, []),
+    "mvs_f16_saturation_count": (C.c_ulonglong, [_i]),
     "mvs_last_error": (C.c_char_p, []),
     "mvs_compose_homography": (_i, [_vp, _i, _i, _vp, _vp]),
     "mvs_homography_from_proj": (_i, [_vp, _vp, _i, _vp, _vp]),

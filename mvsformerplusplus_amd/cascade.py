@@ -111,14 +111,26 @@ class GraphedCascade:
         return self.outputs
 
 
-def patch_model(model: nn.Module) -> nn.Module:
+def patch_model(model: nn.Module, conv_precision: Optional[str] = None, attention_precision: Optional[str] = None) -> nn.Module:
     """Swap every ``model.fusions[i]`` (a reference ``models.cost_volume.StageNet``) for the HIP ``StageNet``.
 
     Parameters are carried over with ``load_state_dict(strict=True)``; device and train/eval mode are preserved.
     The rest of the reference model (backbone, FMT, cascade loop) keeps calling ``fusions[i].forward(...)`` as before.
+    ``conv_precision`` / ``attention_precision``: None = the product defaults ("f16x2" regulariser activations, "attn16" attention
+    operands - both at least as wide as the bf16 autocast / flash-attn the reference's own GPU path uses); "bf16x3" for either selects
+    the fp32-equivalent form.
     """
+    import copy
     for i, old in enumerate(model.fusions):
-        new = StageNet(old.args, old.ndepth, old.stage_idx)
+        args = old.args
+        if conv_precision is not None or attention_precision is not None:
+            args = copy.deepcopy(dict(old.args))
+            if conv_precision is not None:
+                args["conv_precision"] = conv_precision
+            if attention_precision is not None:
+                for tc in args.get("transformer_config", None) or []:
+                    tc["attention_precision"] = attention_precision
+        new = StageNet(args, old.ndepth, old.stage_idx)
         new.load_state_dict(old.state_dict(), strict=True)
         p = next(old.parameters())
         new = new.to(p.device)

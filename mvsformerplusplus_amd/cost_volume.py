@@ -41,6 +41,24 @@ def shard_views(n_src: int, world: int, rank: int):
 STAGE_DEFAULT_PRECISION = DEFAULT_PRECISION      # one constant (module.DEFAULT_PRECISION): "f16x2"
 
 
+_F16_CALLS = 0
+F16_SATURATION_CHECK_EVERY = 4096          # stage calls between two automatic reads of the saturation counter (0 = never)
+
+
+def check_f16_saturation(device=None, warn: bool = True, reset: bool = True) -> int:
+    """Read (and by default clear) the library's fp16 saturation counter on `device`: the number of work-items that stored a regulariser
+    ACTIVATION beyond the fp16 range (clamped to +-65504) in the default "f16x2" format.  0 on sane weights; anything else means the
+    default degraded values that conv_precision="bf16x3" would have kept - a warning says so once per process.  Synchronises the device:
+    StageNet calls it by itself after its 8th inference call and then every F16_SATURATION_CHECK_EVERY calls (never during graph capture)."""
+    import warnings
+    n = ops.f16_saturation_count(reset=reset, device=device)
+    if n and warn:
+        warnings.warn("mvsformerplusplus_amd: %d work-items stored fp16 regulariser activations beyond +-65504 (clamped).  The default "
+                      "conv_precision='f16x2' is degrading this model's values; build the stages with conv_precision='bf16x3' "
+                      "(fp32-equivalent activations) for it." % n, RuntimeWarning, stacklevel=2)
+    return n
+
+
 class StageNet(nn.Module):
     def __init__(self, args: dict, ndepth: int, stage_idx: int):
         super().__init__()
@@ -155,7 +173,21 @@ class StageNet(nn.Module):
                 volume = ops.volume_to_f16(ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)[0])
             else:
                 volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, split=split, f16=f16)
-        return self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split)
+        out = self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split)
+        if self._f16_activations():
+            self._count_f16_call(feats.device)
+        return out
+
+    @staticmethod
+    def _count_f16_call(device):
+        """Automatic saturation check of the fp16 default (check_f16_saturation): after the 8th f16x2 inference call of the process, then
+        every F16_SATURATION_CHECK_EVERY calls; one device synchronisation each time, never inside a hipGraph capture."""
+        global _F16_CALLS
+        _F16_CALLS += 1
+        if F16_SATURATION_CHECK_EVERY and (_F16_CALLS == 8 or _F16_CALLS % F16_SATURATION_CHECK_EVERY == 0):
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return
+            check_f16_saturation(device)
 
     def _split_activations(self) -> bool:
         """The bf16x3 U-Net keeps its activations - cost volume included - in the split hi | lo bf16 format between layers

@@ -66,9 +66,11 @@ template <class Cfg> struct CfgFmt<Cfg, decltype((void)Cfg::ACT_F16)> { static c
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// fp32 quad -> 4 halves, saturated to the fp16 range (an overflow would turn into inf and poison every later layer)
-__device__ __forceinline__ f16x4 f16_pack4(const float4& v) {
+// fp32 quad -> 4 halves, saturated to the fp16 range (an overflow would turn into inf and poison every later layer); amax: the
+// work-item's running maximum |value| for the saturation counter (mvs_common.h)
+__device__ __forceinline__ f16x4 f16_pack4(const float4& v, float& amax) {
     const float m = 65504.0f;
+    sat::track(amax, v.x, v.y, v.z, v.w);
     return f16x4{(_Float16)__builtin_amdgcn_fmed3f(v.x, -m, m), (_Float16)__builtin_amdgcn_fmed3f(v.y, -m, m),
                  (_Float16)__builtin_amdgcn_fmed3f(v.z, -m, m), (_Float16)__builtin_amdgcn_fmed3f(v.w, -m, m)};
 }
@@ -411,6 +413,7 @@ template <class Cfg, bool SPLIT>
 __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
                                                                  float* __restrict__ y, int D, int H, int W, int OD, int OH, int OW,
                                                                  int relu, int tiles_x, int tiles_y, int ntiles) {
+    float sat_amax = 0.0f;                              // fp16 stores: running max |value| of this work-item (sat::commit at the end)
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, SH = Cfg::SH, SW = Cfg::SW, TD = Cfg::TD, TH = Cfg::TH, CH = Cfg::CH;
     constexpr int IH = Cfg::IH, IW = Cfg::IW, MREP = Cfg::MREP, NREP = Cfg::NREP;
     constexpr int OPT = BfConv<Cfg>::OPT, NSTEP = BfConv<Cfg>::NSTEP, SB = BfConv<Cfg>::SB;
@@ -542,11 +545,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
             float4 v = make_float4(acc[mb][nb][0] + bb.x, acc[mb][nb][1] + bb.y, acc[mb][nb][2] + bb.z, acc[mb][nb][3] + bb.w);
             if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
             if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-            if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(o) + co) = f16_pack4(v);
+            if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(o) + co) = f16_pack4(v, sat_amax);
             else if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
             else *reinterpret_cast<float4*>(o + co) = v;
         }
     }
+    if constexpr (F16) sat::commit(sat_amax);
 }
 
 // (Round 3 measured a row-marching form of the 16 -> 16 layer - a workgroup owns 4 z-planes x 30 columns and walks along y, every
@@ -592,6 +596,7 @@ template <class Cfg, bool SPLIT>
 __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const float* __restrict__ x, const void* wp, const float* __restrict__ bias,
                                                                          float* __restrict__ y, float* __restrict__ logits, int D, int H, int W,
                                                                          int OD, int OH, int OW, int relu, int tiles_x, int tiles_y, int ntiles) {
+    float sat_amax = 0.0f;                              // fp16 stores: running max |value| of this work-item (sat::commit at the end)
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, SH = Cfg::SH, SW = Cfg::SW, TD = Cfg::TD, TH = Cfg::TH;
     constexpr int IH = Cfg::IH, IW = Cfg::IW, MREP = Cfg::MREP, NREP = Cfg::NREP;
     constexpr int OPT = BfConv<Cfg>::OPT, NSTEP = BfConv<Cfg>::NSTEP, SB = BfConv<Cfg>::SB;
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
                 float4 v = make_float4(acc[mb][nb][0] + bb[mb].x, acc[mb][nb][1] + bb[mb].y, acc[mb][nb][2] + bb[mb].z, acc[mb][nb][3] + bb[mb].w);
                 if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
                 if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-                if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(o) + co) = f16_pack4(v);
+                if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(o) + co) = f16_pack4(v, sat_amax);
                 else if (SPLIT) split_store_quad(o + (co & ~7), g, v, inside && co < COUT);
                 else *reinterpret_cast<float4*>(o + co) = v;
             }
@@ -710,6 +715,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
         process(tile, su0, sv0);
         if (MVS_PERSIST_PFD == 2 && tile + 1 < t_end) process(tile + 1, su1, sv1);
     }
+    if constexpr (F16) sat::commit(sat_amax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -770,6 +776,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                                                                    const float* __restrict__ prob_w, const float* __restrict__ prob_b,
                                                                    float* __restrict__ logits, int D, int H, int W, int tiles_x,
                                                                    int tiles_y, int ntiles, int relu) {
+    float sat_amax = 0.0f;                              // fp16 stores: running max |value| of this work-item (sat::commit at the end)
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, TDM = Cfg::TDM, THM = Cfg::THM;
     constexpr int LH = Cfg::LH, LW = Cfg::LW, MREP = Cfg::MREP, NREP = Cfg::NREP;
     constexpr int OPT = BfDeconv<Cfg>::OPT, SB = BfDeconv<Cfg>::SB;
@@ -916,7 +923,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                     part += __shfl_xor(part, 16);
                     if ((g & 1) == 0 && inside && !(MVS_ABL == 5 && part != 12345.678f)) logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = part + prob_b[0];
                 } else if (F16) {
-                    if (inside) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + off) = f16_pack4(v);
+                    if (inside) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + off) = f16_pack4(v, sat_amax);
                 } else if (SPLIT) {
                     split_store_quad(yb + off - co, g, v, inside);
                 } else {
@@ -938,12 +945,13 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
                     v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
                 }
                 if (MVS_ABL == 5 && v.x != 12345.678f) continue;
-                if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + off + co) = f16_pack4(v);
+                if constexpr (F16) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + off + co) = f16_pack4(v, sat_amax);
                 else if (SPLIT) split_store_quad(yb + off + (co & ~7), g, v, inside && co < COUT);
                 else *reinterpret_cast<float4*>(yb + off + co) = v;
             }
         }
     }
+    if constexpr (F16) sat::commit(sat_amax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1031,6 +1039,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                                                                            const float* __restrict__ prob_w, const float* __restrict__ prob_b,
                                                                            float* __restrict__ logits, int D, int H, int W, int tiles_x, int tiles_y,
                                                                            int ntiles, int relu) {
+    float sat_amax = 0.0f;                              // fp16 stores: running max |value| of this work-item (sat::commit at the end)
     using P = BfDeconvP<Cfg>;
     const float lo_clamp = relu ? 0.0f : -INFINITY;
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, TDM = Cfg::TDM, THM = Cfg::THM;
@@ -1176,7 +1185,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
                         logits[(size_t)b * OD * OH * OW + ((size_t)oz * OH + oy) * OW + ox] = part + pb;
                 } else if (F16) {
                     if (inside) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(yb) + (((size_t)oz * OH + oy) * OW + ox) * COUT + co) =
-                        f16_pack4(v);
+                        f16_pack4(v, sat_amax);
                 } else if (SPLIT) {
                     split_store_quad(yb + (((size_t)oz * OH + oy) * OW + ox) * COUT, g, v, inside);
                 } else if (inside && !(MVS_ABL == 5 && v.x != 12345.678f)) {
@@ -1187,6 +1196,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
         if (sb && tile + 1 < t_end) issue_skip(tile + 1);
         __syncthreads();                                                     // every wave is done reading this tile's LDS image
     }
+    if constexpr (F16) sat::commit(sat_amax);
 }
 
 // blocks of 256 threads the current device holds at once for a persistent kernel (-1: query failed).  Cached per (kernel, device)
@@ -1310,3 +1320,5 @@ int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, 
 }
 
 }  // namespace mvs
+
+namespace mvs { MVS_DEFINE_SAT_READER(sat_read_conv) }

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     const float rdenom = (normalise & 1) ? 1.0f / (vsum + 1e-6f) : 1.0f;                          // cost_volume.py:101
     const bool split_out = (normalise & 2) != 0;                 // volume in the split activation format of the bf16x3 U-Net
     const bool f16_out = (normalise & 4) != 0;                   // volume as fp16 [D,HW,8] (MVS_PREC_F16X2 U-Net), clamped to the fp16 range
+    float sat_amax = 0.0f;                                       // fp16 saturation counter (mvs_common.h)
     const float inv_cpg = 1.0f / (float)NOCT;
     float rf0[8];                                               // C = 8: the pixel's reference features, once per block
     if (NOCT == 1) gl_load8<TILED, T>(ref, HW, t.pc, rf0);
@@ -364,6 +365,8 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
                 h8 hv;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f);
+                sat::track(sat_amax, r[0], r[1], r[2], r[3]);
+                sat::track(sat_amax, r[4], r[5], r[6], r[7]);
                 *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(vol) + ((size_t)b * D * HW + (size_t)(unsigned)(d0 + dd) * HW + t.pc) * 8) = hv;
                 continue;
             }
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
             o[1] = f32x4{r[4], r[5], r[6], r[7]};
         }
     }
+    if (f16_out) sat::commit(sat_amax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -523,3 +527,5 @@ int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtyp
 }
 
 }  // namespace mvs
+
+namespace mvs { MVS_DEFINE_SAT_READER(sat_read_gather) }

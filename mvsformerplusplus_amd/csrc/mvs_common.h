@@ -27,6 +27,31 @@ namespace mvs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- fp16 saturation counter (round 4) ------------------------------------------------------------------------
+// Every kernel that stores fp16 ACTIVATIONS (MVS_PREC_F16X2) clamps to +-65504; a clamp that really fires means the default format
+// degraded a value that the fp32-equivalent format (bf16x3) would have kept.  Each such kernel keeps the running maximum |value| it
+// stored per work-item (sat_track: two v_max3 per four values, no branch in the epilogue loops) and adds one count per work-item that
+// saw a value beyond the range when it ends (sat_commit).  The counter is one device global PER TRANSLATION UNIT (no relocatable device
+// code); mvs_f16_saturation_count() (capi.hip) sums the units' readers.
+namespace sat {
+static __device__ unsigned int counter;
+__device__ __forceinline__ void track(float& amax, float a, float b, float c, float d) {
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));
+    amax = fmaxf(fmaxf(amax, fabsf(c)), fabsf(d));
+}
+__device__ __forceinline__ void commit(float amax) {
+    if (amax > 65504.0f) atomicAdd(&counter, 1u);
+}
+}  // namespace sat
+// host: read (and optionally reset) this translation unit's counter on the current device
+#define MVS_DEFINE_SAT_READER(fn)                                                        \
+    unsigned int fn(int reset) {                                                         \
+        unsigned int v = 0;                                                              \
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(mvs::sat::counter), sizeof(v)) != hipSuccess) return 0; \
+        if (reset && v) { const unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(mvs::sat::counter), &z, sizeof(z)); } \
+        return v;                                                                        \
+    }
+
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kMaxSrcViews = 16;   // source views handled by one aggregate launch

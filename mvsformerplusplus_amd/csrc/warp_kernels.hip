@@ -386,6 +386,7 @@ __global__ void volume_normalise_kernel(float* __restrict__ vol, const float* __
 // visibility first; clamped to the fp16 range.  Out of place: a compacting in-place conversion would race between work-items.
 __global__ void volume_to_f16_kernel(const float* __restrict__ vol, const float* __restrict__ vis_sum, _Float16* __restrict__ out, int D, int HW, size_t nvox) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    float sat_amax = 0.0f;                                       // fp16 saturation counter (mvs_common.h)
     for (size_t vox = (size_t)blockIdx.x * blockDim.x + threadIdx.x; vox < nvox; vox += (size_t)gridDim.x * blockDim.x) {
         const float4* q = reinterpret_cast<const float4*>(vol + vox * 8);
         const float4 a = q[0], c = q[1];
@@ -393,9 +394,15 @@ __global__ void volume_to_f16_kernel(const float* __restrict__ vol, const float*
         const float den = vis_sum != nullptr ? vis_sum[(vox / ((size_t)D * HW)) * HW + vox % HW] + 1e-6f : 1.0f;
         h8 hv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)fminf(fmaxf(vis_sum != nullptr ? x[j] / den : x[j], -65504.0f), 65504.0f);
+        for (int j = 0; j < 8; ++j) {
+            if (vis_sum != nullptr) x[j] = x[j] / den;
+            hv[j] = (_Float16)fminf(fmaxf(x[j], -65504.0f), 65504.0f);
+        }
+        sat::track(sat_amax, x[0], x[1], x[2], x[3]);
+        sat::track(sat_amax, x[4], x[5], x[6], x[7]);
         *reinterpret_cast<h8*>(out + vox * 8) = hv;
     }
+    sat::commit(sat_amax);
 }
 
 // fp32 channel-last volume [.., 8] -> the split activation format of MVS_PREC_BF16X3_SPLIT (per voxel [hi x8 | lo x8] bf16), in
@@ -754,3 +761,5 @@ extern "C" int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int 
     hipLaunchKernelGGL(volume_normalise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, volume_cl, vis_sum, D, H * W, G, total);
     return check_launch("volume_normalise_kernel");
 }
+
+namespace mvs { MVS_DEFINE_SAT_READER(sat_read_warp) }

@@ -211,6 +211,15 @@ def gather_is_lds_staged(features, G: int, hyp: torch.Tensor) -> bool:
     return bool(lib().mvs_gather_is_lds_staged(layout, Cc, G, hyp.shape[1], H, W))
 
 
+def f16_saturation_count(reset: bool = False, device=None) -> int:
+    """Work-items that stored an fp16 ACTIVATION beyond +-65504 (clamped) on `device` (default: the current one) since the last reset -
+    0 unless the "f16x2" format degraded something the fp32-equivalent "bf16x3" would have kept.  Synchronises the device."""
+    if device is not None and torch.device(device).type == "cuda":
+        with torch.cuda.device(device):
+            return int(lib().mvs_f16_saturation_count(1 if reset else 0))
+    return int(lib().mvs_f16_saturation_count(1 if reset else 0))
+
+
 def volume_to_f16(vol_cl: torch.Tensor, vis_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 volume [B,D,H,W,8] (divided by vis_sum + 1e-6 first when given) -> fp16 in a new buffer, clamped to the fp16 range."""
     B, D, H, W, G = vol_cl.shape
@@ -225,10 +234,11 @@ def slab_pack(vol_cl: torch.Tensor, vis_sum: torch.Tensor, send_bufs, rows) -> N
     import ctypes as C
     B, D, H, W, G = vol_cl.shape
     n = len(send_bufs)
+    fn = lib().mvs_slab_pack          # FIRST: fetching the entry point clears the per-call device record that ptr() fills
     ptrs = (C.c_void_p * n)(*[None if b is None else ptr(b) for b in send_bufs])
     r0 = (C.c_int * n)(*[int(r[0]) for r in rows])
     r1 = (C.c_int * n)(*[int(r[1]) for r in rows])
-    check(lib().mvs_slab_pack(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), C.cast(r0, C.c_void_p), C.cast(r1, C.c_void_p), n, B, D, H, W,
+    check(fn(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), C.cast(r0, C.c_void_p), C.cast(r1, C.c_void_p), n, B, D, H, W,
                               stream_of(vol_cl)), "mvs_slab_pack")
 
 
@@ -238,8 +248,9 @@ def slab_reduce(vol_cl: torch.Tensor, vis_sum: torch.Tensor, recv_bufs, my_rank:
     import ctypes as C
     B, D, H, W, G = vol_cl.shape
     n = len(recv_bufs)
+    fn = lib().mvs_slab_reduce        # before the pointer array, see slab_pack
     ptrs = (C.c_void_p * n)(*[None if b is None else ptr(b) for b in recv_bufs])
-    check(lib().mvs_slab_reduce(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), n, my_rank, ptr(out), r0, r1, B, D, H, W, stream_of(vol_cl)),
+    check(fn(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), n, my_rank, ptr(out), r0, r1, B, D, H, W, stream_of(vol_cl)),
           "mvs_slab_reduce")
     return out
 

@@ -18,6 +18,22 @@ from oracle import ref_path as O
 ARGS = {"base_ch": [8, 8, 8, 8], "depth_type": ["ce"] * 4, "fusion_type": "cnn", "cost_reg_type": ["Normal"] * 4}
 
 
+# ---- precision parametrisation (round 4): `prec` None = the PRODUCT DEFAULT ("f16x2": fp16 regulariser activations, two
+# MFMA terms); "bf16x3" = the fp32-equivalent mode.  Every bound below is written as tol(prec, <fp32-equivalent bound>, <fp16 bound>); the
+# fp16 bounds are ~3x what the emulator (bit-faithful for these kernels) measures on the fixture, and always far inside the 1e-3 depth bar.
+def eff(prec):
+    from conftest import PRODUCT_DEFAULT_PRECISION
+    return prec or PRODUCT_DEFAULT_PRECISION
+
+
+def tol(prec, exact, f16):
+    return f16 if eff(prec) == "f16x2" else exact
+
+
+def with_prec(args, prec):
+    return dict(args, conv_precision=prec) if prec else dict(args)
+
+
 def dev(t, device):
     return t.to(device) if torch.is_tensor(t) else t
 
@@ -54,16 +70,22 @@ def _load_regnet(net, sd, device):
     return net.eval().to(device)
 
 
-def case_regnet_golden(device, name):
+def case_regnet_golden(device, name, prec=None):
     fx = load_golden(name)
     sd = golden_weights(fx)
     net = M.CostRegNet3D(8, 8) if "3d" in name else M.CostRegNet(8, 8)
     net = _load_regnet(net, sd, device)
+    if prec:
+        net.conv_precision = prec
+    assert net.conv_precision == eff(prec)
     with torch.no_grad():
         y = cpu(net(dev(fx["x"], device)))
     assert y.shape == fx["y"].shape
     scale = float(fx["y"].abs().max())
-    assert (y - fx["y"]).abs().max() <= 2e-4 * max(1.0, scale), "regulariser logits differ from the reference"
+    err = float((y - fx["y"]).abs().max()) / max(1.0, scale)
+    # fp16: the input volume and ten layers of activations carry 2^-12 relative rounding each (standalone regulariser: NCDHW fp32 in)
+    assert err <= tol(prec, 2e-4, 1.5e-3), "regulariser logits differ from the reference: %g" % err
+    return err
 
 
 def case_precisions(device):
@@ -99,29 +121,35 @@ def case_precisions(device):
         raise AssertionError("unknown precision names must be rejected")
 
 
-def case_single_layers(device):
-    """Conv3d / Deconv3d wrappers one layer at a time against torch's own conv (fp32 reference of the same op)."""
+def case_single_layers(device, prec=None):
+    """Conv3d / Deconv3d wrappers one layer at a time against torch's own conv (fp32 reference of the same op).  Product default (fp16
+    activations): input and output each carry one fp16 rounding (2^-12 relative of the value, here a few 1e-4 of the output range)."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(0)
+    lt = tol(prec, 1e-4, 1.5e-3)
     for cin, cout, stride, shape in ((8, 16, (2, 2, 2), (8, 8, 24)), (8, 16, (1, 2, 2), (4, 8, 40)), (16, 16, 1, (5, 6, 20)),
                                      (32, 64, (1, 2, 2), (3, 8, 16)), (64, 64, 1, (2, 5, 17))):
         layer = M.Conv3d(cin, cout, stride=stride, padding=1)
         man = synth.state_dict_manifest(layer.state_dict())
         layer.load_state_dict(synth.seeded_state_dict(man, 5))
         layer = layer.eval().to(device)
+        if prec:
+            layer.conv_precision = prec
         x = torch.randn(2, cin, *shape, generator=g)
         ref = F.relu(F.batch_norm(F.conv3d(x, layer.conv.weight.cpu(), None, stride=stride, padding=1), layer.bn.running_mean.cpu(),
                                   layer.bn.running_var.cpu(), layer.bn.weight.cpu(), layer.bn.bias.cpu(), False, 0.1, 1e-5))
         with torch.no_grad():
             y = cpu(layer(dev(x, device)))
         assert y.shape == ref.shape
-        assert (y - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max())), (cin, cout, stride)
+        assert (y - ref).abs().max() <= lt * max(1.0, float(ref.abs().max())), (cin, cout, stride)
     for cin, cout, sd, shape in ((64, 32, 2, (2, 3, 5)), (32, 16, 2, (3, 4, 18)), (16, 8, 2, (4, 5, 16)),
                                  (64, 32, 1, (3, 2, 5)), (16, 8, 1, (4, 6, 17))):
         layer = M.Deconv3d(cin, cout, stride=(sd, 2, 2), padding=1, output_padding=(sd - 1, 1, 1))
         man = synth.state_dict_manifest(layer.state_dict())
         layer.load_state_dict(synth.seeded_state_dict(man, 6))
         layer = layer.eval().to(device)
+        if prec:
+            layer.conv_precision = prec
         x = torch.randn(1, cin, *shape, generator=g)
         ref = F.relu(F.batch_norm(F.conv_transpose3d(x, layer.conv.weight.cpu(), None, stride=(sd, 2, 2), padding=1,
                                                      output_padding=(sd - 1, 1, 1)), layer.bn.running_mean.cpu(),
@@ -129,29 +157,34 @@ def case_single_layers(device):
         with torch.no_grad():
             y = cpu(layer(dev(x, device)))
         assert y.shape == ref.shape
-        assert (y - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max())), (cin, cout, sd)
+        assert (y - ref).abs().max() <= lt * max(1.0, float(ref.abs().max())), (cin, cout, sd)
 
 
 # ---------------------------------------------------------------- a1-a12 one stage
-def make_stage(fx, ndepth, stage_idx, device, depth_type="ce"):
-    args = dict(ARGS)
+def make_stage(fx, ndepth, stage_idx, device, depth_type="ce", prec=None):
+    args = with_prec(ARGS, prec)
     args["depth_type"] = [depth_type] * 4
     net = StageNet(args, ndepth, stage_idx)
     net.load_state_dict(golden_weights(fx), strict=True)      # reference state-dict names, strict
     return net.eval().to(device)
 
 
-def case_stage_golden(device, tag):
+def case_stage_golden(device, tag, prec=None):
     fx = load_golden("f2_stage_%s.npz" % tag)
     D = fx["hyp"].shape[1]
-    net = make_stage(fx, D, int(fx["stage_idx"]), device)
+    net = make_stage(fx, D, int(fx["stage_idx"]), device, prec=prec)
+    assert net.conv_precision == eff(prec)
     with torch.no_grad():
         out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), float(fx["tmp"]))
     assert set(out) == {"depth", "prob_volume", "photometric_confidence", "depth_values", "prob_volume_pre"}
-    assert rel_l1(cpu(out["depth"]), fx["depth"]) <= 2e-5, "stage depth vs reference (bar: 1e-3)"
-    assert (cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max() <= 5e-4
-    assert (cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max() <= 1e-4
-    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-4
+    errs = (rel_l1(cpu(out["depth"]), fx["depth"]), float((cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max()),
+            float((cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max()),
+            float((cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max()))
+    assert errs[0] <= tol(prec, 2e-5, 2e-4), "stage depth vs reference (bar: 1e-3): %g" % errs[0]       # fp16: measured 5e-5 .. 6e-5
+    assert errs[1] <= tol(prec, 5e-4, 1e-2), errs                                                         # logits: 1.3e-3 .. 3.3e-3
+    assert errs[2] <= tol(prec, 1e-4, 2e-3), errs                                                         # probabilities: 1e-4 .. 6e-4
+    assert errs[3] <= tol(prec, 1e-4, 2e-3), errs
+    return errs
 
 
 def case_stage_pieces(device):
@@ -181,33 +214,43 @@ def case_stage_pieces(device):
     assert (cpu(both) - cpu(vol)).abs().max() <= 1e-6
 
 
-def case_stage_modes(device):
+def case_stage_modes(device, prec=None):
+    """The 'ce' head in its train-time form (argmax; the stage runs its TRAINING path, which keeps fp32 activations on the bf16x3 kernels
+    whatever conv_precision says) and the 'reg' head (expectation + confidence window) at inference, fixtures F6."""
     fx = load_golden("f6_stage_train_ce.npz")
-    net = make_stage(fx, 8, 2, device)
+    net = make_stage(fx, 8, 2, device, prec=prec)
     net.training = True                                   # BN layers stay in eval mode, like the fixture
     with torch.no_grad():
         out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), 5.0)
-    assert (cpu(out["depth"]) != fx["depth"]).float().mean() <= 0.005      # argmax may flip on exact near-ties only
-    assert (cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max() <= 1e-4
+    e0 = float((cpu(out["depth"]) != fx["depth"]).float().mean())
+    e1 = float((cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max())
+    assert e0 <= 0.005, e0                                # argmax may flip on exact near-ties only
+    assert e1 <= 1e-4, e1
     fx = load_golden("f6_stage_reg.npz")
-    net = make_stage(fx, 8, 2, device, depth_type="reg")
+    net = make_stage(fx, 8, 2, device, depth_type="reg", prec=prec)
     with torch.no_grad():
         out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
-    assert rel_l1(cpu(out["depth"]), fx["depth"]) <= 2e-5
-    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-4
+    e2 = rel_l1(cpu(out["depth"]), fx["depth"])
+    e3 = float((cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max())
+    assert e2 <= tol(prec, 2e-5, 2e-4), e2                # fp16: measured 4.6e-5
+    assert e3 <= tol(prec, 1e-4, 1e-3), e3                # 2.6e-4
+    return e0, e1, e2, e3
 
 
-def case_stage_lowp_features(device):
+def case_stage_lowp_features(device, prec=None):
     """bf16 / fp16 feature inputs are upcast per element in-kernel (reference: cost_volume.py:67,81,84)."""
     fx = load_golden("f2_stage_s3.npz")
     sd = golden_weights(fx)
-    net = make_stage(fx, 4, 3, device)
+    net = make_stage(fx, 4, 3, device, prec=prec)
+    errs = []
     for dt in (torch.bfloat16, torch.float16):
         f = fx["features"].to(dt)
         ref = O.stage_forward(f.float(), fx["proj"], fx["hyp"], 1.0, sd, G=8)
         with torch.no_grad():
             out = net(dev(f, device), dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
-        assert rel_l1(cpu(out["depth"]), ref["depth"]) <= 2e-5
+        errs.append(rel_l1(cpu(out["depth"]), ref["depth"]))
+        assert errs[-1] <= tol(prec, 2e-5, 2e-4), errs      # fp16: measured 4.8e-5
+    return errs
 
 
 # ---------------------------------------------------------------- a10-a15 small functions
@@ -485,13 +528,26 @@ def case_f16_layers(device):
 def case_f16_saturation(device):
     """fp16 stores saturate instead of overflowing: a layer whose outputs exceed 65504 writes +-65504 (finite), and the aggregate pass
     clamps the cost volume it writes (features scaled until the correlations leave the fp16 range)."""
-    from mvsformerplusplus_amd import _lib
+    import warnings
+    from mvsformerplusplus_amd import _lib, cost_volume
     g = torch.Generator().manual_seed(3)
-    xx = (torch.rand(1, 4, 8, 16, 16, generator=g) * 200.0 + 100.0).half()
-    w = torch.ones(16, 16, 3, 3, 3) * 2.0                                                   # every output ~ 27 * 16 * 2 * 200 >> 65504
+    ops.f16_saturation_count(reset=True)
+    # a layer inside the range leaves the counter alone
+    xs = torch.rand(1, 4, 8, 16, 16, generator=g).half()
+    w = torch.ones(16, 16, 3, 3, 3) * 2.0
     wp = dev(packing.f16x2(packing.pack_conv_weights_bf16x3, w, packing.conv_chunk(16, (1, 1, 1))), device)
+    ops.conv3d_bn_relu(dev(xs, device), wp, dev(torch.zeros(64), device), 16, 3, (1, 1, 1), True, _lib.PREC_F16X2)
+    assert ops.f16_saturation_count() == 0, "no value left the fp16 range, the counter must stay 0"
+    xx = (torch.rand(1, 4, 8, 16, 16, generator=g) * 200.0 + 100.0).half()                  # every output ~ 27 * 16 * 2 * 200 >> 65504
     y = cpu(ops.conv3d_bn_relu(dev(xx, device), wp, dev(torch.zeros(64), device), 16, 3, (1, 1, 1), True, _lib.PREC_F16X2))
     assert torch.isfinite(y).all() and float(y.max()) == 65504.0
+    n_conv = ops.f16_saturation_count()
+    assert n_conv > 0, "the clamped stores must be counted (mvs_f16_saturation_count)"
+    with warnings.catch_warnings(record=True) as rec:                                       # ... and surfaced as a warning, which also clears the counter
+        warnings.simplefilter("always")
+        assert cost_volume.check_f16_saturation(device if device != "cpu" else None) == n_conv
+    assert any("conv_precision='bf16x3'" in str(r.message) for r in rec)
+    assert ops.f16_saturation_count() == 0
     B, V, C, D, H, W = 1, 3, 8, 4, 8, 32
     cams = synth.make_cameras(V, H * 8, W * 8, baseline=30.0, seed=1, batch=B)
     cams[:, :, 1, :2, :] /= 8
@@ -505,7 +561,10 @@ def case_f16_saturation(device):
     assert float(v32.abs().max()) > 65504.0, "the case must leave the fp16 range"
     assert v16.dtype == torch.float16 and torch.isfinite(v16).all()
     assert torch.equal(v16, v32.clamp(-65504.0, 65504.0).half())
+    n_agg = ops.f16_saturation_count(reset=True)
+    assert n_agg > 0, "the aggregate pass's clamped cost-volume writes must be counted"
     assert torch.equal(cpu(ops.volume_to_f16(dev(v32, device))), v16)
+    assert ops.f16_saturation_count(reset=True) > 0, "mvs_volume_to_f16's clamped writes must be counted"
 
 
 def case_f16_cascade(device):
@@ -570,10 +629,10 @@ def case_slab_exchange_kernels(device):
 
 
 # ---------------------------------------------------------------- a16 cascade
-def case_cascade_golden(device):
+def case_cascade_golden(device, prec=None):
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
     fx = load_golden("f4_cascade.npz")
-    args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True)
+    args = with_prec(dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True), prec)
     head = CascadeDepthHead(args)
     for s in range(4):
         head.fusions[s].load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
@@ -584,11 +643,11 @@ def case_cascade_golden(device):
         out = head(feats, projs, dev(fx["depth_values"], device), tmp=[5.0, 5.0, 5.0, 1.0])
     for s in range(1, 5):
         st = out["stage%d" % s]
-        assert rel_l1(cpu(st["depth_values"]), fx["hyp%d" % s]) <= 2e-5, s
-        assert rel_l1(cpu(st["depth"]), fx["depth%d" % s]) <= 5e-5, "stage %d depth vs reference (bar 1e-3)" % s
-        assert (cpu(st["photometric_confidence"]) - fx["conf%d" % s]).abs().max() <= 2e-3
-    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= 5e-5
-    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= 1e-3
+        assert rel_l1(cpu(st["depth_values"]), fx["hyp%d" % s]) <= tol(prec, 2e-5, 3e-4), s
+        assert rel_l1(cpu(st["depth"]), fx["depth%d" % s]) <= tol(prec, 5e-5, 3e-4), "stage %d depth vs reference (bar 1e-3)" % s
+        assert (cpu(st["photometric_confidence"]) - fx["conf%d" % s]).abs().max() <= tol(prec, 2e-3, 2e-2)
+    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= tol(prec, 5e-5, 3e-4)
+    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= tol(prec, 1e-3, 2e-2)
     assert torch.equal(out["refined_depth"], out["stage4"]["depth"])
     # hand-off layout: the same cascade fed octet-tiled features returns the same depth
     with torch.no_grad():
@@ -629,18 +688,18 @@ def case_cascade_vs_oracle(device, H, W, V, peaky=False, conv_precision=None, **
     # confidence = max softmax probability: with x30 logits a near-tie between two planes turns a 1e-5 logit difference
     # into a visible probability difference at isolated pixels, so the check is on the mean (the max is only reported)
     dconf = (cpu(out["photometric_confidence"]) - ref["photometric_confidence"]).abs()
-    assert float(dconf.mean()) <= (1e-2 if conv_precision == "f16x2" else 1e-3), "confidence mean abs error %g" % float(dconf.mean())
+    assert float(dconf.mean()) <= tol(conv_precision, 1e-3, 1e-2), "confidence mean abs error %g" % float(dconf.mean())
     return r
 
 
-def case_cascade_vs_oracle_finite(device, H, W, V, **inputs):
+def case_cascade_vs_oracle_finite(device, H, W, V, conv_precision=None, **inputs):
     """Cascade vs the oracle on a range that makes the reference ITSELF degenerate for part of the image: with a Tanks-and-Temples-
     like 0.5 .. 10 range the stage-2 inverse-depth window 1/depth -/+ 2.67*itv (module.py:712-716) crosses zero for far pixels, the
     hypotheses jump through +-infinity there and neither implementation means anything.  Parity is asserted on every pixel whose
     hypotheses are finite and positive at all four stages IN THE REFERENCE (at least a fifth of the image); the rest only has to be
     reproduced as non-crashing."""
     import torch.nn.functional as F
-    head, args = _seeded_head(device)
+    head, args = _seeded_head(device, conv_precision=conv_precision)
     feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=2, rot_deg=1.0, **inputs)
     sds = [{k: v.cpu() for k, v in st.state_dict().items()} for st in head.fusions]
     with torch.no_grad():
@@ -704,12 +763,13 @@ BASELINE_CFGS = {
 }
 
 
-def case_baseline_cfg1(device):
+def case_baseline_cfg1(device, prec=None):
     """configs[0] / Track S: one StageNet, stage_idx 3 (C = G = 8), 640x512, V = 3, D = 48 fronto-parallel hypotheses
     linspace(425, 935) -> CostRegNet (D > 8) with the 3x3x3 head."""
     from mvsformerplusplus_amd.cost_volume import StageNet
     H, W, V, D = 512, 640, 3, 48
-    st = StageNet(dict(ARGS), D, 3)
+    st = StageNet(with_prec(ARGS, prec), D, 3)
+    assert st.conv_precision == eff(prec)
     st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 5), strict=True)
     st = st.eval().to(device)
     cams = synth.make_cameras(V, H, W, baseline=20.0, seed=0)
@@ -722,8 +782,9 @@ def case_baseline_cfg1(device):
         out = st(dev(feats, device), dev(proj, device), dev(hyp, device), tmp=1.0)
     r = rel_l1(cpu(out["depth"]), ref["depth"])
     assert r <= 1e-3, "cfg1 depth rel-L1 %g" % r
-    assert (cpu(out["prob_volume"]) - ref["prob_volume"]).abs().max() <= 2e-3
-    return r
+    pe = float((cpu(out["prob_volume"]) - ref["prob_volume"]).abs().max())
+    assert pe <= tol(prec, 2e-3, 2e-2), pe
+    return r, pe
 
 
 def case_baseline_cfg_small(device, name, conv_precision=None):
@@ -731,13 +792,13 @@ def case_baseline_cfg_small(device, name, conv_precision=None):
     return case_cascade_vs_oracle(device, c["small"][0], c["small"][1], c["V"], conv_precision=conv_precision, **c["inputs"])
 
 
-def case_baseline_cfg_wide_range(device, name):
+def case_baseline_cfg_wide_range(device, name, prec=None):
     """cfg4 / cfg5 on SURVEY section 8d's literal 0.5 .. 10 range (the cases above use 0.5 .. 3.0)."""
     c = BASELINE_CFGS[name]
     inputs = dict(c["inputs"])
     nd = inputs["numdepth"]
     inputs.update(depth_min=0.5, depth_interval=9.5 / (nd - 1))
-    return case_cascade_vs_oracle_finite(device, c["small"][0], c["small"][1], c["V"], **inputs)
+    return case_cascade_vs_oracle_finite(device, c["small"][0], c["small"][1], c["V"], conv_precision=prec, **inputs)
 
 
 def case_cfg2_fullsize_vs_oracle(device, conv_precision=None):
@@ -745,9 +806,9 @@ def case_cfg2_fullsize_vs_oracle(device, conv_precision=None):
     return case_cascade_vs_oracle(device, 1152, 1536, 5, conv_precision=conv_precision)
 
 
-def case_baseline_cfg_full(device, name):
+def case_baseline_cfg_full(device, name, prec=None):
     c = BASELINE_CFGS[name]
-    case_cascade_fullsize_properties(device, c["full"][0], c["full"][1], c["V"], **c["inputs"])
+    case_cascade_fullsize_properties(device, c["full"][0], c["full"][1], c["V"], conv_precision=prec, **c["inputs"])
 
 
 # ---------------------------------------------------------------- stage-1 transformer regulariser
@@ -815,22 +876,22 @@ def case_cascade_shipped_golden(device, conv_precision=None, attention_precision
         tc["attention_precision"] = attention_precision
     args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True, use_pe3d=True,
                 cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[tc])
-    tol = 1e-4
-    if conv_precision:
-        args["conv_precision"] = conv_precision
-        tol = 3e-4
+    args = with_prec(args, conv_precision)
+    exact = eff(conv_precision) != "f16x2" and attention_precision == "bf16x3"
+    dt = 1e-4 if exact else 3e-4
     head = CascadeDepthHead(args)
     for s, stn in enumerate(head.fusions):
         stn.load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
     head = head.eval().to(device)
+    assert head.fusions[1].conv_precision == eff(conv_precision) and head.fusions[0].cost_reg.attention_precision == (attention_precision or "attn16")
     feats = {"stage%d" % s: dev(f4["features%d" % s], device) for s in range(1, 5)}
     projs = {"stage%d" % s: dev(f4["proj%d" % s], device) for s in range(1, 5)}
     with torch.no_grad():
         out = head(feats, projs, dev(f4["depth_values"], device))
     for s in range(1, 5):
-        assert rel_l1(cpu(out["stage%d" % s]["depth"]), fx["depth%d" % s]) <= tol, s
-    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= tol
-    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= (1e-3 if conv_precision is None else 2e-2)
+        assert rel_l1(cpu(out["stage%d" % s]["depth"]), fx["depth%d" % s]) <= dt, s
+    assert rel_l1(cpu(out["refined_depth"]), fx["refined_depth"]) <= dt
+    assert (cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max() <= (1e-3 if exact else 2e-2)
 
 
 def case_attention_stress(device, n=200, gain=2.0, bf16p=False, mode=None):
@@ -1048,7 +1109,9 @@ def case_train_path_properties(device):
     """Training-path behaviour that needs no golden: eval-mode autograd equals the HIP inference outputs, gradient flows to the
     source AND reference features, and the transformer regulariser refuses to train."""
     fx = load_golden("f2_stage_s3.npz")
-    net = make_stage(fx, fx["hyp"].shape[1], 3, device)          # eval mode: BatchNorm uses running statistics on both paths
+    # eval mode: BatchNorm uses running statistics on both paths; "bf16x3": the autograd path runs the fp32-activation kernels whatever the
+    # stage's inference format is, so this is the like-for-like comparison (the fp16 default against goldens: case_stage_golden)
+    net = make_stage(fx, fx["hyp"].shape[1], 3, device, prec="bf16x3")
     feats, proj, hyp = dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device)
     with torch.no_grad():
         ref = net(feats, proj, hyp, 1.0)

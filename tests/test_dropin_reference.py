@@ -14,7 +14,10 @@ REF = os.environ.get("MVS_REFERENCE", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "models")), reason="reference checkout not present")
 
 
-def test_patch_model_on_the_reference_network(emu):
+@pytest.mark.parametrize("prec", [None, "bf16x3"])
+def test_patch_model_on_the_reference_network(emu, prec):
+    """prec None = the product defaults (fp16 regulariser activations, 16-bit attention operands): 5e-4 on depth; "bf16x3" = the
+    fp32-equivalent forms of both: 2e-4 (the residue is the feature extractor's own fp32 summation order)."""
     sys.path.insert(0, REF)
     try:
         from models.networks.DINOv2_mvsformer_model import DINOv2MVSNet
@@ -34,17 +37,17 @@ def test_patch_model_on_the_reference_network(emu):
     dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None]
     with torch.no_grad():
         ref = model(imgs, projs, dv)
-        patched = patch_model(copy.deepcopy(model))
+        patched = patch_model(copy.deepcopy(model), conv_precision=prec, attention_precision=prec)
         assert all(isinstance(f, HipStageNet) for f in patched.fusions)
         assert patched.fusions[0].cost_reg.kind == "transformer"           # the shipped stage-1 regulariser
         out = patched(imgs, projs, dv)
     assert set(out.keys()) == set(ref.keys())
     for s in range(1, 5):
         a, b = out["stage%d" % s]["depth"], ref["stage%d" % s]["depth"]
-        assert float(((a - b).abs() / b.abs()).mean()) <= 2e-4, s
+        assert float(((a - b).abs() / b.abs()).mean()) <= (2e-4 if prec else 5e-4), s
     r = float(((out["refined_depth"] - ref["refined_depth"]).abs() / ref["refined_depth"].abs()).mean())
-    assert r <= 2e-4, r
-    assert (out["photometric_confidence"] - ref["photometric_confidence"]).abs().max() <= 5e-3
+    assert r <= (2e-4 if prec else 5e-4), r
+    assert (out["photometric_confidence"] - ref["photometric_confidence"]).abs().max() <= (5e-3 if prec else 3e-2)
 
 
 def test_patch_model_trains_like_the_reference_network(emu):

@@ -4,6 +4,7 @@ numbers that count are produced by tests/test_gpu_parity.py on the MI355X."""
 import pytest
 
 import parity_cases as P
+from conftest import PRECS          # [None = the product default ("f16x2"), "bf16x3" = the fp32-equivalent mode]
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -19,30 +20,35 @@ def test_precisions(emu):
     P.case_precisions(emu)
 
 
-def test_single_layers(emu):
-    P.case_single_layers(emu)
+@pytest.mark.parametrize("prec", PRECS)
+def test_single_layers(emu, prec):
+    P.case_single_layers(emu, prec)
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", ["f3_costregnet.npz", "f3_costregnet3d_d4.npz", "f3_costregnet3d_d8.npz"])
-def test_regnet_golden(emu, name):
-    P.case_regnet_golden(emu, name)
+def test_regnet_golden(emu, name, prec):
+    P.case_regnet_golden(emu, name, prec)
 
 
 def test_stage_pieces(emu):
     P.case_stage_pieces(emu)
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag", ["s1", "s3"])
-def test_stage_golden(emu, tag):
-    P.case_stage_golden(emu, tag)
+def test_stage_golden(emu, tag, prec):
+    P.case_stage_golden(emu, tag, prec)
 
 
-def test_stage_modes(emu):
-    P.case_stage_modes(emu)
+@pytest.mark.parametrize("prec", PRECS)
+def test_stage_modes(emu, prec):
+    P.case_stage_modes(emu, prec)
 
 
-def test_stage_lowp_features(emu):
-    P.case_stage_lowp_features(emu)
+@pytest.mark.parametrize("prec", PRECS)
+def test_stage_lowp_features(emu, prec):
+    P.case_stage_lowp_features(emu, prec)
 
 
 def test_small_fns(emu):
@@ -73,8 +79,6 @@ def test_f16_layers(emu):
     P.case_f16_layers(emu)
 
 
-def test_cascade_shipped_golden_f16(emu):
-    P.case_cascade_shipped_golden(emu, conv_precision="f16x2")
 
 
 def test_f16_saturation(emu):
@@ -89,8 +93,9 @@ def test_slab_exchange_kernels(emu):
     P.case_slab_exchange_kernels(emu)
 
 
-def test_cascade_golden(emu):
-    P.case_cascade_golden(emu)
+@pytest.mark.parametrize("prec", PRECS)
+def test_cascade_golden(emu, prec):
+    P.case_cascade_golden(emu, prec)
 
 
 @pytest.mark.parametrize("attn", [None, "bf16x3"])
@@ -103,8 +108,9 @@ def test_stage_transformer_golden(emu, attn):
     P.case_stage_transformer_golden(emu, attn)
 
 
-def test_cascade_shipped_golden(emu):
-    P.case_cascade_shipped_golden(emu)
+@pytest.mark.parametrize("prec,attn", [(None, None), ("bf16x3", "bf16x3")])
+def test_cascade_shipped_golden(emu, prec, attn):
+    P.case_cascade_shipped_golden(emu, conv_precision=prec, attention_precision=attn)
 
 
 def test_attention_stress(emu):

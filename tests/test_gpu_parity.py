@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import parity_cases as P
-from conftest import rel_l1
+from conftest import PRECS, rel_l1      # PRECS = [None (the product default, "f16x2"), "bf16x3" (the fp32-equivalent mode)]
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -34,30 +34,35 @@ def test_precisions():
     P.case_precisions(DEV)
 
 
-def test_single_layers():
-    P.case_single_layers(DEV)
+@pytest.mark.parametrize("prec", PRECS)
+def test_single_layers(prec):
+    P.case_single_layers(DEV, prec)
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", ["f3_costregnet.npz", "f3_costregnet3d_d4.npz", "f3_costregnet3d_d8.npz"])
-def test_regnet_golden(name):
-    P.case_regnet_golden(DEV, name)
+def test_regnet_golden(name, prec):
+    P.case_regnet_golden(DEV, name, prec)
 
 
 def test_stage_pieces():
     P.case_stage_pieces(DEV)
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag", ["s1", "s3"])
-def test_stage_golden(tag):
-    P.case_stage_golden(DEV, tag)
+def test_stage_golden(tag, prec):
+    P.case_stage_golden(DEV, tag, prec)
 
 
-def test_stage_modes():
-    P.case_stage_modes(DEV)
+@pytest.mark.parametrize("prec", PRECS)
+def test_stage_modes(prec):
+    P.case_stage_modes(DEV, prec)
 
 
-def test_stage_lowp_features():
-    P.case_stage_lowp_features(DEV)
+@pytest.mark.parametrize("prec", PRECS)
+def test_stage_lowp_features(prec):
+    P.case_stage_lowp_features(DEV, prec)
 
 
 def test_small_fns():
@@ -117,8 +122,9 @@ def test_train_midsize_vs_cpu_autograd():
     P.case_train_midsize_vs_cpu_autograd(DEV)
 
 
-def test_cascade_golden():
-    P.case_cascade_golden(DEV)
+@pytest.mark.parametrize("prec", PRECS)
+def test_cascade_golden(prec):
+    P.case_cascade_golden(DEV, prec)
 
 
 def test_cpu_tensors_are_refused():
@@ -128,71 +134,55 @@ def test_cpu_tensors_are_refused():
         ops.compose_homography(torch.zeros(1, 2, 2, 4, 4))
 
 
-def test_cascade_midsize_vs_oracle():
-    """384x512, V=5, peaky logits (prob weights x30): final depth within 1e-3 relative L1 of the oracle."""
-    P.case_cascade_vs_oracle(DEV, 384, 512, 5, peaky=True)
+@pytest.mark.parametrize("prec", PRECS)
+def test_cascade_midsize_vs_oracle(prec):
+    """384x512, V=5, peaky logits (prob weights x30): final depth within 1e-3 relative L1 of the oracle - in the product default format
+    (predicted 4e-4 by scripts/study_activation_precision.py) as in the fp32-equivalent one - and the plain set a decade below."""
+    P.case_cascade_vs_oracle(DEV, 384, 512, 5, peaky=True, conv_precision=prec)
+    assert P.case_cascade_vs_oracle(DEV, 384, 512, 5, peaky=False, conv_precision=prec) <= P.tol(prec, 1e-5, 2e-4)
 
 
-def test_cascade_fullsize_properties():
-    """BASELINE configs[1] size (1152x1536, V=5): run-to-run determinism, finite outputs inside the hypothesis range,
-    view-order invariance of the aggregation (size-independent properties; the oracle is too slow to repeat here)."""
-    P.case_cascade_fullsize_properties(DEV)
+@pytest.mark.parametrize("prec", PRECS)
+def test_cascade_fullsize_properties(prec):
+    """BASELINE configs[1] size (1152x1536, V=5): run-to-run determinism, finite outputs inside the hypothesis range, softmax sums,
+    hypothesis ordering, view-order invariance of the aggregation (size-independent properties; the oracle is too slow to repeat here)."""
+    P.case_cascade_fullsize_properties(DEV, conv_precision=prec)
 
 
-def test_baseline_cfg1_stage4_d48():
-    """BASELINE configs[0]: 640x512, V=3, D=48, stage-4-only StageNet vs the oracle."""
-    P.case_baseline_cfg1(DEV)
+@pytest.mark.parametrize("prec", PRECS)
+def test_baseline_cfg1_stage4_d48(prec):
+    """BASELINE configs[0]: 640x512, V=3, D=48, stage-4-only StageNet (CostRegNet + the 3x3x3 head) vs the oracle."""
+    r, pe = P.case_baseline_cfg1(DEV, prec)
+    print("cfg1 %s: depth rel-L1 %.2e, prob_volume max abs %.2e" % (P.eff(prec), r, pe))
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
-def test_baseline_cfgs_small_vs_oracle(name):
+def test_baseline_cfgs_small_vs_oracle(name, prec):
     """BASELINE configs[2..4] (V=10 / 1920x1088 V=11 D=256 / 2048x1536 V=11 D=384 fp16 features) at a reduced image size."""
-    P.case_baseline_cfg_small(DEV, name)
+    P.case_baseline_cfg_small(DEV, name, conv_precision=prec)
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", ["cfg4", "cfg5"])
-def test_baseline_cfgs_wide_range_vs_oracle(name):
+def test_baseline_cfgs_wide_range_vs_oracle(name, prec):
     """cfg4 / cfg5 on the literal 0.5 .. 10 hypothesis range, compared where the reference's own hypotheses stay finite."""
-    P.case_baseline_cfg_wide_range(DEV, name)
+    P.case_baseline_cfg_wide_range(DEV, name, prec)
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_cfg2_fullsize_vs_oracle(prec):
+    """BASELINE configs[1] at full size against the oracle (refined depth within 1e-3 relative L1, every stage too): the north-star bar
+    itself, in the product default format (measured ~5e-5) and in the fp32-equivalent one (~1e-6)."""
+    r = P.case_cfg2_fullsize_vs_oracle(DEV, conv_precision=prec)
+    assert r <= P.tol(prec, 1e-5, 3e-4), r
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
-def test_baseline_cfgs_small_vs_oracle_f16(name):
-    """BASELINE configs[2..4] at a reduced image size in the product default regulariser format."""
-    P.case_baseline_cfg_small(DEV, name, conv_precision="f16x2")
-
-
-def test_cascade_shipped_golden_f16():
-    P.case_cascade_shipped_golden(DEV, conv_precision="f16x2")
-
-
-def test_cascade_fullsize_properties_f16():
-    """Determinism, ranges, softmax sums, hypothesis ordering and view-order invariance at 1152x1536 in the product default format."""
-    P.case_cascade_fullsize_properties(DEV, conv_precision="f16x2")
-
-
-def test_cfg2_fullsize_vs_oracle_f16():
-    """The same with the PRODUCT DEFAULT regulariser format ("f16x2": fp16 activations, 2-term fp16 contraction)."""
-    r = P.case_cfg2_fullsize_vs_oracle(DEV, conv_precision="f16x2")
-    assert r <= 3e-4, r                      # measured ~5e-5; the bar is 1e-3
-
-
-def test_cascade_midsize_vs_oracle_f16():
-    """384x512, V=5, peaky logits (prob weights x30) in the product default format: inside the 1e-3 bar (predicted 4e-4 by
-    scripts/study_activation_precision.py), and the plain set a decade below."""
-    P.case_cascade_vs_oracle(DEV, 384, 512, 5, peaky=True, conv_precision="f16x2")
-    assert P.case_cascade_vs_oracle(DEV, 384, 512, 5, peaky=False, conv_precision="f16x2") <= 2e-4
-
-
-def test_cfg2_fullsize_vs_oracle():
-    """BASELINE configs[1] at full size against the oracle (refined depth within 1e-3 relative L1, every stage too)."""
-    P.case_cfg2_fullsize_vs_oracle(DEV)
-
-
-@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
-def test_baseline_cfgs_fullsize_properties(name):
+def test_baseline_cfgs_fullsize_properties(name, prec):
     """The same configs at their full image size through size-independent properties."""
-    P.case_baseline_cfg_full(DEV, name)
+    P.case_baseline_cfg_full(DEV, name, prec)
 
 
 @pytest.mark.parametrize("attn", [None, "bf16x3"])
@@ -207,9 +197,11 @@ def test_stage_transformer_golden(attn):
     P.case_stage_transformer_golden(DEV, attn)
 
 
-def test_cascade_shipped_golden():
-    """The shipped regulariser mix (cost_reg_type of config/mvsformer++.json) end to end vs fixture f9."""
-    P.case_cascade_shipped_golden(DEV)
+@pytest.mark.parametrize("prec,attn", [(None, None), ("bf16x3", "bf16x3"), (None, "bf16x3")])
+def test_cascade_shipped_golden(prec, attn):
+    """The shipped regulariser mix (cost_reg_type of config/mvsformer++.json) end to end vs fixture f9: product defaults (fp16 U-Nets,
+    16-bit attention), everything fp32-equivalent, and the mixed case."""
+    P.case_cascade_shipped_golden(DEV, conv_precision=prec, attention_precision=attn)
 
 
 @pytest.mark.parametrize("n", [200, 4099])
