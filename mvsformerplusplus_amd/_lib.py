@@ -23,8 +23,10 @@ DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
 LAYOUT_PLANAR, LAYOUT_OCTET_TILED = 0, 1
 REG_COSTREGNET, REG_COSTREGNET3D = 0, 1
-PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT, PREC_F16X2, PREC_ATTN16 = 0, 1, 2, 3, 4, 5
-PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f16x2": PREC_F16X2}
+PREC_FP32, PREC_BF16X3, PREC_BF16P, PREC_BF16X3_SPLIT, PREC_F16X2, PREC_ATTN16, PREC_F16, PREC_F16MIX = 0, 1, 2, 3, 4, 5, 6, 7
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f16x2": PREC_F16X2, "f16": PREC_F16, "f16mix": PREC_F16MIX}
+F16_FORMATS = ("f16x2", "f16", "f16mix")        # conv_precision values whose regulariser ACTIVATIONS are fp16 tensors (they share packed weights)
+F16_CODES = (PREC_F16X2, PREC_F16, PREC_F16MIX)
 VOLUME_F32, VOLUME_SPLIT, VOLUME_F16 = 0, 1, 2
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

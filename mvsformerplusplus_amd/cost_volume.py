@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops, packing
-from .module import (DEFAULT_PRECISION, ConvBnReLU, CostRegNet, CostRegNet3D, PureTransformerCostReg, _bn_dict, _no_grad_path,
+from .module import (DEFAULT_PRECISION, F16_FORMATS, MFMA_FORMATS, ConvBnReLU, CostRegNet, CostRegNet3D, PureTransformerCostReg, _bn_dict, _no_grad_path,
                      _PackedCache, precision_code)
 
 
@@ -99,7 +99,7 @@ class StageNet(nn.Module):
     # ---- packed parameters ----
     def _vis_params(self, device):
         prec = self._vis_precision()
-        if prec == "f16x2":
+        if prec in F16_FORMATS:
             pack = lambda w, ch: packing.f16x2(packing.pack_conv_weights_bf16x3, w, ch)
         else:
             pack = packing.pack_conv_weights_bf16x3 if prec == "bf16x3" else packing.pack_conv_weights
@@ -122,12 +122,12 @@ class StageNet(nn.Module):
     def _vis_precision(self) -> str:
         """Contraction of the visibility CNN's two MFMA layers (its activations stay on chip): the stage's conv_precision - "f16x2" runs
         the fp16 two-term form with fp16 rings."""
-        return self.conv_precision
+        return "f16x2" if self.conv_precision in F16_FORMATS else self.conv_precision      # "f16" / "f16mix": the CNN keeps both weight terms
 
     def _f16_activations(self) -> bool:
         """conv_precision "f16x2": the U-Net's tensors - cost volume included - are fp16 in HBM (MVS_PREC_F16X2); the transformer
         regulariser reads an fp32 volume and is unaffected."""
-        return self.conv_precision == "f16x2" and not isinstance(self.cost_reg, PureTransformerCostReg)
+        return self.conv_precision in F16_FORMATS and not isinstance(self.cost_reg, PureTransformerCostReg)
 
     def _wants_autograd(self, features) -> bool:
         """Training mode (BatchNorm batch statistics) or a caller that differentiates w.r.t. the features."""
@@ -208,7 +208,7 @@ class StageNet(nn.Module):
         volume is in the split activation format and the U-Net runs MVS_PREC_BF16X3_SPLIT."""
         D = hyp.shape[1]
         pcode = _lib.PREC_BF16X3_SPLIT if split else precision_code(self.conv_precision)
-        mfma = self.conv_precision in ("bf16x3", "f16x2")
+        mfma = self.conv_precision in MFMA_FORMATS
         mode, conf_n = self._head_mode(D)
         if isinstance(self.cost_reg, PureTransformerCostReg):
             prob_volume_pre = self.cost_reg.logits_cl(volume, position3d)

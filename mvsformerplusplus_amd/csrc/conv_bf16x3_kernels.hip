@@ -61,8 +61,14 @@ namespace mvs {
 // these layers under bf16 autocast (test.py:250).  A tile configuration opts in by deriving from F16Cfg.
 template <class Base>
 struct F16Cfg : Base { static constexpr int ACT_F16 = 1; };
-template <class Cfg, class = void> struct CfgFmt { static constexpr bool F16 = false; };
-template <class Cfg> struct CfgFmt<Cfg, decltype((void)Cfg::ACT_F16)> { static constexpr bool F16 = true; };
+// ONE fp16 term per weight (round 4, MVS_PREC_F16 / _F16MIX): the lo half of the packed weights is never read - half the MFMAs, half the
+// weight bytes.  Error study on the oracle (scripts/study_weight_precision.py): refined depth 5.5e-5 -> 7.0e-5 on plain inputs and
+// 4.2e-4 -> 4.8e-4 on the x30-logits stress set when EVERY layer drops w_lo; no measurable change when only the 32- and 64-channel
+// layers do (MVS_PREC_F16MIX, the product default).
+template <class Base>
+struct F16x1Cfg : Base { static constexpr int ACT_F16 = 2; };
+template <class Cfg, class = void> struct CfgFmt { static constexpr bool F16 = false, ONE = false; };
+template <class Cfg> struct CfgFmt<Cfg, decltype((void)Cfg::ACT_F16)> { static constexpr bool F16 = true, ONE = Cfg::ACT_F16 == 2; };
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -83,14 +89,16 @@ __device__ __forceinline__ float4 f16_quad_to_f32(const float4& raw) {
 }
 
 // three-term split product, term-outer so that consecutive MFMAs hit different accumulators (F16: the two-term fp16 form, bl unused)
-template <int MREP, int NREP, bool F16 = false>
+template <int MREP, int NREP, bool F16 = false, bool ONE = false>
 __device__ __forceinline__ void bf_mfma_step(const bf16x8* ah, const bf16x8* al, const bf16x8* bh, const bf16x8* bl, f32x4 (*acc)[NREP]) {
     if constexpr (F16) {
+        if constexpr (!ONE) {                          // ONE: w_lo is not used - its loads are dead code and disappear with it
 #pragma unroll
-        for (int mb = 0; mb < MREP; ++mb)
+            for (int mb = 0; mb < MREP; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NREP; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[mb]), __builtin_bit_cast(f16x8, bh[nb]), acc[mb][nb], 0, 0, 0);
+                for (int nb = 0; nb < NREP; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[mb]), __builtin_bit_cast(f16x8, bh[nb]), acc[mb][nb], 0, 0, 0);
+        }
 #pragma unroll
         for (int mb = 0; mb < MREP; ++mb)
 #pragma unroll
@@ -160,7 +168,17 @@ struct BfConv {
                                      : (PLANES ? (Cfg::NVOX * 32 + 255) / 256 * 256 + 16 : 32);    // byte offset of octet 1
     static constexpr size_t LDS_BYTES = F16 ? (size_t)OPT * PLANE : (PLANES ? (size_t)2 * PLANE : Cfg::LDS_BYTES);
     // persistent, weights-in-registers form (below): one pass whose packed weights take at most 64 VGPRs
-    static constexpr bool PERSIST = MVS_PERSIST && Cfg::CIN == 8 && Cfg::NPASS == 1 && NSTEP * Cfg::MREP * 8 <= 64;
+    // (one-term fp16 weights: 4 VGPRs per step and output block - the stride-1 16 -> 16 layer fits too: 14 x 4 = 56)
+    static constexpr bool ONE = CfgFmt<Cfg>::ONE;
+    static constexpr bool PERSIST = MVS_PERSIST && (Cfg::CIN == 8 || ONE) && Cfg::NPASS == 1 && NSTEP * Cfg::MREP * (ONE ? 4 : 8) <= 64;
+    // ... and where those registers would cost resident blocks (Cin = 16: 56 weight + 24 prefetch registers on top of 32 operand registers = 2
+    // blocks per CU) the block keeps the weights in LDS instead, behind the tile image: one more conflict-free ds_read_b128 per step and wave
+#ifndef MVS_PERSIST_WLDS
+#define MVS_PERSIST_WLDS 1
+#endif
+    static constexpr bool PERSIST_WLDS = MVS_PERSIST_WLDS && PERSIST && ONE && Cfg::CIN == 16;
+    static constexpr int WLDS_OFF = ((int)LDS_BYTES + 255) / 256 * 256;
+    static constexpr size_t PERSIST_LDS_BYTES = PERSIST_WLDS ? (size_t)WLDS_OFF + (size_t)NSTEP * Cfg::MREP * 1024 : LDS_BYTES;
     // staging of the one-tile-per-block kernel: all loads of a pass issued back to back (registers: 8 per 256 voxel-octets of the
     // tile).  The 32 -> 32 layer loses a resident block to those registers and runs faster with the rolled loop (68 vs 74 us).
     static constexpr bool UNROLL_STAGE = !(Cfg::CIN == 32 && Cfg::COUT == 32);
@@ -292,8 +310,8 @@ struct BfConvSteps {
                 else bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah[T % NW], al[T % NW], bh0, bl0, acc);
-            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah[T % NW], al[T % NW], bh1, bl1, acc);
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(ah[T % NW], al[T % NW], bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(ah[T % NW], al[T % NW], bh1, bl1, acc);
             BfConvSteps<Cfg, T + 1>::run(g, wq, ldsb, voxbase0, acc, ah, al, bh0, bl0, bh1, bl1);
         }
     }
@@ -398,8 +416,8 @@ struct BfWldsSteps {
                 else bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah, al, bh0, bl0, acc);
-            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(ah, al, bh1, bl1, acc);
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(ah, al, bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(ah, al, bh1, bl1, acc);
             if constexpr (T % W::WC == W::WC - 1) {              // end of a chunk: hand the next one over
                 if (gc + 1 < nchunk_total) bf_wlds_store<Cfg>(ring, gc + 1, tid, piece);
                 __syncthreads();                                 // chunk gc + 1 visible; everybody has read chunk gc (its slot is free for gc + 2)
@@ -576,18 +594,26 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
 // ------------------------------------------------------------------------------------------------
 template <class Cfg, int T>
 struct BfConvStepsWreg {
+    // wlane: PERSIST_WLDS only - this lane's 16-byte slot of the resident weight image (fragment (T, mb) at (T * MREP + mb) * 1024)
     static __device__ __forceinline__ void run(int g, const bf16x8 (*wh)[Cfg::MREP], const bf16x8 (*wl)[Cfg::MREP], const char* ldsb, int voxbase0,
-                                               f32x4 (*acc)[Cfg::NREP], bf16x8* bh0, bf16x8* bl0, bf16x8* bh1, bf16x8* bl1) {
+                                               f32x4 (*acc)[Cfg::NREP], bf16x8* bh0, bf16x8* bl0, bf16x8* bh1, bf16x8* bl1, const char* wlane = nullptr) {
         constexpr int NSTEP = BfConv<Cfg>::NSTEP;
         if constexpr (T < NSTEP) {
+            bf16x8 aw[Cfg::MREP];
+            if constexpr (BfConv<Cfg>::PERSIST_WLDS) {
+#pragma unroll
+                for (int mb = 0; mb < Cfg::MREP; ++mb) aw[mb] = *reinterpret_cast<const bf16x8*>(wlane + (T * Cfg::MREP + mb) * 1024);
+            }
             if constexpr (T + 1 < NSTEP) {
                 if constexpr ((T & 1) == 0) bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh1, bl1);
                 else bf_conv_load_x<Cfg, T + 1>(g, ldsb, voxbase0, bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(wh[T], wl[T], bh0, bl0, acc);
-            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16>(wh[T], wl[T], bh1, bl1, acc);
-            BfConvStepsWreg<Cfg, T + 1>::run(g, wh, wl, ldsb, voxbase0, acc, bh0, bl0, bh1, bl1);
+            const bf16x8* a_hi = BfConv<Cfg>::PERSIST_WLDS ? aw : wh[T];
+            const bf16x8* a_lo = BfConv<Cfg>::PERSIST_WLDS ? aw : wl[T];          // PERSIST_WLDS implies one term: never read
+            if constexpr ((T & 1) == 0) bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(a_hi, a_lo, bh0, bl0, acc);
+            else bf_mfma_step<Cfg::MREP, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(a_hi, a_lo, bh1, bl1, acc);
+            BfConvStepsWreg<Cfg, T + 1>::run(g, wh, wl, ldsb, voxbase0, acc, bh0, bl0, bh1, bl1, wlane);
         }
     }
 };
@@ -614,13 +640,21 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
 
     const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + lane;
     bf16x8 wh[NSTEP][MREP], wl[NSTEP][MREP];
+    constexpr bool WL = BfConv<Cfg>::PERSIST_WLDS;
+    const char* wlane = ldsb + BfConv<Cfg>::WLDS_OFF + lane * 16;
+    if constexpr (WL) {
+        // the hi fragments, compacted, behind the tile image: visible after the first tile's commit barrier
+        bf16x8* dst = reinterpret_cast<bf16x8*>(ldsb + BfConv<Cfg>::WLDS_OFF);
+        for (int i = tid; i < NSTEP * MREP * 64; i += 256) dst[i] = reinterpret_cast<const bf16x8*>(wp)[(size_t)((i >> 6) * 2) * 64 + (i & 63)];
+    } else {
 #pragma unroll
-    for (int t = 0; t < NSTEP; ++t)
+        for (int t = 0; t < NSTEP; ++t)
 #pragma unroll
-        for (int mb = 0; mb < MREP; ++mb) {
-            wh[t][mb] = wq[(size_t)((t * MREP + mb) * 2) * 64];
-            wl[t][mb] = wq[(size_t)((t * MREP + mb) * 2 + 1) * 64];
-        }
+            for (int mb = 0; mb < MREP; ++mb) {
+                wh[t][mb] = wq[(size_t)((t * MREP + mb) * 2) * 64];
+                wl[t][mb] = wq[(size_t)((t * MREP + mb) * 2 + 1) * 64];
+            }
+    }
     float4 bb[MREP];
 #pragma unroll
     for (int mb = 0; mb < MREP; ++mb) bb[mb] = (16 * mb + 4 * g < COUT) ? *reinterpret_cast<const float4*>(bias + 16 * mb + 4 * g) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -676,7 +710,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
         {
             bf16x8 bh0[NREP], bl0[NREP], bh1[NREP], bl1[NREP];
             bf_conv_load_x<Cfg, 0>(g, ldsb, voxbase[0], bh0, bl0);
-            BfConvStepsWreg<Cfg, 0>::run(g, wh, wl, ldsb, voxbase[0], acc, bh0, bl0, bh1, bl1);
+            BfConvStepsWreg<Cfg, 0>::run(g, wh, wl, ldsb, voxbase[0], acc, bh0, bl0, bh1, bl1, wlane);
         }
 
         const int tx = tile % tiles_x;
@@ -1026,8 +1060,8 @@ struct BfDeconvSteps {
                 else bfd_load_step<Cfg, IT, T + 1>(g, lane, ldsx, ldsw, voxbase0, a0[0], a0[1], bh0, bl0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((T & 1) == 0) bf_mfma_step<1, Cfg::NREP, CfgFmt<Cfg>::F16>(&a0[0], &a0[1], bh0, bl0, acc);
-            else bf_mfma_step<1, Cfg::NREP, CfgFmt<Cfg>::F16>(&a1[0], &a1[1], bh1, bl1, acc);
+            if constexpr ((T & 1) == 0) bf_mfma_step<1, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(&a0[0], &a0[1], bh0, bl0, acc);
+            else bf_mfma_step<1, Cfg::NREP, CfgFmt<Cfg>::F16, CfgFmt<Cfg>::ONE>(&a1[0], &a1[1], bh1, bl1, acc);
             BfDeconvSteps<Cfg, IT, T + 1>::run(g, lane, ldsx, ldsw, voxbase0, acc, a0, bh0, bl0, a1, bh1, bl1);
         }
     }
@@ -1231,7 +1265,7 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
     const int OD = (D + 2 * Cfg::PD - Cfg::KD) / Cfg::SD + 1, OH = (H - 1) / Cfg::SH + 1, OW = (W - 1) / Cfg::SW + 1;
     const int tx = (int)ceil_div(OW, 16), ty = (int)ceil_div(OH, Cfg::TH), tz = (int)ceil_div(OD, Cfg::TD);
     const int ntiles = tx * ty * tz;
-    constexpr size_t LDS = BfConv<Cfg>::LDS_BYTES;
+    constexpr size_t LDS = BfConv<Cfg>::PERSIST ? BfConv<Cfg>::PERSIST_LDS_BYTES : BfConv<Cfg>::LDS_BYTES;
     if constexpr (BfConv<Cfg>::PERSIST) {
         // grid = the number of blocks the chip holds at once (occupancy query once per kernel and DEVICE)
         const int resident = resident_blocks(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_persist_kernel<Cfg, SPLIT>), LDS);
@@ -1280,7 +1314,7 @@ static int launch_deconv_bf(const float* x, const void* wp, const float* bias, c
 
 // the staging loops address one batch item of the input through 32-bit byte offsets and a buffer descriptor
 static bool bf_input_fits(const char* who, int Cin, int D, int H, int W, int split) {
-    const long long bytes = (long long)D * H * W * Cin * (split == 2 ? 2 : 4);
+    const long long bytes = (long long)D * H * W * Cin * (split >= 2 ? 2 : 4);
     if (bytes < (1LL << 31)) return true;
     set_error("%s: one batch item of the input is %lld bytes; the MFMA convolutions address it with 32-bit offsets (< 2 GB)", who, bytes);
     return false;
@@ -1292,6 +1326,7 @@ int conv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, fl
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW) {                    \
         typedef typename BfSplitOf<ConvCfg<CI, CO, KD, SD, SH, SW, TD, TH, CH>>::type K;              \
+        if (split == 3) return launch_conv_bf<F16x1Cfg<K>, false>(x, wp, bias, y, B, D, H, W, relu, st, logits); \
         if (split == 2) return launch_conv_bf<F16Cfg<K>, false>(x, wp, bias, y, B, D, H, W, relu, st, logits);   \
         return split ? launch_conv_bf<K, true>(x, wp, bias, y, B, D, H, W, relu, st, logits)          \
                      : launch_conv_bf<K, false>(x, wp, bias, y, B, D, H, W, relu, st, logits);        \
@@ -1309,6 +1344,7 @@ int deconv3d_dispatch_bf16x3(const float* x, const void* wp, const float* bias, 
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
     if (Cin == CI && Cout == CO && sd == SD) {                                                          \
         typedef typename BfDeconvSplitOf<DeconvCfg<CI, CO, SD, TDM, THM>>::type K;                      \
+        if (split == 3) return launch_deconv_bf<F16x1Cfg<K>, false>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);    \
         if (split == 2) return launch_deconv_bf<F16Cfg<K>, false>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);      \
         return split ? launch_deconv_bf<K, true>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu)    \
                      : launch_deconv_bf<K, false>(x, wp, bias, skip, y, prob_w, prob_b, logits, B, D, H, W, st, relu);  \

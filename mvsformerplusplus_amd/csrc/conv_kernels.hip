@@ -334,11 +334,25 @@ static int launch_deconv(const float* x, const float* wp, const float* bias, con
     return check_launch("deconv3d_mfma_kernel");
 }
 
+// activation / weight form of one MFMA layer under `prec`: -1 = not an MFMA precision, 0 = fp32 activations (split on the fly), 1 = split
+// bf16 pairs in HBM, 2 = fp16 activations + fp16 hi / lo weights, 3 = fp16 activations + ONE fp16 weight term.  MVS_PREC_F16MIX drops w_lo
+// on the layers with 32 / 64 channels on both sides or 64 on one (conv4-conv7: where the second term costs most and changes nothing
+// measurable, scripts/study_weight_precision.py), MVS_PREC_F16 on every layer.
+static int mfma_form(int prec, int Cin, int Cout) {
+    switch (prec) {
+        case MVS_PREC_BF16X3: return 0;
+        case MVS_PREC_BF16X3_SPLIT: return 1;
+        case MVS_PREC_F16X2: return 2;
+        case MVS_PREC_F16: return 3;
+        case MVS_PREC_F16MIX: return ((Cin < Cout ? Cin : Cout) >= 32 || (Cin > Cout ? Cin : Cout) >= 64) ? 3 : 2;
+        default: return -1;
+    }
+}
+
 int conv3d_dispatch(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
                     int sd, int sh, int sw, int relu, int prec, hipStream_t st) {
-    if (prec == MVS_PREC_BF16X3 || prec == MVS_PREC_BF16X3_SPLIT || prec == MVS_PREC_F16X2)
-        return conv3d_dispatch_bf16x3(x, wp, bias, y, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, st, nullptr,
-                                      prec == MVS_PREC_F16X2 ? 2 : (prec == MVS_PREC_BF16X3_SPLIT ? 1 : 0));
+    if (mfma_form(prec, Cin, Cout) >= 0)
+        return conv3d_dispatch_bf16x3(x, wp, bias, y, B, Cin, Cout, D, H, W, kd, sd, sh, sw, relu, st, nullptr, mfma_form(prec, Cin, Cout));
     if (prec != MVS_PREC_FP32) { set_error("conv3d: unknown precision %d", prec); return MVS_ERR_ARG; }
 #define MVS_X(CI, CO, KD, SD, SH, SW, TD, TH, CH)                                                     \
     if (Cin == CI && Cout == CO && kd == KD && sd == SD && sh == SH && sw == SW)                      \
@@ -352,9 +366,8 @@ int conv3d_dispatch(const float* x, const void* wp, const float* bias, float* y,
 int deconv3d_dispatch(const float* x, const void* wp, const float* bias, const float* skip, float* y, int B, int Cin, int Cout, int D,
                       int H, int W, int sd, int prec, hipStream_t st, const float* prob_w = nullptr, const float* prob_b = nullptr,
                       float* logits = nullptr) {
-    if (prec == MVS_PREC_BF16X3 || prec == MVS_PREC_BF16X3_SPLIT || prec == MVS_PREC_F16X2)
-        return deconv3d_dispatch_bf16x3(x, wp, bias, skip, y, B, Cin, Cout, D, H, W, sd, st, prob_w, prob_b, logits, 1,
-                                        prec == MVS_PREC_F16X2 ? 2 : (prec == MVS_PREC_BF16X3_SPLIT ? 1 : 0));
+    if (mfma_form(prec, Cin, Cout) >= 0)
+        return deconv3d_dispatch_bf16x3(x, wp, bias, skip, y, B, Cin, Cout, D, H, W, sd, st, prob_w, prob_b, logits, 1, mfma_form(prec, Cin, Cout));
     if (prob_w != nullptr) { set_error("deconv3d: the fused prob head exists for the bf16x3 contraction only"); return MVS_ERR_UNSUPPORTED; }
     if (prec != MVS_PREC_FP32) { set_error("deconv3d: unknown precision %d", prec); return MVS_ERR_ARG; }
 #define MVS_X(CI, CO, SD, TDM, THM)                                                                     \
@@ -386,7 +399,8 @@ extern "C" int mvs_deconv3d_linear_fwd(const float* x_cl, const void* w_packed, 
 extern "C" int mvs_conv3d_logits_fwd(const float* x_cl, const void* w_packed, const float* bias, float* logits, int B, int D, int H, int W,
                                      int precision, void* stream) {
     if (!x_cl || !w_packed || !bias || !logits || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_conv3d_logits_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (precision != MVS_PREC_BF16X3 && precision != MVS_PREC_BF16X3_SPLIT && precision != MVS_PREC_F16X2) { set_error("mvs_conv3d_logits_fwd: only MVS_PREC_BF16X3 / _SPLIT / MVS_PREC_F16X2 (use mvs_prob_regress_fwd for the exact-fp32 head)"); return MVS_ERR_UNSUPPORTED; }
+    if (precision == MVS_PREC_F16 || precision == MVS_PREC_F16MIX) precision = MVS_PREC_F16X2;      // the one-row head keeps both weight terms
+    if (precision != MVS_PREC_BF16X3 && precision != MVS_PREC_BF16X3_SPLIT && precision != MVS_PREC_F16X2) { set_error("mvs_conv3d_logits_fwd: only MVS_PREC_BF16X3 / _SPLIT / MVS_PREC_F16X2 / _F16 / _F16MIX (use mvs_prob_regress_fwd for the exact-fp32 head)"); return MVS_ERR_UNSUPPORTED; }
     return conv3d_dispatch_bf16x3(x_cl, w_packed, bias, nullptr, B, 8, 16, D, H, W, 3, 1, 1, 1, 0, (hipStream_t)stream, logits,
                                   precision == MVS_PREC_F16X2 ? 2 : (precision == MVS_PREC_BF16X3_SPLIT ? 1 : 0));
 }
@@ -509,7 +523,7 @@ extern "C" int mvs_regnet_logits_fwd(int kind, const float* volume_cl, const voi
                                      const float* prob_w, const float* prob_b, float* logits, void* workspace, size_t workspace_bytes, int B,
                                      int D, int H, int W, int precision, void* stream) {
     if (!prob_w || !prob_b || !logits) { set_error("mvs_regnet_logits_fwd: bad arguments"); return MVS_ERR_ARG; }
-    if (precision != MVS_PREC_BF16X3 && precision != MVS_PREC_BF16X3_SPLIT && precision != MVS_PREC_F16X2) { set_error("mvs_regnet_logits_fwd: the fused 1x1x1 head exists for MVS_PREC_BF16X3 / _SPLIT / MVS_PREC_F16X2 only"); return MVS_ERR_UNSUPPORTED; }
+    if (mfma_form(precision, 16, 8) < 0) { set_error("mvs_regnet_logits_fwd: the fused 1x1x1 head exists for the MFMA precisions only (MVS_PREC_BF16X3 / _SPLIT / F16X2 / F16 / F16MIX)"); return MVS_ERR_UNSUPPORTED; }
     return regnet_run(kind, volume_cl, w_packed, bias, nullptr, prob_w, prob_b, logits, workspace, workspace_bytes, B, D, H, W, precision, stream,
                       "mvs_regnet_logits_fwd");
 }

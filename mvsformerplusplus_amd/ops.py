@@ -276,7 +276,7 @@ def from_split(s_cl: torch.Tensor) -> torch.Tensor:
 # ---- a7-a9 --------------------------------------------------------------------------------------
 def _act_dtype(x_cl: torch.Tensor, precision: int):
     """Element type of the activation tensors of a call: fp16 for MVS_PREC_F16X2, fp32 (plain or split pairs) otherwise."""
-    want = torch.float16 if precision == _lib.PREC_F16X2 else torch.float32
+    want = torch.float16 if precision in _lib.F16_CODES else torch.float32
     if x_cl.dtype != want:
         raise _lib.MvsHipError("precision %d takes %s activations, got %s" % (precision, want, x_cl.dtype))
     return want

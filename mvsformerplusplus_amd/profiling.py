@@ -202,7 +202,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         prec = _lib.PRECISIONS[net._vis_precision()]
         N = B * (V - 1)
         vis_flops = 2.0 * N * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8)
-        if net._vis_precision() in ("bf16x3", "f16x2"):
+        if net._vis_precision() in ("bf16x3", "f16x2"):             # (_vis_precision maps every fp16 format to "f16x2")
             # one row-streaming launch; algorithmic traffic = entropy in + visibility out
             vis = _timed(launches, "vis_cnn_kernel", s, vis_flops, 4.0 * N * HW * 2, lambda: ops.vis_weight(ent, vp, prec))
         else:
@@ -240,7 +240,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             confs.append(r3[1])
             continue
         ks = net.cost_reg.prob_ksize
-        if ks == 1 and net.conv_precision in ("bf16x3", "f16x2") and net.fuse_prob_head:
+        if ks == 1 and net.conv_precision in _lib.F16_FORMATS + ("bf16x3",) and net.fuse_prob_head:
             logits = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, fused_head=True, split=split)
             r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW),
                         lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
@@ -249,7 +249,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
             continue
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, split=split)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
-        if ks == 3 and net.conv_precision in ("bf16x3", "f16x2"):
+        if ks == 3 and net.conv_precision in _lib.F16_FORMATS + ("bf16x3",):
             logits = _timed(launches, "conv3d_mfma<8,1,k3,s111> prob head", s, 2.0 * B * D * HW * 8 * 27, B * (float(feat_cl.element_size()) * 8 * D * HW + 4.0 * D * HW),
                             lambda: ops.conv3d_logits(feat_cl, prob_w, prob_b, _lib.PREC_BF16X3_SPLIT if split else _lib.PRECISIONS[net.conv_precision]))
             r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW),

@@ -605,7 +605,7 @@ def stage_forward_train(net, features, proj_matrices, depth_values, tmp, positio
     # are per call there, so the views are kept as separate calls here as well
     if G != 8:
         raise NotImplementedError("base_ch=%d: the HIP training kernels are built for 8 groups (all shipped configs)" % G)   # as in inference
-    if getattr(net, "conv_precision", "bf16x3") not in ("bf16x3", "f16x2"):    # "f16x2" is an inference storage format: training keeps fp32 activations on the bf16x3 kernels
+    if getattr(net, "conv_precision", "bf16x3") not in ("bf16x3",) + _lib.F16_FORMATS:    # "f16x2" is an inference storage format: training keeps fp32 activations on the bf16x3 kernels
         raise NotImplementedError("conv_precision=%r: the native training kernels contract in split bf16 (forward and data gradients) "
                                   "and fp32 MFMA (weight gradients)" % net.conv_precision)
     vis = vis_forward_native(net.vis, entropy)                                                    # [B,V-1,H,W]

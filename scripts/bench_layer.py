@@ -11,14 +11,15 @@ g = torch.Generator().manual_seed(0)
 LAYERS = [  # (cin, cout, stride, [B, D, H, W] input shape)
     (16, 16, (1, 1, 1), (1, 4, 576, 768)), (16, 16, (1, 1, 1), (1, 8, 288, 384)),
     (32, 32, (1, 1, 1), (1, 4, 288, 384)), (64, 64, (1, 1, 1), (1, 4, 144, 192)),
-    (16, 32, (1, 2, 2), (1, 4, 576, 768)), (32, 64, (1, 2, 2), (1, 4, 288, 384)),
+    (16, 32, (1, 2, 2), (1, 4, 576, 768)), (32, 64, (1, 2, 2), (1, 4, 288, 384)), (8, 16, (1, 2, 2), (1, 4, 1152, 1536)),
 ]
 for ci, co, stride, shape in LAYERS:
     w = torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1
     bias = torch.randn(64, generator=g).to(dev)
     x32 = torch.randn(*shape, ci, generator=g)
     forms = {"split": (_lib.PREC_BF16X3_SPLIT, ops.to_split(x32).to(dev), packing.pack_conv_weights_bf16x3(w, packing.conv_chunk(ci, stride)).to(dev)),
-             "f16": (_lib.PREC_F16X2, x32.half().to(dev), packing.f16x2(packing.pack_conv_weights_bf16x3, w, packing.conv_chunk(ci, stride)).to(dev))}
+             "f16x2": (_lib.PREC_F16X2, x32.half().to(dev), packing.f16x2(packing.pack_conv_weights_bf16x3, w, packing.conv_chunk(ci, stride)).to(dev)),
+             "f16 (one term)": (_lib.PREC_F16, x32.half().to(dev), packing.f16x2(packing.pack_conv_weights_bf16x3, w, packing.conv_chunk(ci, stride)).to(dev))}
     res = {}
     for rep in range(3):
         for name, (prec, x, wp) in forms.items():

@@ -1,0 +1,64 @@
+"""Numerics study (CPU, oracle only): ONE fp16 term for the regularisers' weights.  The product default "f16x2" keeps
+weights as fp16 hi + lo (22 bits) and activations as fp16 (11 bits); how far does the final depth move when the weights are fp16 too
+(w_lo dropped: half the MFMAs, half the weight bytes)?  Activations rounded to fp16 in every case (the default's storage format), fp32
+accumulation.  Per-layer variants: all layers / only the 32- and 64-channel layers (where w_lo costs most: 4-16 output blocks per read).
+    python scripts/study_weight_precision.py [H W]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import torch.nn.functional as F
+import parity_cases as P
+from conftest import rel_l1
+from oracle import ref_path as O
+from mvsformerplusplus_amd import synth
+from mvsformerplusplus_amd.cost_volume import StageNet
+
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 320)
+_conv3d, _convt3d = F.conv3d, F.conv_transpose3d
+NDEPTHS, RATIO = [32, 16, 8, 4], [4.0, 2.67, 1.5, 1.0]
+h = lambda x: x.half().float()
+
+
+def state_dicts(peaky, seed=11):
+    sds = []
+    for i in range(4):
+        net = StageNet(dict(P.ARGS), NDEPTHS[i], i)
+        sd = synth.seeded_state_dict(synth.state_dict_manifest(net.state_dict()), seed + i)
+        if peaky:
+            sd["cost_reg.prob.weight"] = sd["cost_reg.prob.weight"] * 30.0
+        sds.append(sd)
+    return sds
+
+
+def patched(wsel):
+    """activations fp16; weights of the layers `wsel(cin, cout)` picks rounded to fp16"""
+    def c3(x, w, *a, **k):
+        return _conv3d(h(x), h(w) if wsel(w.shape[1], w.shape[0]) else w, *a, **k)
+    def ct3(x, w, *a, **k):
+        return _convt3d(h(x), h(w) if wsel(w.shape[0], w.shape[1]) else w, *a, **k)
+    return c3, ct3
+
+
+MODES = {"f16x2 (today: activations fp16, weights exact)": lambda ci, co: False,
+         "weights fp16 on the 32/64-channel layers": lambda ci, co: min(ci, co) >= 32 or max(ci, co) >= 64,
+         "weights fp16 on every layer but the 1-channel head": lambda ci, co: co > 1,
+         "weights fp16 everywhere": lambda ci, co: True}
+for peaky in (False, True):
+    sds = state_dicts(peaky)
+    for seed in (2, 5):
+        feats, projs, dv = synth.make_cascade_inputs(H, W, 5, seed=seed, rot_deg=1.0)
+        run = lambda: O.cascade_forward(feats, projs, dv, sds, ndepths=NDEPTHS, depth_interals_ratio=RATIO, base_ch=P.ARGS["base_ch"])
+        with torch.no_grad():
+            ref = run()
+            for name, wsel in MODES.items():
+                F.conv3d, F.conv_transpose3d = patched(wsel)
+                try:
+                    res = run()
+                finally:
+                    F.conv3d, F.conv_transpose3d = _conv3d, _convt3d
+                errs = [rel_l1(res["stage%d" % s]["depth"], ref["stage%d" % s]["depth"]) for s in range(1, 5)]
+                print("peaky=%d seed=%d  %-52s refined depth rel-L1 %.2e   stages %s   conf mean abs %.1e" % (
+                    peaky, seed, name, rel_l1(res["refined_depth"], ref["refined_depth"]), " ".join("%.1e" % e for e in errs),
+                    float((res["photometric_confidence"] - ref["photometric_confidence"]).abs().mean())), flush=True)

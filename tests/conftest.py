@@ -13,11 +13,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # Round 4: NO session-wide precision override any more.  A stage / regulariser built without an explicit
-# conv_precision runs the PRODUCT DEFAULT ("f16x2"); the golden / oracle cases are parametrised over PRECS = [None (= the default),
+# conv_precision runs the PRODUCT DEFAULT ("f16mix"); the golden / oracle cases are parametrised over PRECS = [None (= the default),
 # "bf16x3" (the fp32-equivalent mode)] and assert per-mode bounds (parity_cases.tol).
 from mvsformerplusplus_amd import cost_volume as _cv  # noqa: E402
 PRODUCT_DEFAULT_PRECISION = _cv.STAGE_DEFAULT_PRECISION
 PRECS = [None, "bf16x3"]
+PRECS_ALL = [None, "bf16x3", "f16x2", "f16"]       # + the two other fp16 formats: both weight terms everywhere / one term everywhere
 
 
 def pytest_configure(config):

@@ -27,7 +27,7 @@ def eff(prec):
 
 
 def tol(prec, exact, f16):
-    return f16 if eff(prec) == "f16x2" else exact
+    return f16 if eff(prec) in _lib.F16_FORMATS else exact
 
 
 def with_prec(args, prec):
@@ -877,7 +877,7 @@ def case_cascade_shipped_golden(device, conv_precision=None, attention_precision
     args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True, use_pe3d=True,
                 cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[tc])
     args = with_prec(args, conv_precision)
-    exact = eff(conv_precision) != "f16x2" and attention_precision == "bf16x3"
+    exact = eff(conv_precision) not in _lib.F16_FORMATS and attention_precision == "bf16x3"
     dt = 1e-4 if exact else 3e-4
     head = CascadeDepthHead(args)
     for s, stn in enumerate(head.fusions):

@@ -19,15 +19,18 @@ def header_symbols():
 
 
 def test_product_default_precision():
-    """The product's default regulariser format is "f16x2" - ONE constant for stages, standalone regularisers and layer wrappers, and
+    """The product's default regulariser format is "f16mix" (fp16 activations, the second weight term only on the 8/16-channel layers) - ONE constant for stages, standalone regularisers and layer wrappers, and
     the test session does not override it; an explicit conv_precision wins; training accepts an f16x2 stage (it runs the bf16x3 kernels
     on fp32 activations)."""
     import conftest
     from mvsformerplusplus_amd import cost_volume, module
     from mvsformerplusplus_amd.cost_volume import StageNet
-    assert conftest.PRODUCT_DEFAULT_PRECISION == cost_volume.STAGE_DEFAULT_PRECISION == module.DEFAULT_PRECISION == "f16x2"
-    assert StageNet({"base_ch": 8, "depth_type": "ce"}, 4, 3).conv_precision == "f16x2"
-    assert module.CostRegNet3D(8, 8).conv_precision == "f16x2"
+    assert conftest.PRODUCT_DEFAULT_PRECISION == cost_volume.STAGE_DEFAULT_PRECISION == module.DEFAULT_PRECISION == "f16mix"
+    assert StageNet({"base_ch": 8, "depth_type": "ce"}, 4, 3).conv_precision == "f16mix"
+    assert module.CostRegNet3D(8, 8).conv_precision == "f16mix"
+    for fmt in ("f16mix", "f16", "f16x2"):
+        n = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": fmt}, 4, 3)
+        assert n._f16_activations() and not n._split_activations() and n._vis_precision() == "f16x2"
     assert StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "bf16x3"}, 4, 3).conv_precision == "bf16x3"
     net = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "f16x2"}, 4, 3)
     assert net._f16_activations() and not net._split_activations() and net._vis_precision() == "f16x2"

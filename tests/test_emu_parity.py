@@ -4,7 +4,7 @@ numbers that count are produced by tests/test_gpu_parity.py on the MI355X."""
 import pytest
 
 import parity_cases as P
-from conftest import PRECS          # [None = the product default ("f16x2"), "bf16x3" = the fp32-equivalent mode]
+from conftest import PRECS, PRECS_ALL          # [None = the product default ("f16x2"), "bf16x3" = the fp32-equivalent mode]
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -35,7 +35,7 @@ def test_stage_pieces(emu):
     P.case_stage_pieces(emu)
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_ALL)
 @pytest.mark.parametrize("tag", ["s1", "s3"])
 def test_stage_golden(emu, tag, prec):
     P.case_stage_golden(emu, tag, prec)
@@ -93,7 +93,7 @@ def test_slab_exchange_kernels(emu):
     P.case_slab_exchange_kernels(emu)
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_ALL)
 def test_cascade_golden(emu, prec):
     P.case_cascade_golden(emu, prec)
 

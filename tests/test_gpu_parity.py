@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import parity_cases as P
-from conftest import PRECS, rel_l1      # PRECS = [None (the product default, "f16x2"), "bf16x3" (the fp32-equivalent mode)]
+from conftest import PRECS, PRECS_ALL, rel_l1      # PRECS = [None (the product default, "f16x2"), "bf16x3" (the fp32-equivalent mode)]
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -49,7 +49,7 @@ def test_stage_pieces():
     P.case_stage_pieces(DEV)
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_ALL)
 @pytest.mark.parametrize("tag", ["s1", "s3"])
 def test_stage_golden(tag, prec):
     P.case_stage_golden(DEV, tag, prec)
@@ -122,7 +122,7 @@ def test_train_midsize_vs_cpu_autograd():
     P.case_train_midsize_vs_cpu_autograd(DEV)
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_ALL)
 def test_cascade_golden(prec):
     P.case_cascade_golden(DEV, prec)
 
@@ -134,7 +134,7 @@ def test_cpu_tensors_are_refused():
         ops.compose_homography(torch.zeros(1, 2, 2, 4, 4))
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_ALL)
 def test_cascade_midsize_vs_oracle(prec):
     """384x512, V=5, peaky logits (prob weights x30): final depth within 1e-3 relative L1 of the oracle - in the product default format
     (predicted 4e-4 by scripts/study_activation_precision.py) as in the fp32-equivalent one - and the plain set a decade below."""
@@ -170,7 +170,7 @@ def test_baseline_cfgs_wide_range_vs_oracle(name, prec):
     P.case_baseline_cfg_wide_range(DEV, name, prec)
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_ALL)
 def test_cfg2_fullsize_vs_oracle(prec):
     """BASELINE configs[1] at full size against the oracle (refined depth within 1e-3 relative L1, every stage too): the north-star bar
     itself, in the product default format (measured ~5e-5) and in the fp32-equivalent one (~1e-6)."""
