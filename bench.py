@@ -145,7 +145,7 @@ def main():
                          "layout [B,V,C/8,H,W,8] (SURVEY.md section 8f #4) as a producer-side emitter would hand it over - packed once, "
                          "outside the timed region")
     ap.add_argument("--view-sharded-timeout", type=int, default=240, help="N > 1: seconds the extra view-sharded latency leg may take")
-    ap.add_argument("--conv-precision", choices=["bf16x3", "f16x2", "fp32"], default=None,
+    ap.add_argument("--conv-precision", choices=["bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
                     help="contraction / activation format of the 3-D regularisers (default: the package default, cost_volume.STAGE_DEFAULT_PRECISION)")
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
                     help="normal: all-'Normal' regularisers (Track R headline); shipped: stage-1 transformer + PE3D as in the shipped config")
@@ -289,8 +289,13 @@ def main():
         "f16x2": "f16x2: U-Net activations (cost volume included) stored as fp16, weights as fp16 hi + lo, two MFMA terms per product on "
                  "v_mfma_f32_16x16x32_f16, fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the "
                  "regulariser under bf16 autocast, test.py:250)",
+        "f16mix": "f16mix (product default): fp16 U-Net activations as in f16x2; weights fp16 hi + lo (two MFMA terms) on the 8- / 16-channel layers, "
+                  "ONE fp16 term on the 32- / 64-channel layers conv4..conv7 (no measurable change of the depth error, scripts/study_weight_precision.py); "
+                  "fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the regulariser under bf16 autocast, "
+                  "test.py:250)",
+        "f16": "f16: fp16 U-Net activations, ONE fp16 weight term on every layer (depth 7e-5 / 4.8e-4 from the fp32 oracle on plain / stress inputs)",
         "fp32": "fp32-exact MFMA contraction"}[prec0]
-    if prec0 == "f16x2":
+    if prec0 in ("f16x2", "f16mix", "f16"):
         result["dtype"] = "f32 (fp16 storage of the regulariser's activations)"
 
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
@@ -307,11 +312,11 @@ def main():
         per_launch = dom["flops" if mfma else "bytes"] / dom["calls"]
         achieved = (dom["tflops"] if mfma else dom["gbs"])
         prec = head.fusions[0].conv_precision
-        terms = {"bf16x3": 3, "f16x2": 2, "f16": 1}.get(prec, 1)
+        terms = {"bf16x3": 3, "f16x2": 2, "f16mix": 2, "f16": 1}.get(prec, 1)       # f16mix: the visibility CNN and the 8/16-channel layers keep 2
         if not mfma:
             peak, note = profiling.PEAK_HBM_GBS, ("algorithmic HBM bytes per launch (SURVEY.md section 8d: every feature map once + hypotheses once + "
                                                   "outputs once, at the tensors' real element sizes) / HIP-event launch time on the launch stream")
-        elif prec in ("bf16x3", "f16x2", "f16"):
+        elif prec in ("bf16x3", "f16x2", "f16mix", "f16"):
             # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak 2.5 PFLOP/s.  `frac` is against THAT peak (the guide's); the contraction issues
             # `terms` MFMA products per algorithmic product, an implementation choice reported separately as frac_of_issued_mfma
             peak, note = profiling.PEAK_F16_MFMA_TFLOPS, ("algorithmic FLOPs (2 x MACs of the operator) / HIP-event launch time vs the dense %s MFMA peak of "
@@ -357,7 +362,7 @@ def main():
                 work = sum(v["flops"] for v in ks.values()) / reps
                 ach = work / ms / 1e9                            # TFLOP/s
                 fp = fam_prec or prec
-                tm = {"bf16x3": 3, "f16x2": 2}.get(fp, 1)
+                tm = {"bf16x3": 3, "f16x2": 2, "f16mix": 2}.get(fp, 1)
                 pk = profiling.PEAK_F32_MFMA_TFLOPS if fp == "fp32" else profiling.PEAK_F16_MFMA_TFLOPS
                 return {"ms_per_ref_view": ms, "bound": "mfma", "algorithmic_gflop_per_ref_view": work / 1e9, "achieved_tflops": ach, "peak_tflops": pk,
                         "frac": ach / pk, "mfma_terms_per_product": tm, "frac_of_issued_mfma": ach * tm / pk,
@@ -402,7 +407,7 @@ def main():
                         miss.append(k)
                     else:
                         pm += tj[hit]["hbm_bytes_per_launch"] * v["calls"] / reps
-                if "_whole_path" in tj and a.cost_reg != "shipped" and prec == "f16x2":
+                if "_whole_path" in tj and a.cost_reg != "shipped" and prec in ("f16x2", "f16mix"):
                     pm, miss = tj["_whole_path"]["hbm_bytes_per_ref_view"], []       # every launch of the PMC run / its reference views
                 wp["pmc_bytes_per_ref_view"] = pm
                 wp["frac_pmc"] = pm * vps / 8.0e12
@@ -440,7 +445,7 @@ def main():
 
     # ---- extra: the fp32-equivalent regulariser format ("bf16x3") on the same weights, inputs and loop, outside the timed headline: the
     #      driver's own BENCH line then carries both modes (the headline runs the product default, "f16x2") ----
-    if world == 1 and not a.no_profile and a.cost_reg != "shipped" and head.fusions[0].conv_precision == "f16x2" and not a.graph:
+    if world == 1 and not a.no_profile and a.cost_reg != "shipped" and head.fusions[0].conv_precision in ("f16x2", "f16mix", "f16") and not a.graph:
         try:
             head32 = build_head(device, conv_precision="bf16x3")
             n2 = max(2, a.steps // 4)

@@ -753,6 +753,168 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// Loader-wave form of the fp16 tile convolutions (round 4): 4 contracting waves + 1 wave that only moves data.
+//
+// Why.  Every one-tile kernel above runs ~2.5x above BOTH of its floors (stage-4 16 -> 16: 58 us against 22 us of MFMA issue and 19 us
+// of HBM time; 32 -> 32 and the transposed layers alike), and the counters say the SIMDs wait (wait 38-48 %, stall 33-43 %, MFMA busy
+// 22-24 %).  A block's life is load tile -> commit -> contract -> store; the co-resident blocks of a CU start together and stay in step,
+// so the chip alternates between a phase in which nobody contracts and a phase in which nobody has loads in flight (round 2's ablation:
+// the phases ADD).  Bytes in flight are what a latency-bound stream is made of: ~18 KB per CU on average in the one-tile form.  The
+// remedy is a block that prefetches the next tile while it contracts this one - but a wave that loads weights in its contraction cannot
+// also have the prefetch in flight: vmcnt retires in order, so the first weight it waits for drags the whole prefetch along (round 3's
+// LDS-DMA kernel issued both from the same waves and lost 1.2-1.8x).  Hence a FIFTH wave with its own vmcnt: it copies chunk c + 1
+// (one tile x one pass of 16 / 8 input channels) into the other LDS image with LDS-DMA (global_load_lds_dwordx4: no registers, no
+// ds_write; lanes outside the volume read a zeroed 16-byte line), while waves 0-3 contract chunk c exactly as the one-tile kernel does
+// (same operand layout, same weight path through L2).  One barrier per chunk; blocks are persistent over a contiguous run of tiles.
+// fp16 activations only (both weight forms); the Cin = 8 layers keep their weights-in-registers persistent form.
+// ------------------------------------------------------------------------------------------------
+// MEASURED (profiles/r04_conv_loader_ab.txt, stage-4 shapes, us per launch, loader form vs one-tile form): 16 -> 16 two-term 75.1 vs 57.0,
+// 32 -> 32 54.7 vs 58.5, 64 -> 64 54.9 vs 49.2, 16 -> 32 s122 53.4 vs 43.9, 32 -> 64 s122 49.2 vs 38.8; one-term weights: 32 -> 32 38.6 vs
+// 32.2, 64 -> 64 50.0 vs 32.6; whole path 539 vs 572 ref-views/s.  The pipelined form loses: 152 VGPRs and two 20-KB images leave 3 blocks
+// of 4 contracting waves per CU where the one-tile form holds 4-5, and one loader wave fills LDS at ~25 GB/s per CU (MI355X_MICROARCH.md
+// "ldsdma-fill"), i.e. a 20-KB chunk takes about as long as its contraction.  Resident waves, not bytes in flight, carry these kernels.
+// Kept as an experiment (MVS_CONV_LOADER=1 builds it; MVS_CONV_LOADER_OFF=1 then switches it off at run time); not compiled by default.
+#ifndef MVS_CONV_LOADER
+#define MVS_CONV_LOADER 0
+#endif
+#if MVS_CONV_LOADER
+__device__ float4 g_conv_zero_line[4];               // zero-initialised: the source of every out-of-volume run
+
+template <class Cfg>
+struct BfConvLd {
+    static constexpr int OPT = BfConv<Cfg>::OPT;
+    static constexpr int IMG = ((int)BfConv<Cfg>::LDS_BYTES + 255) / 256 * 256;     // one staged chunk; two of them ping-pong
+    static constexpr int NPC = (Cfg::NVOX + 63) / 64;                               // 1-KiB pieces per octet plane
+    static constexpr int NP = OPT * NPC;
+    static constexpr size_t LDS_BYTES = (size_t)2 * IMG;
+    static constexpr bool ENABLED = MVS_CONV_LOADER && BfConv<Cfg>::F16 && !BfConv<Cfg>::PERSIST && Cfg::KD == 3;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(320) void conv3d_mfma_f16_loader_kernel(const _Float16* __restrict__ x, const void* wp, const float* __restrict__ bias,
+                                                                     _Float16* __restrict__ y, int D, int H, int W, int OD, int OH, int OW,
+                                                                     int relu, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, SD = Cfg::SD, SH = Cfg::SH, SW = Cfg::SW, TD = Cfg::TD, TH = Cfg::TH, CH = Cfg::CH;
+    constexpr int IH = Cfg::IH, IW = Cfg::IW, MREP = Cfg::MREP, NREP = Cfg::NREP, NPASS = Cfg::NPASS, NVOX = Cfg::NVOX;
+    constexpr int NSTEP = BfConv<Cfg>::NSTEP, SB = BfConv<Cfg>::SB, PLANE = BfConv<Cfg>::PLANE;
+    constexpr int IMG = BfConvLd<Cfg>::IMG, NPC = BfConvLd<Cfg>::NPC, NP = BfConvLd<Cfg>::NP;
+    static_assert(BfConv<Cfg>::F16 && SB == 16, "fp16 activations: 16 bytes per voxel and octet");
+    HIP_DYNAMIC_SHARED(float4, lds4)
+    char* lds = reinterpret_cast<char*>(lds4);
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.y;
+    // a contiguous run of tiles per block; neighbouring runs on the same XCD (shared halo rows hit its L2)
+    const int nblk = (int)gridDim.x, per = (ntiles + nblk - 1) / nblk;
+    const int t_begin = (int)xcd_remap(blockIdx.x, (unsigned)nblk) * per;
+    const int t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+    if (t_begin >= t_end) return;
+    const int nchunk = (t_end - t_begin) * NPASS;
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)b * D * H * W * CIN * 2;
+
+    if (wave == 4) {
+        // ---------------- loader wave: piece k = 64 consecutive voxels of octet plane k / NPC; lane -> voxel 64 (k % NPC) + lane
+        const char* zero = reinterpret_cast<const char*>(g_conv_zero_line);
+        int crd[NPC];                                           // packed tile-local halo coordinates dz << 16 | dy << 8 | dx, -1: no such voxel
+        int rel[NPC];                                           // byte offset of the voxel from the tile's first halo voxel
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) {
+            const int v = 64 * k + lane;
+            const int dx = v % IW, t2 = v / IW, dy = t2 % IH, dz = t2 / IH;
+            crd[k] = v < NVOX ? (dz << 16 | dy << 8 | dx) : -1;
+            rel[k] = ((dz * H + dy) * W + dx) * (CIN * 2);
+        }
+        auto issue = [&](int c, int buf) {
+            const int tile = t_begin + c / NPASS, pass = c - (c / NPASS) * NPASS;
+            const int tx = tile % tiles_x, t1 = tile / tiles_x;
+            const int ty = t1 % tiles_y, tz = t1 / tiles_y;
+            const int iz0 = tz * TD * SD - Cfg::PD, iy0 = ty * TH * SH - 1, ix0 = tx * 16 * SW - 1;
+            const long long base = ((long long)(iz0 * H + iy0) * W + ix0) * (CIN * 2) + pass * (CH * 2);
+            char* img = lds + buf * IMG;
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) {
+                if (crd[k] < 0) continue;                       // tail of the plane: these lanes take no part (their LDS slots lie beyond the plane)
+                const int z = iz0 + (crd[k] >> 16), yy = iy0 + ((crd[k] >> 8) & 0xff), xx = ix0 + (crd[k] & 0xff);
+                const bool ok = MVS_ABL != 1 && (unsigned)z < (unsigned)D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+#pragma unroll
+                for (int oc = 0; oc < BfConvLd<Cfg>::OPT; ++oc) {
+                    const char* src = ok ? xb + base + rel[k] + oc * 16 : zero;
+                    MVS_GLOBAL_LOAD_LDS16(src, img + oc * PLANE + k * 1024);
+                }
+            }
+        };
+        issue(0, 0);
+        MVS_WAIT_VMEM();
+        __syncthreads();                                        // chunk 0 is in LDS
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) issue(c + 1, (c + 1) & 1);      // lands while waves 0-3 contract chunk c
+            MVS_WAIT_VMEM();
+            __syncthreads();                                    // chunk c + 1 visible; everybody has left chunk c (its image is free for c + 2)
+        }
+        return;
+    }
+
+    // ---------------- contracting waves: the one-tile kernel's mapping (tid 0..255)
+    float sat_amax = 0.0f;
+    const int li = lane & 15, g = lane >> 4;
+    constexpr int MSPLIT = CfgSplit<Cfg>::MSPLIT, MREP_ALL = CfgSplit<Cfg>::MREP_ALL;
+    const int mb0 = (wave % MSPLIT) * MREP, rowgrp = wave / MSPLIT;       // this wave's output blocks and rows (SplitCfg)
+    int voxbase[NREP];
+#pragma unroll
+    for (int nb = 0; nb < NREP; ++nb) {
+        const int nbg = rowgrp * NREP + nb;
+        const int oz = nbg / TH, oy = nbg % TH;
+        voxbase[nb] = (((oz * SD) * IH + oy * SH) * IW + li * SW) * SB;
+    }
+    float4 bb[MREP];
+#pragma unroll
+    for (int mb = 0; mb < MREP; ++mb) {
+        const int co = 16 * (mb0 + mb) + 4 * g;
+        bb[mb] = co < COUT ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    _Float16* yb = y + (size_t)b * OD * OH * OW * COUT;
+    f32x4 acc[MREP][NREP];
+    __syncthreads();                                            // chunk 0 is in LDS
+    for (int c = 0; c < nchunk; ++c) {
+        const int tile = t_begin + c / NPASS, pass = c - (c / NPASS) * NPASS;
+        const char* cur = lds + (c & 1) * IMG;
+        const bf16x8* wq = reinterpret_cast<const bf16x8*>(wp) + ((size_t)pass * NSTEP * MREP_ALL + mb0) * 2 * 64 + lane;
+        bf16x8 ah[MVS_WPF + 1][MREP], al[MVS_WPF + 1][MREP];
+        bf_conv_preload_w<Cfg>(wq, ah, al);
+        if (pass == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MREP; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NREP; ++nb) acc[mb][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        bf_conv_contract<Cfg>(wq, cur, voxbase, g, acc, ah, al);
+        if (pass == NPASS - 1) {
+            const int tx = tile % tiles_x, t1 = tile / tiles_x;
+            const int ty = t1 % tiles_y, tz = t1 / tiles_y;
+            const int oz0 = tz * TD, oy0 = ty * TH, ox0 = tx * 16;
+#pragma unroll
+            for (int nb = 0; nb < NREP; ++nb) {
+                const int nbg = rowgrp * NREP + nb;
+                const int oz = oz0 + nbg / TH, oy = oy0 + nbg % TH, ox = ox0 + li;
+                if (!(oz < OD && oy < OH && ox < OW)) continue;
+                _Float16* o = yb + (((size_t)oz * OH + oy) * OW + ox) * COUT;
+#pragma unroll
+                for (int mb = 0; mb < MREP; ++mb) {
+                    const int co = 16 * (mb0 + mb) + 4 * g;
+                    if (co >= COUT) continue;
+                    float4 v = make_float4(acc[mb][nb][0] + bb[mb].x, acc[mb][nb][1] + bb[mb].y, acc[mb][nb][2] + bb[mb].z, acc[mb][nb][3] + bb[mb].w);
+                    if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+                    *reinterpret_cast<f16x4*>(o + co) = f16_pack4(v, sat_amax);
+                }
+            }
+        }
+        __syncthreads();                                        // chunk c + 1 has landed; this chunk's image may be overwritten
+    }
+    sat::commit(sat_amax);
+}
+#endif  // MVS_CONV_LOADER
+
+// ------------------------------------------------------------------------------------------------
 // ConvTranspose3d (parity classes as in conv_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 template <class Cfg>
@@ -1236,7 +1398,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
 // blocks of 256 threads the current device holds at once for a persistent kernel (-1: query failed).  Cached per (kernel, device)
 // under a mutex; the dynamic-LDS attribute is set on every query miss, i.e. once per device (a function-local static
 // shared one device's answer with all others and was not thread-safe).
-static int resident_blocks(const void* func, size_t lds) {
+static int resident_blocks(const void* func, size_t lds, int threads = 256) {
     static std::mutex mu;
     static std::map<std::pair<const void*, int>, int> cache;
     int dev = 0;
@@ -1247,7 +1409,7 @@ static int resident_blocks(const void* func, size_t lds) {
     int per_cu = 0;
     hipDeviceProp_t prop;
     if (lds > 48 * 1024) hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, 256, lds) != hipSuccess || per_cu < 1)
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, threads, lds) != hipSuccess || per_cu < 1)
         return -1;
     return cache[std::make_pair(func, dev)] = per_cu * prop.multiProcessorCount;
 }
@@ -1276,6 +1438,20 @@ static int launch_conv_bf(const float* x, const void* wp, const float* bias, flo
         return check_launch("conv3d_mfma_bf16x3_persist_kernel");
     }
     if (logits != nullptr) { set_error("conv3d(bf16x3): the planar single-channel output needs a persistent (Cin = 8) kernel"); return MVS_ERR_UNSUPPORTED; }
+#if MVS_CONV_LOADER
+    if constexpr (BfConvLd<Cfg>::ENABLED) {
+        static const bool off = getenv("MVS_CONV_LOADER_OFF") != nullptr;            // A/B switch (scripts/bench_layer.py)
+        if (!off) {
+            constexpr size_t LLDS = BfConvLd<Cfg>::LDS_BYTES;
+            const int resident = resident_blocks(reinterpret_cast<const void*>(&conv3d_mfma_f16_loader_kernel<Cfg>), LLDS, 320);
+            if (resident < 1) { set_error("conv3d(f16, loader): occupancy query failed"); return MVS_ERR_LAUNCH; }
+            const int nblk = ntiles < resident ? ntiles : resident;
+            hipLaunchKernelGGL((conv3d_mfma_f16_loader_kernel<Cfg>), dim3(nblk, B), dim3(320), LLDS, st, reinterpret_cast<const _Float16*>(x), wp, bias,
+                               reinterpret_cast<_Float16*>(y), D, H, W, OD, OH, OW, relu, tx, ty, ntiles);
+            return check_launch("conv3d_mfma_f16_loader_kernel");
+        }
+    }
+#endif
     constexpr size_t TLDS = BfWlds<Cfg>::ENABLED ? BfWlds<Cfg>::LDS_BYTES : LDS;
     if (TLDS > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_bf16x3_kernel<Cfg, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TLDS);
