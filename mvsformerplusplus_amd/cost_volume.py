@@ -122,7 +122,7 @@ class StageNet(nn.Module):
     def _vis_precision(self) -> str:
         """Contraction of the visibility CNN's two MFMA layers (its activations stay on chip): the stage's conv_precision - "f16x2" runs
         the fp16 two-term form with fp16 rings."""
-        return "f16x2" if self.conv_precision in F16_FORMATS else self.conv_precision      # "f16" / "f16mix": the CNN keeps both weight terms
+        return self.conv_precision           # every fp16 format shares the fp16 rings; "f16" / "f16mix" drop the CNN's second weight term too
 
     def _f16_activations(self) -> bool:
         """conv_precision "f16x2": the U-Net's tensors - cost volume included - are fp16 in HBM (MVS_PREC_F16X2); the transformer

@@ -426,7 +426,7 @@ extern "C" int mvs_vis_out_fwd(const float* x_cl8, const float* w4, const float*
 }
 
 extern "C" size_t mvs_vis_workspace_bytes(int N, int H, int W, int precision) {
-    if (precision == MVS_PREC_BF16X3 || precision == MVS_PREC_F16X2) return 16;         // the row-streaming kernel keeps every intermediate in LDS
+    if (precision == MVS_PREC_BF16X3 || precision == MVS_PREC_F16X2 || precision == MVS_PREC_F16 || precision == MVS_PREC_F16MIX) return 16;   // the row-streaming kernel keeps every intermediate in LDS
     return (size_t)N * H * W * 32 * sizeof(float);
 }
 
@@ -437,8 +437,10 @@ extern "C" int mvs_vis_weight_fwd(const float* entropy, const float* w1, const f
     if (workspace_bytes < mvs_vis_workspace_bytes(N, H, W, precision)) { set_error("mvs_vis_weight_fwd: workspace too small (%zu < %zu)", workspace_bytes, mvs_vis_workspace_bytes(N, H, W, precision)); return MVS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const size_t HW = (size_t)H * W;
-    if (precision == MVS_PREC_BF16X3 || precision == MVS_PREC_F16X2)       // one row-streaming launch, every intermediate in LDS (vis_kernels.hip)
-        return vis_weight_stream_bf16x3(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st, precision == MVS_PREC_F16X2);
+    if (precision == MVS_PREC_BF16X3 || precision == MVS_PREC_F16X2 || precision == MVS_PREC_F16 || precision == MVS_PREC_F16MIX)
+        // one row-streaming launch, every intermediate in LDS (vis_kernels.hip); F16 / F16MIX: one weight term
+        return vis_weight_stream_bf16x3(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st,
+                                        precision == MVS_PREC_F16X2 ? 1 : (precision == MVS_PREC_BF16X3 ? 0 : 2));
     float* t1 = static_cast<float*>(workspace);          // [N,H,W,16]
     float* t2 = t1 + (size_t)N * HW * 16;                // [N,H,W,16]
     hipLaunchKernelGGL(vis_conv1_kernel, dim3(ceil_div((long long)HW, 256), N), dim3(256), 0, st, entropy, w1, b1, t1, H, W);

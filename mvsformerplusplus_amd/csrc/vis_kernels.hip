@@ -94,7 +94,9 @@ __device__ __forceinline__ f32x4 vs_mfma_hi(const vs_bf16x8& wh, const VsOperand
 
 // one MFMA layer row: 5 contraction steps, three split-bf16 terms on three accumulators, the operand reads of step t+1 issued
 // before the MFMAs of step t
-template <int SLOT0, bool F16>
+// ONE (round 4, MVS_PREC_F16 / _F16MIX): the weights' lo term is not used - 10 instead of 20 MFMAs per row and wave (error study:
+// scripts/study_weight_precision.py, "visibility CNN one term")
+template <int SLOT0, bool F16, bool ONE = false>
 __device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, const vs_bf16x8* wh, const vs_bf16x8* wl) {
     constexpr int POSB = VsL<F16>::POSB;
     f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0;
@@ -104,7 +106,7 @@ __device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff
         VsOperand nxt = cur;
         if (t < 4) nxt = vs_load<F16>(lds_layer + vs_step_off<SLOT0, POSB>(laneoff, tapsel, t + 1));
         __builtin_amdgcn_sched_barrier(0);
-        a0 = vs_mfma_lo<F16>(wl[t], cur, a0);
+        if constexpr (!ONE) a0 = vs_mfma_lo<F16>(wl[t], cur, a0);
         if constexpr (!F16) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t], cur.l, a1, 0, 0, 0);
         a2 = vs_mfma_hi<F16>(wh[t], cur, a2);
         cur = nxt;
@@ -115,7 +117,7 @@ __device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff
 // both MFMA layers of one iteration interleaved (layer 2 reads ring 1, layer 3 reads ring 2: independent): four operand
 // reads in flight under six MFMAs; one accumulator per layer - the two chains alternate, so a chain's next link is issued two
 // MFMAs (32 cycles) after the previous one
-template <int SLOT2, int SLOT3, bool F16>
+template <int SLOT2, int SLOT3, bool F16, bool ONE = false>
 __device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* lds2, int laneoff, int tapsel, const vs_bf16x8* w2h,
                                                   const vs_bf16x8* w2l, const vs_bf16x8* w3h, const vs_bf16x8* w3l, f32x4& out2, f32x4& out3) {
     constexpr int POSB = VsL<F16>::POSB;
@@ -130,8 +132,10 @@ __device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* 
             nc = vs_load<F16>(lds2 + vs_step_off<SLOT3, POSB>(laneoff, tapsel, t + 1));
         }
         __builtin_amdgcn_sched_barrier(0);
-        a = vs_mfma_lo<F16>(w2l[t], cb, a);
-        c = vs_mfma_lo<F16>(w3l[t], cc, c);
+        if constexpr (!ONE) {
+            a = vs_mfma_lo<F16>(w2l[t], cb, a);
+            c = vs_mfma_lo<F16>(w3l[t], cc, c);
+        }
         if constexpr (!F16) {
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t], cb.l, a, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[t], cc.l, c, 0, 0, 0);
@@ -148,7 +152,7 @@ __device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* 
 template <int V> struct VsInt { static constexpr int value = V; };
 
 // grid = (strips, row segments, N)
-template <bool F16>
+template <bool F16, bool ONE = false>
 __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ ent, const float* __restrict__ w1 /*[9][16]*/,
                                                       const float* __restrict__ b1, const void* __restrict__ wp2, const float* __restrict__ b2,
                                                       const void* __restrict__ wp3, const float* __restrict__ b3, const float* __restrict__ w4,
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             w3h[t] = q3[(t * 2) * 64]; w3l[t] = q3[(t * 2 + 1) * 64];
             // opaque: the compiler must keep them in registers instead of re-loading the invariant memory every row
 #ifndef MVS_NO_OPAQUE_VEC
-            asm volatile("" : "+" MVS_OPAQUE_VEC(w2h[t]), "+" MVS_OPAQUE_VEC(w2l[t]), "+" MVS_OPAQUE_VEC(w3h[t]), "+" MVS_OPAQUE_VEC(w3l[t]));
+            if constexpr (ONE) asm volatile("" : "+" MVS_OPAQUE_VEC(w2h[t]), "+" MVS_OPAQUE_VEC(w3h[t]));
+            else asm volatile("" : "+" MVS_OPAQUE_VEC(w2h[t]), "+" MVS_OPAQUE_VEC(w2l[t]), "+" MVS_OPAQUE_VEC(w3h[t]), "+" MVS_OPAQUE_VEC(w3l[t]));
 #endif
         }
     }
@@ -258,9 +263,9 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
         const bool doB = yb >= r0 - 1 && yb <= r1, doC = yc >= r0;
         constexpr int S2 = (PH + 1) & 3, S3 = (PH + 3) & 3;          // slots of rows i-3 and i-5
         f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc3 = acc2;
-        if (doB && doC) vs_two_layer_rows<S2, S3, F16>(lds1, lds2, laneoff, tapsel, w2h, w2l, w3h, w3l, acc2, acc3);
-        else if (doB) acc2 = vs_layer_row<S2, F16>(lds1, laneoff, tapsel, w2h, w2l);
-        else if (doC) acc3 = vs_layer_row<S3, F16>(lds2, laneoff, tapsel, w3h, w3l);
+        if (doB && doC) vs_two_layer_rows<S2, S3, F16, ONE>(lds1, lds2, laneoff, tapsel, w2h, w2l, w3h, w3l, acc2, acc3);
+        else if (doB) acc2 = vs_layer_row<S2, F16, ONE>(lds1, laneoff, tapsel, w2h, w2l);
+        else if (doC) acc3 = vs_layer_row<S3, F16, ONE>(lds2, laneoff, tapsel, w3h, w3l);
         if (doB) {
             const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
             float v[4];
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     }
 }
 
-template <bool F16>
+template <bool F16, bool ONE = false>
 static int vis_weight_stream_t(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                                const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st) {
     constexpr int VS_LDS = VsL<F16>::LDS;
@@ -315,14 +320,16 @@ static int vis_weight_stream_t(const float* entropy, const float* w1, const floa
         if (best < 0 || cost < best) { best = cost; segs = (int)ceil_div(H, sh); SH = sh; }
     }
     if (VS_LDS > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS);
-    hipLaunchKernelGGL((vis_cnn_kernel<F16>), dim3(strips, segs, N), dim3(256), VS_LDS, st, entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, H, W, SH);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_kernel<F16, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS);
+    hipLaunchKernelGGL((vis_cnn_kernel<F16, ONE>), dim3(strips, segs, N), dim3(256), VS_LDS, st, entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, H, W, SH);
     return check_launch("vis_cnn_kernel");
 }
 
-// f16: the fp16 two-term form (MVS_PREC_F16X2: rings in fp16, w2 / w3 packed as fp16 hi + lo)
+// f16: 1 = the fp16 two-term form (MVS_PREC_F16X2: rings in fp16, w2 / w3 packed as fp16 hi + lo), 2 = the same with ONE weight term
+// (MVS_PREC_F16 / MVS_PREC_F16MIX)
 int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                              const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st, int f16) {
+    if (f16 == 2) return vis_weight_stream_t<true, true>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
     return f16 ? vis_weight_stream_t<true>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st)
                : vis_weight_stream_t<false>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
 }

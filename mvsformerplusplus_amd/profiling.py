@@ -202,7 +202,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         prec = _lib.PRECISIONS[net._vis_precision()]
         N = B * (V - 1)
         vis_flops = 2.0 * N * HW * (9 * 16 + 9 * 16 * 16 + 9 * 16 * 8 + 8)
-        if net._vis_precision() in ("bf16x3", "f16x2"):             # (_vis_precision maps every fp16 format to "f16x2")
+        if net._vis_precision() in ("bf16x3",) + _lib.F16_FORMATS:
             # one row-streaming launch; algorithmic traffic = entropy in + visibility out
             vis = _timed(launches, "vis_cnn_kernel", s, vis_flops, 4.0 * N * HW * 2, lambda: ops.vis_weight(ent, vp, prec))
         else:

@@ -16,7 +16,7 @@ from mvsformerplusplus_amd import synth
 from mvsformerplusplus_amd.cost_volume import StageNet
 
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 320)
-_conv3d, _convt3d = F.conv3d, F.conv_transpose3d
+_conv3d, _convt3d, _conv2d = F.conv3d, F.conv_transpose3d, F.conv2d
 NDEPTHS, RATIO = [32, 16, 8, 4], [4.0, 2.67, 1.5, 1.0]
 h = lambda x: x.half().float()
 
@@ -41,10 +41,20 @@ def patched(wsel):
     return c3, ct3
 
 
+def vis_one_term(x, w, *a, **k):
+    """visibility CNN (conv2d): layers 2 and 3 run on MFMA with fp16 rings - activations fp16, weights ONE fp16 term; layer 1 (1 -> 16) and
+    the 1x1 output layer are fp32 VALU code"""
+    if w.shape[1] >= 8 and w.shape[-1] == 3:
+        return _conv2d(h(x), h(w), *a, **k)
+    return _conv2d(x, w, *a, **k)
+
+
+VIS_ONE = [False]
 MODES = {"f16x2 (today: activations fp16, weights exact)": lambda ci, co: False,
          "weights fp16 on the 32/64-channel layers": lambda ci, co: min(ci, co) >= 32 or max(ci, co) >= 64,
          "weights fp16 on every layer but the 1-channel head": lambda ci, co: co > 1,
-         "weights fp16 everywhere": lambda ci, co: True}
+         "weights fp16 everywhere": lambda ci, co: True,
+         "f16mix + visibility CNN one term": "vis"}
 for peaky in (False, True):
     sds = state_dicts(peaky)
     for seed in (2, 5):
@@ -53,11 +63,15 @@ for peaky in (False, True):
         with torch.no_grad():
             ref = run()
             for name, wsel in MODES.items():
+                vis = wsel == "vis"
+                if vis:
+                    wsel = MODES["weights fp16 on the 32/64-channel layers"]
+                    F.conv2d = vis_one_term
                 F.conv3d, F.conv_transpose3d = patched(wsel)
                 try:
                     res = run()
                 finally:
-                    F.conv3d, F.conv_transpose3d = _conv3d, _convt3d
+                    F.conv3d, F.conv_transpose3d, F.conv2d = _conv3d, _convt3d, _conv2d
                 errs = [rel_l1(res["stage%d" % s]["depth"], ref["stage%d" % s]["depth"]) for s in range(1, 5)]
                 print("peaky=%d seed=%d  %-52s refined depth rel-L1 %.2e   stages %s   conf mean abs %.1e" % (
                     peaky, seed, name, rel_l1(res["refined_depth"], ref["refined_depth"]), " ".join("%.1e" % e for e in errs),

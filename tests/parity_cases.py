@@ -325,7 +325,8 @@ def case_vis_cnn(device):
     for (N, H, W) in ((3, 37, 130), (2, 70, 61), (1, 9, 24), (2, 64, 120)):
         ent = torch.rand(1, N, H, W, generator=g) * 2.0
         ref = torch.stack([O.vis_weight(ent[:, n:n + 1], sd) for n in range(N)], 1)[:, :, 0]      # [1, N, H, W]
-        for prec, tol in (("bf16x3", 1e-4), ("fp32", 2e-5), ("f16x2", 3e-3)):      # f16x2: fp16 rings (2^-11) through two layers + the sigmoid
+        # f16x2: fp16 rings (2^-11) through two layers + the sigmoid; f16 / f16mix: the same with ONE fp16 weight term
+        for prec, tol in (("bf16x3", 1e-4), ("fp32", 2e-5), ("f16x2", 3e-3), ("f16", 4e-3), ("f16mix", 4e-3)):
             st.conv_precision = prec
             vis = ops.vis_weight(dev(ent, device), st._vis_params(torch.device(device) if isinstance(device, str) else device), _lib.PRECISIONS[prec])
             assert vis.shape == ent.shape

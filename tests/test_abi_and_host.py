@@ -30,10 +30,10 @@ def test_product_default_precision():
     assert module.CostRegNet3D(8, 8).conv_precision == "f16mix"
     for fmt in ("f16mix", "f16", "f16x2"):
         n = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": fmt}, 4, 3)
-        assert n._f16_activations() and not n._split_activations() and n._vis_precision() == "f16x2"
+        assert n._f16_activations() and not n._split_activations() and n._vis_precision() == fmt
     assert StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "bf16x3"}, 4, 3).conv_precision == "bf16x3"
     net = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "f16x2"}, 4, 3)
-    assert net._f16_activations() and not net._split_activations() and net._vis_precision() == "f16x2"
+    assert net._f16_activations() and not net._split_activations() and net._vis_precision() == "f16x2"       # explicit f16x2: both terms
 
 
 def test_header_matches_binding_table():
