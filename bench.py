@@ -145,6 +145,10 @@ def main():
                          "layout [B,V,C/8,H,W,8] (SURVEY.md section 8f #4) as a producer-side emitter would hand it over - packed once, "
                          "outside the timed region")
     ap.add_argument("--view-sharded-timeout", type=int, default=240, help="N > 1: seconds the extra view-sharded latency leg may take")
+    ap.add_argument("--view-sharded-only", action="store_true",
+                    help="N > 1: run ONLY the view-sharded latency mode (SURVEY.md section 8e: the source views of ONE reference view over the ranks, "
+                         "RCCL all-reduce / slab exchange per stage, BASELINE configs[2]'s V = 10) and print its JSON line: value = reference views "
+                         "per second of the whole group, scaling 'strong'.  For a first RCCL contact without the data-parallel headline in front of it")
     ap.add_argument("--conv-precision", choices=["bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
                     help="contraction / activation format of the 3-D regularisers (default: the package default, cost_volume.STAGE_DEFAULT_PRECISION)")
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
@@ -175,6 +179,27 @@ def main():
     from mvsformerplusplus_amd import profiling, synth
     head = build_head(device, shipped=a.cost_reg == "shipped", conv_precision=a.conv_precision)
     fdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.feat_dtype]
+    if a.view_sharded_only:
+        if world < 2:
+            print("--view-sharded-only needs N > 1 ranks (torch.distributed.run)", file=sys.stderr)
+            sys.exit(2)
+
+        def _sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        vs = view_sharded_leg(head, a, device, world, rank, _sync, fdt)
+        if rank == 0:
+            print(json.dumps({"metric": "ref-views/sec at 1152x1536 N=5 D=192 4-stage; achieved HBM GB/s vs peak", "mode": "view-sharded-only",
+                              "value": vs["ref_views_per_s"], "unit": "ref-views/s", "n_gpus": world, "steps": max(3, a.steps // 4), "warmup": 2,
+                              "ms_per_step": vs["ms_per_ref_view"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                              "dtype": "f32 (fp16 storage of the regulariser's activations)", "data": "synthetic",
+                              "config": {"workload": "BASELINE configs[2]: 1152x1536, V = %d, 4-stage cascade, source views sharded over %d ranks" % (vs["views"], world),
+                                         "parallelism": "source views over %d ranks, one reference view at a time" % world},
+                              "view_sharded": vs}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     nsets = max(1, a.input_sets)
     BATCH = max(1, a.batch)
     sets = [synth.make_cascade_inputs(a.height, a.width, a.views, seed=100 * rank + i, device=device, feat_dtype=fdt, batch=BATCH) for i in range(nsets)]

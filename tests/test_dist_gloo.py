@@ -167,10 +167,11 @@ def test_view_sharded_cascade_matches_single_process(world, V, mode):
         assert same, "ranks hold different results"
 
 
-def _two_views_worker(rank, world, port, emu_path, q):
+def _two_views_worker(rank, world, port, emu_path, V, mode, q):
     """Two reference views through ONE view-sharded head back to back (the schedule of two views in flight per group: every rank
-    issues A, B, A): the persistent scratch of the slab exchange is reused across views, so A must come out the same both times,
-    B must not be disturbed by A's buffers, and the ranks must agree on all three."""
+    issues A, B, A): the persistent scratch of the exchange is reused across views, so A must come out the same both times,
+    B must not be disturbed by A's buffers, and the ranks must agree on all three.  V > the fixture's view count: views repeated with
+    shifted cameras (BASELINE configs[2]: 9 source views over 8 ranks = one rank carries two)."""
     _setup(rank, world, port, emu_path)
     from conftest import golden_weights, load_golden
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
@@ -182,11 +183,19 @@ def _two_views_worker(rank, world, port, emu_path, q):
     head.eval()
     fa = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
     projs = {"stage%d" % s: fx["proj%d" % s] for s in range(1, 5)}
+    if V > fa["stage1"].shape[1]:
+        for k in fa:
+            n = fa[k].shape[1]
+            reps = (V + n - 1) // n
+            fa[k] = fa[k].repeat(1, reps, 1, 1, 1)[:, :V].contiguous()
+            projs[k] = projs[k].repeat(1, reps, 1, 1, 1)[:, :V].clone()
+            for v in range(V):
+                projs[k][:, v, 0, 0, 3] += 2.0 * v
     g = torch.Generator().manual_seed(4)
     fb = {k: v + 0.3 * torch.randn(v.shape, generator=g) for k, v in fa.items()}        # a second reference view: other features, same rig
     with torch.no_grad():
         single_b = head(fb, projs, fx["depth_values"])["refined_depth"]
-        head.set_view_group(dist.group.WORLD, shard_mode="slab")
+        head.set_view_group(dist.group.WORLD, shard_mode=mode)
         a1 = head(fa, projs, fx["depth_values"])["refined_depth"].clone()
         b1 = head(fb, projs, fx["depth_values"])["refined_depth"].clone()
         a2 = head(fa, projs, fx["depth_values"])["refined_depth"].clone()
@@ -196,9 +205,12 @@ def _two_views_worker(rank, world, port, emu_path, q):
     dist.destroy_process_group()
 
 
-def test_two_views_in_flight_schedule_is_repeatable_and_rank_identical():
-    for rank, err, ok in _run(_two_views_worker, 2):
-        assert err <= 1e-4, "rank %d: second view's sharded depth differs from its single-process depth by %g" % (rank, err)
+@pytest.mark.parametrize("world,V,mode", [(2, 4, "slab"), (8, 10, "auto")])
+def test_two_views_in_flight_schedule_is_repeatable_and_rank_identical(world, V, mode):
+    """(2 ranks, slab exchange forced) and BASELINE configs[2]'s split: 9 source views over 8 ranks (one rank carries two views, seven carry
+    one; product-default precision), two reference views in flight through one sharded head."""
+    for rank, err, ok in _run(_two_views_worker, world, V, mode):
+        assert err <= 3e-4, "rank %d: second view's sharded depth differs from its single-process depth by %g" % (rank, err)
         assert ok, "views issued back to back through one sharded head disturbed each other or the ranks disagree"
 
 
