@@ -149,8 +149,12 @@ class StageNet(nn.Module):
             raise NotImplementedError("base_ch=%d: the HIP regulariser is built for 8 groups (all shipped configs)" % G)
         feats, code = ops._feat(features)
         hyp = ops._f32c(depth_values)
-        if hyp.dim() != 4:
-            raise ValueError("depth_values must be [B,D,H,W] inside the cascade")
+        if hyp.dim() == 2:
+            # [B, D]: fronto-parallel planes shared by every pixel (a plain MVSNet call; the reference's warp broadcasts them, warping.py:91,
+            # and depth_regression views them as [B, D, 1, 1], module.py:650-652).  The kernels read per-pixel hypotheses: expand once.
+            hyp = hyp[:, :, None, None].expand(B, hyp.shape[1], H, W).contiguous()
+        elif hyp.dim() != 4:
+            raise ValueError("depth_values must be [B,D] or [B,D,H,W], got shape %s" % (tuple(depth_values.shape),))
         hom = ops.compose_homography(proj_matrices)
         vis_params = self._vis_params(feats.device)
         prec = precision_code(self._vis_precision())
@@ -351,6 +355,12 @@ class StageNet(nn.Module):
             # Overlap comes from the caller keeping two or more reference views in flight per group on separate streams (bench.py issues
             # them round-robin): the scratch buffers are per stream, the collectives of a view are enqueued behind its own launches
             # only, and every rank issues the views in the same order.
+            # Stream safety on RCCL (backend "nccl"): ProcessGroupNCCL runs the grouped send / recv on its own stream, ordered behind an
+            # event recorded on the CURRENT stream at this call (so slab_pack's writes are seen), and work.wait() makes the current stream
+            # wait for the communication - every later kernel of this view (slab_reduce, and the next call's slab_pack into the same send
+            # buffers) is ordered behind it.  The buffers come from _buffer(): persistent per (name, shape, device, issuing stream), never
+            # handed back to the caching allocator while a collective can touch them, never shared between streams - the cases
+            # Tensor.record_stream exists for (free / reuse by another stream) cannot arise.
             for w in dist.batch_isend_irecv(p2p):
                 w.wait()
         self.last_collective_bytes = sum(t.numel() for t in sends if t is not None) * 4

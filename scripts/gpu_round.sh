@@ -39,7 +39,8 @@ python -c "
 import json; r = json.loads(open('gpurun_out/bench_tiled_bf16.json').read().strip().splitlines()[-1]); print('tiled bf16', r['value'], r['ms_per_ref_view'])"
 echo "== N = 2 flow of bench.py on this one-GPU box (both ranks on the device, gloo): code path check, not a measurement =="
 MVS_BENCH_ONE_DEVICE=1 MVS_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-  --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --views-per-step 4 --no-profile > $OUT/bench_n2.json 2> $OUT/bench_n2.err
+  --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --views-per-step 4 --no-profile > $OUT/bench_n2.raw 2> $OUT/bench_n2.err
+grep '^{' $OUT/bench_n2.raw | tail -1 > $OUT/bench_n2.json          # gloo prints "[Gloo] Rank ..." lines on stdout: keep the JSON line only
 python - <<'PY'
 import json
 try:

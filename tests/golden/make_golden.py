@@ -111,6 +111,48 @@ def f2_stage():
 
 
 @torch.no_grad()
+def f14_stage_bd_hypotheses():
+    """StageNet.forward with depth_values of shape [B, D] (fronto-parallel planes shared by every pixel; the reference's warp broadcasts them,
+    warping.py:91, and depth_regression views them as [B, D, 1, 1], module.py:650-652) - the call form of a plain (non-cascade) MVSNet."""
+    stage_idx, C, D = 3, 8, 8
+    torch.manual_seed(61)
+    net = StageNet(dict(ARGS), D, stage_idx).eval()
+    wman = seed_weights(net, 261)
+    feats, cams, _ = stage_inputs(C, D, 32, 40, 3, 61, down=1)
+    hyp = (1.0 / torch.linspace(1.0 / 935.0, 1.0 / 425.0, D))[None].contiguous()            # [1, D]
+    out = net(feats, cams, hyp, tmp=1.0)
+    npz("f14_stage_bd_hyp.npz", features=feats, proj=cams, hyp=hyp, depth=out["depth"], prob_volume=out["prob_volume"],
+        photometric_confidence=out["photometric_confidence"], prob_volume_pre=out["prob_volume_pre"], **wman)
+
+
+def pin_weights():
+    """tests/golden/weights_sha256.json: SHA-256 of every weight set the fixtures regenerate from (manifest, seed) - checked on every load
+    (tests/conftest.py golden_weights)."""
+    import glob
+    import hashlib
+    sums = {}
+    for path in sorted(glob.glob(os.path.join(HERE, "*.npz"))):
+        z = np.load(path, allow_pickle=False)
+        for key in z.files:
+            if not key.endswith("keys"):
+                continue
+            prefix = key[:-4]
+            keys = [str(k) for k in z[prefix + "keys"].tolist()]
+            shapes = [tuple(json.loads(str(x))) for x in z[prefix + "shapes"].tolist()]
+            sd = synth.seeded_state_dict(dict(zip(keys, shapes)), int(z[prefix + "seed"]))
+            h = hashlib.sha256()
+            for k in sorted(sd):
+                h.update(k.encode())
+                h.update(sd[k].contiguous().numpy().tobytes())
+            sums[os.path.basename(path) + ":" + prefix] = h.hexdigest()
+    old = json.load(open(os.path.join(HERE, "weights_sha256.json")))
+    for k, v in old.items():
+        assert sums.get(k, v) == v, "weights of %s changed" % k
+    json.dump(sums, open(os.path.join(HERE, "weights_sha256.json"), "w"), indent=1, sort_keys=True)
+    print("pinned %d weight sets (%d new)" % (len(sums), len(set(sums) - set(old))))
+
+
+@torch.no_grad()
 def f3_regnets():
     g = torch.Generator().manual_seed(3)
     torch.manual_seed(3)
@@ -465,3 +507,5 @@ if __name__ == "__main__":
     f6_train_mode()
     f12_train_backward()
     f13_train_backward_transformer()
+    f14_stage_bd_hypotheses()
+    pin_weights()

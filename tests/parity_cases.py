@@ -187,6 +187,23 @@ def case_stage_golden(device, tag, prec=None):
     return errs
 
 
+def case_stage_bd_hypotheses(device, prec=None):
+    """depth_values of shape [B, D] (one set of fronto-parallel planes for every pixel) against fixture F14 from the reference; the output
+    dict hands the caller's [B, D] tensor back under 'depth_values' like the reference does."""
+    fx = load_golden("f14_stage_bd_hyp.npz")
+    net = make_stage(fx, fx["hyp"].shape[1], 3, device, prec=prec)
+    hyp = dev(fx["hyp"], device)
+    assert hyp.dim() == 2
+    with torch.no_grad():
+        out = net(dev(fx["features"], device), dev(fx["proj"], device), hyp, 1.0)
+    assert out["depth_values"].shape == hyp.shape
+    e = (rel_l1(cpu(out["depth"]), fx["depth"]), float((cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max()),
+         float((cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max()))
+    assert e[0] <= tol(prec, 2e-5, 2e-4), e
+    assert e[1] <= tol(prec, 1e-4, 2e-3) and e[2] <= tol(prec, 1e-4, 2e-3), e
+    return e
+
+
 def case_stage_pieces(device):
     """Intermediate tensors of one stage (entropy, visibility, cost volume) against the oracle's intermediates."""
     fx = load_golden("f2_stage_s1.npz")

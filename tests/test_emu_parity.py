@@ -42,6 +42,11 @@ def test_stage_golden(emu, tag, prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+def test_stage_bd_hypotheses(emu, prec):
+    P.case_stage_bd_hypotheses(emu, prec)
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_stage_modes(emu, prec):
     P.case_stage_modes(emu, prec)
 

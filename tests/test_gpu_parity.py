@@ -56,6 +56,12 @@ def test_stage_golden(tag, prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+def test_stage_bd_hypotheses(prec):
+    """[B, D] hypotheses vs fixture F14 generated from the reference."""
+    P.case_stage_bd_hypotheses(DEV, prec)
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_stage_modes(prec):
     P.case_stage_modes(DEV, prec)
 

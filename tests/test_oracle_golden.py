@@ -32,6 +32,17 @@ def test_f2_stage(tag):
     assert rel_l1(out["depth"], fx["depth"]) <= 1e-6
 
 
+def test_f14_stage_bd_hypotheses():
+    """[B, D] hypotheses: the oracle broadcasts them exactly as the reference's warp / depth_regression do (warping.py:91, module.py:650-652)."""
+    fx = load_golden("f14_stage_bd_hyp.npz")
+    sd = golden_weights(fx)
+    assert fx["hyp"].dim() == 2
+    out = O.stage_forward(fx["features"], fx["proj"], fx["hyp"], 1.0, sd, G=8)
+    assert (out["prob_volume_pre"] - fx["prob_volume_pre"]).abs().max() <= 1e-4
+    assert (out["prob_volume"] - fx["prob_volume"]).abs().max() <= 1e-5
+    assert rel_l1(out["depth"], fx["depth"]) <= 1e-6
+
+
 @pytest.mark.parametrize("name,fn", [("f3_costregnet.npz", O.cost_regnet), ("f3_costregnet3d_d4.npz", O.cost_regnet3d),
                                      ("f3_costregnet3d_d8.npz", O.cost_regnet3d)])
 def test_f3_regnets(name, fn):
