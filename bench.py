@@ -151,6 +151,8 @@ def main():
                          "per second of the whole group, scaling 'strong'.  For a first RCCL contact without the data-parallel headline in front of it")
     ap.add_argument("--conv-precision", choices=["bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
                     help="contraction / activation format of the 3-D regularisers (default: the package default, cost_volume.STAGE_DEFAULT_PRECISION)")
+    ap.add_argument("--no-keep-correlations", action="store_true",
+                    help="A/B: pass 2 of every stage gathers again instead of streaming the fp16 correlations kept by pass 1 (StageNet.keep_correlations)")
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
                     help="normal: all-'Normal' regularisers (Track R headline); shipped: stage-1 transformer + PE3D as in the shipped config")
     a = ap.parse_args()
@@ -178,6 +180,9 @@ def main():
 
     from mvsformerplusplus_amd import profiling, synth
     head = build_head(device, shipped=a.cost_reg == "shipped", conv_precision=a.conv_precision)
+    if a.no_keep_correlations:
+        for st in head.fusions:
+            st.keep_correlations = False
     fdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.feat_dtype]
     if a.view_sharded_only:
         if world < 2:
@@ -322,6 +327,8 @@ def main():
         "fp32": "fp32-exact MFMA contraction"}[prec0]
     if prec0 in ("f16x2", "f16mix", "f16"):
         result["dtype"] = "f32 (fp16 storage of the regulariser's activations)"
+        result["config"]["gather_pass2"] = ("second gather on every stage (--no-keep-correlations)" if a.no_keep_correlations else
+                                            "stages with D > 4: stream of the fp16 per-view correlations kept by pass 1; D <= 4: second gather")
 
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
     if not a.no_profile:
@@ -369,9 +376,9 @@ def main():
         # the two gather passes (the kernels VERDICT r1 named: 6 % of the HBM roofline then), per instantiation, by the SURVEY 8d byte count
         result["gather_roofline"] = {k: {"achieved_gbs": v["gbs"], "frac_of_8TBs": v["gbs"] / profiling.PEAK_HBM_GBS, "avg_launch_ms": v["avg_ms"],
                                          "algorithmic_bytes_per_launch": v["bytes"] / v["calls"]}
-                                     for k, v in agg.items() if k.startswith(("gl_", "warp_corr_"))}
-        gb = sum(v["bytes"] for k, v in agg.items() if k.startswith(("gl_", "warp_corr_")))
-        gt = sum(v["ms"] for k, v in agg.items() if k.startswith(("gl_", "warp_corr_")))
+                                     for k, v in agg.items() if k.startswith(("gl_", "warp_corr_", "corr_aggregate"))}
+        gb = sum(v["bytes"] for k, v in agg.items() if k.startswith(("gl_", "warp_corr_", "corr_aggregate")))
+        gt = sum(v["ms"] for k, v in agg.items() if k.startswith(("gl_", "warp_corr_", "corr_aggregate")))
         result["gather_roofline"]["all_passes"] = {"achieved_gbs": gb / max(gt, 1e-9) / 1e6, "frac_of_8TBs": gb / max(gt, 1e-9) / 1e6 / profiling.PEAK_HBM_GBS,
                                                    "ms_per_ref_view": gt / reps}
         result["kernels"] = {k: {"calls_per_ref_view": v["calls"] / reps, "ms_per_ref_view": v["ms"] / reps, "gbs": v["gbs"], "tflops": v["tflops"]}
@@ -396,7 +403,7 @@ def main():
             ach = work / ms / 1e6                                # GB/s
             return {"ms_per_ref_view": ms, "bound": "hbm", "algorithmic_mb_per_ref_view": work / 1e6, "achieved_gbs": ach, "peak_gbs": profiling.PEAK_HBM_GBS,
                     "frac": ach / profiling.PEAK_HBM_GBS, "launches_per_ref_view": sum(v["calls"] for v in ks.values()) / reps}
-        is_gather = lambda k: k.startswith(("gl_", "warp_corr_"))
+        is_gather = lambda k: k.startswith(("gl_", "warp_corr_", "corr_aggregate"))
         is_conv = lambda k: k.startswith(("conv3d_mfma", "deconv3d_mfma"))
         is_vis = lambda k: k.startswith(("vis_",)) or k.startswith("conv3d_mfma<16,16,k1") or k.startswith("conv3d_mfma<16,8,k1")
         families = {"gather": fam(is_gather, "hbm"), "visibility_cnn": fam(is_vis, "mfma"),

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 8
+ABI_VERSION = 9
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
@@ -49,6 +49,9 @@ SIGNATURES = {
     "mvs_volume_normalise": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_volume_to_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_gather_is_lds_staged": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mvs_gather_keeps_correlations": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mvs_warp_corr_entropy_keep_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
+    "mvs_corr_aggregate_fwd": (_i, [_vp, _vp, _vp] + [_i] * 5 + [_vp]),
     "mvs_slab_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_slab_reduce": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),

@@ -42,6 +42,7 @@ STAGE_DEFAULT_PRECISION = DEFAULT_PRECISION      # one constant (module.DEFAULT_
 
 
 _F16_CALLS = 0
+KEEP_CORRELATIONS_MAX_BYTES = 1 << 30      # largest kept per-view correlation tensor ([B,V-1,D,H,W,8] fp16) of the streaming pass 2
 F16_SATURATION_CHECK_EVERY = 4096          # stage calls between two automatic reads of the saturation counter (0 = never)
 
 
@@ -87,6 +88,7 @@ class StageNet(nn.Module):
         # "auto": all-reduce of the partial volumes on coarse stages, H-slab exchange + 1/R of the regulariser where a slab is
         # at least one halo tall; "allreduce" / "slab" force one form
         self.shard_mode = "auto"
+        self.keep_correlations = "auto"   # fp16 formats, D > 4: pass 1 keeps fp16 per-view correlations, pass 2 streams them (_keeps_correlations)
         self.fuse_prob_head = True        # CostRegNet3D + bf16x3: `prob` applied in the last deconvolution's epilogue
         self.last_collective_bytes = 0
         self._buffers_cache = {}
@@ -123,6 +125,17 @@ class StageNet(nn.Module):
         """Contraction of the visibility CNN's two MFMA layers (its activations stay on chip): the stage's conv_precision - "f16x2" runs
         the fp16 two-term form with fp16 rings."""
         return self.conv_precision           # every fp16 format shares the fp16 rings; "f16" / "f16mix" drop the CNN's second weight term too
+
+    def _keeps_correlations(self, feats, G, hyp) -> bool:
+        """Pass 2 as a stream over fp16 correlations kept by pass 1 (ops.warp_corr_entropy_keep / corr_aggregate) instead of a second
+        gather: `keep_correlations` True / "auto" (default) where the library builds it (LDS-staged shapes, D > 4) and the kept tensor
+        fits KEEP_CORRELATIONS_MAX_BYTES; False = always gather twice."""
+        if not self.keep_correlations:
+            return False
+        B, V, _, H, W = feats.shape
+        if (V - 1) * B * hyp.shape[1] * H * W * 16 > KEEP_CORRELATIONS_MAX_BYTES:
+            return False
+        return ops.gather_keeps_correlations(feats, G, hyp)
 
     def _f16_activations(self) -> bool:
         """conv_precision "f16x2": the U-Net's tensors - cost volume included - are fp16 in HBM (MVS_PREC_F16X2); the transformer
@@ -167,16 +180,23 @@ class StageNet(nn.Module):
             volume = self._sharded_volume(feats, code, hom, hyp, G, vis_params)
             split = self._split_activations()
         else:
-            # pass 1 (entropy per view) -> visibility CNN -> pass 2 gathers again and writes the cost volume once: the per-view
-            # correlation volumes are never kept (round 1 kept them for D >= 8: 2 x 32 B per voxel and view of HBM traffic)
-            entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
-            vis = ops.vis_weight(entropy, vis_params, prec)
             split = self._split_activations()
             f16 = self._f16_activations()
-            if f16 and not ops.gather_is_lds_staged(feats, G, hyp):   # shapes the LDS-staged gather does not cover: fp32 volume, converted
-                volume = ops.volume_to_f16(ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)[0])
+            if f16 and self._keeps_correlations(feats, G, hyp):
+                # fp16 volume formats, D >= 8: pass 1 keeps the per-view group correlations as fp16 (16 B per voxel and view) and pass 2
+                # streams them - cheaper than the second gather, which is bound by window staging and LDS reads
+                entropy, corr = ops.warp_corr_entropy_keep(feats, code, hom, hyp, G)
+                vis = ops.vis_weight(entropy, vis_params, prec)
+                volume = ops.corr_aggregate(corr, vis)
+                del corr
             else:
-                volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, split=split, f16=f16)
+                # pass 1 -> visibility CNN -> pass 2 gathers again and writes the cost volume once (no per-view intermediate in HBM)
+                entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
+                vis = ops.vis_weight(entropy, vis_params, prec)
+                if f16 and not ops.gather_is_lds_staged(feats, G, hyp):   # shapes the LDS-staged gather does not cover: fp32 volume, converted
+                    volume = ops.volume_to_f16(ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)[0])
+                else:
+                    volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, split=split, f16=f16)
         out = self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split)
         if self._f16_activations():
             self._count_f16_call(feats.device)

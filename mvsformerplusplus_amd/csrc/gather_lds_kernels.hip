@@ -15,9 +15,11 @@
 //   4. gathers the four taps with ds_read_b128 (two quads per tap: 8 channels in two reads, 256 B/clk/CU) and
 //      reduces the channel groups in registers.
 // A unit whose window exceeds the LDS capacity (steep surface parts seen from a far view) falls back, block-uniformly,
-// to pair loads from global memory for that unit only.  Pass 2 gathers again instead of streaming correlation volumes
-// kept by pass 1: the kept volumes cost 2 x 32 B per voxel and view of HBM traffic (1.85 GB per reference view at
-// cfg2), the second gather re-reads the features from L2 / Infinity Cache.
+// to pair loads from global memory for that unit only.  Pass 2 has two forms: gather again (gl_aggregate_kernel: the
+// features come back from L2 / Infinity Cache, no intermediate in HBM), or - fp16 volume formats, stages with D >= 8 -
+// stream the per-view group correlations pass 1 KEPT as fp16 (gl_entropy_kernel<KEEP>: 2 x 16 B per voxel and view;
+// corr_aggregate_kernel).  The second gather is bound by its window staging and LDS reads, not by HBM, so trading it
+// for 0.4 GB of streamed traffic per reference view (cfg2, stages 1-3) is a net gain.
 //
 // Algorithmic HBM bytes per launch: pass 1 = features (1 + n_views) * C*HW*sizeof(T) +
 // hypotheses D*HW*4 + entropy n_views*HW*4; pass 2 = the same inputs + visibility + G*D*HW*4 volume write.
@@ -226,9 +228,12 @@ struct GlTile {
 // pass 1: entropy of the depth-softmax of the group-summed correlation          cost_volume.py:79-92
 // grid = (tiles, ceil(views in launch / vpb), B); a block walks `vpb` consecutive source views of its tile
 // ------------------------------------------------------------------------------------------------
-template <int DT, int NOCT, int NS, bool TILED>
+// KEEP: the per-view GROUP correlations (mean over the group's channels, cost_volume.py:79-84) are also written, as fp16
+// [B, V-1, D, HW, 8] clamped to the fp16 range, for corr_aggregate_kernel; the group sum the entropy needs is taken from them.
+template <int DT, int NOCT, int NS, bool TILED, bool KEEP>
 __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
-                                                         const float* __restrict__ hyp, float* __restrict__ entropy, int V, int D, int H,
+                                                         const float* __restrict__ hyp, float* __restrict__ entropy,
+                                                         _Float16* __restrict__ corr, int V, int D, int H,
                                                          int W, int view_begin, int view_end, int vpb, int ntx, int nblk) {
     typedef typename FeatT<DT>::type T;
     HIP_DYNAMIC_SHARED(float, smem)
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
     }
     const int v0 = view_begin + (int)blockIdx.y * vpb, v1 = v0 + vpb < view_end ? v0 + vpb : view_end;
     int unit = 0;
+    float sat_amax = 0.0f;                                      // fp16 saturation counter (mvs_common.h), KEEP only
     for (int v = v0; v < v1; ++v) {
         const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
         const T* src = feat + (size_t)v * C * HW;
@@ -266,7 +272,30 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
             for (int dd = 0; dd < GL_DCH; ++dd) depth[dd] = hp[(unsigned)(d0 + dd < D ? d0 + dd : D - 1) * HW + t.pc];
 #pragma unroll
             for (int dd = 0; dd < GL_DCH; ++dd) s[dd] = 0.0f;
-            gl_unit<T, NOCT, false, TILED>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, s);   // sum_g mean_c = (1/cpg) sum_c
+            if (KEEP) {
+                float acc[8 * GL_DCH];
+#pragma unroll
+                for (int i = 0; i < 8 * GL_DCH; ++i) acc[i] = 0.0f;
+                gl_unit<T, NOCT, true, TILED>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, acc);
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                h8* cv = reinterpret_cast<h8*>(corr) + (size_t)(b * (V - 1) + (v - 1)) * D * HW + t.pc;
+#pragma unroll
+                for (int dd = 0; dd < GL_DCH; ++dd) {
+                    float r[8];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) { r[g] = acc[g * GL_DCH + dd]; s[dd] += r[g]; }
+                    if (active && d0 + dd < D) {
+                        h8 hv;
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f);
+                        sat::track(sat_amax, r[0], r[1], r[2], r[3]);
+                        sat::track(sat_amax, r[4], r[5], r[6], r[7]);
+                        cv[(size_t)(unsigned)(d0 + dd) * HW] = hv;
+                    }
+                }
+            } else {
+                gl_unit<T, NOCT, false, TILED>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, s);   // sum_g mean_c = (1/cpg) sum_c
+            }
             if (NS > 1 || niter > 1) {
                 if (chunk < nch) {
 #pragma unroll
@@ -299,6 +328,57 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
             if (t.slot == 0 && t.valid) gl_softmax_entropy_store(sim + t.pi, TP, D, dst);
         }
     }
+    if (KEEP) sat::commit(sat_amax);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2, streaming form: volume = sum_v vis_v * corr_v / (sum_v vis_v + 1e-6)     cost_volume.py:97-101
+// corr [B, V-1, D, HW, 8] fp16 (gl_entropy_kernel<KEEP>), vis [B, V-1, HW] -> vol [B, D, HW, 8] fp16.
+// grid = (ceil(HW / 256), ceil(D / 4), B); a thread owns one pixel and four planes (a view's visibility weight is loaded
+// once for the four), 16-byte loads and stores.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_aggregate_kernel(const _Float16* __restrict__ corr, const float* __restrict__ vis,
+                                                             _Float16* __restrict__ vol, int NV, int D, unsigned HW) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= HW) return;
+    const int b = (int)blockIdx.z, d0 = (int)blockIdx.y * 4;
+    const float* vp = vis + (size_t)b * NV * HW + p;
+    const h8* cp = reinterpret_cast<const h8*>(corr) + (size_t)b * NV * D * HW + p;
+    float acc[4][8];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc[dd][g] = 0.0f;
+    float vsum = 0.0f;
+#pragma unroll 2
+    for (int v = 0; v < NV; ++v) {
+        const float w = vp[(size_t)v * HW];
+        vsum += w;                                                                                   // cost_volume.py:98
+        const h8* cv = cp + (size_t)v * D * HW;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = d0 + dd < D ? d0 + dd : D - 1;
+            const h8 c = cv[(size_t)(unsigned)d * HW];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) acc[dd][g] += w * (float)c[g];                                // cost_volume.py:97
+        }
+    }
+    const float rdenom = 1.0f / (vsum + 1e-6f);                                                      // cost_volume.py:101
+    float sat_amax = 0.0f;
+    h8* op = reinterpret_cast<h8*>(vol) + (size_t)b * D * HW + p;
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        if (d0 + dd >= D) continue;
+        h8 hv;
+        float r[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { r[g] = acc[dd][g] * rdenom; hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f); }
+        sat::track(sat_amax, r[0], r[1], r[2], r[3]);
+        sat::track(sat_amax, r[4], r[5], r[6], r[7]);
+        op[(size_t)(unsigned)(d0 + dd) * HW] = hv;
+    }
+    sat::commit(sat_amax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,9 +486,9 @@ bool gl_supported(int C, int G, int D, int H, int W) {
     return (size_t)D * (256 / gl_slots(D)) * sizeof(float) <= 64 * 1024;
 }
 
-template <int DT, int NOCT, int NS, bool TILED>
+template <int DT, int NOCT, int NS, bool TILED, bool KEEP = false>
 static int gl_launch_entropy_t(const void* feat, const float* hom, const float* hyp, float* ent, int B, int V, int D, int H, int W, int vb,
-                               int ve, hipStream_t st) {
+                               int ve, hipStream_t st, _Float16* corr = nullptr) {
     constexpr int TP = 256 / NS, TW = TP / GL_TH;
     const int ntx = (int)ceil_div(W, TW), nty = (int)ceil_div(H, GL_TH);
     const int nblk = ntx * nty;
@@ -417,9 +497,9 @@ static int gl_launch_entropy_t(const void* feat, const float* hom, const float* 
     const int vpb = (long long)nblk * B >= 4096 ? ve - vb : 1;
     const size_t lds = GL_WIN_BYTES + GL_RED_BYTES + (size_t)D * TP * sizeof(float);
     if (lds > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_entropy_kernel<DT, NOCT, NS, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gl_entropy_kernel<DT, NOCT, NS, TILED>), dim3(nblk, ceil_div(ve - vb, vpb), B), dim3(256), lds, st, feat, hom, hyp, ent, V, D, H,
-                       W, vb, ve, vpb, ntx, nblk);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_entropy_kernel<DT, NOCT, NS, TILED, KEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gl_entropy_kernel<DT, NOCT, NS, TILED, KEEP>), dim3(nblk, ceil_div(ve - vb, vpb), B), dim3(256), lds, st, feat, hom, hyp, ent,
+                       corr, V, D, H, W, vb, ve, vpb, ntx, nblk);
     return check_launch("gl_entropy_kernel");
 }
 
@@ -466,6 +546,32 @@ static int gl_launch_aggregate_t(const void* feat, const float* hom, const float
 int gl_launch_entropy(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H, int W,
                       int vb, int ve, hipStream_t st) {
     GL_DISPATCH(gl_launch_entropy_t, feat, hom, hyp, ent, B, V, D, H, W, vb, ve, st);
+}
+
+// KEEP form: the launcher with NS = 1 (D <= 4) is not instantiated - the streaming pass 2 never pays there (gl_keep_supported)
+template <int DT, int NOCT, int NS, bool TILED>
+static int gl_launch_entropy_keep_t(const void* feat, const float* hom, const float* hyp, float* ent, _Float16* corr, int B, int V, int D, int H, int W,
+                                    hipStream_t st) {
+    if constexpr (NS == 1) {
+        set_error("mvs_warp_corr_entropy_keep_fwd: D <= 4 is not built (the second gather is the faster pass 2 there)");
+        return MVS_ERR_UNSUPPORTED;
+    } else {
+        return gl_launch_entropy_t<DT, NOCT, NS, TILED, true>(feat, hom, hyp, ent, B, V, D, H, W, 1, V, st, corr);
+    }
+}
+
+bool gl_keep_supported(int C, int G, int D, int H, int W) { return gl_supported(C, G, D, H, W) && D > GL_DCH; }
+
+int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C, int D,
+                           int H, int W, hipStream_t st) {
+    GL_DISPATCH(gl_launch_entropy_keep_t, feat, hom, hyp, ent, static_cast<_Float16*>(corr), B, V, D, H, W, st);
+}
+
+int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int B, int V, int D, int H, int W, hipStream_t st) {
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    hipLaunchKernelGGL(corr_aggregate_kernel, dim3(ceil_div(HW, 256), ceil_div(D, 4), B), dim3(256), 0, st, static_cast<const _Float16*>(corr), vis,
+                       static_cast<_Float16*>(vol), V - 1, D, HW);
+    return check_launch("corr_aggregate_kernel");
 }
 
 int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol, float* vis_sum,

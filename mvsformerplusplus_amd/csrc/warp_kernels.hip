@@ -576,6 +576,10 @@ int gl_launch_entropy(const void* feat, int dtype, int layout, const float* hom,
                       int W, int vb, int ve, hipStream_t st);
 int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol,
                         float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
+bool gl_keep_supported(int C, int G, int D, int H, int W);
+int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C, int D,
+                           int H, int W, hipStream_t st);
+int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int B, int V, int D, int H, int W, hipStream_t st);
 int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W, hipStream_t st);
 
 // MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels (A/B measurements); anything else = LDS-staged where supported.
@@ -655,6 +659,32 @@ extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int la
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
         default: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
     }
+}
+
+extern "C" int mvs_gather_keeps_correlations(int layout, int C, int G, int D, int H, int W) {
+    if (layout != MVS_LAYOUT_OCTET_TILED && gather_impl(C, G, D, H, W) != 1) return 0;
+    return gl_keep_supported(C, G, D, H, W) ? 1 : 0;
+}
+
+extern "C" int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, float* entropy,
+                                              void* corr_f16, int B, int V, int C, int G, int D, int H, int W, void* stream) {
+    int rc = check_corr_args("mvs_warp_corr_entropy_keep_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, 1, V);
+    if (rc != MVS_OK) return rc;
+    if (!entropy || !corr_f16) { set_error("mvs_warp_corr_entropy_keep_fwd: null output"); return MVS_ERR_ARG; }
+    rc = check_layout("mvs_warp_corr_entropy_keep_fwd", layout, C, G, D, H, W);
+    if (rc != MVS_OK) return rc;
+    if (!gl_keep_supported(C, G, D, H, W)) {
+        set_error("mvs_warp_corr_entropy_keep_fwd: built for the LDS-staged gather with D > 4 (G == 8, C in {8,16,32,64}, W %% 8 == 0); "
+                  "mvs_gather_keeps_correlations() says which shapes qualify");
+        return MVS_ERR_UNSUPPORTED;
+    }
+    return gl_launch_entropy_keep(features, dtype, layout, homography, hyp, entropy, corr_f16, B, V, C, D, H, W, (hipStream_t)stream);
+}
+
+extern "C" int mvs_corr_aggregate_fwd(const void* corr_f16, const float* vis, void* volume_f16, int B, int V, int D, int H, int W, void* stream) {
+    if (!corr_f16 || !vis || !volume_f16) { set_error("mvs_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
+    if (B < 1 || V < 2 || D < 1 || H < 1 || W < 1 || (long long)D * H * W > 0x7fffffffLL) { set_error("mvs_corr_aggregate_fwd: bad shape"); return MVS_ERR_ARG; }
+    return launch_corr_aggregate(corr_f16, vis, volume_f16, B, V, D, H, W, (hipStream_t)stream);
 }
 
 extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, const float* vis,

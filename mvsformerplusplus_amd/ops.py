@@ -211,6 +211,37 @@ def gather_is_lds_staged(features, G: int, hyp: torch.Tensor) -> bool:
     return bool(lib().mvs_gather_is_lds_staged(layout, Cc, G, hyp.shape[1], H, W))
 
 
+def gather_keeps_correlations(features, G: int, hyp: torch.Tensor) -> bool:
+    """Is the correlation-keeping pass 1 (warp_corr_entropy_keep + corr_aggregate) built for this call's shapes?"""
+    B, V, Cc, H, W = features.shape
+    _, layout = _feat_ptr(features)
+    return bool(lib().mvs_gather_keeps_correlations(layout, Cc, G, hyp.shape[1], H, W))
+
+
+def warp_corr_entropy_keep(features, code: int, homography: torch.Tensor, hyp: torch.Tensor, G: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pass 1 over all source views that also KEEPS the per-view group correlations (cost_volume.py:79-84) as fp16:
+    -> (entropy [B,V-1,H,W] fp32, corr [B,V-1,D,H,W,8] fp16)."""
+    B, V, Cc, H, W = features.shape
+    D = hyp.shape[1]
+    ft, layout = _feat_ptr(features)
+    ent = torch.empty(B, V - 1, H, W, dtype=torch.float32, device=ft.device)
+    corr = torch.empty(B, V - 1, D, H, W, 8, dtype=torch.float16, device=ft.device)
+    check(lib().mvs_warp_corr_entropy_keep_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(ent), ptr(corr), B, V, Cc, G, D, H, W,
+                                               stream_of(ft)), "mvs_warp_corr_entropy_keep_fwd")
+    return ent, corr
+
+
+def corr_aggregate(corr: torch.Tensor, vis: torch.Tensor) -> torch.Tensor:
+    """corr [B,V-1,D,H,W,8] fp16, vis [B,V-1,H,W] fp32 -> the normalised fp16 cost volume [B,D,H,W,8] (cost_volume.py:97-101)."""
+    assert corr.dtype == torch.float16 and corr.is_contiguous() and corr.dim() == 6 and corr.shape[-1] == 8
+    B, NV, D, H, W, _ = corr.shape
+    v = _f32c(vis)
+    assert v.shape == (B, NV, H, W)
+    vol = torch.empty(B, D, H, W, 8, dtype=torch.float16, device=corr.device)
+    check(lib().mvs_corr_aggregate_fwd(ptr(corr), ptr(v), ptr(vol), B, NV + 1, D, H, W, stream_of(corr)), "mvs_corr_aggregate_fwd")
+    return vol
+
+
 def f16_saturation_count(reset: bool = False, device=None) -> int:
     """Work-items that stored an fp16 ACTIVATION beyond +-65504 (clamped) on `device` (default: the current one) since the last reset -
     0 unless the "f16x2" format degraded something the fp32-equivalent "bf16x3" would have kept.  Synchronises the device."""

@@ -76,12 +76,14 @@ class Launch:
         self.ms = 0.0
 
 
-def gather_kernel_name(which: str, code: int, C: int, D: int, W: int, tiled: bool = False) -> str:
+def gather_kernel_name(which: str, code: int, C: int, D: int, W: int, tiled: bool = False, keep=None) -> str:
     """Symbol rocprofv3 reports for the gather pass of a stage (template args: feature dtype, C / 8, work-items per pixel,
-    octet-tiled layout)."""
+    octet-tiled layout; the entropy pass also: does it keep the per-view correlations)."""
     if C in (8, 16, 32, 64) and W % 8 == 0:
         nch = (D + 3) // 4
         ns = 8 if nch >= 8 else 4 if nch >= 4 else 2 if nch >= 2 else 1
+        if which == "entropy":
+            return "gl_entropy_kernel<%d, %d, %d, %s, %s>" % (code, C // 8, ns, "true" if tiled else "false", "true" if keep else "false")
         return "gl_%s_kernel<%d, %d, %d, %s>" % (which, code, C // 8, ns, "true" if tiled else "false")
     return "warp_corr_%s_kernel" % which
 
@@ -196,8 +198,16 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
         # every feature map once, the hypotheses once, the entropy maps out
-        ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, isinstance(feats, ops.PackedFeatures)), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
-                     lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
+        tiled = isinstance(feats, ops.PackedFeatures)
+        keep = net._f16_activations() and net._keeps_correlations(feats, 8, hyp)       # exactly StageNet.forward's choice
+        corr_bytes = B * (V - 1) * D * HW * 16.0                                        # fp16 per-view group correlations (as-built traffic)
+        if keep:
+            ent, corr = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, True), s, corr_flops,
+                               B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4) + corr_bytes,
+                               lambda: ops.warp_corr_entropy_keep(feats, code, hom, hyp, 8))
+        else:
+            ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, False), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
+                         lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
         vp = net._vis_params(feats.device)
         prec = _lib.PRECISIONS[net._vis_precision()]
         N = B * (V - 1)
@@ -217,8 +227,12 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
         split = net._split_activations()
         f16 = net._f16_activations()
-        agg_name = gather_kernel_name("aggregate", code, C, D, W, isinstance(feats, ops.PackedFeatures))
-        if f16 and not ops.gather_is_lds_staged(feats, 8, hyp):
+        agg_name = gather_kernel_name("aggregate", code, C, D, W, tiled)
+        if keep:
+            vol = _timed(launches, "corr_aggregate_kernel", s, 2.0 * B * (V - 1) * D * HW * 8, corr_bytes + B * ((V - 1) * HW * 4 + 8 * D * HW * 2),
+                         lambda: ops.corr_aggregate(corr, vis))
+            del corr
+        elif f16 and not ops.gather_is_lds_staged(feats, 8, hyp):
             # shapes outside the LDS-staged gather: fp32 volume + conversion, exactly as StageNet.forward does
             v32 = _timed(launches, agg_name, s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4 + 8 * D * HW * 4),
                          lambda: ops.warp_corr_aggregate(feats, code, hom, hyp, vis, 8, normalise=True)[0])

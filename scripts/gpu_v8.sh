@@ -1,0 +1,26 @@
+#!/bin/bash
+# GPU visit 8: the correlation-keeping pass 1 + streaming pass 2 (A/B against the two-gather form)
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out; mkdir -p $OUT
+export PYTHONDONTWRITEBYTECODE=1
+echo "== pytest subset =="
+timeout 900 python -m pytest tests -m gpu -x -q -k "gather or stage_golden or cascade_golden or saturation or cascade_vs_oracle" 2>&1 | tail -3
+for mode in keep nokeep; do
+  flag=""; [ $mode = nokeep ] && flag="--no-keep-correlations"
+  echo "== bench $mode =="
+  timeout 600 python bench.py --steps 8 --warmup 3 --profile-table --no-cpu-baseline --no-train-leg $flag > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err
+  grep -v "amdgpu.ids" $OUT/bench_$mode.err | grep -E "gl_|corr_agg|sum of" | head -14
+  python - $OUT/bench_$mode.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print({k: r[k] for k in ('value', 'ms_per_ref_view') if k in r}, 'latency', r['latency']['single_stream_ms_per_ref_view'], 'fam', {k: round(v['ms_per_ref_view'], 3) for k, v in r.get('families', {}).items()})
+PY
+done
+echo "== bench keep, tiled fp16 features =="
+timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-train-leg --feat-layout tiled --feat-dtype fp16 > $OUT/bench_keep_tiled.json 2> $OUT/bench_keep_tiled.err
+python - $OUT/bench_keep_tiled.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print({k: r[k] for k in ('value', 'ms_per_ref_view') if k in r}, 'latency', r['latency']['single_stream_ms_per_ref_view'], 'fam', {k: round(v['ms_per_ref_view'], 3) for k, v in r.get('families', {}).items()})
+PY

@@ -388,6 +388,28 @@ def case_gather_variants(device, quick=False):
         expect = acc / (vsum[:, None, None] + 1e-6)
         scale = max(1.0, float(expect.abs().max()))
         assert (cpu(vol).permute(0, 4, 1, 2, 3) - expect).abs().max() <= 5e-5 * scale, (C, D, "volume")
+        # streaming pass 2 of the fp16 formats: pass 1 keeps the per-view group correlations as fp16, corr_aggregate streams them
+        hd = dev(hyp, device)
+        assert ops.gather_keeps_correlations(f, G, hd) == (D > 4), (C, D, "keep policy")
+        if D > 4:
+            for fk in (f, ops.pack_features(f)):
+                ent_k, corr = ops.warp_corr_entropy_keep(fk, ops._feat(fk)[1], hom, hd, G)
+                assert (cpu(ent_k) - ent).abs().max() <= 2e-5, (C, D, "entropy of the keeping pass")
+                for v in range(1, V):
+                    warped, _ = O.homo_warping_3D_with_mask(ff[:, v], O.compose_proj(cams[:, v]), ref_p, hyp)
+                    ip = O.group_correlation(ff[:, 0], warped, G)
+                    got = cpu(corr[:, v - 1]).float().permute(0, 4, 1, 2, 3)
+                    assert (got - ip).abs().max() <= 6e-4 * max(1.0, float(ip.abs().max())), (C, D, v, "kept correlations")   # one fp16 rounding
+                vol_k = cpu(ops.corr_aggregate(corr, dev(vis, device))).float().permute(0, 4, 1, 2, 3)
+                assert (vol_k - expect).abs().max() <= 1.2e-3 * scale, (C, D, "streamed volume")                             # two fp16 roundings
+                vol16 = cpu(ops.warp_corr_aggregate(fk, ops._feat(fk)[1], hom, hd, dev(vis, device), G, f16=True)[0]).float().permute(0, 4, 1, 2, 3)
+                assert (vol_k - vol16).abs().max() <= 1.2e-3 * scale, (C, D, "streamed vs gathered fp16 volume")
+        else:
+            try:
+                ops.warp_corr_entropy_keep(f, code, hom, hd, G)
+                raise AssertionError("D <= 4 must be refused by the keeping pass")
+            except RuntimeError as e:
+                assert "not built" in str(e) or "D > 4" in str(e), str(e)
         # hand-off layout: the same features octet-tiled give the same numbers, in fp32 and - packed
         # down to bf16 - the numbers of bf16 planar features
         for pdt in (None, torch.bfloat16):
