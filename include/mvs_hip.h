@@ -68,6 +68,11 @@ enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2, MVS_PREC_BF16
  * format of MVS_PREC_BF16X3_SPLIT, or fp16 [B,D,H,W,8] for MVS_PREC_F16X2 (aggregate only; normalised volumes of 8 groups only;
  * partial sums are always fp32) */
 enum { MVS_VOLUME_F32 = 0, MVS_VOLUME_SPLIT = 1, MVS_VOLUME_F16 = 2 };
+/* how the LDS-staged gather holds the SOURCE-view window: fp32 (exact; the fp32-equivalent formats), or one fp16 octet per position -
+ * half the LDS reads; the source features are rounded to fp16 once (exact for fp16 / in-range bf16 features), everything else stays fp32.
+ * MVS_VOLUME_F16 (aggregate) and mvs_warp_corr_entropy_keep_fwd imply MVS_GATHER_F16; kernels outside the LDS-staged form ignore it.
+ * The reference rounds the features to a 16-bit type under its autocast (test.py:250, cost_volume.py:67).                              */
+enum { MVS_GATHER_F32 = 0, MVS_GATHER_F16 = 1 };
 /* epilogues of mvs_tr_linear_fwd */
 enum { MVS_TR_EPI_BIAS = 0, MVS_TR_EPI_GELU = 1, MVS_TR_EPI_RES_LN = 2 };
 
@@ -100,10 +105,11 @@ int mvs_homo_warp_fwd(const void* src_fea, int dtype, const float* homography /*
 /* ---- a2-a5 fused: warp + group-wise correlation + softmax-entropy, cost_volume.py:65-92 --------
  * features [B,V,C,H,W] (dtype; view 0 = reference), hyp [B,D,H,W]
  * -> entropy [B,V-1,H,W].  No [C,D,H,W] or [G,D,H,W] intermediate is materialised.
- * Only source views in [view_begin, view_end) (1-based view indices) are processed.              */
+ * Only source views in [view_begin, view_end) (1-based view indices) are processed.
+ * gather_format: MVS_GATHER_F32 / MVS_GATHER_F16 (above).                                        */
 int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int layout, const float* homography /*[B,V-1,12]*/,
                               const float* hyp, float* entropy, int B, int V, int C, int G, int D, int H, int W,
-                              int view_begin, int view_end, void* stream);
+                              int view_begin, int view_end, int gather_format, void* stream);
 
 /* ---- pass 1 that KEEPS the per-view group correlations + the streaming pass 2 (fp16 volume formats) -----------------------
  * cost_volume.py:74-101 with the [B,G,D,H,W] per-view correlation the reference materialises kept as fp16 [B,V-1,D,H,W,8]

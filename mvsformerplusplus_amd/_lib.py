@@ -39,7 +39,7 @@ SIGNATURES = {
     "mvs_compose_homography": (_i, [_vp, _i, _i, _vp, _vp]),
     "mvs_homography_from_proj": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mvs_homo_warp_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mvs_pack_features": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_vis_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _i, _vp]),

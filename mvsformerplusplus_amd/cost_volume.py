@@ -191,7 +191,7 @@ class StageNet(nn.Module):
                 del corr
             else:
                 # pass 1 -> visibility CNN -> pass 2 gathers again and writes the cost volume once (no per-view intermediate in HBM)
-                entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G)
+                entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, f16_window=f16)
                 vis = ops.vis_weight(entropy, vis_params, prec)
                 if f16 and not ops.gather_is_lds_staged(feats, G, hyp):   # shapes the LDS-staged gather does not cover: fp32 volume, converted
                     volume = ops.volume_to_f16(ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)[0])

@@ -27,12 +27,16 @@ int check_launch(const char* what) {
 // one reader per translation unit that stores fp16 activations (the counter is a per-unit device global, mvs_common.h)
 unsigned int sat_read_conv(int reset);
 unsigned int sat_read_gather(int reset);
+unsigned int sat_read_gather_keep(int reset);
+unsigned int sat_read_gather_agg(int reset);
+unsigned int sat_read_gather_agg16(int reset);
 unsigned int sat_read_warp(int reset);
 
 }  // namespace mvs
 
 extern "C" unsigned long long mvs_f16_saturation_count(int reset) {
-    return (unsigned long long)mvs::sat_read_conv(reset) + mvs::sat_read_gather(reset) + mvs::sat_read_warp(reset);
+    return (unsigned long long)mvs::sat_read_conv(reset) + mvs::sat_read_gather(reset) + mvs::sat_read_gather_keep(reset) +
+           mvs::sat_read_gather_agg(reset) + mvs::sat_read_gather_agg16(reset) + mvs::sat_read_warp(reset);
 }
 
 extern "C" int mvs_abi_version(void) { return MVS_ABI_VERSION; }

@@ -1,0 +1,83 @@
+// LDS-staged gather, translation unit 3 of 5 (gather_lds.h): the entropy pass that keeps the per-view group correlations as fp16, and
+// the streaming pass 2 over them.
+#include "gather_lds.h"
+
+namespace mvs {
+
+// ------------------------------------------------------------------------------------------------
+// pass 2, streaming form: volume = sum_v vis_v * corr_v / (sum_v vis_v + 1e-6)     cost_volume.py:97-101
+// corr [B, V-1, D, HW, 8] fp16 (gl_entropy_kernel<KEEP>), vis [B, V-1, HW] -> vol [B, D, HW, 8] fp16.
+// grid = (ceil(HW / 256), ceil(D / 4), B); a thread owns one pixel and four planes (a view's visibility weight is loaded
+// once for the four), 16-byte loads and stores.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_aggregate_kernel(const _Float16* __restrict__ corr, const float* __restrict__ vis,
+                                                             _Float16* __restrict__ vol, int NV, int D, unsigned HW) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= HW) return;
+    const int b = (int)blockIdx.z, d0 = (int)blockIdx.y * 4;
+    const float* vp = vis + (size_t)b * NV * HW + p;
+    const h8* cp = reinterpret_cast<const h8*>(corr) + (size_t)b * NV * D * HW + p;
+    float acc[4][8];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc[dd][g] = 0.0f;
+    float vsum = 0.0f;
+#pragma unroll 2
+    for (int v = 0; v < NV; ++v) {
+        const float w = vp[(size_t)v * HW];
+        vsum += w;                                                                                   // cost_volume.py:98
+        const h8* cv = cp + (size_t)v * D * HW;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = d0 + dd < D ? d0 + dd : D - 1;
+            const h8 c = cv[(size_t)(unsigned)d * HW];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) acc[dd][g] += w * (float)c[g];                                // cost_volume.py:97
+        }
+    }
+    const float rdenom = 1.0f / (vsum + 1e-6f);                                                      // cost_volume.py:101
+    float sat_amax = 0.0f;
+    h8* op = reinterpret_cast<h8*>(vol) + (size_t)b * D * HW + p;
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        if (d0 + dd >= D) continue;
+        h8 hv;
+        float r[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { r[g] = acc[dd][g] * rdenom; hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f); }
+        sat::track(sat_amax, r[0], r[1], r[2], r[3]);
+        sat::track(sat_amax, r[4], r[5], r[6], r[7]);
+        op[(size_t)(unsigned)(d0 + dd) * HW] = hv;
+    }
+    sat::commit(sat_amax);
+}
+
+// KEEP form: the launcher with NS = 1 (D <= 4) is not instantiated - the streaming pass 2 never pays there (gl_keep_supported)
+template <int DT, int NOCT, int NS, bool TILED>
+static int gl_launch_entropy_keep_t(const void* feat, const float* hom, const float* hyp, float* ent, _Float16* corr, int B, int V, int D, int H, int W,
+                                    hipStream_t st) {
+    if constexpr (NS == 1) {
+        set_error("mvs_warp_corr_entropy_keep_fwd: D <= 4 is not built (the second gather is the faster pass 2 there)");
+        return MVS_ERR_UNSUPPORTED;
+    } else {
+        return gl_launch_entropy_t<DT, NOCT, NS, TILED, true, true>(feat, hom, hyp, ent, B, V, D, H, W, 1, V, st, corr);
+    }
+}
+
+int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C, int D,
+                           int H, int W, hipStream_t st) {
+    GL_DISPATCH(gl_launch_entropy_keep_t, feat, hom, hyp, ent, static_cast<_Float16*>(corr), B, V, D, H, W, st);
+}
+
+int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int B, int V, int D, int H, int W, hipStream_t st) {
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    hipLaunchKernelGGL(corr_aggregate_kernel, dim3(ceil_div(HW, 256), ceil_div(D, 4), B), dim3(256), 0, st, static_cast<const _Float16*>(corr), vis,
+                       static_cast<_Float16*>(vol), V - 1, D, HW);
+    return check_launch("corr_aggregate_kernel");
+}
+
+}  // namespace mvs
+
+namespace mvs { MVS_DEFINE_SAT_READER(sat_read_gather_keep) }

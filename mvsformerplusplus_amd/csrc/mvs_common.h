@@ -23,6 +23,25 @@
 #define MVS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
+// v_fma_mix_f32: fp32 fma whose first operand is the low / high fp16 half of a 32-bit register (converted on the fly - no v_cvt, and
+// the compiler cannot turn it into v_cvt + v_pk_fma_f32, which costs 1.5x the instructions).  The host emulator defines C forms first.
+#ifndef MVS_FMA_MIX_LO
+namespace mvs {
+__device__ __forceinline__ float fma_mix_lo(unsigned h2, float w, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned h2, float w, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(acc));
+    return r;
+}
+}  // namespace mvs
+#define MVS_FMA_MIX_LO(h2, w, acc) mvs::fma_mix_lo(h2, w, acc)
+#define MVS_FMA_MIX_HI(h2, w, acc) mvs::fma_mix_hi(h2, w, acc)
+#endif
+
 namespace mvs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

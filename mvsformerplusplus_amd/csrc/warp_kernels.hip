@@ -573,7 +573,7 @@ static int check_corr_args(const char* who, const void* feat, const float* hom, 
 // LDS-staged form of the two gather passes (gather_lds_kernels.hip)
 bool gl_supported(int C, int G, int D, int H, int W);
 int gl_launch_entropy(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H,
-                      int W, int vb, int ve, hipStream_t st);
+                      int W, int vb, int ve, int w16, hipStream_t st);
 int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol,
                         float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
 bool gl_keep_supported(int C, int G, int D, int H, int W);
@@ -644,16 +644,18 @@ static int check_layout(const char* who, int layout, int C, int G, int D, int H,
 }
 
 extern "C" int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, float* entropy,
-                                         int B, int V, int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream) {
+                                         int B, int V, int C, int G, int D, int H, int W, int view_begin, int view_end, int gather_format,
+                                         void* stream) {
     int rc = check_corr_args("mvs_warp_corr_entropy_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, view_begin, view_end);
     if (rc != MVS_OK) return rc;
     if (!entropy) { set_error("mvs_warp_corr_entropy_fwd: null output"); return MVS_ERR_ARG; }
+    if (gather_format != MVS_GATHER_F32 && gather_format != MVS_GATHER_F16) { set_error("mvs_warp_corr_entropy_fwd: unknown gather format %d", gather_format); return MVS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     rc = check_layout("mvs_warp_corr_entropy_fwd", layout, C, G, D, H, W);
     if (rc != MVS_OK) return rc;
     const int impl = gather_impl(C, G, D, H, W);
     if (layout == MVS_LAYOUT_OCTET_TILED || impl == 1)
-        return gl_launch_entropy(features, dtype, layout, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, st);
+        return gl_launch_entropy(features, dtype, layout, homography, hyp, entropy, B, V, C, D, H, W, view_begin, view_end, gather_format == MVS_GATHER_F16, st);
     switch (dtype) {
         case MVS_DTYPE_F32: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_F32, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);
         case MVS_DTYPE_BF16: MVS_DISPATCH_CG(launch_entropy, MVS_DTYPE_BF16, features, homography, hyp, entropy, B, V, C, G, D, H, W, view_begin, view_end, st);

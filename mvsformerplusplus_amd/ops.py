@@ -116,9 +116,10 @@ def homo_warp(src_fea: torch.Tensor, homography: torch.Tensor, depth_values: tor
 
 # ---- a2-a6 --------------------------------------------------------------------------------------
 def warp_corr_entropy(features: torch.Tensor, code: int, homography: torch.Tensor, hyp: torch.Tensor, G: int,
-                      view_begin: int = 1, view_end: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      view_begin: int = 1, view_end: Optional[int] = None, out: Optional[torch.Tensor] = None, f16_window: bool = False) -> torch.Tensor:
     """features [B,V,C,H,W] contiguous; -> entropy [B,V-1,H,W] (only views in [view_begin, view_end) are written; pass a
-    preallocated `out` to skip the zero fill when every view is written)."""
+    preallocated `out` to skip the zero fill when every view is written).  f16_window: MVS_GATHER_F16 (the fp16 formats' gather:
+    source window staged as fp16)."""
     B, V, Cc, H, W = features.shape
     D = hyp.shape[1]
     view_end = V if view_end is None else view_end
@@ -130,7 +131,7 @@ def warp_corr_entropy(features: torch.Tensor, code: int, homography: torch.Tenso
         ent = torch.zeros(B, V - 1, H, W, dtype=torch.float32, device=features.device)
     ft, layout = _feat_ptr(features)
     check(lib().mvs_warp_corr_entropy_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(ent), B, V, Cc, G, D, H, W,
-                                          view_begin, view_end, stream_of(ft)), "mvs_warp_corr_entropy_fwd")
+                                          view_begin, view_end, 1 if f16_window else 0, stream_of(ft)), "mvs_warp_corr_entropy_fwd")
     return ent
 
 

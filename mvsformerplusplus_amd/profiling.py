@@ -76,15 +76,18 @@ class Launch:
         self.ms = 0.0
 
 
-def gather_kernel_name(which: str, code: int, C: int, D: int, W: int, tiled: bool = False, keep=None) -> str:
+def gather_kernel_name(which: str, code: int, C: int, D: int, W: int, tiled: bool = False, keep=None, w16=False) -> str:
     """Symbol rocprofv3 reports for the gather pass of a stage (template args: feature dtype, C / 8, work-items per pixel,
-    octet-tiled layout; the entropy pass also: does it keep the per-view correlations)."""
+    octet-tiled layout; the entropy pass also: does it keep the per-view correlations; fp16 window)."""
+    import os
+    w16 = bool(w16 or keep) and not os.environ.get("MVS_GATHER_WINDOW", "").startswith("f3")
+    b = lambda v: "true" if v else "false"
     if C in (8, 16, 32, 64) and W % 8 == 0:
         nch = (D + 3) // 4
         ns = 8 if nch >= 8 else 4 if nch >= 4 else 2 if nch >= 2 else 1
         if which == "entropy":
-            return "gl_entropy_kernel<%d, %d, %d, %s, %s>" % (code, C // 8, ns, "true" if tiled else "false", "true" if keep else "false")
-        return "gl_%s_kernel<%d, %d, %d, %s>" % (which, code, C // 8, ns, "true" if tiled else "false")
+            return "gl_entropy_kernel<%d, %d, %d, %s, %s, %s>" % (code, C // 8, ns, b(tiled), b(keep), b(w16 or keep))
+        return "gl_%s_kernel<%d, %d, %d, %s, %s>" % (which, code, C // 8, ns, b(tiled), b(w16))
     return "warp_corr_%s_kernel" % which
 
 
@@ -206,8 +209,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                                B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4) + corr_bytes,
                                lambda: ops.warp_corr_entropy_keep(feats, code, hom, hyp, 8))
         else:
-            ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, False), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
-                         lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8))
+            ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, False, net._f16_activations()), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
+                         lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8, f16_window=net._f16_activations()))
         vp = net._vis_params(feats.device)
         prec = _lib.PRECISIONS[net._vis_precision()]
         N = B * (V - 1)
@@ -227,7 +230,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                          lambda: ops.vis_out(t3.reshape(N, H, W, 8), vp[6], vp[7], ent.shape))
         split = net._split_activations()
         f16 = net._f16_activations()
-        agg_name = gather_kernel_name("aggregate", code, C, D, W, tiled)
+        agg_name = gather_kernel_name("aggregate", code, C, D, W, tiled, w16=f16 and ops.gather_is_lds_staged(feats, 8, hyp))
         if keep:
             vol = _timed(launches, "corr_aggregate_kernel", s, 2.0 * B * (V - 1) * D * HW * 8, corr_bytes + B * ((V - 1) * HW * 4 + 8 * D * HW * 2),
                          lambda: ops.corr_aggregate(corr, vis))

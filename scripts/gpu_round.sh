@@ -10,6 +10,15 @@ echo "== pytest -m gpu =="
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/pytest_gpu.log
 echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
+# PMC first: bench.py's roofline.traffic / whole_path.frac_pmc read profiles/pmc_traffic.json, which must describe THIS build's kernels
+(cd /tmp && export TMPDIR=/tmp
+echo "== PMC: HBM traffic of every kernel (separate passes) =="
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_f.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_w.log 2>&1
+)
+mkdir -p $OUT/profiles_$TAG
+python scripts/pmc_traffic.py $OUT/pmc_$TAG $OUT/profiles_$TAG/pmc_traffic.json $OUT/profiles_$TAG/${TAG}_pmc_fetch_write_raw.json
+cp $OUT/profiles_$TAG/pmc_traffic.json profiles/pmc_traffic.json
 echo "== bench (driver's command) =="
 timeout 900 python bench.py --steps 20 --warmup 5 --profile-table > $OUT/bench.json 2> $OUT/bench.err
 grep -v "amdgpu.ids" $OUT/bench.err | tail -45
@@ -56,12 +65,7 @@ tail -2 $ROOT/$OUT/rocprof.log
 # the same with ONE stream: kernels of different reference views do not overlap, so the average durations are the launches' own
 # (what bench.py's HIP-event table and its `roofline` object measure); with 3 streams co-running kernels stretch each other
 timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --streams 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof1.log 2>&1
-echo "== PMC: HBM traffic of every kernel (separate passes) =="
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_f.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_w.log 2>&1
 cd $ROOT
-mkdir -p $OUT/profiles_$TAG
-python scripts/pmc_traffic.py $OUT/pmc_$TAG $OUT/profiles_$TAG/pmc_traffic.json $OUT/profiles_$TAG/${TAG}_pmc_fetch_write_raw.json
 DB=$(find $OUT/prof_$TAG -name '*.db' | head -1)
 if [ -n "$DB" ]; then
   python scripts/rocpd_stats.py $DB > $OUT/profiles_$TAG/${TAG}_kernel_stats_whole_process.csv

@@ -301,6 +301,14 @@ static inline int hipemu_any(int pred) {
     return 0;
 }
 #define __any(p) hipemu_any((p) ? 1 : 0)
+static inline float hipemu_half_of(unsigned h2, int hi) {
+    const unsigned short b = (unsigned short)(hi ? (h2 >> 16) : (h2 & 0xffffu));
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (float)h;
+}
+#define MVS_FMA_MIX_LO(h2, w, acc) fmaf(hipemu_half_of((h2), 0), (w), (acc))
+#define MVS_FMA_MIX_HI(h2, w, acc) fmaf(hipemu_half_of((h2), 1), (w), (acc))
 #define MVS_OPAQUE_REG "r"      // x86 register class for the kernels' opaque-value asm
 #define MVS_OPAQUE_SREG "r"
 #define MVS_NO_OPAQUE_VEC 1    // 128-bit bf16 vectors have no x86 asm register class; the laundering is a GPU register-allocation hint only

@@ -393,15 +393,22 @@ def case_gather_variants(device, quick=False):
         assert ops.gather_keeps_correlations(f, G, hd) == (D > 4), (C, D, "keep policy")
         if D > 4:
             for fk in (f, ops.pack_features(f)):
+                # the fp16 formats' gather (MVS_GATHER_F16): the SOURCE features are rounded to fp16 once, nothing else changes
                 ent_k, corr = ops.warp_corr_entropy_keep(fk, ops._feat(fk)[1], hom, hd, G)
-                assert (cpu(ent_k) - ent).abs().max() <= 2e-5, (C, D, "entropy of the keeping pass")
+                ent_w = ops.warp_corr_entropy(fk, ops._feat(fk)[1], hom, hd, G, f16_window=True)
+                assert (cpu(ent_k) - cpu(ent_w)).abs().max() <= 2e-5, (C, D, "fp16-window entropy pass == keeping pass")
+                acc16, f16src = 0.0, ff.half().float()
                 for v in range(1, V):
-                    warped, _ = O.homo_warping_3D_with_mask(ff[:, v], O.compose_proj(cams[:, v]), ref_p, hyp)
+                    warped, _ = O.homo_warping_3D_with_mask(f16src[:, v], O.compose_proj(cams[:, v]), ref_p, hyp)
                     ip = O.group_correlation(ff[:, 0], warped, G)
+                    assert (cpu(ent_k)[:, v - 1] - O.entropy_of_similarity(ip)[:, 0]).abs().max() <= 5e-5, (C, D, v, "entropy, fp16 source features")
                     got = cpu(corr[:, v - 1]).float().permute(0, 4, 1, 2, 3)
                     assert (got - ip).abs().max() <= 6e-4 * max(1.0, float(ip.abs().max())), (C, D, v, "kept correlations")   # one fp16 rounding
+                    acc16 = acc16 + ip * vis[:, v - 1][:, None, None]
+                expect16 = acc16 / (vsum[:, None, None] + 1e-6)
+                assert (expect16 - expect).abs().max() <= 1e-3 * scale, (C, D, "effect of the rounded source features")
                 vol_k = cpu(ops.corr_aggregate(corr, dev(vis, device))).float().permute(0, 4, 1, 2, 3)
-                assert (vol_k - expect).abs().max() <= 1.2e-3 * scale, (C, D, "streamed volume")                             # two fp16 roundings
+                assert (vol_k - expect16).abs().max() <= 1.2e-3 * scale, (C, D, "streamed volume")                           # two fp16 roundings
                 vol16 = cpu(ops.warp_corr_aggregate(fk, ops._feat(fk)[1], hom, hd, dev(vis, device), G, f16=True)[0]).float().permute(0, 4, 1, 2, 3)
                 assert (vol_k - vol16).abs().max() <= 1.2e-3 * scale, (C, D, "streamed vs gathered fp16 volume")
         else:
@@ -600,10 +607,15 @@ def case_f16_saturation(device):
     v16 = cpu(ops.warp_corr_aggregate(f, code, hom, dev(hyp, device), vis, 8, f16=True)[0])
     assert float(v32.abs().max()) > 65504.0, "the case must leave the fp16 range"
     assert v16.dtype == torch.float16 and torch.isfinite(v16).all()
-    assert torch.equal(v16, v32.clamp(-65504.0, 65504.0).half())
+    # the fp16 volume's gather stages the SOURCE features as fp16 (MVS_GATHER_F16): same numbers as the fp32 gather of once-rounded sources
+    fr = feats.clone()
+    fr[:, 1:] = fr[:, 1:].half().float()
+    v32r = cpu(ops.warp_corr_aggregate(dev(fr, device), code, hom, dev(hyp, device), vis, 8)[0])
+    want = v32r.clamp(-65504.0, 65504.0).half().float()
+    assert ((v16.float() - want).abs() <= 1e-3 * want.abs() + 1e-3).all() and float(v16.float().abs().max()) == 65504.0      # 1 ulp: fma contraction differs
     n_agg = ops.f16_saturation_count(reset=True)
     assert n_agg > 0, "the aggregate pass's clamped cost-volume writes must be counted"
-    assert torch.equal(cpu(ops.volume_to_f16(dev(v32, device))), v16)
+    assert torch.equal(cpu(ops.volume_to_f16(dev(v32, device))), v32.clamp(-65504.0, 65504.0).half())
     assert ops.f16_saturation_count(reset=True) > 0, "mvs_volume_to_f16's clamped writes must be counted"
 
 
