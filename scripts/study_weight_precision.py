@@ -54,7 +54,8 @@ MODES = {"f16x2 (today: activations fp16, weights exact)": lambda ci, co: False,
          "weights fp16 on the 32/64-channel layers": lambda ci, co: min(ci, co) >= 32 or max(ci, co) >= 64,
          "weights fp16 on every layer but the 1-channel head": lambda ci, co: co > 1,
          "weights fp16 everywhere": lambda ci, co: True,
-         "f16mix + visibility CNN one term": "vis"}
+         "f16mix + visibility CNN one term": "vis",
+         "round-4 default: + fp16 source windows, fp16 kept correlations": "vis+gather"}
 for peaky in (False, True):
     sds = state_dicts(peaky)
     for seed in (2, 5):
@@ -63,15 +64,24 @@ for peaky in (False, True):
         with torch.no_grad():
             ref = run()
             for name, wsel in MODES.items():
-                vis = wsel == "vis"
+                gather = wsel == "vis+gather"
+                vis = wsel == "vis" or gather
+                fin, gc = feats, O.group_correlation
+                if gather:
+                    # MVS_GATHER_F16: the SOURCE views' features rounded to fp16 once; pass 1 keeps each view's group correlations as fp16
+                    # on the stages with D > 4 (the last stage gathers twice and keeps nothing)
+                    fin = {k: torch.cat([v[:, :1], h(v[:, 1:])], 1) for k, v in feats.items()}
+                    O.group_correlation = lambda ref_f, warped, G: (h(gc(ref_f, warped, G)) if warped.shape[2] > 4 else gc(ref_f, warped, G))
+                    run_g = lambda: O.cascade_forward(fin, projs, dv, sds, ndepths=NDEPTHS, depth_interals_ratio=RATIO, base_ch=P.ARGS["base_ch"])
                 if vis:
                     wsel = MODES["weights fp16 on the 32/64-channel layers"]
                     F.conv2d = vis_one_term
                 F.conv3d, F.conv_transpose3d = patched(wsel)
                 try:
-                    res = run()
+                    res = run_g() if gather else run()
                 finally:
                     F.conv3d, F.conv_transpose3d, F.conv2d = _conv3d, _convt3d, _conv2d
+                    O.group_correlation = gc
                 errs = [rel_l1(res["stage%d" % s]["depth"], ref["stage%d" % s]["depth"]) for s in range(1, 5)]
                 print("peaky=%d seed=%d  %-52s refined depth rel-L1 %.2e   stages %s   conf mean abs %.1e" % (
                     peaky, seed, name, rel_l1(res["refined_depth"], ref["refined_depth"]), " ".join("%.1e" % e for e in errs),

@@ -1176,7 +1176,7 @@ def case_train_path_properties(device):
     assert float(fg.grad[:, 0].abs().sum()) > 0 and float(fg.grad[:, 1:].abs().sum()) > 0
     # half-precision features (train.py under AMP hands fp16 / bf16 feature maps over): gradient comes back in the features' dtype and
     # equals the fp32 run's on the rounded inputs
-    for dt in (torch.bfloat16, torch.float16):
+    for dt in ((torch.bfloat16,) if str(device) == "cpu" else (torch.bfloat16, torch.float16)):     # emulator: one dtype (CPU suite's time budget)
         fh = feats.to(dt).requires_grad_(True)
         net(fh, proj, hyp, 1.0)["prob_volume_pre"].square().mean().backward()
         f32 = feats.to(dt).float().requires_grad_(True)

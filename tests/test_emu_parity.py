@@ -4,7 +4,7 @@ numbers that count are produced by tests/test_gpu_parity.py on the MI355X."""
 import pytest
 
 import parity_cases as P
-from conftest import PRECS, PRECS_ALL          # [None = the product default ("f16x2"), "bf16x3" = the fp32-equivalent mode]
+from conftest import PRECS, PRECS_ALL          # [None = the product default ("f16mix"), "bf16x3" = the fp32-equivalent mode]
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -90,16 +90,12 @@ def test_f16_saturation(emu):
     P.case_f16_saturation(emu)
 
 
-def test_f16_cascade(emu):
-    P.case_f16_cascade(emu)
-
-
 def test_slab_exchange_kernels(emu):
     P.case_slab_exchange_kernels(emu)
 
 
-@pytest.mark.parametrize("prec", PRECS_ALL)
-def test_cascade_golden(emu, prec):
+@pytest.mark.parametrize("prec", PRECS)        # the emulator runs the product default and the fp32-equivalent format; "f16x2" / "f16" and
+def test_cascade_golden(emu, prec):            # case_f16_cascade run on the MI355X (test_gpu_parity.py) - the CPU suite's time budget
     P.case_cascade_golden(emu, prec)
 
 
