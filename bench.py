@@ -73,6 +73,36 @@ def build_head(device, shipped=False, conv_precision=None):
     return head.eval().to(device)
 
 
+class HeadlineGuard:
+    """Keeps rank 0's ONE JSON line alive across a leg that may take the process down (first RCCL contact of the view-sharded mode): a
+    small detached Python process (own session, SIGTERM / SIGINT / SIGHUP ignored, this process's stdout) reads the fallback line from
+    a pipe and prints it if the pipe closes before `disarm()` said that this process will print the line itself."""
+    _CHILD = ("import sys, signal\n"
+              "for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP): signal.signal(s, signal.SIG_IGN)\n"
+              "line = sys.stdin.readline()\n"
+              "ok = sys.stdin.readline()\n"
+              "if ok.strip() != 'OK':\n"
+              "    sys.stdout.write(line if line.endswith('\\n') else line + '\\n'); sys.stdout.flush()\n")
+
+    def __init__(self, fallback: dict):
+        import subprocess
+        sys.stdout.flush()
+        self.proc = subprocess.Popen([sys.executable, "-c", self._CHILD], stdin=subprocess.PIPE, start_new_session=True, close_fds=True)
+        self.proc.stdin.write((json.dumps(fallback) + "\n").encode())
+        self.proc.stdin.flush()
+
+    def disarm(self):
+        if self.proc is None:
+            return
+        try:
+            self.proc.stdin.write(b"OK\n")
+            self.proc.stdin.close()
+            self.proc.wait(timeout=10)
+        except Exception:
+            pass
+        self.proc = None
+
+
 def cpu_baseline(head, feats, projs, dv, max_threads=None, shipped=False):
     """The oracle (CPU restatement of the reference PyTorch path, fp32) on the host cores, SURVEY.md section 8d: one warm-up pass
     (the first call is slower), then the MEDIAN of three passes on 16 threads, and the median of three on 8 threads beside it (the
@@ -513,10 +543,15 @@ def main():
         # The headline above is already measured.  The extra leg exercises collectives that have only ever run on gloo in the build
         # container: a watchdog prints the JSON line without it and ends the process if it does not come back.
         import threading
+        # ... and if the process is KILLED inside the leg (an abort inside the communicator on this or another rank: torchrun then
+        # terminates every worker) nothing in this interpreter gets to print: a detached helper process holds the headline line and
+        # prints it to this rank's stdout if the pipe to it closes without the all-clear.
+        guard = HeadlineGuard(dict(result, view_sharded={"error": "the process was terminated inside the view-sharded leg"})) if rank == 0 else None
 
         def _give_up():
             result["view_sharded"] = {"error": "view-sharded leg did not finish within %d s (abandoned by the watchdog)" % a.view_sharded_timeout}
             if rank == 0:
+                guard.disarm()
                 print(json.dumps(result), flush=True)
             os._exit(0)
         dog = threading.Timer(a.view_sharded_timeout, _give_up)
@@ -527,6 +562,8 @@ def main():
         except Exception as e:  # report the failure instead of dying
             result["view_sharded"] = {"error": repr(e)}
         dog.cancel()
+        if guard is not None:
+            guard.disarm()
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) + a parity read-out ----
     if world == 1 and not a.no_cpu_baseline:

@@ -60,6 +60,28 @@ def check_f16_saturation(device=None, warn: bool = True, reset: bool = True) -> 
     return n
 
 
+_HYP_WARNED = False
+
+
+def check_hypothesis_conditioning(hyp: torch.Tensor, warn: bool = True) -> float:
+    """Fraction of depth hypotheses that are not finite or not positive.  The reference's inverse-depth schedule (module.py:712-716) takes
+    1 / depth -/+ ratio * interval; on a wide range (depth_max / depth_min > (ndepths[0] - 1) / ratio + 1, e.g. 0.5 .. 10 with 32 planes) the
+    window crosses zero for far pixels: their hypotheses jump through +-infinity, the result there means nothing in ANY arithmetic, and
+    the pixels around them are ill-conditioned - a 6e-5 perturbation (the fp16 formats' noise) becomes 3.6e-3 mean relative depth error on
+    BASELINE cfg4's literal range, where conv_precision="bf16x3" stays at 2e-4.  One warning per process says so.
+    Synchronises the device; StageNet calls it with the saturation check (8th call, then every F16_SATURATION_CHECK_EVERY calls)."""
+    global _HYP_WARNED
+    bad = float((~torch.isfinite(hyp) | (hyp <= 0)).float().mean())
+    if bad > 0 and warn and not _HYP_WARNED:
+        import warnings
+        _HYP_WARNED = True
+        warnings.warn("mvsformerplusplus_amd: %.1f %% of the depth hypotheses of a stage are non-finite or non-positive - the inverse-depth "
+                      "schedule crossed zero (depth range too wide for the number of planes).  Depth there is meaningless and ill-conditioned "
+                      "around it; the fp16 regulariser formats lose accuracy on such inputs (build the stages with conv_precision='bf16x3')."
+                      % (100.0 * bad), RuntimeWarning, stacklevel=2)
+    return bad
+
+
 class StageNet(nn.Module):
     def __init__(self, args: dict, ndepth: int, stage_idx: int):
         super().__init__()
@@ -199,19 +221,21 @@ class StageNet(nn.Module):
                     volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, split=split, f16=f16)
         out = self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split)
         if self._f16_activations():
-            self._count_f16_call(feats.device)
+            self._count_f16_call(feats.device, hyp)
         return out
 
     @staticmethod
-    def _count_f16_call(device):
-        """Automatic saturation check of the fp16 default (check_f16_saturation): after the 8th f16x2 inference call of the process, then
-        every F16_SATURATION_CHECK_EVERY calls; one device synchronisation each time, never inside a hipGraph capture."""
+    def _count_f16_call(device, hyp=None):
+        """Automatic checks of the fp16 default (check_f16_saturation, check_hypothesis_conditioning): after the 8th fp16-format inference
+        call of the process, then every F16_SATURATION_CHECK_EVERY calls; one device synchronisation each time, never inside a hipGraph capture."""
         global _F16_CALLS
         _F16_CALLS += 1
         if F16_SATURATION_CHECK_EVERY and (_F16_CALLS == 8 or _F16_CALLS % F16_SATURATION_CHECK_EVERY == 0):
             if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
                 return
             check_f16_saturation(device)
+            if hyp is not None:
+                check_hypothesis_conditioning(hyp)
 
     def _split_activations(self) -> bool:
         """The bf16x3 U-Net keeps its activations - cost volume included - in the split hi | lo bf16 format between layers

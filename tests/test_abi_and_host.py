@@ -269,3 +269,45 @@ def test_packed_cache_sees_replaced_and_rewritten_parameters():
     bn = {"weight": torch.ones(2), "bias": torch.zeros(2), "running_mean": torch.zeros(2), "running_var": torch.ones(2), "eps": 3.0}
     wf, _ = packing.fold_bn(w, bn, 0)
     assert torch.allclose(wf.flatten(), torch.full((2,), 0.5))  # 1 / sqrt(1 + 3)
+
+
+def test_bench_headline_guard_prints_the_line_when_the_process_is_killed():
+    """bench.py, N > 1: the view-sharded extra leg is the first RCCL contact of that path; if the process is taken down inside it, a detached
+    helper prints rank 0's one JSON line (HeadlineGuard).  disarm() = the process prints its own line, the helper stays silent."""
+    import signal
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent('''
+        import sys, os, signal
+        sys.path.insert(0, %r)
+        import bench
+        g = bench.HeadlineGuard({"metric": "m", "value": 1.5})
+        if sys.argv[1] == "ok":
+            g.disarm(); print("OWN LINE"); sys.exit(0)
+        os.kill(os.getpid(), signal.SIGKILL if sys.argv[1] == "kill" else signal.SIGTERM)
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode, want in (("ok", "OWN LINE"), ("kill", '{"metric": "m", "value": 1.5}'), ("term", '{"metric": "m", "value": 1.5}')):
+        p = subprocess.Popen([sys.executable, "-c", code, mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        out, _ = p.communicate(timeout=300)
+        assert out.decode().strip() == want, (mode, out)
+
+
+def test_hypothesis_conditioning_check_reports_a_degenerate_schedule():
+    """cost_volume.check_hypothesis_conditioning: non-finite / non-positive hypotheses (the reference's inverse-depth window crossing zero,
+    module.py:712-716) are counted and warned about once per process; sane hypotheses are silent."""
+    import warnings
+    from mvsformerplusplus_amd import cost_volume
+    hyp = torch.linspace(400.0, 900.0, 8)[None, :, None, None].expand(1, 8, 4, 6).clone()
+    cost_volume._HYP_WARNED = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert cost_volume.check_hypothesis_conditioning(hyp) == 0.0
+        assert not rec
+        hyp[0, 7, 0, :3] = float("inf")
+        hyp[0, 6, 1, 0] = -3.0
+        bad = cost_volume.check_hypothesis_conditioning(hyp)
+        assert abs(bad - 4.0 / hyp.numel()) < 1e-9
+        cost_volume.check_hypothesis_conditioning(hyp)                    # second time: counted, not warned again
+    assert len(rec) == 1 and "conv_precision='bf16x3'" in str(rec[0].message)
+    cost_volume._HYP_WARNED = False
