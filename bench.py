@@ -16,7 +16,8 @@ fp32 features, all-"Normal" regularisers, synthetic features / cameras and seede
 statistics (no dataset or checkpoint exists offline).
 
 Arithmetic: warp, correlation, visibility, heads and every accumulation in fp32; the 3-D regularisers in the PRODUCT DEFAULT format
-"f16x2" (cost_volume.STAGE_DEFAULT_PRECISION: fp16 activation tensors, fp16 hi + lo weights, two MFMA terms per product) - wider than
+"f16mix" (module.DEFAULT_PRECISION: fp16 activation tensors; fp16 hi + lo weights = two MFMA terms per product on the 8- / 16-channel
+layers, one fp16 term on conv4..conv7 and in the visibility CNN; fp16 source windows and kept correlations in the gather) - wider than
 the bf16 autocast the reference's own GPU path runs these layers under (test.py:250); `--conv-precision bf16x3` selects the
 fp32-equivalent mode of rounds 1-2.  `parity` = this run's refined depth against the fp32 CPU oracle on the same inputs (bar 1e-3).
 
@@ -71,6 +72,23 @@ def build_head(device, shipped=False, conv_precision=None):
         st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 100 + i), strict=True)
         st.return_prob_volumes = True       # reference-faithful outputs (a12): prob_volume / prob_volume_pre are written
     return head.eval().to(device)
+
+
+def mfma_terms(label: str, prec: str) -> int:
+    """MFMA products a kernel issues per algorithmic product: 3 (split bf16), 2 (fp16 hi + lo weights), 1 (one fp16 weight term).  "f16mix"
+    (csrc/conv_kernels.hip mfma_form): one term where min(Cin, Cout) >= 32 or max >= 64 and in the visibility CNN, two elsewhere."""
+    import re
+    if prec in ("bf16x3", "f16x2", "f16"):
+        return {"bf16x3": 3, "f16x2": 2, "f16": 1}[prec]
+    if prec != "f16mix":
+        return 1
+    if label.startswith("vis_cnn"):
+        return 1
+    m = re.match(r"(?:de)?conv3d_mfma<(\d+),(\d+)", label)
+    if m:
+        ci, co = int(m.group(1)), int(m.group(2))
+        return 1 if (min(ci, co) >= 32 or max(ci, co) >= 64) else 2
+    return 2
 
 
 class HeadlineGuard:
@@ -374,7 +392,7 @@ def main():
         per_launch = dom["flops" if mfma else "bytes"] / dom["calls"]
         achieved = (dom["tflops"] if mfma else dom["gbs"])
         prec = head.fusions[0].conv_precision
-        terms = {"bf16x3": 3, "f16x2": 2, "f16mix": 2, "f16": 1}.get(prec, 1)       # f16mix: the visibility CNN and the 8/16-channel layers keep 2
+        terms = mfma_terms(dom_name, prec)
         if not mfma:
             peak, note = profiling.PEAK_HBM_GBS, ("algorithmic HBM bytes per launch (SURVEY.md section 8d: every feature map once + hypotheses once + "
                                                   "outputs once, at the tensors' real element sizes) / HIP-event launch time on the launch stream")
@@ -398,7 +416,7 @@ def main():
                               "avg_launch_ms": dom["avg_ms"], "algorithmic_per_launch": per_launch,
                               "share_of_step": dom["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-9),
                               "launches_per_ref_view": dom["calls"] / reps, "note": note}
-        if mfma and terms > 1:
+        if mfma:
             result["roofline"]["mfma_terms_per_product"] = terms
             result["roofline"]["frac_of_issued_mfma"] = achieved * terms / peak
         if mfma:
@@ -424,10 +442,10 @@ def main():
                 work = sum(v["flops"] for v in ks.values()) / reps
                 ach = work / ms / 1e9                            # TFLOP/s
                 fp = fam_prec or prec
-                tm = {"bf16x3": 3, "f16x2": 2, "f16mix": 2}.get(fp, 1)
+                issued = sum(v["flops"] * mfma_terms(k, fp) for k, v in ks.items()) / reps / ms / 1e9      # TFLOP/s of MFMA products actually issued
                 pk = profiling.PEAK_F32_MFMA_TFLOPS if fp == "fp32" else profiling.PEAK_F16_MFMA_TFLOPS
                 return {"ms_per_ref_view": ms, "bound": "mfma", "algorithmic_gflop_per_ref_view": work / 1e9, "achieved_tflops": ach, "peak_tflops": pk,
-                        "frac": ach / pk, "mfma_terms_per_product": tm, "frac_of_issued_mfma": ach * tm / pk,
+                        "frac": ach / pk, "mfma_terms_per_product": issued / max(ach, 1e-12), "frac_of_issued_mfma": issued / pk,
                         "launches_per_ref_view": sum(v["calls"] for v in ks.values()) / reps}
             work = sum(v["bytes"] for v in ks.values()) / reps
             ach = work / ms / 1e6                                # GB/s
@@ -506,7 +524,7 @@ def main():
             result["attention_bf16p"] = {"error": repr(e)}
 
     # ---- extra: the fp32-equivalent regulariser format ("bf16x3") on the same weights, inputs and loop, outside the timed headline: the
-    #      driver's own BENCH line then carries both modes (the headline runs the product default, "f16x2") ----
+    #      driver's own BENCH line then carries both modes (the headline runs the product default, "f16mix") ----
     if world == 1 and not a.no_profile and a.cost_reg != "shipped" and head.fusions[0].conv_precision in ("f16x2", "f16mix", "f16") and not a.graph:
         try:
             head32 = build_head(device, conv_precision="bf16x3")

@@ -33,12 +33,13 @@ def shard_views(n_src: int, world: int, rank: int):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-# Default contraction / activation format of a stage's 3-D regulariser at INFERENCE: "f16x2" - the U-Net's tensors (cost volume
-# included) in HBM as fp16, weights as fp16 hi + lo, two MFMA terms per product, fp32 accumulation.  Depth vs the fp32 oracle:
-# ~5e-5 relative L1 on plain inputs, 4e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers
+# Default contraction / activation format of a stage's 3-D regulariser at INFERENCE: "f16mix" - the U-Net's tensors (cost volume
+# included) in HBM as fp16, weights as fp16 hi + lo (two MFMA terms per product) on the 8- / 16-channel layers and ONE fp16 term on
+# conv4..conv7 and in the visibility CNN, fp32 accumulation; "f16x2" = two terms everywhere, "f16" = one everywhere.  Depth vs the fp32
+# oracle: ~6e-5 relative L1 on plain inputs, 4e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers
 # under bf16 autocast (test.py:250).  "bf16x3" = fp32-equivalent activations (split bf16 pairs, three terms; 1e-6 from the oracle),
 # "fp32" = exact.  args["conv_precision"] overrides it per head.  Training always runs the bf16x3 kernels on fp32 activations.
-STAGE_DEFAULT_PRECISION = DEFAULT_PRECISION      # one constant (module.DEFAULT_PRECISION): "f16x2"
+STAGE_DEFAULT_PRECISION = DEFAULT_PRECISION      # one constant (module.DEFAULT_PRECISION): "f16mix"
 
 
 _F16_CALLS = 0
@@ -48,14 +49,14 @@ F16_SATURATION_CHECK_EVERY = 4096          # stage calls between two automatic r
 
 def check_f16_saturation(device=None, warn: bool = True, reset: bool = True) -> int:
     """Read (and by default clear) the library's fp16 saturation counter on `device`: the number of work-items that stored a regulariser
-    ACTIVATION beyond the fp16 range (clamped to +-65504) in the default "f16x2" format.  0 on sane weights; anything else means the
+    ACTIVATION beyond the fp16 range (clamped to +-65504) in the fp16 formats (the default "f16mix", "f16x2", "f16").  0 on sane weights; anything else means the
     default degraded values that conv_precision="bf16x3" would have kept - a warning says so once per process.  Synchronises the device:
     StageNet calls it by itself after its 8th inference call and then every F16_SATURATION_CHECK_EVERY calls (never during graph capture)."""
     import warnings
     n = ops.f16_saturation_count(reset=reset, device=device)
     if n and warn:
         warnings.warn("mvsformerplusplus_amd: %d work-items stored fp16 regulariser activations beyond +-65504 (clamped).  The default "
-                      "conv_precision='f16x2' is degrading this model's values; build the stages with conv_precision='bf16x3' "
+                      "fp16 regulariser format is degrading this model's values; build the stages with conv_precision='bf16x3' "
                       "(fp32-equivalent activations) for it." % n, RuntimeWarning, stacklevel=2)
     return n
 

@@ -51,6 +51,13 @@ typedef _Float16 vs_f16x4 __attribute__((ext_vector_type(4)));
 #define MVS_OPAQUE_VEC "v"
 #endif
 
+// four fp32 -> four halves as TWO v_cvt_pk_f16_f32 (vector conversion: the element-wise form compiled to 4 v_cvt + 2 v_pack here, with
+// the zero-padding selects on the four scalars; on the packed pairs they are two)
+__device__ __forceinline__ vs_f16x4 vs_cvt4(const float* v) {
+    typedef float vs_f32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_convertvector((vs_f32x4){v[0], v[1], v[2], v[3]}, vs_f16x4);
+}
+
 __device__ __forceinline__ void vs_split4(const float* v, vs_bf16x4& hi, vs_bf16x4& lo) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -96,10 +103,11 @@ __device__ __forceinline__ f32x4 vs_mfma_hi(const vs_bf16x8& wh, const VsOperand
 // before the MFMAs of step t
 // ONE (round 4, MVS_PREC_F16 / _F16MIX): the weights' lo term is not used - 10 instead of 20 MFMAs per row and wave (error study:
 // scripts/study_weight_precision.py, "visibility CNN one term")
+// `init`: the layer's bias, which rides in the first MFMA's accumulator input instead of four v_add_f32 in the epilogue
 template <int SLOT0, bool F16, bool ONE = false>
-__device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, const vs_bf16x8* wh, const vs_bf16x8* wl) {
+__device__ __forceinline__ f32x4 vs_layer_row(const char* lds_layer, int laneoff, int tapsel, const vs_bf16x8* wh, const vs_bf16x8* wl, f32x4 init) {
     constexpr int POSB = VsL<F16>::POSB;
-    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0;
+    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = init;
     VsOperand cur = vs_load<F16>(lds_layer + vs_step_off<SLOT0, POSB>(laneoff, tapsel, 0));
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
@@ -121,7 +129,7 @@ template <int SLOT2, int SLOT3, bool F16, bool ONE = false>
 __device__ __forceinline__ void vs_two_layer_rows(const char* lds1, const char* lds2, int laneoff, int tapsel, const vs_bf16x8* w2h,
                                                   const vs_bf16x8* w2l, const vs_bf16x8* w3h, const vs_bf16x8* w3l, f32x4& out2, f32x4& out3) {
     constexpr int POSB = VsL<F16>::POSB;
-    f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, c = a;
+    f32x4 a = out2, c = out3;                                   // in: the layers' biases (accumulator init), out: the rows
     VsOperand cb = vs_load<F16>(lds1 + vs_step_off<SLOT2, POSB>(laneoff, tapsel, 0));
     VsOperand cc = vs_load<F16>(lds2 + vs_step_off<SLOT3, POSB>(laneoff, tapsel, 0));
 #pragma unroll
@@ -224,10 +232,13 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     const int c2 = 16 * wave + li;                                 // layer-2 / layer-3 column of this lane
     const int xb = x0 - 1 + c2, xc = x0 + c2;
 
-    auto iteration = [&](auto phase, int i) {
+    // steady: every stage has a row to produce (r0 + 4 <= i <= r1 + 1) - no range logic, no branches
+    auto iteration = [&](auto phase, auto steady, int i) __attribute__((always_inline)) {      // eight call sites: without the attribute the body is
+                                                                                                 // outlined, its captures go through scratch and generic pointers
         constexpr int PH = decltype(phase)::value;                  // == i & 3: ring slot of row i + k is (PH + k) & 3
+        constexpr bool STEADY = decltype(steady)::value != 0;
         // ---- A: layer-1 row i ----
-        if (i <= r1 + 1) {
+        if (STEADY || i <= r1 + 1) {
             float er[3][3];                                        // entropy rows i-1 .. i+1, columns xa-1 .. xa+1
             const float* ep = ent_s + (i - 1 - (r0 - 3)) * VS_EP + lane;
 #pragma unroll
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r) a[r] = in ? fmaxf(a[r], 0.0f) : 0.0f;
             char* p = lds1 + wrA + PH * (VS_P * VS_POSB);
             if constexpr (F16) {
-                *reinterpret_cast<vs_f16x4*>(p) = vs_f16x4{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
+                *reinterpret_cast<vs_f16x4*>(p) = vs_cvt4(a);
             } else {
                 vs_bf16x4 hi, lo;
                 vs_split4(a, hi, lo);
@@ -260,20 +271,20 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
         }
         // ---- B: layer-2 row i-2 from layer-1 rows i-3 .. i-1;  C: layer-3 row i-4 from layer-2 rows i-5 .. i-3 ----
         const int yb = i - 2, yc = i - 4;
-        const bool doB = yb >= r0 - 1 && yb <= r1, doC = yc >= r0;
+        const bool doB = STEADY || (yb >= r0 - 1 && yb <= r1), doC = STEADY || yc >= r0;
         constexpr int S2 = (PH + 1) & 3, S3 = (PH + 3) & 3;          // slots of rows i-3 and i-5
-        f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc3 = acc2;
-        if (doB && doC) vs_two_layer_rows<S2, S3, F16, ONE>(lds1, lds2, laneoff, tapsel, w2h, w2l, w3h, w3l, acc2, acc3);
-        else if (doB) acc2 = vs_layer_row<S2, F16, ONE>(lds1, laneoff, tapsel, w2h, w2l);
-        else if (doC) acc3 = vs_layer_row<S3, F16, ONE>(lds2, laneoff, tapsel, w3h, w3l);
+        f32x4 acc2 = {b2v[0], b2v[1], b2v[2], b2v[3]}, acc3 = {b3v[0], b3v[1], b3v[2], b3v[3]};
+        if (STEADY || (doB && doC)) vs_two_layer_rows<S2, S3, F16, ONE>(lds1, lds2, laneoff, tapsel, w2h, w2l, w3h, w3l, acc2, acc3);
+        else if (doB) acc2 = vs_layer_row<S2, F16, ONE>(lds1, laneoff, tapsel, w2h, w2l, acc2);
+        else if (doC) acc3 = vs_layer_row<S3, F16, ONE>(lds2, laneoff, tapsel, w3h, w3l, acc3);
         if (doB) {
             const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc2[r] + b2v[r], 0.0f) : 0.0f;
+            for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc2[r], 0.0f) : 0.0f;
             char* p = lds2 + wrB + ((PH + 2) & 3) * (VS_P * VS_POSB);          // row i-2
             if constexpr (F16) {
-                *reinterpret_cast<vs_f16x4*>(p) = vs_f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<vs_f16x4*>(p) = vs_cvt4(v);
             } else {
                 vs_bf16x4 hi, lo;
                 vs_split4(v, hi, lo);
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
         if (doC) {                                                  // 1x1 + sigmoid
             float part = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part += fmaxf(acc3[r] + b3v[r], 0.0f) * w4v[r];          // rows 8..15 of the tile: zero weights
+            for (int r = 0; r < 4; ++r) part += fmaxf(acc3[r], 0.0f) * w4v[r];                   // rows 8..15 of the tile: zero weights
             part += __shfl_xor(part, 16);
             if (g == 0 && c2 < VS_TW && xc < W && yc < r1) {
                 const float z = part + bias4;
@@ -293,14 +304,23 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
         }
         __syncthreads();
     };
-    for (int i = i0; i < i1; ++i) {
+    auto general = [&](int i) __attribute__((always_inline)) {
         switch (i & 3) {
-            case 0: iteration(VsInt<0>(), i); break;
-            case 1: iteration(VsInt<1>(), i); break;
-            case 2: iteration(VsInt<2>(), i); break;
-            default: iteration(VsInt<3>(), i); break;
+            case 0: iteration(VsInt<0>(), VsInt<0>(), i); break;
+            case 1: iteration(VsInt<1>(), VsInt<0>(), i); break;
+            case 2: iteration(VsInt<2>(), VsInt<0>(), i); break;
+            default: iteration(VsInt<3>(), VsInt<0>(), i); break;
         }
+    };
+    int i = i0;
+    for (; i < i1 && (i < r0 + 4 || (i & 3) != 0); ++i) general(i);          // warm-up rows, then up to the next multiple of four
+    for (; i + 3 <= r1 + 1; i += 4) {                                         // steady state, four rows (= the ring) per trip
+        iteration(VsInt<0>(), VsInt<1>(), i);
+        iteration(VsInt<1>(), VsInt<1>(), i + 1);
+        iteration(VsInt<2>(), VsInt<1>(), i + 2);
+        iteration(VsInt<3>(), VsInt<1>(), i + 3);
     }
+    for (; i < i1; ++i) general(i);                                           // drain
 }
 
 template <bool F16, bool ONE = false>

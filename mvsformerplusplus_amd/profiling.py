@@ -61,7 +61,7 @@ def match_kernel(label: str, table: dict):
         return None
     f16 = [k for k in cands if "F16Cfg" in k]
     if f16 and len(f16) < len(cands):
-        # both formats were sampled: the caller's table comes from the product default (f16x2) run
+        # both formats were sampled: the caller's table comes from the product default (fp16-format) run
         cands = f16
     return max(cands, key=lambda k: table[k].get("launches_sampled", 0))
 
