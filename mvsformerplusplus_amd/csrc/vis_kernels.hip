@@ -35,12 +35,22 @@ constexpr int VS_ENT_BYTES = (VS_SH_MAX + 6) * VS_EP * 4;
 // F16 = false: split bf16 rings ([hi x8 | lo x8] = 32 B per position and octet, three MFMA terms); F16 = true (MVS_PREC_F16X2): fp16
 // rings (16 B per position and octet), weights fp16 hi + lo, two MFMA terms - 20 instead of 30 MFMAs and 10 instead of 20 operand
 // reads per row and wave
+// fp16 rings: the second octet plane on the SAME 16-byte slots as the first (see bf_f16_plane_shift in conv_bf16x3_kernels.hip: the
+// service groups of a ds_read_b128 pair lanes {0-3, 12-15} of one operand group with {20-27} of the other; rounds 3-4 shipped 128 and
+// with it a 2-way conflict on every operand read - 40 % of the kernel's LDS cycles)
+#ifndef VS_F16_PLANE_SHIFT
+#ifdef MVS_F16_PLANE_SHIFT
+#define VS_F16_PLANE_SHIFT MVS_F16_PLANE_SHIFT
+#else
+#define VS_F16_PLANE_SHIFT 0
+#endif
+#endif
 template <bool F16>
 struct VsL {
     static constexpr int POSB = F16 ? 16 : 32;                 // bytes per (position, octet)
-    // one octet plane; the octet-1 lanes of a ds_read_b128 group sit beside the octet-0 lanes in the 256-byte bank row: 16 B away for
-    // the 32-byte positions (which cover the even 16-byte slots), 128 B away for the 16-byte positions (which cover the first half)
-    static constexpr int PLANE = ((VS_RING * VS_P + 2) * POSB + 255) / 256 * 256 + (F16 ? 128 : 16);
+    // one octet plane; the octet-1 lanes of a ds_read_b128 service group ({20-27} beside {0-3, 12-15}) take the free 16-byte slots of the
+    // 256-byte bank row: 16 B away for the 32-byte positions (which cover the even slots), 0 B for the 16-byte positions (slots 4-11)
+    static constexpr int PLANE = ((VS_RING * VS_P + 2) * POSB + 255) / 256 * 256 + (F16 ? VS_F16_PLANE_SHIFT : 16);
     static constexpr int LAYER = 2 * PLANE;
     static constexpr int LDS = 2 * LAYER + VS_ENT_BYTES;
 };
@@ -329,8 +339,9 @@ static int vis_weight_stream_t(const float* entropy, const float* w1, const floa
     constexpr int VS_LDS = VsL<F16>::LDS;
     const int strips = (int)ceil_div(W, VS_TW);
     // segment height: a block's run time is ~ (SH + 6) row iterations (6 warm-up rows) and the launch takes ceil(blocks / resident
-    // blocks) of those back to back - pick the segment count that minimises that product (3 blocks per CU fit: 52 KB LDS, 152 VGPRs)
-    const long long per_seg = (long long)strips * N, resident = 3 * 256;
+    // blocks) of those back to back - pick the segment count that minimises that product (blocks per CU: 3 with the split-bf16 rings'
+    // 52 KB of LDS, 4 with the fp16 rings' 36 KB and 114 VGPRs)
+    const long long per_seg = (long long)strips * N, resident = (160 * 1024 / VS_LDS < 4 ? 160 * 1024 / VS_LDS : 4) * 256;
     int segs = (int)ceil_div(H, VS_SH_MAX), SH = (int)ceil_div(H, segs);
     long long best = -1;
     for (int sg = (int)ceil_div(H, VS_SH_MAX); sg <= (H + 7) / 8; ++sg) {
