@@ -85,4 +85,11 @@ grep -v "amdgpu.ids" $OUT/bench_bf16x3.err > $OUT/profiles_$TAG/${TAG}_bench_ker
 grep -v "amdgpu.ids" $OUT/bench.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table.txt
 grep -v "amdgpu.ids" $OUT/bench_shipped.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_shipped.txt
 rm -rf $OUT/prof_$TAG $OUT/prof1_$TAG $OUT/pmc_$TAG
+echo "== PMC pipe utilisation per kernel (three counter passes over a short bench run) =="
+bash scripts/gpu_pmc_bench.sh $TAG --no-train-leg --views-per-step 8 > $OUT/pmc_pipe.log 2>&1
+cp $OUT/pmc_$TAG/summary.txt $OUT/profiles_$TAG/${TAG}_pmc_pipe_utilisation.txt
+cp $OUT/pmc_$TAG/table.txt $OUT/profiles_$TAG/${TAG}_pmc_pipe_table_raw.txt
+head -30 $OUT/profiles_$TAG/${TAG}_pmc_pipe_utilisation.txt | cut -c1-200
+# the stride-1 layers run once per stage (launch i of a view = stage i + 1): the same table per stage
+{ for i in 0 1 2 3; do echo "== stage $((i+1)) (launch index $i of each reference view) =="; python scripts/pmc_table_summary.py $OUT/pmc_$TAG/table.txt "ConvCfg<(16,16|32,32|64,64),3,1,1,1|vis_cnn|gl_entropy|gl_aggregate" $i | cut -c1-230; done; } > $OUT/profiles_$TAG/${TAG}_pmc_pipe_per_stage.txt
 ls -la $OUT/profiles_$TAG

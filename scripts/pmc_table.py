@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Merge rocprofv3 counter_collection CSVs (one per --pmc pass) into a per-kernel table: scripts/pmc_table.py gpurun_out/pmc_x [filter]"""
-import csv, glob, re, sys, collections
+import csv, glob, os, re, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _demangle import demangle_mvs          # rocprofv3 leaves symbols with _Float16 parameters mangled
 root = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else ""
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(root + "/p*/p*_counter_collection.csv")):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"]
+        name = demangle_mvs(row["Kernel_Name"])
         if filt and not re.search(filt, name): continue
-        m = re.search(r"(warp_corr_\w+|conv3d_mfma\w*|deconv3d_mfma\w*|\w+_kernel)<?([^>]*)", name)
-        short = (m.group(1) + "<" + m.group(2)[:28] + ">") if m else name[:50]
+        # operator + its whole template argument list (tile configuration included), namespaces and the parameter list dropped
+        m = re.search(r"(warp_corr_\w+|conv3d_mfma\w*|deconv3d_mfma\w*|\w+_kernel)(<.*>)?\(", name)
+        short = (m.group(1) + (m.group(2) or "").replace("mvs::", "").replace(" ", "")) if m else name[:50]
         per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in per.items():
         for c, vals in cs.items():

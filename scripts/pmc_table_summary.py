@@ -25,6 +25,6 @@ for k, c in ker.items():
                  wc * 4 / simd if simd else float("nan"), pct(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), simd), pct(m.get("SQ_ACTIVE_INST_VALU", 0) * 4, simd),
                  pct(m.get("SQ_LDS_IDX_ACTIVE", 0), gui * 256.0), pct(m.get("SQ_LDS_BANK_CONFLICT", 0), m.get("SQ_LDS_IDX_ACTIVE", 0)), pct(m.get("TA_TA_BUSY", 0), gui * 256.0),
                  c.get("SQ_WAVES", (0, 0))[1]))
-print("%-64s %7s %6s %5s %5s %5s %5s %5s | %5s %5s %5s | %4s | %5s %5s %5s %5s %5s | %3s" % ("kernel", "kcyc", "waves", "valu", "mfma", "lds", "salu", "vmem", "wait%", "stal%", "iss%", "w/S", "MFMA%", "VALU%", "LDS%", "conf%", "TA%", "n"))
+print("%-96s %7s %6s %5s %5s %5s %5s %5s | %5s %5s %5s | %4s | %5s %5s %5s %5s %5s | %3s" % ("kernel", "kcyc", "waves", "valu", "mfma", "lds", "salu", "vmem", "wait%", "stal%", "iss%", "w/S", "MFMA%", "VALU%", "LDS%", "conf%", "TA%", "n"))
 for r in sorted(rows, reverse=True):
-    print("%-64s %7.0f %6.0f %5.0f %5.0f %5.0f %5.0f %5.0f | %5.1f %5.1f %5.1f | %4.1f | %5.1f %5.1f %5.1f %5.1f %5.1f | %3d" % ((r[1][:64], r[0] / 1e3) + r[2:]))
+    print("%-96s %7.0f %6.0f %5.0f %5.0f %5.0f %5.0f %5.0f | %5.1f %5.1f %5.1f | %4.1f | %5.1f %5.1f %5.1f %5.1f %5.1f | %3d" % ((r[1][:96], r[0] / 1e3) + r[2:]))
