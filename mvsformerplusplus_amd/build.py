@@ -25,7 +25,9 @@ FILE_FLAGS = {"transformer_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", 
               "attention_f16_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans", "-fno-slp-vectorize"],
               # vis_kernels: every MFMA result of the row-streaming CNN goes straight into a VALU epilogue (bias, ReLU, bf16 split, 1x1 +
               # sigmoid): VGPR accumulators save 40 v_accvgpr moves per row and wave (18 % of the kernel's non-MFMA VALU instructions)
-              "vis_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+              # -fno-honor-nans: ReLU on an MFMA result is then ONE v_max_f32 (with NaNs honoured the compiler first canonicalises the
+              # accumulator, a second v_max per value: 8 of 63 VALU per row and wave)
+              "vis_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]}
 
 
 def _digest():

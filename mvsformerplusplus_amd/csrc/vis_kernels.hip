@@ -63,6 +63,15 @@ typedef _Float16 vs_f16x4 __attribute__((ext_vector_type(4)));
 
 // four fp32 -> four halves as TWO v_cvt_pk_f16_f32 (vector conversion: the element-wise form compiled to 4 v_cvt + 2 v_pack here, with
 // the zero-padding selects on the four scalars; on the packed pairs they are two)
+// zero padding on the packed result: two selects instead of four on the fp32 values
+__device__ __forceinline__ vs_f16x4 vs_mask4(vs_f16x4 h, bool in) {
+    typedef unsigned vs_u32x2 __attribute__((ext_vector_type(2)));
+    vs_u32x2 u = __builtin_bit_cast(vs_u32x2, h);
+    u[0] = in ? u[0] : 0u;
+    u[1] = in ? u[1] : 0u;
+    return __builtin_bit_cast(vs_f16x4, u);
+}
+
 __device__ __forceinline__ vs_f16x4 vs_cvt4(const float* v) {
     typedef float vs_f32x4 __attribute__((ext_vector_type(4)));
     return __builtin_convertvector((vs_f32x4){v[0], v[1], v[2], v[3]}, vs_f16x4);
@@ -203,7 +212,26 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
 #endif
         }
     }
-    float w1s[9][4], b1s[4];                                      // layer 1: channels 4*wave .. 4*wave+3 (wave-uniform -> SGPRs)
+    // Layer 1 (1 -> 16 channels, 3x3) in the one-term fp16 formats: ONE MFMA per 16 pixels.  K = 18 of 32: lane group g < 3 carries
+    // kernel row kh = g as [e_hi(kw 0..2) | e_lo(kw 0..2) | 0 0] against the weights [w(kw 0..2) | w(kw 0..2) | 0 0] (one fp16 term, like the
+    // two MFMA layers) - the entropy keeps its full precision as an fp16 hi + lo pair, the result layout (lane (pixel, g): channels
+    // 4g .. 4g + 3) is the B-operand quad the ring stores, exactly like a layer-2 row.  6 VALU + 3 LDS reads + 1 MFMA per row and wave
+    // instead of 18 v_pk_fma_f32 + 9 reads on four channels of all 64 columns.
+    constexpr bool L1MFMA = F16 && ONE;
+    vs_f16x8 w1a = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 b1q = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (L1MFMA) {
+        const int kh = g < 3 ? g : 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const _Float16 wv = g < 3 ? (_Float16)w1[(kh * 3 + kw) * 16 + li] : (_Float16)0.0f;       // A operand: row = output channel li
+            w1a[kw] = wv;
+            w1a[3 + kw] = wv;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1q[r] = b1[4 * g + r];
+    }
+    float w1s[9][4], b1s[4];                                      // layer 1 on the VALU: channels 4*wave .. 4*wave+3 (wave-uniform -> SGPRs)
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -248,7 +276,29 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
         constexpr int PH = decltype(phase)::value;                  // == i & 3: ring slot of row i + k is (PH + k) & 3
         constexpr bool STEADY = decltype(steady)::value != 0;
         // ---- A: layer-1 row i ----
-        if (STEADY || i <= r1 + 1) {
+        if constexpr (L1MFMA) {
+            if (STEADY || i <= r1 + 1) {
+                // entropy row i - 1 + g, columns (x0 - 2 + c2) - 1 .. + 1 of this lane's pixel; group 3 re-reads group 2's row against zero weights
+                const float* ep = ent_s + (i - 1 + (g < 3 ? g : 2) - (r0 - 3)) * VS_EP + c2;
+                const float e0 = ep[0], e1 = ep[1], e2 = ep[2];
+                typedef float vs_f32x2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 vs_f16x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned vs_u32x4 __attribute__((ext_vector_type(4)));
+                const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((vs_f32x2){e0, e1}, vs_f16x2));     // [hi0, hi1]
+                const float l0 = MVS_FMA_MIX_LO(p0, -1.0f, e0), l1 = MVS_FMA_MIX_HI(p0, -1.0f, e1);                           // e - (float)hi
+                const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((vs_f32x2){e2, l0}, vs_f16x2));     // [hi2, lo0]
+                const float l2 = MVS_FMA_MIX_LO(p1, -1.0f, e2);
+                const unsigned p2 = __builtin_bit_cast(unsigned, __builtin_convertvector((vs_f32x2){l1, l2}, vs_f16x2));     // [lo1, lo2]
+                const vs_f16x8 bop = __builtin_bit_cast(vs_f16x8, (vs_u32x4){p0, p1, p2, 0u});
+                const f32x4 r1v = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1a, bop, b1q, 0, 0, 0);
+                const int xa1 = x0 - 2 + c2;
+                const bool in = xa1 >= 0 && xa1 < W && i >= 0 && i < H;
+                float a[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = fmaxf(r1v[r], 0.0f);
+                *reinterpret_cast<vs_f16x4*>(lds1 + wrB + PH * (VS_P * VS_POSB)) = vs_mask4(vs_cvt4(a), in);
+            }
+        } else if (STEADY || i <= r1 + 1) {
             float er[3][3];                                        // entropy rows i-1 .. i+1, columns xa-1 .. xa+1
             const float* ep = ent_s + (i - 1 - (r0 - 3)) * VS_EP + lane;
 #pragma unroll
@@ -268,10 +318,10 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             float a[4] = {a01[0], a01[1], a23[0], a23[1]};
             const bool in = colmaskA && i >= 0 && i < H;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = in ? fmaxf(a[r], 0.0f) : 0.0f;
+            for (int r = 0; r < 4; ++r) a[r] = F16 ? fmaxf(a[r], 0.0f) : (in ? fmaxf(a[r], 0.0f) : 0.0f);   // F16: the zero padding is applied to the packed halves
             char* p = lds1 + wrA + PH * (VS_P * VS_POSB);
             if constexpr (F16) {
-                *reinterpret_cast<vs_f16x4*>(p) = vs_cvt4(a);
+                *reinterpret_cast<vs_f16x4*>(p) = vs_mask4(vs_cvt4(a), in);
             } else {
                 vs_bf16x4 hi, lo;
                 vs_split4(a, hi, lo);
@@ -291,10 +341,10 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
             const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc2[r], 0.0f) : 0.0f;
+            for (int r = 0; r < 4; ++r) v[r] = F16 ? fmaxf(acc2[r], 0.0f) : (in ? fmaxf(acc2[r], 0.0f) : 0.0f);
             char* p = lds2 + wrB + ((PH + 2) & 3) * (VS_P * VS_POSB);          // row i-2
             if constexpr (F16) {
-                *reinterpret_cast<vs_f16x4*>(p) = vs_cvt4(v);
+                *reinterpret_cast<vs_f16x4*>(p) = vs_mask4(vs_cvt4(v), in);
             } else {
                 vs_bf16x4 hi, lo;
                 vs_split4(v, hi, lo);

@@ -42,10 +42,12 @@ def patched(wsel):
 
 
 def vis_one_term(x, w, *a, **k):
-    """visibility CNN (conv2d): layers 2 and 3 run on MFMA with fp16 rings - activations fp16, weights ONE fp16 term; layer 1 (1 -> 16) and
-    the 1x1 output layer are fp32 VALU code"""
+    """visibility CNN (conv2d): layers 1 - 3 run on MFMA - layer 1 (1 -> 16) with the entropy as an fp16 hi + lo pair and ONE fp16 weight term,
+    layers 2 and 3 with fp16 rings (activations fp16) and ONE fp16 weight term; the 1x1 output layer is fp32 VALU code"""
     if w.shape[1] >= 8 and w.shape[-1] == 3:
         return _conv2d(h(x), h(w), *a, **k)
+    if w.shape[1] == 1 and w.shape[-1] == 3:           # layer 1 on the matrix pipe: entropy as an fp16 hi + lo pair (kept exact here), weights ONE fp16 term
+        return _conv2d(x, h(w), *a, **k)
     return _conv2d(x, w, *a, **k)
 
 
