@@ -21,7 +21,8 @@ What is native and what is not, stated plainly:
   source view like the reference's per-view calls) and CostRegNet's 3x3x3 `prob` (``Prob3Train``) are native as well;
 * still PyTorch-ROCm autograd, all of it element-wise or tiny: the visibility CNN's 1x1 Conv2d + sigmoid, CostRegNet3D's 1x1x1 `prob`,
   the softmax / argmax / regression head, the running-statistics momentum update.  There is no second backend in this module: a
-  stage the native kernels do not cover (base_ch != 8, conv_precision "fp32") raises.  The comparator that routes every conv /
+  stage the native kernels do not cover (base_ch != 8) raises; a head configured with conv_precision "fp32" (exact contraction at
+  inference) trains on the fp32-equivalent split-bf16 kernels and says so once.  The comparator that routes every conv /
   BatchNorm layer through PyTorch-ROCm autograd ops lives with the tests (``tests/train_torch_route.py``; on the MI355X image MIOpen
   picks naive kernels for these 3-D and 2-D convolutions: 400 ms per stage-4 step against 11.8 ms natively).
 
@@ -584,6 +585,9 @@ def transformer_forward_torch(reg, x: torch.Tensor, position3d) -> torch.Tensor:
     return reg.prob(_layer_norm_channels(reg.up[0](x), reg.up[1]))
 
 
+_FP32_TRAIN_WARNED = False
+
+
 def stage_forward_train(net, features, proj_matrices, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
     """StageNet.forward with autograd (cost_volume.py:51-133).  See the module docstring for what runs where."""
     from .module import PureTransformerCostReg
@@ -605,7 +609,17 @@ def stage_forward_train(net, features, proj_matrices, depth_values, tmp, positio
     # are per call there, so the views are kept as separate calls here as well
     if G != 8:
         raise NotImplementedError("base_ch=%d: the HIP training kernels are built for 8 groups (all shipped configs)" % G)   # as in inference
-    if getattr(net, "conv_precision", "bf16x3") not in ("bf16x3",) + _lib.F16_FORMATS:    # "f16x2" is an inference storage format: training keeps fp32 activations on the bf16x3 kernels
+    prec = getattr(net, "conv_precision", "bf16x3")
+    if prec == "fp32":
+        # a head configured for exact-fp32 INFERENCE can still be fine-tuned: the training kernels contract in split bf16
+        # (three terms: 1e-6 from fp32) with fp32-MFMA weight gradients and fp32 activations - said once, not refused
+        global _FP32_TRAIN_WARNED
+        if not _FP32_TRAIN_WARNED:
+            import warnings
+            _FP32_TRAIN_WARNED = True
+            warnings.warn("mvsformerplusplus_amd: conv_precision='fp32' selects the exact contraction at inference only; the training path runs "
+                          "the fp32-equivalent split-bf16 kernels (forward / data gradients) and fp32-MFMA weight gradients.", RuntimeWarning, stacklevel=3)
+    elif prec not in ("bf16x3",) + _lib.F16_FORMATS:       # the fp16 formats are inference storage formats: training keeps fp32 activations on the bf16x3 kernels
         raise NotImplementedError("conv_precision=%r: the native training kernels contract in split bf16 (forward and data gradients) "
                                   "and fp32 MFMA (weight gradients)" % net.conv_precision)
     vis = vis_forward_native(net.vis, entropy)                                                    # [B,V-1,H,W]

@@ -1174,6 +1174,30 @@ def case_train_backward_golden(device, tag):
         print("train-backward golden %s: worst relative max-norm error %.2e over %d tensors" % (tag, max(errs), len(errs)))
 
 
+def case_train_fp32_configured_head(device):
+    """A head configured for exact-fp32 INFERENCE (conv_precision="fp32") still trains: the training path runs the same
+    fp32-equivalent split-bf16 kernels as for "bf16x3" - bit-identical loss and gradients - and says so once."""
+    import warnings
+    from mvsformerplusplus_amd import training
+    fx = load_golden("f12_train_backward_s3.npz")
+    D = fx["hyp"].shape[1]
+    grads = {}
+    training._FP32_TRAIN_WARNED = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for prec in ("bf16x3", "fp32"):
+            net = StageNet(with_prec(ARGS, prec), D, int(fx["stage_idx"]))
+            net.load_state_dict(golden_weights(fx), strict=True)
+            net = net.to(device).train()
+            feats = dev(fx["features"], device).requires_grad_(True)
+            out = net(feats, dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
+            ((out["prob_volume"] * dev(fx["R"], device)).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()).backward()
+            grads[prec] = [cpu(feats.grad)] + [cpu(p.grad) for p in net.parameters()]
+    assert sum("conv_precision='fp32'" in str(w.message) for w in rec) == 1, "one warning, from the fp32-configured head"
+    assert all(torch.equal(a, b) for a, b in zip(grads["bf16x3"], grads["fp32"]))
+    training._FP32_TRAIN_WARNED = False
+
+
 def case_train_path_properties(device):
     """Training-path behaviour that needs no golden: eval-mode autograd equals the HIP inference outputs, gradient flows to the
     source AND reference features, and the transformer regulariser refuses to train."""

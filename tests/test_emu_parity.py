@@ -177,3 +177,7 @@ def test_train_backward_transformer_golden(emu):
 
 def test_device_packing(emu):
     P.case_device_packing(emu)
+
+
+def test_train_fp32_configured_head(emu):
+    P.case_train_fp32_configured_head(emu)

@@ -289,3 +289,7 @@ def test_train_backward_transformer_golden():
 
 def test_device_packing():
     P.case_device_packing(DEV)
+
+
+def test_train_fp32_configured_head():
+    P.case_train_fp32_configured_head(DEV)
