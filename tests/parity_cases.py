@@ -1176,7 +1176,7 @@ def case_train_backward_golden(device, tag):
 
 def case_train_fp32_configured_head(device):
     """A head configured for exact-fp32 INFERENCE (conv_precision="fp32") still trains: the training path runs the same
-    fp32-equivalent split-bf16 kernels as for "bf16x3" - bit-identical loss and gradients - and says so once."""
+    fp32-equivalent split-bf16 kernels as for "bf16x3" - the same loss and gradients - and says so once."""
     import warnings
     from mvsformerplusplus_amd import training
     fx = load_golden("f12_train_backward_s3.npz")
@@ -1194,7 +1194,9 @@ def case_train_fp32_configured_head(device):
             ((out["prob_volume"] * dev(fx["R"], device)).sum() + 0.05 * out["prob_volume_pre"].pow(2).mean()).backward()
             grads[prec] = [cpu(feats.grad)] + [cpu(p.grad) for p in net.parameters()]
     assert sum("conv_precision='fp32'" in str(w.message) for w in rec) == 1, "one warning, from the fp32-configured head"
-    assert all(torch.equal(a, b) for a, b in zip(grads["bf16x3"], grads["fp32"]))
+    # the same kernels: equal up to the summation order of the gather backward's atomic scatter (bit-identical on the emulator)
+    for a, b in zip(grads["bf16x3"], grads["fp32"]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12)
     training._FP32_TRAIN_WARNED = False
 
 

@@ -176,8 +176,8 @@ def test_baseline_cfgs_wide_range_vs_oracle(name, prec):
     P.case_baseline_cfg_wide_range(DEV, name, prec)
 
 
-@pytest.mark.parametrize("prec", PRECS_ALL)
-def test_cfg2_fullsize_vs_oracle(prec):
+@pytest.mark.parametrize("prec", PRECS)         # full size: the product default and the fp32-equivalent format (28 s each, most of it the CPU oracle);
+def test_cfg2_fullsize_vs_oracle(prec):         # "f16x2" / "f16" run the same comparison at 384x512 (test_cascade_midsize_vs_oracle)
     """BASELINE configs[1] at full size against the oracle (refined depth within 1e-3 relative L1, every stage too): the north-star bar
     itself, in the product default format (measured ~5e-5) and in the fp32-equivalent one (~1e-6)."""
     r = P.case_cfg2_fullsize_vs_oracle(DEV, conv_precision=prec)
