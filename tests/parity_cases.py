@@ -1226,6 +1226,8 @@ def case_train_path_properties(device):
         net(f32, proj, hyp, 1.0)["prob_volume_pre"].square().mean().backward()
         assert fh.grad.dtype == dt and torch.isfinite(fh.grad).all()
         assert (fh.grad.float() - f32.grad).abs().max() <= 1e-2 * f32.grad.abs().max() + 1e-6, dt
+    if str(device) == "cpu":
+        return            # emulator: the cascade-level check below runs on the MI355X only (CPU suite's time budget; stage-level training: F12 / F13)
     # the 4-stage cascade trains end to end: every stage's parameters and every stage's features receive a gradient
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
     fx = load_golden("f4_cascade.npz")

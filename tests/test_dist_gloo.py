@@ -158,10 +158,11 @@ def test_slab_mode_matches_single_process(precision, tol):
         assert same, "ranks disagree after the slab all-gather"
 
 
-@pytest.mark.parametrize("world,V,mode", [(2, 4, "slab"), (4, 10, "auto")])
+@pytest.mark.parametrize("world,V,mode", [(4, 10, "auto")])
 def test_view_sharded_cascade_matches_single_process(world, V, mode):
-    """The whole 4-stage cascade: 2 ranks / 3 source views with the slab exchange forced on every stage, and the uneven BASELINE
-    configs[2] split - 9 source views over 4 ranks (3 + 2 + 2 + 2) in "auto" mode ((2, 4, "auto") runs inside the two-views test)."""
+    """The whole 4-stage cascade on the uneven BASELINE configs[2] split - 9 source views over 4 ranks (3 + 2 + 2 + 2) in "auto" mode.  (2 ranks
+    with the slab exchange forced on every stage, and 9 views over 8 ranks, run inside the two-views test below, which also compares the
+    sharded result with the single-process one.)"""
     for rank, err, same in _run(_cascade_worker, world, V, mode):
         assert err <= 1e-4, "rank %d: sharded refined depth rel-L1 %g vs the single-process cascade" % (rank, err)
         assert same, "ranks hold different results"
