@@ -17,7 +17,9 @@ statistics (no dataset or checkpoint exists offline).
 
 Arithmetic: warp, correlation, visibility, heads and every accumulation in fp32; the 3-D regularisers in the PRODUCT DEFAULT format
 "f16mix" (module.DEFAULT_PRECISION: fp16 activation tensors; fp16 hi + lo weights = two MFMA terms per product on the 8- / 16-channel
-layers, one fp16 term on conv4..conv7 and in the visibility CNN; fp16 source windows and kept correlations in the gather) - wider than
+layers, one fp16 term on conv4..conv7 and in the visibility CNN; fp16 source windows and kept correlations in the gather;
+`--conv-precision stagemix` runs the coarse stages - D = 32 / 16, whose depth schedules the next stage's hypotheses - in the
+fp32-equivalent format instead: 4x closer to the fp32 oracle for 4 % of the throughput) - wider than
 the bf16 autocast the reference's own GPU path runs these layers under (test.py:250); `--conv-precision bf16x3` selects the
 fp32-equivalent mode of rounds 1-2.  `parity` = this run's refined depth against the fp32 CPU oracle on the same inputs (bar 1e-3).
 
@@ -72,23 +74,6 @@ def build_head(device, shipped=False, conv_precision=None):
         st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 100 + i), strict=True)
         st.return_prob_volumes = True       # reference-faithful outputs (a12): prob_volume / prob_volume_pre are written
     return head.eval().to(device)
-
-
-def mfma_terms(label: str, prec: str) -> int:
-    """MFMA products a kernel issues per algorithmic product: 3 (split bf16), 2 (fp16 hi + lo weights), 1 (one fp16 weight term).  "f16mix"
-    (csrc/conv_kernels.hip mfma_form): one term where min(Cin, Cout) >= 32 or max >= 64 and in the visibility CNN, two elsewhere."""
-    import re
-    if prec in ("bf16x3", "f16x2", "f16"):
-        return {"bf16x3": 3, "f16x2": 2, "f16": 1}[prec]
-    if prec != "f16mix":
-        return 1
-    if label.startswith("vis_cnn"):
-        return 1
-    m = re.match(r"(?:de)?conv3d_mfma<(\d+),(\d+)", label)
-    if m:
-        ci, co = int(m.group(1)), int(m.group(2))
-        return 1 if (min(ci, co) >= 32 or max(ci, co) >= 64) else 2
-    return 2
 
 
 class HeadlineGuard:
@@ -197,7 +182,7 @@ def main():
                     help="N > 1: run ONLY the view-sharded latency mode (SURVEY.md section 8e: the source views of ONE reference view over the ranks, "
                          "RCCL all-reduce / slab exchange per stage, BASELINE configs[2]'s V = 10) and print its JSON line: value = reference views "
                          "per second of the whole group, scaling 'strong'.  For a first RCCL contact without the data-parallel headline in front of it")
-    ap.add_argument("--conv-precision", choices=["bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
+    ap.add_argument("--conv-precision", choices=["stagemix", "bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
                     help="contraction / activation format of the 3-D regularisers (default: the package default, cost_volume.STAGE_DEFAULT_PRECISION)")
     ap.add_argument("--no-keep-correlations", action="store_true",
                     help="A/B: pass 2 of every stage gathers again instead of streaming the fp16 correlations kept by pass 1 (StageNet.keep_correlations)")
@@ -360,7 +345,7 @@ def main():
                                         "really have / the PMC-counted HBM bytes, same views/s, same peak"}
 
     result["config"]["cost_reg_type"] = SHIPPED["cost_reg_type"] if a.cost_reg == "shipped" else ["Normal"] * 4
-    prec0 = head.fusions[0].conv_precision
+    prec0 = head.fusions[0].precision_policy
     result["config"]["conv_precision"] = {
         "bf16x3": "bf16x3 MFMA contraction, fp32 accumulation; fp32-equivalent activations (between the U-Net layers stored as split hi | lo bf16 pairs, "
                   "the same 4 bytes per element)",
@@ -372,8 +357,13 @@ def main():
                   "fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the regulariser under bf16 autocast, "
                   "test.py:250)",
         "f16": "f16: fp16 U-Net activations, ONE fp16 weight term on every layer (depth 7e-5 / 4.8e-4 from the fp32 oracle on plain / stress inputs)",
+        "stagemix": "stagemix (opt-in policy): the coarse stages (ndepth > model_th: CostRegNet, D = 32 / 16 - their depth schedules the next stage's "
+                    "hypotheses) run the fp32-equivalent bf16x3 regulariser and visibility CNN, the CostRegNet3D stages (D = 8 / 4) run f16mix (fp16 "
+                    "activations; fp16 hi + lo weights on the 8- / 16-channel layers, one fp16 term on conv4..conv7 and in the visibility CNN); the gather of "
+                    "every stage keeps fp16 source windows and fp16 per-view correlations; fp32 accumulation everywhere (the reference's GPU path runs the "
+                    "regulariser under bf16 autocast, test.py:250)",
         "fp32": "fp32-exact MFMA contraction"}[prec0]
-    if prec0 in ("f16x2", "f16mix", "f16"):
+    if prec0 in ("f16x2", "f16mix", "f16", "stagemix"):
         result["dtype"] = "f32 (fp16 storage of the regulariser's activations)"
         result["config"]["gather_pass2"] = ("second gather on every stage (--no-keep-correlations)" if a.no_keep_correlations else
                                             "stages with D > 4: stream of the fp16 per-view correlations kept by pass 1; D <= 4: second gather")
@@ -391,17 +381,17 @@ def main():
         mfma = dom_name.startswith("conv3d") or dom_name.startswith("deconv3d") or dom_name.startswith("vis_cnn")
         per_launch = dom["flops" if mfma else "bytes"] / dom["calls"]
         achieved = (dom["tflops"] if mfma else dom["gbs"])
-        prec = head.fusions[0].conv_precision
-        terms = mfma_terms(dom_name, prec)
+        prec = head.fusions[0].precision_policy          # "stagemix" (default): bf16x3 on the coarse stages, f16mix on the fine ones
+        terms = dom["issued_flops"] / max(dom["flops"], 1e-12) if mfma else 1      # MFMA products issued per algorithmic product, launch-weighted
         if not mfma:
             peak, note = profiling.PEAK_HBM_GBS, ("algorithmic HBM bytes per launch (SURVEY.md section 8d: every feature map once + hypotheses once + "
                                                   "outputs once, at the tensors' real element sizes) / HIP-event launch time on the launch stream")
-        elif prec in ("bf16x3", "f16x2", "f16mix", "f16"):
+        elif prec != "fp32":
             # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak 2.5 PFLOP/s.  `frac` is against THAT peak (the guide's); the contraction issues
             # `terms` MFMA products per algorithmic product, an implementation choice reported separately as frac_of_issued_mfma
             peak, note = profiling.PEAK_F16_MFMA_TFLOPS, ("algorithmic FLOPs (2 x MACs of the operator) / HIP-event launch time vs the dense %s MFMA peak of "
-                                                         "MI355X_MICROARCH.md; the kernel issues %d MFMA term(s) per algorithmic product" %
-                                                         ("bf16" if prec == "bf16x3" else "fp16", terms))
+                                                         "MI355X_MICROARCH.md; the kernel issues %.2f MFMA term(s) per algorithmic product (over its launches)" %
+                                                         ("bf16" if prec == "bf16x3" else "fp16 / bf16", terms))
         else:
             peak, note = profiling.PEAK_F32_MFMA_TFLOPS, "fp32-exact contraction on v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense peak)"
         traffic, tsrc = None, None
@@ -442,7 +432,7 @@ def main():
                 work = sum(v["flops"] for v in ks.values()) / reps
                 ach = work / ms / 1e9                            # TFLOP/s
                 fp = fam_prec or prec
-                issued = sum(v["flops"] * mfma_terms(k, fp) for k, v in ks.items()) / reps / ms / 1e9      # TFLOP/s of MFMA products actually issued
+                issued = sum(v["issued_flops"] for v in ks.values()) / reps / ms / 1e9                       # TFLOP/s of MFMA products actually issued
                 pk = profiling.PEAK_F32_MFMA_TFLOPS if fp == "fp32" else profiling.PEAK_F16_MFMA_TFLOPS
                 return {"ms_per_ref_view": ms, "bound": "mfma", "algorithmic_gflop_per_ref_view": work / 1e9, "achieved_tflops": ach, "peak_tflops": pk,
                         "frac": ach / pk, "mfma_terms_per_product": issued / max(ach, 1e-12), "frac_of_issued_mfma": issued / pk,
@@ -525,7 +515,7 @@ def main():
 
     # ---- extra: the fp32-equivalent regulariser format ("bf16x3") on the same weights, inputs and loop, outside the timed headline: the
     #      driver's own BENCH line then carries both modes (the headline runs the product default, "f16mix") ----
-    if world == 1 and not a.no_profile and a.cost_reg != "shipped" and head.fusions[0].conv_precision in ("f16x2", "f16mix", "f16") and not a.graph:
+    if world == 1 and not a.no_profile and a.cost_reg != "shipped" and head.fusions[0].precision_policy in ("f16x2", "f16mix", "f16", "stagemix") and not a.graph:
         try:
             head32 = build_head(device, conv_precision="bf16x3")
             n2 = max(2, a.steps // 4)

@@ -115,14 +115,14 @@ int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int layout, const
  * cost_volume.py:74-101 with the [B,G,D,H,W] per-view correlation the reference materialises kept as fp16 [B,V-1,D,H,W,8]
  * (clamped to the fp16 range; mvs_f16_saturation_count) instead of warping twice.  mvs_warp_corr_entropy_keep_fwd = the entropy
  * pass over ALL source views + `corr_f16`; mvs_corr_aggregate_fwd = sum_v vis_v * corr_v / (sum_v vis_v + 1e-6) -> the normalised
- * fp16 volume [B,D,H,W,8] of MVS_VOLUME_F16.  Built where mvs_gather_keeps_correlations() returns 1 (the LDS-staged gather's
+ * volume [B,D,H,W,8] in `volume_format` (MVS_VOLUME_F16 / _SPLIT / _F32: the regulariser's format is independent of the gather's).  Built where mvs_gather_keeps_correlations() returns 1 (the LDS-staged gather's
  * shapes with D > 4); MVS_ERR_UNSUPPORTED elsewhere - the two-gather pair above covers every shape.                           */
 int mvs_gather_keeps_correlations(int layout, int C, int G, int D, int H, int W);
 int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, int layout, const float* homography /*[B,V-1,12]*/,
                                    const float* hyp, float* entropy, void* corr_f16, int B, int V, int C, int G, int D, int H,
                                    int W, void* stream);
-int mvs_corr_aggregate_fwd(const void* corr_f16, const float* vis /*[B,V-1,H,W]*/, void* volume_f16, int B, int V, int D, int H,
-                           int W, void* stream);
+int mvs_corr_aggregate_fwd(const void* corr_f16, const float* vis /*[B,V-1,H,W]*/, void* volume_cl, int volume_format, int B, int V,
+                           int D, int H, int W, void* stream);
 
 /* ---- section 8f #4: feature hand-off -------------------------------------------------------------------
  * features [N,C,H,W] (dtype) -> tiled [N,C/8,H,W,8] (out_dtype); C % 8 == 0.  fp32 / bf16 / fp16 in, any of them out except

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops, packing
-from .module import (DEFAULT_PRECISION, F16_FORMATS, MFMA_FORMATS, ConvBnReLU, CostRegNet, CostRegNet3D, PureTransformerCostReg, _bn_dict, _no_grad_path,
+from .module import (DEFAULT_PRECISION, DEFAULT_STAGE_POLICY, resolve_stage_precision, F16_FORMATS, MFMA_FORMATS, ConvBnReLU, CostRegNet, CostRegNet3D, PureTransformerCostReg, _bn_dict, _no_grad_path,
                      _PackedCache, precision_code)
 
 
@@ -39,7 +39,7 @@ def shard_views(n_src: int, world: int, rank: int):
 # oracle: ~6e-5 relative L1 on plain inputs, 4e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers
 # under bf16 autocast (test.py:250).  "bf16x3" = fp32-equivalent activations (split bf16 pairs, three terms; 1e-6 from the oracle),
 # "fp32" = exact.  args["conv_precision"] overrides it per head.  Training always runs the bf16x3 kernels on fp32 activations.
-STAGE_DEFAULT_PRECISION = DEFAULT_PRECISION      # one constant (module.DEFAULT_PRECISION): "f16mix"
+STAGE_DEFAULT_PRECISION = DEFAULT_STAGE_POLICY   # = module.DEFAULT_PRECISION ("f16mix") on every stage; "stagemix" (module.py) is the opt-in policy
 
 
 _F16_CALLS = 0
@@ -78,7 +78,7 @@ def check_hypothesis_conditioning(hyp: torch.Tensor, warn: bool = True) -> float
         _HYP_WARNED = True
         warnings.warn("mvsformerplusplus_amd: %.1f %% of the depth hypotheses of a stage are non-finite or non-positive - the inverse-depth "
                       "schedule crossed zero (depth range too wide for the number of planes).  Depth there is meaningless and ill-conditioned "
-                      "around it; the fp16 regulariser formats lose accuracy on such inputs (build the stages with conv_precision='bf16x3')."
+                      "around it; the fp16 regulariser formats lose accuracy on such inputs (build the stages with conv_precision='bf16x3', or 'stagemix')."
                       % (100.0 * bad), RuntimeWarning, stacklevel=2)
     return bad
 
@@ -118,8 +118,21 @@ class StageNet(nn.Module):
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
         # contraction of every MFMA convolution of the stage: "bf16x3" (3-term split bf16, ~2^-16 relative) or "fp32"
         # or "f16x2" (fp16 activations + fp16 hi / lo weights, 2 terms: 4e-4 from the oracle on the stress set, 1.3x faster)
-        self.conv_precision = args.get("conv_precision", STAGE_DEFAULT_PRECISION)
+        # args["conv_precision"]: a policy ("stagemix", the default) or one format for every stage; resolved per stage here - conv_precision
+        # is always a concrete format ("bf16x3" | "f16mix" | ...), gather_precision "f16" (fp16 windows + kept correlations) or "f32"
+        self.conv_precision = args.get("conv_precision", STAGE_DEFAULT_PRECISION)        # property: resolves the policy for this stage
         self._vis_cache = _PackedCache()
+
+    @property
+    def conv_precision(self) -> str:
+        """The stage's concrete regulariser / visibility-CNN format.  Assigning a policy ("stagemix") or a format re-resolves
+        `precision_policy`, `conv_precision` and `gather_precision` for this stage (module.resolve_stage_precision)."""
+        return self._conv_precision
+
+    @conv_precision.setter
+    def conv_precision(self, policy: str) -> None:
+        self.precision_policy = policy
+        self._conv_precision, self.gather_precision = resolve_stage_precision(policy, self.ndepth, self.args.get("model_th", 8))
 
     # ---- packed parameters ----
     def _vis_params(self, device):
@@ -153,7 +166,7 @@ class StageNet(nn.Module):
         """Pass 2 as a stream over fp16 correlations kept by pass 1 (ops.warp_corr_entropy_keep / corr_aggregate) instead of a second
         gather: `keep_correlations` True / "auto" (default) where the library builds it (LDS-staged shapes, D > 4) and the kept tensor
         fits KEEP_CORRELATIONS_MAX_BYTES; False = always gather twice."""
-        if not self.keep_correlations:
+        if not self.keep_correlations or self.gather_precision != "f16":
             return False
         B, V, _, H, W = feats.shape
         if (V - 1) * B * hyp.shape[1] * H * W * 16 > KEEP_CORRELATIONS_MAX_BYTES:
@@ -205,12 +218,13 @@ class StageNet(nn.Module):
         else:
             split = self._split_activations()
             f16 = self._f16_activations()
-            if f16 and self._keeps_correlations(feats, G, hyp):
-                # fp16 volume formats, D >= 8: pass 1 keeps the per-view group correlations as fp16 (16 B per voxel and view) and pass 2
-                # streams them - cheaper than the second gather, which is bound by window staging and LDS reads
+            if self._keeps_correlations(feats, G, hyp):
+                # fp16 gather forms, D >= 8: pass 1 keeps the per-view group correlations as fp16 (16 B per voxel and view) and pass 2
+                # streams them - cheaper than the second gather, which is bound by window staging and LDS reads.  The
+                # volume comes out in the regulariser's own format (fp16 / split bf16 / fp32), whatever the gather keeps
                 entropy, corr = ops.warp_corr_entropy_keep(feats, code, hom, hyp, G)
                 vis = ops.vis_weight(entropy, vis_params, prec)
-                volume = ops.corr_aggregate(corr, vis)
+                volume = ops.corr_aggregate(corr, vis, split=split, f16=f16)
                 del corr
             else:
                 # pass 1 -> visibility CNN -> pass 2 gathers again and writes the cost volume once (no per-view intermediate in HBM)

@@ -10,8 +10,11 @@ namespace mvs {
 // grid = (ceil(HW / 256), ceil(D / 4), B); a thread owns one pixel and four planes (a view's visibility weight is loaded
 // once for the four), 16-byte loads and stores.
 // ------------------------------------------------------------------------------------------------
+// FMT: the volume's format - MVS_VOLUME_F16 (fp16 octet, 16 B per voxel), MVS_VOLUME_SPLIT ([hi x8 | lo x8] bf16 of the bf16x3 U-Net, 32 B) or
+// MVS_VOLUME_F32 (32 B): the kept correlations are fp16 in every case - the stage's REGULARISER format is independent of the gather's
+template <int FMT>
 __global__ __launch_bounds__(256) void corr_aggregate_kernel(const _Float16* __restrict__ corr, const float* __restrict__ vis,
-                                                             _Float16* __restrict__ vol, int NV, int D, unsigned HW) {
+                                                             void* __restrict__ vol, int NV, int D, unsigned HW) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const unsigned p = blockIdx.x * 256u + threadIdx.x;
     if (p >= HW) return;
@@ -39,19 +42,40 @@ __global__ __launch_bounds__(256) void corr_aggregate_kernel(const _Float16* __r
     }
     const float rdenom = 1.0f / (vsum + 1e-6f);                                                      // cost_volume.py:101
     float sat_amax = 0.0f;
-    h8* op = reinterpret_cast<h8*>(vol) + (size_t)b * D * HW + p;
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd) {
         if (d0 + dd >= D) continue;
-        h8 hv;
         float r[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) { r[g] = acc[dd][g] * rdenom; hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f); }
-        sat::track(sat_amax, r[0], r[1], r[2], r[3]);
-        sat::track(sat_amax, r[4], r[5], r[6], r[7]);
-        op[(size_t)(unsigned)(d0 + dd) * HW] = hv;
+        for (int g = 0; g < 8; ++g) r[g] = acc[dd][g] * rdenom;
+        const size_t vox = (size_t)b * D * HW + (size_t)(unsigned)(d0 + dd) * HW + p;
+        if constexpr (FMT == MVS_VOLUME_F16) {
+            h8 hv;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f);
+            sat::track(sat_amax, r[0], r[1], r[2], r[3]);
+            sat::track(sat_amax, r[4], r[5], r[6], r[7]);
+            reinterpret_cast<h8*>(vol)[vox] = hv;
+        } else {
+            f32x4* o = reinterpret_cast<f32x4*>(vol) + vox * 2;
+            if constexpr (FMT == MVS_VOLUME_SPLIT) {             // [hi x8 | lo x8] bf16: the same 32 bytes (conv_bf16x3_kernels.hip)
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint16_t h0 = from_f32<uint16_t>(r[2 * j]), h1 = from_f32<uint16_t>(r[2 * j + 1]);
+                    const uint16_t l0 = from_f32<uint16_t>(r[2 * j] - to_f32(h0)), l1 = from_f32<uint16_t>(r[2 * j + 1] - to_f32(h1));
+                    hw[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    lw[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+                o[0] = f32x4{__builtin_bit_cast(float, hw[0]), __builtin_bit_cast(float, hw[1]), __builtin_bit_cast(float, hw[2]), __builtin_bit_cast(float, hw[3])};
+                o[1] = f32x4{__builtin_bit_cast(float, lw[0]), __builtin_bit_cast(float, lw[1]), __builtin_bit_cast(float, lw[2]), __builtin_bit_cast(float, lw[3])};
+            } else {
+                o[0] = f32x4{r[0], r[1], r[2], r[3]};
+                o[1] = f32x4{r[4], r[5], r[6], r[7]};
+            }
+        }
     }
-    sat::commit(sat_amax);
+    if constexpr (FMT == MVS_VOLUME_F16) sat::commit(sat_amax);
 }
 
 // KEEP form: the launcher with NS = 1 (D <= 4) is not instantiated - the streaming pass 2 never pays there (gl_keep_supported)
@@ -71,10 +95,15 @@ int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float*
     GL_DISPATCH(gl_launch_entropy_keep_t, feat, hom, hyp, ent, static_cast<_Float16*>(corr), B, V, D, H, W, st);
 }
 
-int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int B, int V, int D, int H, int W, hipStream_t st) {
+int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W, hipStream_t st) {
     const unsigned HW = (unsigned)H * (unsigned)W;
-    hipLaunchKernelGGL(corr_aggregate_kernel, dim3(ceil_div(HW, 256), ceil_div(D, 4), B), dim3(256), 0, st, static_cast<const _Float16*>(corr), vis,
-                       static_cast<_Float16*>(vol), V - 1, D, HW);
+    const dim3 grid(ceil_div(HW, 256), ceil_div(D, 4), B);
+    const _Float16* c = static_cast<const _Float16*>(corr);
+    switch (volume_format) {
+        case MVS_VOLUME_F16: hipLaunchKernelGGL(corr_aggregate_kernel<MVS_VOLUME_F16>, grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
+        case MVS_VOLUME_SPLIT: hipLaunchKernelGGL(corr_aggregate_kernel<MVS_VOLUME_SPLIT>, grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
+        default: hipLaunchKernelGGL(corr_aggregate_kernel<MVS_VOLUME_F32>, grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
+    }
     return check_launch("corr_aggregate_kernel");
 }
 

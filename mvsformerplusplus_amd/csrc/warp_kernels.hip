@@ -579,7 +579,7 @@ int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* ho
 bool gl_keep_supported(int C, int G, int D, int H, int W);
 int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C, int D,
                            int H, int W, hipStream_t st);
-int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int B, int V, int D, int H, int W, hipStream_t st);
+int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W, hipStream_t st);
 int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W, hipStream_t st);
 
 // MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels (A/B measurements); anything else = LDS-staged where supported.
@@ -683,10 +683,12 @@ extern "C" int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, i
     return gl_launch_entropy_keep(features, dtype, layout, homography, hyp, entropy, corr_f16, B, V, C, D, H, W, (hipStream_t)stream);
 }
 
-extern "C" int mvs_corr_aggregate_fwd(const void* corr_f16, const float* vis, void* volume_f16, int B, int V, int D, int H, int W, void* stream) {
-    if (!corr_f16 || !vis || !volume_f16) { set_error("mvs_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
+extern "C" int mvs_corr_aggregate_fwd(const void* corr_f16, const float* vis, void* volume_cl, int volume_format, int B, int V, int D, int H, int W,
+                                      void* stream) {
+    if (!corr_f16 || !vis || !volume_cl) { set_error("mvs_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
     if (B < 1 || V < 2 || D < 1 || H < 1 || W < 1 || (long long)D * H * W > 0x7fffffffLL) { set_error("mvs_corr_aggregate_fwd: bad shape"); return MVS_ERR_ARG; }
-    return launch_corr_aggregate(corr_f16, vis, volume_f16, B, V, D, H, W, (hipStream_t)stream);
+    if (volume_format != MVS_VOLUME_F32 && volume_format != MVS_VOLUME_SPLIT && volume_format != MVS_VOLUME_F16) { set_error("mvs_corr_aggregate_fwd: unknown volume format %d", volume_format); return MVS_ERR_ARG; }
+    return launch_corr_aggregate(corr_f16, vis, volume_cl, volume_format, B, V, D, H, W, (hipStream_t)stream);
 }
 
 extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, const float* vis,

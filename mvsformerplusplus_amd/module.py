@@ -43,6 +43,25 @@ DEFAULT_PRECISION = "f16mix"
 # 5.5e-5 / 4.2e-4 for "f16x2", scripts/study_weight_precision.py).  All three store fp16 activations and share the packed weights.
 F16_FORMATS = _lib.F16_FORMATS
 MFMA_FORMATS = ("bf16x3",) + F16_FORMATS
+# Round 4, late: args["conv_precision"] of a STAGE is a policy.  Besides one format for every stage there is "stagemix": the stages
+# regularised by CostRegNet / the transformer (ndepth > model_th: the coarse stages, whose depth schedules the next stage's hypotheses -
+# their noise is what the cascade amplifies) run the fp32-equivalent "bf16x3" regulariser and visibility CNN, the CostRegNet3D stages
+# (the large ones) run DEFAULT_PRECISION, the gather of EVERY stage keeps its fp16 storage forms (fp16 source windows, per-view
+# correlations kept as fp16).  Refined depth vs the fp32 oracle: 1.5e-5 plain / 1.0e-4 on the x30-logits stress set against 6e-5 / 4.8e-4
+# with DEFAULT_PRECISION on every stage (scripts/study_stage_mix.py, profiles/r04_stage_mix_study.txt), for 4.4 % of the throughput
+# (614 vs 642 ref-views/s on one box).  The DEFAULT stays the faster one - both are inside the 1e-3 bar with room; "stagemix" is the
+# choice for wide hypothesis ranges ("Degenerate hypothesis ranges").
+DEFAULT_STAGE_POLICY = DEFAULT_PRECISION
+
+
+def resolve_stage_precision(policy: str, ndepth: int, model_th: int = 8):
+    """(conv_precision, gather_precision) of a stage under `policy` = args["conv_precision"]: "stagemix" (above) or one format for every
+    stage - an fp16 format keeps the fp16 gather forms, "bf16x3" / "fp32" gather with fp32 windows and no kept correlations."""
+    if policy == "stagemix":
+        return ("bf16x3" if ndepth > model_th else DEFAULT_PRECISION), "f16"
+    if policy in F16_FORMATS:
+        return policy, "f16"
+    return policy, "f32"
 
 
 def _to_act(x_cl: torch.Tensor, precision: str) -> torch.Tensor:

@@ -232,14 +232,17 @@ def warp_corr_entropy_keep(features, code: int, homography: torch.Tensor, hyp: t
     return ent, corr
 
 
-def corr_aggregate(corr: torch.Tensor, vis: torch.Tensor) -> torch.Tensor:
-    """corr [B,V-1,D,H,W,8] fp16, vis [B,V-1,H,W] fp32 -> the normalised fp16 cost volume [B,D,H,W,8] (cost_volume.py:97-101)."""
+def corr_aggregate(corr: torch.Tensor, vis: torch.Tensor, split: bool = False, f16: bool = True) -> torch.Tensor:
+    """corr [B,V-1,D,H,W,8] fp16, vis [B,V-1,H,W] fp32 -> the normalised cost volume [B,D,H,W,8] (cost_volume.py:97-101): fp16 (f16, the
+    fp16 U-Nets' format), the split activation format of the bf16x3 U-Net (split) or fp32 (neither; the transformer regulariser)."""
     assert corr.dtype == torch.float16 and corr.is_contiguous() and corr.dim() == 6 and corr.shape[-1] == 8
     B, NV, D, H, W, _ = corr.shape
     v = _f32c(vis)
     assert v.shape == (B, NV, H, W)
-    vol = torch.empty(B, D, H, W, 8, dtype=torch.float16, device=corr.device)
-    check(lib().mvs_corr_aggregate_fwd(ptr(corr), ptr(v), ptr(vol), B, NV + 1, D, H, W, stream_of(corr)), "mvs_corr_aggregate_fwd")
+    f16 = f16 and not split
+    vol = torch.empty(B, D, H, W, 8, dtype=torch.float16 if f16 else torch.float32, device=corr.device)
+    fmt = _lib.VOLUME_F16 if f16 else (_lib.VOLUME_SPLIT if split else _lib.VOLUME_F32)
+    check(lib().mvs_corr_aggregate_fwd(ptr(corr), ptr(v), ptr(vol), fmt, B, NV + 1, D, H, W, stream_of(corr)), "mvs_corr_aggregate_fwd")
     return vol
 
 

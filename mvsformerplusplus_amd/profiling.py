@@ -66,10 +66,31 @@ def match_kernel(label: str, table: dict):
     return max(cands, key=lambda k: table[k].get("launches_sampled", 0))
 
 
+def mfma_terms(label: str, prec: str) -> int:
+    """MFMA products a kernel issues per algorithmic product: 3 (split bf16), 2 (fp16 hi + lo weights), 1 (one fp16 weight term).  "f16mix"
+    (csrc/conv_kernels.hip mfma_form): one term where min(Cin, Cout) >= 32 or max >= 64 and in the visibility CNN, two elsewhere."""
+    import re
+    if prec in ("bf16x3", "f16x2", "f16"):
+        return {"bf16x3": 3, "f16x2": 2, "f16": 1}[prec]
+    if prec != "f16mix":
+        return 1
+    if label.startswith("vis_cnn"):
+        return 1
+    m = re.match(r"(?:de)?conv3d_mfma<(\d+),(\d+)", label)
+    if m:
+        ci, co = int(m.group(1)), int(m.group(2))
+        return 1 if (min(ci, co) >= 32 or max(ci, co) >= 64) else 2
+    return 2
+
+
+_CUR_PREC = [None]           # conv_precision of the stage profile_cascade is timing (stages differ under the "stagemix" policy)
+
+
 class Launch:
-    __slots__ = ("kernel", "stage", "flops", "bytes", "start", "end", "ms")
+    __slots__ = ("kernel", "stage", "flops", "bytes", "start", "end", "ms", "prec")
 
     def __init__(self, kernel, stage, flops, nbytes):
+        self.prec = _CUR_PREC[0]
         self.kernel, self.stage, self.flops, self.bytes = kernel, stage, float(flops), float(nbytes)
         self.start = torch.cuda.Event(enable_timing=True)
         self.end = torch.cuda.Event(enable_timing=True)
@@ -185,6 +206,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
     for s in range(n):
         key = "stage%d" % (s + 1)
         net = head.fusions[s]
+        _CUR_PREC[0] = net.conv_precision
         feats, code = ops._feat(features[key])
         proj = proj_matrices[key]
         B, V, C, H, W = feats.shape
@@ -202,7 +224,7 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
         # every feature map once, the hypotheses once, the entropy maps out
         tiled = isinstance(feats, ops.PackedFeatures)
-        keep = net._f16_activations() and net._keeps_correlations(feats, 8, hyp)       # exactly StageNet.forward's choice
+        keep = net._keeps_correlations(feats, 8, hyp)                                   # exactly StageNet.forward's choice
         corr_bytes = B * (V - 1) * D * HW * 16.0                                        # fp16 per-view group correlations (as-built traffic)
         if keep:
             ent, corr = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, True), s, corr_flops,
@@ -232,8 +254,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         f16 = net._f16_activations()
         agg_name = gather_kernel_name("aggregate", code, C, D, W, tiled, w16=f16 and ops.gather_is_lds_staged(feats, 8, hyp))
         if keep:
-            vol = _timed(launches, "corr_aggregate_kernel", s, 2.0 * B * (V - 1) * D * HW * 8, corr_bytes + B * ((V - 1) * HW * 4 + 8 * D * HW * 2),
-                         lambda: ops.corr_aggregate(corr, vis))
+            vol = _timed(launches, "corr_aggregate_kernel", s, 2.0 * B * (V - 1) * D * HW * 8, corr_bytes + B * ((V - 1) * HW * 4 + 8 * D * HW * (2 if f16 else 4)),
+                         lambda: ops.corr_aggregate(corr, vis, split=split, f16=f16))
             del corr
         elif f16 and not ops.gather_is_lds_staged(feats, 8, hyp):
             # shapes outside the LDS-staged gather: fp32 volume + conversion, exactly as StageNet.forward does
@@ -291,11 +313,12 @@ def summarize(launches: Sequence[Launch]) -> "OrderedDict[str, dict]":
     """Aggregate by kernel name: calls, total ms, average ms, achieved GB/s and TFLOP/s."""
     agg: "OrderedDict[str, dict]" = OrderedDict()
     for l in launches:
-        a = agg.setdefault(l.kernel, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        a = agg.setdefault(l.kernel, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "issued_flops": 0.0})
         a["calls"] += 1
         a["ms"] += l.ms
         a["flops"] += l.flops
         a["bytes"] += l.bytes
+        a["issued_flops"] += l.flops * (mfma_terms(l.kernel, l.prec) if l.prec else 1)       # MFMA products actually issued (terms per product)
     for a in agg.values():
         t = max(a["ms"], 1e-9) * 1e-3
         a["avg_ms"] = a["ms"] / a["calls"]

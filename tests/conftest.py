@@ -18,7 +18,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 from mvsformerplusplus_amd import cost_volume as _cv  # noqa: E402
 PRODUCT_DEFAULT_PRECISION = _cv.STAGE_DEFAULT_PRECISION
 PRECS = [None, "bf16x3"]
-PRECS_ALL = [None, "bf16x3", "f16x2", "f16"]       # + the two other fp16 formats: both weight terms everywhere / one term everywhere
+PRECS_ALL = [None, "bf16x3", "stagemix", "f16x2", "f16"]   # + the per-stage policy (bf16x3 coarse / f16mix fine) and the two other fp16 formats
 
 
 def pytest_configure(config):

@@ -26,8 +26,14 @@ def eff(prec):
     return prec or PRODUCT_DEFAULT_PRECISION
 
 
+def is_f16(prec):
+    """Does `prec` (None = the product default) store any regulariser activations as fp16?  The default policy "stagemix" does on the fine
+    stages (the coarse ones run bf16x3): it is held to the fp16 bounds, which the all-fp16 formats meet too."""
+    return eff(prec) in _lib.F16_FORMATS + ("stagemix",)
+
+
 def tol(prec, exact, f16):
-    return f16 if eff(prec) in _lib.F16_FORMATS else exact
+    return f16 if is_f16(prec) else exact
 
 
 def with_prec(args, prec):
@@ -77,7 +83,7 @@ def case_regnet_golden(device, name, prec=None):
     net = _load_regnet(net, sd, device)
     if prec:
         net.conv_precision = prec
-    assert net.conv_precision == eff(prec)
+    assert net.conv_precision == (prec or M.DEFAULT_PRECISION)          # a bare regulariser module: the layer-level default ("f16mix")
     with torch.no_grad():
         y = cpu(net(dev(fx["x"], device)))
     assert y.shape == fx["y"].shape
@@ -173,7 +179,7 @@ def case_stage_golden(device, tag, prec=None):
     fx = load_golden("f2_stage_%s.npz" % tag)
     D = fx["hyp"].shape[1]
     net = make_stage(fx, D, int(fx["stage_idx"]), device, prec=prec)
-    assert net.conv_precision == eff(prec)
+    assert net.precision_policy == eff(prec) and net.conv_precision == M.resolve_stage_precision(eff(prec), D)[0]
     with torch.no_grad():
         out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), float(fx["tmp"]))
     assert set(out) == {"depth", "prob_volume", "photometric_confidence", "depth_values", "prob_volume_pre"}
@@ -409,6 +415,11 @@ def case_gather_variants(device, quick=False):
                 assert (expect16 - expect).abs().max() <= 1e-3 * scale, (C, D, "effect of the rounded source features")
                 vol_k = cpu(ops.corr_aggregate(corr, dev(vis, device))).float().permute(0, 4, 1, 2, 3)
                 assert (vol_k - expect16).abs().max() <= 1.2e-3 * scale, (C, D, "streamed volume")                           # two fp16 roundings
+                # ... and in the other regulariser formats (a bf16x3 / transformer stage under the "stagemix" policy): fp32 and split bf16
+                vol_f = cpu(ops.corr_aggregate(corr, dev(vis, device), f16=False)).permute(0, 4, 1, 2, 3)
+                assert vol_f.dtype == torch.float32 and (vol_f - expect16).abs().max() <= 6e-4 * scale, (C, D, "streamed volume, fp32 out")
+                vol_s = cpu(ops.from_split(ops.corr_aggregate(corr, dev(vis, device), split=True))).permute(0, 4, 1, 2, 3)
+                assert (vol_s - vol_f).abs().max() <= 2e-5 * scale, (C, D, "streamed volume, split out")
                 vol16 = cpu(ops.warp_corr_aggregate(fk, ops._feat(fk)[1], hom, hd, dev(vis, device), G, f16=True)[0]).float().permute(0, 4, 1, 2, 3)
                 assert (vol_k - vol16).abs().max() <= 1.2e-3 * scale, (C, D, "streamed vs gathered fp16 volume")
         else:
@@ -770,7 +781,7 @@ def case_cascade_vs_oracle_finite(device, H, W, V, conv_precision=None, **inputs
     d, r = cpu(out["refined_depth"]), ref["refined_depth"]
     err = ((d - r).abs() / r.abs())[ok]
     rel = float(err.mean())
-    if eff(conv_precision) in _lib.F16_FORMATS:
+    if is_f16(conv_precision):
         # The pixels next to the degenerate ones are ill-conditioned (hypotheses of 40 scene units beside a true depth of 8: a 1e-4
         # probability difference moves the regressed depth by 5e-4): the fp32-equivalent format's 1e-6 noise becomes 2e-4 here, the fp16
         # formats' 6e-5 becomes 3-5e-3 on the mean (median 8e-4).  Asserted as measured, documented in DESIGN.md section 5 and warned
@@ -838,7 +849,7 @@ def case_baseline_cfg1(device, prec=None):
     from mvsformerplusplus_amd.cost_volume import StageNet
     H, W, V, D = 512, 640, 3, 48
     st = StageNet(with_prec(ARGS, prec), D, 3)
-    assert st.conv_precision == eff(prec)
+    assert st.precision_policy == eff(prec)
     st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 5), strict=True)
     st = st.eval().to(device)
     cams = synth.make_cameras(V, H, W, baseline=20.0, seed=0)
@@ -946,13 +957,13 @@ def case_cascade_shipped_golden(device, conv_precision=None, attention_precision
     args = dict(ARGS, ndepths=[32, 16, 8, 4], depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], inverse_depth=True, use_pe3d=True,
                 cost_reg_type=["PureTransformerCostReg", "Normal", "Normal", "Normal"], transformer_config=[tc])
     args = with_prec(args, conv_precision)
-    exact = eff(conv_precision) not in _lib.F16_FORMATS and attention_precision == "bf16x3"
+    exact = not is_f16(conv_precision) and attention_precision == "bf16x3"
     dt = 1e-4 if exact else 3e-4
     head = CascadeDepthHead(args)
     for s, stn in enumerate(head.fusions):
         stn.load_state_dict(golden_weights(fx, "w%d." % (s + 1)), strict=True)
     head = head.eval().to(device)
-    assert head.fusions[1].conv_precision == eff(conv_precision) and head.fusions[0].cost_reg.attention_precision == (attention_precision or "attn16")
+    assert head.fusions[1].precision_policy == eff(conv_precision) and head.fusions[0].cost_reg.attention_precision == (attention_precision or "attn16")
     feats = {"stage%d" % s: dev(f4["features%d" % s], device) for s in range(1, 5)}
     projs = {"stage%d" % s: dev(f4["proj%d" % s], device) for s in range(1, 5)}
     with torch.no_grad():

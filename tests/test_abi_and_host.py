@@ -19,21 +19,34 @@ def header_symbols():
 
 
 def test_product_default_precision():
-    """The product's default regulariser format is "f16mix" (fp16 activations, the second weight term only on the 8/16-channel layers) - ONE constant for stages, standalone regularisers and layer wrappers, and
-    the test session does not override it; an explicit conv_precision wins; training accepts an f16x2 stage (it runs the bf16x3 kernels
-    on fp32 activations)."""
+    """The product default is ONE constant: "f16mix" (fp16 activations, the second weight term only on the 8 / 16-channel layers) for
+    stages, standalone regularisers and layer wrappers; the test session does not override it; an explicit conv_precision puts every stage
+    on that format.  args["conv_precision"] may also be the POLICY "stagemix": the coarse stages (ndepth > model_th, whose depth schedules
+    the next stage's hypotheses) on the fp32-equivalent "bf16x3" regulariser, the CostRegNet3D stages on "f16mix", the fp16 gather forms on
+    every stage.  Assigning conv_precision later re-resolves the stage."""
     import conftest
     from mvsformerplusplus_amd import cost_volume, module
     from mvsformerplusplus_amd.cost_volume import StageNet
-    assert conftest.PRODUCT_DEFAULT_PRECISION == cost_volume.STAGE_DEFAULT_PRECISION == module.DEFAULT_PRECISION == "f16mix"
-    assert StageNet({"base_ch": 8, "depth_type": "ce"}, 4, 3).conv_precision == "f16mix"
+    assert conftest.PRODUCT_DEFAULT_PRECISION == cost_volume.STAGE_DEFAULT_PRECISION == module.DEFAULT_STAGE_POLICY == module.DEFAULT_PRECISION == "f16mix"
     assert module.CostRegNet3D(8, 8).conv_precision == "f16mix"
+    args = {"base_ch": 8, "depth_type": "ce"}
+    for nd, si in ((32, 0), (4, 3)):
+        n = StageNet(dict(args), nd, si)
+        assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("f16mix", "f16mix", "f16") and n._f16_activations()
+    for nd, si, want in ((32, 0, "bf16x3"), (16, 1, "bf16x3"), (8, 2, "f16mix"), (4, 3, "f16mix")):
+        n = StageNet(dict(args, conv_precision="stagemix"), nd, si)
+        assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("stagemix", want, "f16"), (nd, n.conv_precision)
+        assert n._f16_activations() == (want == "f16mix") and n._split_activations() == (want == "bf16x3")
+    assert StageNet(dict(args, model_th=16, conv_precision="stagemix"), 16, 1).conv_precision == "f16mix"      # model_th moves the CostRegNet3D boundary
     for fmt in ("f16mix", "f16", "f16x2"):
-        n = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": fmt}, 4, 3)
-        assert n._f16_activations() and not n._split_activations() and n._vis_precision() == fmt
-    assert StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "bf16x3"}, 4, 3).conv_precision == "bf16x3"
-    net = StageNet({"base_ch": 8, "depth_type": "ce", "conv_precision": "f16x2"}, 4, 3)
-    assert net._f16_activations() and not net._split_activations() and net._vis_precision() == "f16x2"       # explicit f16x2: both terms
+        for nd in (32, 4):
+            n = StageNet(dict(args, conv_precision=fmt), nd, 3)
+            assert n._f16_activations() and not n._split_activations() and n._vis_precision() == fmt and n.gather_precision == "f16"
+    for fmt in ("bf16x3", "fp32"):
+        n = StageNet(dict(args, conv_precision=fmt), 4, 3)
+        assert n.conv_precision == fmt and n.gather_precision == "f32" and not n._f16_activations()
+    n.conv_precision = "stagemix"                                                # assignment = a new policy for this stage
+    assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("stagemix", "f16mix", "f16")
 
 
 def test_header_matches_binding_table():
