@@ -89,10 +89,15 @@ class HeadlineGuard:
 
     def __init__(self, fallback: dict):
         import subprocess
-        sys.stdout.flush()
-        self.proc = subprocess.Popen([sys.executable, "-c", self._CHILD], stdin=subprocess.PIPE, start_new_session=True, close_fds=True)
-        self.proc.stdin.write((json.dumps(fallback) + "\n").encode())
-        self.proc.stdin.flush()
+        self.proc = None
+        try:                                   # the guard is a convenience: if the helper cannot be started the leg runs unguarded
+            sys.stdout.flush()
+            self.proc = subprocess.Popen([sys.executable, "-c", self._CHILD], stdin=subprocess.PIPE, start_new_session=True, close_fds=True)
+            self.proc.stdin.write((json.dumps(fallback) + "\n").encode())
+            self.proc.stdin.flush()
+        except Exception as e:
+            print("bench.py: headline guard not started (%r)" % (e,), file=sys.stderr)
+            self.proc = None
 
     def disarm(self):
         if self.proc is None:
