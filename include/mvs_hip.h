@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 9
+#define MVS_ABI_VERSION 10
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -261,6 +261,24 @@ int mvs_deconv3d_bn_relu_add_fwd(const float* x_cl, const void* w_packed, const 
                                  float* y_cl, int B, int Cin, int Cout, int D, int H, int W, int sd, int precision,
                                  void* stream);
 
+/* ---- a7-a9, layer shapes OUTSIDE the tuned tables: shape-generic exact-fp32 Conv3d / ConvTranspose3d -------------------------------
+ * Replaces nn.Conv3d / nn.ConvTranspose3d (+ folded BatchNorm3d, ReLU, skip add) of module.py:89-165 for any channel counts, kernel
+ * size, stride and padding (dilation 1, groups 1): what a regulariser built with base_ch != 8 (cost_volume.py:29-49: CostRegNet(G, G),
+ * widths 2G / 4G / 8G), the 1x1x1 `inner` convolution of in_channels != base_channels (module.py:385-388, 481-484) and a `prob` head of
+ * G != 8 channels run on.  No shipped config reaches it: an FMA kernel built for coverage and exactness, not for the roofline.
+ *   x_cl [B,D,H,W,Cin] fp32 -> y_cl [B,OD,OH,OW,Cout] fp32;  w_tck [kd*kh*kw][Cin][Cout] fp32 (BN folded; a ConvTranspose3d weight
+ *   [Cin,Cout,kd,kh,kw] is laid out the same way, NOT flipped: the kernel gathers i = (o + p - k) / s);  bias [Cout] or NULL;
+ *   skip_cl [B,OD,OH,OW,Cout] or NULL, added after bias and ReLU (module.py:403-405).
+ *   transposed = 0: O = (N + 2p - k) / s + 1 per axis;  transposed = 1: O = (N - 1) s - 2p + k + output_padding, 0 <= output_padding < s
+ *   (the caller states OD, OH, OW; anything else is MVS_ERR_ARG).  Cout == 1 writes what is also a planar [B,OD,OH,OW] volume.          */
+int mvs_conv3d_generic_fwd(const float* x_cl, const float* w_tck, const float* bias, const float* skip_cl, float* y_cl, int B,
+                           int Cin, int Cout, int D, int H, int W, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh,
+                           int sw, int pd, int ph, int pw, int transposed, int relu, void* stream);
+/* 1 when mvs_conv3d_bn_relu_fwd / mvs_deconv3d_bn_relu_add_fwd have a tuned MFMA kernel for the layer shape (kernel (kd,3,3), padding
+ * (kd/2,1,1) / the k3 p1 (sd,2,2) transposed form), else 0: the host mirror routes the layer to mvs_conv3d_generic_fwd then */
+int mvs_conv3d_is_tuned(int Cin, int Cout, int kd, int sd, int sh, int sw);
+int mvs_deconv3d_is_tuned(int Cin, int Cout, int sd);
+
 /* the last U-Net layer with the 1x1x1 `prob` head in its epilogue (Cout = 8): x_cl [B,D,H,W,Cin] -> logits [B,D*sd,2H,2W]
  * = prob(skip + relu(bn(deconv(x)))); MVS_PREC_BF16X3 only.  mvs_regnet_logits_fwd chains it after the other eight layers. */
 int mvs_deconv3d_prob_fwd(const float* x_cl, const void* w_packed, const float* bias, const float* skip_cl, const float* prob_w,
@@ -302,12 +320,16 @@ int mvs_conf_regression_fwd(const float* p, int n, float* out, int B, int D, int
 /* ---- a13-a15: hypothesis ranges, module.py:674-741 ----------------------------------------------*/
 int mvs_init_range_fwd(const float* depth_values /*[B,N]*/, int N, int inverse, float* hyp /*[B,D,H,W]*/, int B,
                        int D, int H, int W, void* stream);
-/* prev_depth [B,H/2,W/2], prev_hyp [B,Dprev,H/2,W/2] -> hyp [B,D,H,W]; ratio = depth_interals_ratio */
-int mvs_schedule_inverse_range_fwd(const float* prev_depth, const float* prev_hyp, int Dprev, float ratio,
+/* the per-pixel form of the two (module.py:683-688, 698-703): depth_values [B,H,W,N], every pixel's own first / last depth */
+int mvs_init_range_pixel_fwd(const float* depth_values /*[B,H,W,N]*/, int N, int inverse, float* hyp /*[B,D,H,W]*/, int B,
+                             int D, int H, int W, void* stream);
+/* prev_depth [B,H/2,W/2], prev_hyp [B,Dprev,H/2,W/2] -> hyp [B,D,H,W]; ratio = depth_interals_ratio; shift != 0: the reference's
+ * `shift=True` branch (module.py:712-715), statement by statement                                                             */
+int mvs_schedule_inverse_range_fwd(const float* prev_depth, const float* prev_hyp, int Dprev, float ratio, int shift,
                                    float* hyp, int B, int D, int H, int W, void* stream);
-/* interval [B] = depth_interals_ratio * depth_interval (module.py:727-741) */
-int mvs_schedule_range_fwd(const float* prev_depth, const float* interval, float* hyp, int B, int D, int H, int W,
-                           void* stream);
+/* interval [B] = depth_interals_ratio * depth_interval, or (interval_per_pixel != 0) [B,H/2,W/2] (module.py:727-741) */
+int mvs_schedule_range_fwd(const float* prev_depth, const float* interval, int interval_per_pixel, float* hyp, int B, int D,
+                           int H, int W, void* stream);
 
 /* ---- a16: confidence fusion, DINOv2_mvsformer_model.py:167-177 -----------------------------------
  * out[b,y,x] = mean_s conf_s[b, y >> shift_s, x >> shift_s] (nearest upsample), n_stages <= 8.      */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 9
+ABI_VERSION = 10
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
@@ -56,6 +56,9 @@ SIGNATURES = {
     "mvs_slab_reduce": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "mvs_conv3d_generic_fwd": (_i, [_vp] * 5 + [_i] * 20 + [_vp]),
+    "mvs_conv3d_is_tuned": (_i, [_i] * 6),
+    "mvs_deconv3d_is_tuned": (_i, [_i] * 3),
     "mvs_deconv3d_prob_fwd": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "mvs_conv3d_logits_fwd": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "mvs_deconv3d_linear_fwd": (_i, [_vp] * 4 + [_i] * 8 + [_vp]),
@@ -80,8 +83,9 @@ SIGNATURES = {
     "mvs_depth_regression_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_conf_regression_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "mvs_init_range_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
-    "mvs_schedule_inverse_range_fwd": (_i, [_vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp]),
-    "mvs_schedule_range_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_init_range_pixel_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_schedule_inverse_range_fwd": (_i, [_vp, _vp, _i, _f, _i, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_schedule_range_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "mvs_confidence_average": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "mvs_position3d_workspace_bytes": (_sz, []),
     "mvs_position3d_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp, _i, _i, _i, _i, _vp]),

@@ -176,7 +176,14 @@ class StageNet(nn.Module):
     def _f16_activations(self) -> bool:
         """conv_precision "f16x2": the U-Net's tensors - cost volume included - are fp16 in HBM (MVS_PREC_F16X2); the transformer
         regulariser reads an fp32 volume and is unaffected."""
-        return self.conv_precision in F16_FORMATS and not isinstance(self.cost_reg, PureTransformerCostReg)
+        return self.conv_precision in F16_FORMATS and not isinstance(self.cost_reg, PureTransformerCostReg) and not self._generic_regulariser()
+
+    def _generic_regulariser(self) -> bool:
+        """base_ch != 8: the reference builds CostRegNet(G, G) / CostRegNet3D(G, G) (cost_volume.py:44-49) - widths no tuned MFMA kernel
+        exists for.  The stage then gathers with the direct kernels (any G dividing C), keeps an fp32 volume [B,D,H,W,G] and regularises
+        it layer by layer on the shape-generic exact-fp32 convolution (module._RegNetBase.forward_cl_generic); conv_precision still
+        selects the visibility CNN's format."""
+        return bool(getattr(self.cost_reg, "is_generic", False))
 
     def _wants_autograd(self, features) -> bool:
         """Training mode (BatchNorm batch statistics) or a caller that differentiates w.r.t. the features."""
@@ -194,8 +201,8 @@ class StageNet(nn.Module):
         G = self.in_channels
         if G > C:
             raise AssertionError("G must <= C!")                                                  # cost_volume.py:87
-        if G != 8:
-            raise NotImplementedError("base_ch=%d: the HIP regulariser is built for 8 groups (all shipped configs)" % G)
+        if C % G != 0:
+            raise AssertionError("base_ch=%d must divide the %d feature channels (the reference's .view(B, G, C // G, ...), cost_volume.py:80)" % (G, C))
         feats, code = ops._feat(features)
         hyp = ops._f32c(depth_values)
         if hyp.dim() == 2:
@@ -255,7 +262,7 @@ class StageNet(nn.Module):
     def _split_activations(self) -> bool:
         """The bf16x3 U-Net keeps its activations - cost volume included - in the split hi | lo bf16 format between layers
         (MVS_PREC_BF16X3_SPLIT, csrc/conv_bf16x3_kernels.hip); the transformer regulariser and the fp32 contraction read fp32."""
-        return self.conv_precision == "bf16x3" and not isinstance(self.cost_reg, PureTransformerCostReg)
+        return self.conv_precision == "bf16x3" and not isinstance(self.cost_reg, PureTransformerCostReg) and not self._generic_regulariser()
 
     def _head_mode(self, D):
         conf_n = 0
@@ -275,6 +282,9 @@ class StageNet(nn.Module):
         mode, conf_n = self._head_mode(D)
         if isinstance(self.cost_reg, PureTransformerCostReg):
             prob_volume_pre = self.cost_reg.logits_cl(volume, position3d)
+            depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+        elif self._generic_regulariser():
+            prob_volume_pre = self.cost_reg.logits_cl_generic(volume)
             depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
         else:
             ws, bs, prob_w, prob_b = self.cost_reg.packed_all(volume.device, self.conv_precision)

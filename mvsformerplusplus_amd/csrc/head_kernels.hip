@@ -186,20 +186,31 @@ __global__ void conf_regression_kernel(const float* __restrict__ p, int n, float
 // ------------------------------------------------------------------------------------------------
 // a13 / init_range: [B,N] depth values -> [B,D,H,W] hypotheses              module.py:674-704
 // ------------------------------------------------------------------------------------------------
-__global__ void init_range_kernel(const float* __restrict__ dv, int N, int inverse, float* __restrict__ hyp, int D, int HW) {
-    const int b = (int)blockIdx.z, d = (int)blockIdx.y;
-    const float first = dv[(size_t)b * N], last = dv[(size_t)b * N + N - 1];
-    float v;
+__device__ __forceinline__ float init_range_value(float first, float last, int inverse, int d, int D) {
     if (inverse) {
         const float inv_min = 1.0f / first, inv_max = 1.0f / last;
         const float itv = (float)d / (float)(D - 1);
-        v = 1.0f / (inv_max + (inv_min - inv_max) * itv);                           // module.py:697-704
-    } else {
-        const float interval = (last - first) / (float)(D - 1);
-        v = first + (float)d * interval;                                            // module.py:676-682
+        return 1.0f / (inv_max + (inv_min - inv_max) * itv);                        // module.py:697-704
     }
+    const float interval = (last - first) / (float)(D - 1);
+    return first + (float)d * interval;                                             // module.py:676-682
+}
+
+__global__ void init_range_kernel(const float* __restrict__ dv, int N, int inverse, float* __restrict__ hyp, int D, int HW) {
+    const int b = (int)blockIdx.z, d = (int)blockIdx.y;
+    const float v = init_range_value(dv[(size_t)b * N], dv[(size_t)b * N + N - 1], inverse, d, D);
     float* o = hyp + ((size_t)b * D + d) * HW;
     for (int p = (int)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (int)gridDim.x * blockDim.x) o[p] = v;
+}
+
+// the per-pixel form (module.py:683-688, 698-703: cur_depth [B,H,W,N] - every pixel carries its own first / last depth)
+__global__ void init_range_pixel_kernel(const float* __restrict__ dv, int N, int inverse, float* __restrict__ hyp, int D, int HW) {
+    const int b = (int)blockIdx.z, d = (int)blockIdx.y;
+    float* o = hyp + ((size_t)b * D + d) * HW;
+    for (int p = (int)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (int)gridDim.x * blockDim.x) {
+        const float* px = dv + ((size_t)b * HW + p) * N;
+        o[p] = init_range_value(px[0], px[N - 1], inverse, d, D);
+    }
 }
 
 // bilinear source coordinates of F.interpolate(..., align_corners=True) along one axis
@@ -219,7 +230,7 @@ __device__ __forceinline__ void lin_coord(int dst, int in_size, int out_size, in
 // a14 (mode 0, inverse) / a15 (mode 1, linear): prev stage [h,w] -> [D,H,W] with H = 2h, W = 2w (any ratio works)
 __global__ __launch_bounds__(256) void schedule_range_kernel(const float* __restrict__ prev_depth, const float* __restrict__ prev_hyp,
                                                              int Dprev, float ratio, const float* __restrict__ interval, int linear,
-                                                             float* __restrict__ hyp, int D, int H, int W, int h, int w) {
+                                                             float* __restrict__ hyp, int D, int H, int W, int h, int w, int variant) {
     const int HW = H * W, hw = h * w;
     const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
     const int b = (int)blockIdx.y;
@@ -239,12 +250,19 @@ __global__ __launch_bounds__(256) void schedule_range_kernel(const float* __rest
             const float h1 = prev_hyp[((size_t)b * Dprev + 1) * hw + q];
             const float h2 = prev_hyp[((size_t)b * Dprev + 2) * hw + q];
             const float last_itv = 1.0f / h2 - 1.0f / h1;                           // module.py:708
-            const float inv_min = 1.0f / dep + ratio * last_itv;
-            const float inv_max = 1.0f / dep - ratio * last_itv;
+            float inv_min = 1.0f / dep + ratio * last_itv;
+            float inv_max = 1.0f / dep - ratio * last_itv;
+            if (variant) {
+                // shift = True (module.py:712-715), statement by statement: the second line reads the ALREADY shifted inverse_max_depth,
+                // so inverse_min_depth moves by the rounding residue of the first line only - the reference's behaviour, kept
+                const float is_neg = inv_max < 0.002f ? 1.0f : 0.0f;
+                inv_max = inv_max - (inv_max - 0.002f) * is_neg;
+                inv_min = inv_min - (inv_max - 0.002f) * is_neg;
+            }
             lo[k] = inv_max;
             span[k] = inv_min - inv_max;
         } else {
-            const float itv = interval[b];
+            const float itv = variant ? interval[(size_t)b * hw + q] : interval[b];          // per-pixel [B,h,w] intervals (module.py:731-732)
             float dmin = dep - (float)D / 2.0f * itv;                               // module.py:733-736
             dmin = dmin < 0.001f ? 0.001f : dmin;
             const float dmax = dep + (float)D / 2.0f * itv;
@@ -375,18 +393,27 @@ extern "C" int mvs_init_range_fwd(const float* depth_values, int N, int inverse,
     return check_launch("init_range_kernel");
 }
 
-extern "C" int mvs_schedule_inverse_range_fwd(const float* prev_depth, const float* prev_hyp, int Dprev, float ratio, float* hyp, int B,
-                                              int D, int H, int W, void* stream) {
+extern "C" int mvs_init_range_pixel_fwd(const float* depth_values, int N, int inverse, float* hyp, int B, int D, int H, int W, void* stream) {
+    if (!depth_values || !hyp || N < 1 || B < 1 || D < 2 || H < 1 || W < 1) { set_error("mvs_init_range_pixel_fwd: bad arguments"); return MVS_ERR_ARG; }
+    const int HW = H * W;
+    const unsigned gx = ceil_div(HW, 256) > 256 ? 256 : ceil_div(HW, 256);
+    hipLaunchKernelGGL(init_range_pixel_kernel, dim3(gx, D, B), dim3(256), 0, (hipStream_t)stream, depth_values, N, inverse, hyp, D, HW);
+    return check_launch("init_range_pixel_kernel");
+}
+
+extern "C" int mvs_schedule_inverse_range_fwd(const float* prev_depth, const float* prev_hyp, int Dprev, float ratio, int shift, float* hyp,
+                                              int B, int D, int H, int W, void* stream) {
     if (!prev_depth || !prev_hyp || !hyp || Dprev < 3 || B < 1 || D < 2 || H < 2 || W < 2) { set_error("mvs_schedule_inverse_range_fwd: bad arguments (needs Dprev >= 3, module.py:708)"); return MVS_ERR_ARG; }
     hipLaunchKernelGGL(schedule_range_kernel, dim3(ceil_div((long long)H * W, 256), B), dim3(256), 0, (hipStream_t)stream, prev_depth, prev_hyp,
-                       Dprev, ratio, (const float*)nullptr, 0, hyp, D, H, W, H / 2, W / 2);
+                       Dprev, ratio, (const float*)nullptr, 0, hyp, D, H, W, H / 2, W / 2, shift ? 1 : 0);
     return check_launch("schedule_range_kernel");
 }
 
-extern "C" int mvs_schedule_range_fwd(const float* prev_depth, const float* interval, float* hyp, int B, int D, int H, int W, void* stream) {
+extern "C" int mvs_schedule_range_fwd(const float* prev_depth, const float* interval, int interval_per_pixel, float* hyp, int B, int D, int H,
+                                      int W, void* stream) {
     if (!prev_depth || !interval || !hyp || B < 1 || D < 2 || H < 2 || W < 2) { set_error("mvs_schedule_range_fwd: bad arguments"); return MVS_ERR_ARG; }
     hipLaunchKernelGGL(schedule_range_kernel, dim3(ceil_div((long long)H * W, 256), B), dim3(256), 0, (hipStream_t)stream, prev_depth,
-                       (const float*)nullptr, 0, 0.0f, interval, 1, hyp, D, H, W, H / 2, W / 2);
+                       (const float*)nullptr, 0, 0.0f, interval, 1, hyp, D, H, W, H / 2, W / 2, interval_per_pixel ? 1 : 0);
     return check_launch("schedule_range_kernel");
 }
 

@@ -126,6 +126,51 @@ def _triple(v):
     return (v, v, v) if isinstance(v, int) else tuple(v)
 
 
+GENERIC = "generic"          # cache tag / format name of the shape-generic exact-fp32 layer form (csrc/conv_generic_kernels.hip)
+
+
+def _conv_is_tuned(conv: nn.Conv3d) -> bool:
+    """The layer has a tuned MFMA kernel (csrc/conv_cfg.h): kernel (1|3,3,3), 'same' padding, a (Cin, Cout, stride) of the shipped U-Nets."""
+    k, s, p = _triple(conv.kernel_size), _triple(conv.stride), _triple(conv.padding)
+    if k[1:] != (3, 3) or p != (k[0] // 2, 1, 1) or _triple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
+        return False
+    return ops.conv3d_is_tuned(conv.in_channels, conv.out_channels, k[0], s)
+
+
+def _deconv_is_tuned(conv: nn.ConvTranspose3d) -> bool:
+    s, p, op, k = _triple(conv.stride), _triple(conv.padding), _triple(conv.output_padding), _triple(conv.kernel_size)
+    if k != (3, 3, 3) or p != (1, 1, 1) or s[1:] != (2, 2) or op != (s[0] - 1, 1, 1) or s[0] not in (1, 2):
+        return False
+    if _triple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
+        return False
+    return ops.deconv3d_is_tuned(conv.in_channels, conv.out_channels, s[0])
+
+
+def _pack_generic(conv: nn.Module, bn: Optional[nn.Module], dev):
+    """(w_tck, bias) of an nn.Conv3d / nn.ConvTranspose3d (+ eval-mode BatchNorm3d folded) for ops.conv3d_generic."""
+    if _triple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
+        raise NotImplementedError("dilated / grouped 3-D convolutions do not occur in the reference's regularisers (module.py:89-165)")
+    transposed = isinstance(conv, nn.ConvTranspose3d)
+    w = conv.weight.detach().cpu().float()
+    if bn is not None:
+        w, b = packing.fold_bn(w, _bn_dict(bn), 1 if transposed else 0)
+        if conv.bias is not None:       # conv bias in front of a BatchNorm: it goes through the same scale
+            bnd = _bn_dict(bn)
+            scale = bnd["weight"].double() / torch.sqrt(bnd["running_var"].double() + bnd["eps"])
+            b = (b.double() + conv.bias.detach().cpu().double() * scale).float()
+    else:
+        b = conv.bias.detach().cpu().float() if conv.bias is not None else None
+    wt = packing.pack_generic_deconv_weights(w) if transposed else packing.pack_generic_conv_weights(w)
+    return wt.to(dev), (b.contiguous().to(dev) if b is not None else None)
+
+
+def _run_generic(conv: nn.Module, params, x_cl: torch.Tensor, relu: bool, skip_cl: Optional[torch.Tensor] = None) -> torch.Tensor:
+    w, b = params
+    transposed = isinstance(conv, nn.ConvTranspose3d)
+    return ops.conv3d_generic(x_cl, w, b, conv.out_channels, _triple(conv.kernel_size), _triple(conv.stride), _triple(conv.padding), relu,
+                              skip_cl, transposed, _triple(conv.output_padding) if transposed else (0, 0, 0))
+
+
 class Conv3d(nn.Module):
     """3D convolution + optional BatchNorm3d + optional ReLU (reference module.py:89-126)."""
 
@@ -153,16 +198,26 @@ class Conv3d(nn.Module):
         precision_code(precision)
         return self._cache.get(self, build, precision)
 
+    def is_tuned(self) -> bool:
+        return _conv_is_tuned(self.conv)
+
+    def packed_generic(self, device):
+        return self._cache.get(self, lambda dev: _pack_generic(self.conv, self.bn, dev), GENERIC)
+
     def forward_cl(self, x_cl, precision=DEFAULT_PRECISION):
+        """x_cl channel-last in the activation dtype of `precision`.  A layer shape without a tuned kernel (any other channel counts,
+        kernel size, stride or padding) runs the shape-generic exact-fp32 kernel on fp32 activations, whatever `precision` says."""
+        if precision == GENERIC or not self.is_tuned():
+            return _run_generic(self.conv, self.packed_generic(x_cl.device), x_cl.float() if x_cl.dtype != torch.float32 else x_cl, self.relu)
         w, b = self.packed(x_cl.device, precision)
         k = _triple(self.conv.kernel_size)
-        if k[1:] != (3, 3) or _triple(self.conv.padding) != (k[0] // 2, 1, 1):
-            raise NotImplementedError("HIP Conv3d supports kernel (1|3,3,3) with 'same' padding only")
         return ops.conv3d_bn_relu(x_cl, w, b, self.conv.out_channels, k[0], _triple(self.conv.stride), self.relu, precision_code(precision))
 
     def forward(self, x):
         _no_grad_path(x)
         prec = getattr(self, "conv_precision", DEFAULT_PRECISION)
+        if not self.is_tuned():
+            return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x), GENERIC))
         return ops.cl_to_ncdhw(self.forward_cl(_to_act(ops.ncdhw_to_cl(x), prec), prec).float())
 
 
@@ -182,15 +237,25 @@ class Deconv3d(nn.Module):
         precision_code(precision)
         return self._cache.get(self, lambda dev: _pack_deconv(self.conv, self.bn, dev, precision), precision)
 
+    def is_tuned(self) -> bool:
+        """The tuned kernels implement the BN + ReLU form of the regularisers at k3 / p1 / stride (1|2,2,2) and the shipped widths."""
+        return self.relu and self.bn is not None and _deconv_is_tuned(self.conv)
+
+    def packed_generic(self, device):
+        return self._cache.get(self, lambda dev: _pack_generic(self.conv, self.bn, dev), GENERIC)
+
     def forward_cl(self, x_cl, skip_cl=None, precision=DEFAULT_PRECISION):
-        if not self.relu or self.bn is None:
-            raise NotImplementedError("HIP Deconv3d implements the BN + ReLU form used by the regularisers")
+        if precision == GENERIC or not self.is_tuned():
+            f32 = lambda t: t if t is None or t.dtype == torch.float32 else t.float()
+            return _run_generic(self.conv, self.packed_generic(x_cl.device), f32(x_cl), self.relu, f32(skip_cl))
         w, b = self.packed(x_cl.device, precision)
         return ops.deconv3d_bn_relu_add(x_cl, w, b, self.conv.out_channels, _deconv_sd(self.conv), skip_cl, precision_code(precision))
 
     def forward(self, x):
         _no_grad_path(x)
         prec = getattr(self, "conv_precision", DEFAULT_PRECISION)
+        if not self.is_tuned():
+            return ops.cl_to_ncdhw(self.forward_cl(ops.ncdhw_to_cl(x), None, GENERIC))
         return ops.cl_to_ncdhw(self.forward_cl(_to_act(ops.ncdhw_to_cl(x), prec), None, prec).float())
 
 
@@ -263,18 +328,90 @@ class _RegNetBase(nn.Module):
             prob_b = self.prob.bias.detach().cpu().float().reshape(-1)[:1].contiguous().to(dev)
         return ws, bs, prob_w, prob_b
 
+    # ---- the shape-generic form: every width the tuned tables do not hold ---------------------------------------------------------
+    @property
+    def is_generic(self) -> bool:
+        """True when this U-Net is NOT the 8 -> 16 -> 32 -> 64 network of the shipped configs (base_ch != 8: the reference builds
+        CostRegNet(G, G), cost_volume.py:44-49; in_channels != base_channels: the 1x1x1 `inner` convolution, module.py:385-388 / 481-484;
+        last_layer = False / log_var = True).  Such a network runs layer by layer on the shape-generic exact-fp32 kernel
+        (csrc/conv_generic_kernels.hip): fp32 activations, no fused head, conv_precision is not consulted."""
+        flag = self.__dict__.get("_generic_flag")
+        if flag is None:                      # the architecture is fixed at construction: decided once (nine table look-ups in the library)
+            if getattr(self, "prob", None) is None or not isinstance(self.inner, nn.Identity):
+                flag = True
+            elif tuple(self.prob.weight.shape[:2]) != (1, 8):
+                flag = True
+            else:
+                flag = not (all(getattr(self, n).is_tuned() for n in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6"))
+                            and all(self._deconv_is_tuned(getattr(self, n)) for n in ("conv7", "conv9", "conv11")))
+            self.__dict__["_generic_flag"] = flag
+        return flag
+
+    def _build_generic(self, dev):
+        out = {n: _pack_generic(getattr(self, n).conv, getattr(self, n).bn, dev) for n in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6")}
+        for n in ("conv7", "conv9", "conv11"):
+            conv, bn = self._deconv_parts(getattr(self, n))
+            out[n] = _pack_generic(conv, bn, dev)
+        if not isinstance(self.inner, nn.Identity):
+            out["inner"] = _pack_generic(self.inner, None, dev)
+        if getattr(self, "prob", None) is not None:
+            out["prob"] = _pack_generic(self.prob, None, dev)
+        return out
+
+    def forward_cl_generic(self, volume_cl: torch.Tensor, head: bool = True) -> torch.Tensor:
+        """[B,D,H,W,Cin] fp32 cost volume -> the U-Net's features [B,D,H,W,base] (head = False or no `prob` layer) or the `prob` layer's
+        output [B,D,H,W,1|2]; reference module.py:398-408 / 494-504 layer by layer: conv + folded BN + ReLU, skip added after the ReLU."""
+        if volume_cl.dtype != torch.float32:
+            volume_cl = volume_cl.float()
+        pk = self._cache.get(self, self._build_generic, GENERIC)
+        run = lambda n, x, skip=None: _run_generic(self._conv_of(n), pk[n], x, True, skip)
+        conv2 = run("conv2", run("conv1", volume_cl))
+        conv4 = run("conv4", run("conv3", conv2))
+        x = run("conv6", run("conv5", conv4))
+        up = lambda n, x, skip: self._checked_skip(n, x, skip, pk)
+        x = up("conv7", x, conv4)
+        x = up("conv9", x, conv2)
+        inner = volume_cl if isinstance(self.inner, nn.Identity) else _run_generic(self.inner, pk["inner"], volume_cl, False)
+        x = up("conv11", x, inner)
+        if head and "prob" in pk:
+            x = _run_generic(self.prob, pk["prob"], x, False)
+        return x
+
+    def _conv_of(self, name):
+        layer = getattr(self, name)
+        return layer.conv if hasattr(layer, "conv") else layer[0]
+
+    def _checked_skip(self, name, x, skip, pk):
+        conv = self._conv_of(name)
+        k, st, p, op = (_triple(getattr(conv, a)) for a in ("kernel_size", "stride", "padding", "output_padding"))
+        out = tuple((n - 1) * st[i] - 2 * p[i] + k[i] + op[i] for i, n in enumerate(x.shape[1:4]))
+        if out != tuple(skip.shape[1:4]):
+            raise ValueError("U-Net skip add: %s upsamples %s to %s but the skip tensor is %s - the volume's %s must be divisible by 8 "
+                             "(reference module.py:403-405)" % (name, tuple(x.shape[1:4]), out, tuple(skip.shape[1:4]),
+                                                                "D, H, W" if self.kind == _lib.REG_COSTREGNET else "H, W"))
+        return _run_generic(conv, pk[name], x, True, skip)
+
+    def logits_cl_generic(self, volume_cl: torch.Tensor) -> torch.Tensor:
+        """Planar logits [B,D,H,W] of the generic network (`prob` with one output channel)."""
+        y = self.forward_cl_generic(volume_cl)
+        if y.shape[-1] != 1:
+            raise NotImplementedError("the depth head reads ONE logit per voxel (log_var = True / last_layer = False have no consumer on the "
+                                      "reference's hot path, cost_volume.py:103-106)")
+        return y.squeeze(-1)
+
     def packed_all(self, device, precision=None):
         precision = precision or self.conv_precision
         precision_code(precision)
-        if not isinstance(self.inner, nn.Identity):
-            raise NotImplementedError("in_channels != base_channels (1x1x1 `inner` conv) is not used by any shipped config")
-        if self.prob.weight.shape[0] != 1 or self.prob.weight.shape[1] != 8:
-            raise NotImplementedError("HIP head supports an 8 -> 1 channel `prob` layer")
+        if self.is_generic:
+            raise _lib.MvsHipError("internal: the tuned-kernel parameter pack was requested for a shape-generic regulariser")
         return self._cache.get(self, lambda dev: self._build(dev, precision), precision)
 
     def forward_cl(self, volume_cl: torch.Tensor, precision=None) -> torch.Tensor:
         """[B,D,H,W,8] channel-last cost volume -> [B,D,H,W,8] features that feed `prob`.  With precision "f16x2" the U-Net's tensors are
-        fp16: an fp32 volume is converted on the way in (clamped to the fp16 range, ops.volume_to_f16) and the features come back fp16."""
+        fp16: an fp32 volume is converted on the way in (clamped to the fp16 range, ops.volume_to_f16) and the features come back fp16.
+        A shape-generic network (is_generic) returns fp32 features [B,D,H,W,base] from the exact-fp32 kernel."""
+        if self.is_generic:
+            return self.forward_cl_generic(volume_cl, head=False)
         precision = precision or self.conv_precision
         ws, bs, _, _ = self.packed_all(volume_cl.device, precision)
         if precision in F16_FORMATS and volume_cl.dtype == torch.float32:
@@ -285,6 +422,8 @@ class _RegNetBase(nn.Module):
         """NCDHW in, logits [B,1,D,H,W] out - the reference's call form (module.py:393-396 / 488-492)."""
         _no_grad_path(x)
         vol = ops.ncdhw_to_cl(x)
+        if self.is_generic:
+            return ops.cl_to_ncdhw(self.forward_cl_generic(vol))
         feat = self.forward_cl(vol)
         _, _, prob_w, prob_b = self.packed_all(x.device)
         B, D, H, W, _ = feat.shape
@@ -306,9 +445,7 @@ class CostRegNet(_RegNetBase):
 
     def __init__(self, in_channels, base_channels, last_layer=True):
         super().__init__()
-        if not last_layer:
-            raise NotImplementedError("last_layer=False is unused by the hot path")
-        self.last_layer = last_layer
+        self.last_layer = last_layer          # False: no `prob` layer, the features come back (module.py:390-391, 406-408): generic form
         c = base_channels
         plan = [("conv1", in_channels, 2 * c, 2), ("conv2", 2 * c, 2 * c, 1), ("conv3", 2 * c, 4 * c, 2),
                 ("conv4", 4 * c, 4 * c, 1), ("conv5", 4 * c, 8 * c, 2), ("conv6", 8 * c, 8 * c, 1)]
@@ -317,12 +454,21 @@ class CostRegNet(_RegNetBase):
         for name, ci, co in (("conv7", 8 * c, 4 * c), ("conv9", 4 * c, 2 * c), ("conv11", 2 * c, c)):
             setattr(self, name, Deconv3d(ci, co, stride=2, padding=1, output_padding=1))
         self.inner = nn.Conv3d(in_channels, c, 1, 1) if in_channels != c else nn.Identity()
-        self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
+        if last_layer:
+            self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
         self._cache = _PackedCache()
 
     @staticmethod
     def _deconv_packed(layer, dev, precision):
         return layer.packed(dev, precision)
+
+    @staticmethod
+    def _deconv_is_tuned(layer):
+        return layer.is_tuned()
+
+    @staticmethod
+    def _deconv_parts(layer):
+        return layer.conv, layer.bn
 
 
 class CostRegNet3D(_RegNetBase):
@@ -332,9 +478,7 @@ class CostRegNet3D(_RegNetBase):
 
     def __init__(self, in_channels, base_channel=8, log_var=False):
         super().__init__()
-        if log_var:
-            raise NotImplementedError("log_var=True is unused by the hot path")
-        self.log_var = log_var
+        self.log_var = log_var                # True: `prob` has two output channels (module.py:486): generic form, no depth-head consumer
         c = base_channel
         s = (1, 2, 2)
         plan = [("conv1", in_channels, 2 * c, s), ("conv2", 2 * c, 2 * c, 1), ("conv3", 2 * c, 4 * c, s),
@@ -346,13 +490,21 @@ class CostRegNet3D(_RegNetBase):
                 nn.ConvTranspose3d(ci, co, kernel_size=3, padding=1, output_padding=(0, 1, 1), stride=s, bias=False),
                 nn.BatchNorm3d(co), nn.ReLU(inplace=True)))
         self.inner = nn.Conv3d(in_channels, c, 1, 1) if in_channels != c else nn.Identity()
-        self.prob = nn.Conv3d(c, 1, 1, stride=1, padding=0)
+        self.prob = nn.Conv3d(c, 2 if log_var else 1, 1, stride=1, padding=0)
         self._cache = _PackedCache()
 
     @staticmethod
     def _deconv_packed(seq, dev, precision):
         _deconv_sd(seq[0])
         return _pack_deconv(seq[0], seq[1], dev, precision)
+
+    @staticmethod
+    def _deconv_is_tuned(seq):
+        return _deconv_is_tuned(seq[0])
+
+    @staticmethod
+    def _deconv_parts(seq):
+        return seq[0], seq[1]
 
 
 # --------------------------------------------------------------------------------------------------
@@ -526,27 +678,30 @@ def conf_regression(p: torch.Tensor, n: int = 4) -> torch.Tensor:
     return ops.conf_regression(p, n)
 
 
+def _range_rank(cur_depth):
+    if cur_depth.dim() not in (2, 4):
+        raise ValueError("cur_depth must be [B,N] or a per-pixel [B,H,W,N] range (reference module.py:675,683), got %s" % (tuple(cur_depth.shape),))
+
+
 def init_range(cur_depth, ndepths, device, dtype, H, W):
-    if cur_depth.dim() != 2:
-        raise NotImplementedError("per-pixel [B,H,W,n] initial ranges are unused by the shipped configs")
+    """reference module.py:674-689; cur_depth [B,N] or per-pixel [B,H,W,N]."""
+    _range_rank(cur_depth)
     return ops.init_range(cur_depth.to(device), ndepths, H, W, inverse=False).to(dtype)
 
 
 def init_inverse_range(cur_depth, ndepths, device, dtype, H, W):
-    if cur_depth.dim() != 2:
-        raise NotImplementedError("per-pixel [B,H,W,n] initial ranges are unused by the shipped configs")
+    """reference module.py:692-704; cur_depth [B,N] or per-pixel [B,H,W,N]."""
+    _range_rank(cur_depth)
     return ops.init_range(cur_depth.to(device), ndepths, H, W, inverse=True).to(dtype)
 
 
 def schedule_inverse_range(depth, depth_hypo, ndepths, split_itv, H, W, shift=False):
-    if shift:
-        raise NotImplementedError("shift=True is never enabled by the reference (module.py:712-715)")
-    return ops.schedule_inverse_range(depth, depth_hypo, ndepths, float(split_itv), H, W)
+    """reference module.py:707-724, including its `shift` branch (:712-715) as written there."""
+    return ops.schedule_inverse_range(depth, depth_hypo, ndepths, float(split_itv), H, W, shift=bool(shift))
 
 
 def schedule_range(cur_depth, ndepth, depth_inteval_pixel, H, W):
+    """reference module.py:727-741; depth_inteval_pixel a scalar, [B] or per-pixel [B,H/2,W/2]."""
     if not torch.is_tensor(depth_inteval_pixel):
         depth_inteval_pixel = torch.tensor([float(depth_inteval_pixel)], device=cur_depth.device)
-    if depth_inteval_pixel.dim() == 3:
-        raise NotImplementedError("per-pixel depth intervals are unused by the shipped configs")
     return ops.schedule_range(cur_depth, ndepth, depth_inteval_pixel.to(cur_depth.device), H, W)

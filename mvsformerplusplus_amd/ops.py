@@ -340,6 +340,39 @@ def deconv3d_bn_relu_add(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch
     return y
 
 
+def conv3d_is_tuned(cin: int, cout: int, kd: int, stride: Tuple[int, int, int]) -> bool:
+    """A tuned MFMA kernel exists for Conv3d(cin, cout, (kd,3,3), stride, padding (kd//2,1,1)) (the table of csrc/conv_cfg.h)."""
+    return bool(lib().mvs_conv3d_is_tuned(cin, cout, kd, *stride))
+
+
+def deconv3d_is_tuned(cin: int, cout: int, sd: int) -> bool:
+    return bool(lib().mvs_deconv3d_is_tuned(cin, cout, sd))
+
+
+def conv3d_generic(x_cl: torch.Tensor, w_tck: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ksize: Tuple[int, int, int],
+                   stride: Tuple[int, int, int], padding: Tuple[int, int, int], relu: bool = False, skip_cl: Optional[torch.Tensor] = None,
+                   transposed: bool = False, output_padding: Tuple[int, int, int] = (0, 0, 0)) -> torch.Tensor:
+    """Shape-generic exact-fp32 Conv3d / ConvTranspose3d + bias + ReLU + skip (mvs_conv3d_generic_fwd): x_cl [B,D,H,W,Cin] fp32 ->
+    [B,OD,OH,OW,cout] fp32; w_tck = packing.pack_generic_conv_weights / pack_generic_deconv_weights ([taps][Cin][Cout])."""
+    if x_cl.dtype != torch.float32:
+        raise _lib.MvsHipError("the generic convolution takes fp32 activations, got %s" % x_cl.dtype)
+    B, D, H, W, cin = x_cl.shape
+    k, s, p = tuple(ksize), tuple(stride), tuple(padding)
+    if tuple(w_tck.shape) != (k[0] * k[1] * k[2], cin, cout):
+        raise _lib.MvsHipError("generic convolution weights %s do not match [%d][%d][%d]" % (tuple(w_tck.shape), k[0] * k[1] * k[2], cin, cout))
+    if transposed:
+        out = [(n - 1) * s[i] - 2 * p[i] + k[i] + output_padding[i] for i, n in enumerate((D, H, W))]
+    else:
+        out = [(n + 2 * p[i] - k[i]) // s[i] + 1 for i, n in enumerate((D, H, W))]
+    y = torch.empty(B, out[0], out[1], out[2], cout, dtype=torch.float32, device=x_cl.device)
+    if skip_cl is not None and (tuple(skip_cl.shape) != tuple(y.shape) or skip_cl.dtype != torch.float32):
+        raise _lib.MvsHipError("skip tensor %s / %s does not match the layer output %s fp32" % (tuple(skip_cl.shape), skip_cl.dtype, tuple(y.shape)))
+    check(lib().mvs_conv3d_generic_fwd(ptr(x_cl), ptr(w_tck), ptr(bias), ptr(skip_cl), ptr(y), B, cin, cout, D, H, W, out[0], out[1], out[2],
+                                       k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2], 1 if transposed else 0, 1 if relu else 0,
+                                       stream_of(x_cl)), "mvs_conv3d_generic_fwd")
+    return y
+
+
 def deconv3d_prob(x_cl: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, sd: int, skip_cl: torch.Tensor, prob_w: torch.Tensor,
                   prob_b: torch.Tensor, precision: int) -> torch.Tensor:
     """Last U-Net layer (Cout = 8) + skip + 1x1x1 `prob` in one launch -> logits [B, D*sd, 2H, 2W]."""
@@ -723,19 +756,28 @@ def conf_regression(p: torch.Tensor, n: int) -> torch.Tensor:
 
 
 def init_range(depth_values: torch.Tensor, ndepths: int, H: int, W: int, inverse: bool) -> torch.Tensor:
+    """depth_values [B,N] (one range per image) or [B,H,W,N] (one per pixel, module.py:683-688 / 698-703) -> hypotheses [B,D,H,W]."""
     dv = _f32c(depth_values)
+    if dv.dim() == 4:
+        B, h, w, N = dv.shape
+        if (h, w) != (H, W):
+            raise _lib.MvsHipError("per-pixel initial ranges %s do not match the %dx%d hypothesis maps" % (tuple(dv.shape), H, W))
+        hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=dv.device)
+        check(lib().mvs_init_range_pixel_fwd(ptr(dv), N, 1 if inverse else 0, ptr(hyp), B, ndepths, H, W, stream_of(dv)), "mvs_init_range_pixel_fwd")
+        return hyp
     B, N = dv.shape
     hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=dv.device)
     check(lib().mvs_init_range_fwd(ptr(dv), N, 1 if inverse else 0, ptr(hyp), B, ndepths, H, W, stream_of(dv)), "mvs_init_range_fwd")
     return hyp
 
 
-def schedule_inverse_range(prev_depth: torch.Tensor, prev_hyp: torch.Tensor, ndepths: int, ratio: float, H: int, W: int) -> torch.Tensor:
+def schedule_inverse_range(prev_depth: torch.Tensor, prev_hyp: torch.Tensor, ndepths: int, ratio: float, H: int, W: int,
+                           shift: bool = False) -> torch.Tensor:
     d, h = _f32c(prev_depth), _f32c(prev_hyp)
     B, Dp = h.shape[:2]
     assert tuple(d.shape[-2:]) == (H // 2, W // 2) and tuple(h.shape[-2:]) == (H // 2, W // 2)
     hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=d.device)
-    check(lib().mvs_schedule_inverse_range_fwd(ptr(d), ptr(h), Dp, float(ratio), ptr(hyp), B, ndepths, H, W, stream_of(d)),
+    check(lib().mvs_schedule_inverse_range_fwd(ptr(d), ptr(h), Dp, float(ratio), 1 if shift else 0, ptr(hyp), B, ndepths, H, W, stream_of(d)),
           "mvs_schedule_inverse_range_fwd")
     return hyp
 
@@ -743,9 +785,15 @@ def schedule_inverse_range(prev_depth: torch.Tensor, prev_hyp: torch.Tensor, nde
 def schedule_range(prev_depth: torch.Tensor, ndepths: int, interval: torch.Tensor, H: int, W: int) -> torch.Tensor:
     d = _f32c(prev_depth)
     B = d.shape[0]
-    itv = _f32c(interval.reshape(-1).expand(B) if interval.numel() == 1 else interval.reshape(B))
+    per_pixel = interval.dim() == 3                       # [B,H/2,W/2] intervals (module.py:731-732 takes them as they are)
+    if per_pixel:
+        if tuple(interval.shape) != tuple(d.shape):
+            raise _lib.MvsHipError("per-pixel depth intervals %s do not match the depth map %s" % (tuple(interval.shape), tuple(d.shape)))
+        itv = _f32c(interval)
+    else:
+        itv = _f32c(interval.reshape(-1).expand(B) if interval.numel() == 1 else interval.reshape(B))
     hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=d.device)
-    check(lib().mvs_schedule_range_fwd(ptr(d), ptr(itv), ptr(hyp), B, ndepths, H, W, stream_of(d)), "mvs_schedule_range_fwd")
+    check(lib().mvs_schedule_range_fwd(ptr(d), ptr(itv), 1 if per_pixel else 0, ptr(hyp), B, ndepths, H, W, stream_of(d)), "mvs_schedule_range_fwd")
     return hyp
 
 

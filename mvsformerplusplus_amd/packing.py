@@ -186,3 +186,16 @@ def pad_bias(b: torch.Tensor) -> torch.Tensor:
     out = torch.zeros(n, dtype=torch.float32, device=b.device)
     out[: b.numel()] = b.float()
     return out
+
+
+def pack_generic_conv_weights(w: torch.Tensor) -> torch.Tensor:
+    """nn.Conv3d weight [Cout, Cin, kd, kh, kw] (BN already folded) -> [kd*kh*kw][Cin][Cout] fp32 (mvs_conv3d_generic_fwd)."""
+    cout, cin = w.shape[:2]
+    return w.float().permute(2, 3, 4, 1, 0).reshape(-1, cin, cout).contiguous()
+
+
+def pack_generic_deconv_weights(w: torch.Tensor) -> torch.Tensor:
+    """nn.ConvTranspose3d weight [Cin, Cout, kd, kh, kw] (BN folded along dim 1) -> [kd*kh*kw][Cin][Cout] fp32, taps NOT flipped
+    (the kernel gathers input i = (o + p - k) / s for kernel index k)."""
+    cin, cout = w.shape[:2]
+    return w.float().permute(2, 3, 4, 0, 1).reshape(-1, cin, cout).contiguous()

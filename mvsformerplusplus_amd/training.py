@@ -330,7 +330,7 @@ class RegNetTrain(torch.autograd.Function):
 def regnet_forward_native(reg, volume_cl: torch.Tensor) -> torch.Tensor:
     """CostRegNet / CostRegNet3D up to `prob` on the library's kernels, channel-last in and out."""
     if not isinstance(reg.inner, nn.Identity):
-        raise NotImplementedError("in_channels != base_channels (1x1x1 `inner` conv) is not used by any shipped config")
+        raise NotImplementedError("in_channels != base_channels (1x1x1 `inner` conv): inference only (shape-generic kernel); no training kernels")
     params = []
     for name in RegNetTrain.NAMES:
         conv, bn, _ = _block_parts(getattr(reg, name))
@@ -608,7 +608,10 @@ def stage_forward_train(net, features, proj_matrices, depth_values, tmp, positio
     # the reference runs the visibility CNN once per source view on a batch of B maps (cost_volume.py:93); BatchNorm statistics
     # are per call there, so the views are kept as separate calls here as well
     if G != 8:
-        raise NotImplementedError("base_ch=%d: the HIP training kernels are built for 8 groups (all shipped configs)" % G)   # as in inference
+        # inference runs such a stage on the shape-generic convolution kernel (module._RegNetBase.forward_cl_generic); the training
+        # kernels (BatchNorm statistics, weight gradients, data gradients) exist for the tuned tables' widths only
+        raise NotImplementedError("base_ch=%d: the HIP training kernels are built for 8 groups (all shipped configs); inference of this "
+                                  "stage works (shape-generic kernel), fine-tuning it does not" % G)
     prec = getattr(net, "conv_precision", "bf16x3")
     if prec == "fp32":
         # a head configured for exact-fp32 INFERENCE can still be fine-tuned: the training kernels contract in split bf16

@@ -128,8 +128,17 @@ def _deconv3d_bn_relu(x, sd, wkey, bnprefix, stride, output_padding):
     return F.relu(_bn(x, sd, bnprefix))
 
 
+def _inner(conv0: torch.Tensor, sd: SD, p: str) -> torch.Tensor:
+    """``self.inner`` module.py:385-388 / 481-484: nn.Conv3d(in_channels, base_channels, 1, 1) (with bias) when the two differ, else
+    nn.Identity (then the state dict has no ``inner.*`` keys)."""
+    if (p + "inner.weight") in sd:
+        return F.conv3d(conv0, sd[p + "inner.weight"], sd[p + "inner.bias"], stride=1, padding=0)
+    return conv0
+
+
 def cost_regnet(x: torch.Tensor, sd: SD, prefix: str = "cost_reg") -> torch.Tensor:
-    """``CostRegNet.forward_once`` module.py:398-408 (in_channels == base_channels -> inner = Identity)."""
+    """``CostRegNet.forward_once`` module.py:398-408, any in_channels / base_channels (the widths are the state dict's); without
+    ``prob.weight`` in the state dict it is the ``last_layer=False`` form and the features come back (module.py:406-408)."""
     p = prefix + "."
     conv0 = x
     conv2 = _conv3d_bn_relu(_conv3d_bn_relu(conv0, sd, p + "conv1", 2), sd, p + "conv2", 1)
@@ -137,7 +146,9 @@ def cost_regnet(x: torch.Tensor, sd: SD, prefix: str = "cost_reg") -> torch.Tens
     x = _conv3d_bn_relu(_conv3d_bn_relu(conv4, sd, p + "conv5", 2), sd, p + "conv6", 1)
     x = conv4 + _deconv3d_bn_relu(x, sd, p + "conv7.conv.weight", p + "conv7.bn", 2, 1)
     x = conv2 + _deconv3d_bn_relu(x, sd, p + "conv9.conv.weight", p + "conv9.bn", 2, 1)
-    x = conv0 + _deconv3d_bn_relu(x, sd, p + "conv11.conv.weight", p + "conv11.bn", 2, 1)
+    x = _inner(conv0, sd, p) + _deconv3d_bn_relu(x, sd, p + "conv11.conv.weight", p + "conv11.bn", 2, 1)
+    if (p + "prob.weight") not in sd:
+        return x
     return F.conv3d(x, sd[p + "prob.weight"], None, stride=1, padding=1)          # module.py:391 (3x3x3, no bias)
 
 
@@ -152,7 +163,7 @@ def cost_regnet3d(x: torch.Tensor, sd: SD, prefix: str = "cost_reg") -> torch.Te
     x = _conv3d_bn_relu(_conv3d_bn_relu(conv4, sd, p + "conv5", s), sd, p + "conv6", 1)
     x = conv4 + _deconv3d_bn_relu(x, sd, p + "conv7.0.weight", p + "conv7.1", s, op)
     x = conv2 + _deconv3d_bn_relu(x, sd, p + "conv9.0.weight", p + "conv9.1", s, op)
-    x = conv0 + _deconv3d_bn_relu(x, sd, p + "conv11.0.weight", p + "conv11.1", s, op)
+    x = _inner(conv0, sd, p) + _deconv3d_bn_relu(x, sd, p + "conv11.0.weight", p + "conv11.1", s, op)
     return F.conv3d(x, sd[p + "prob.weight"], sd[p + "prob.bias"], stride=1, padding=0)    # module.py:486
 
 

@@ -125,6 +125,48 @@ def f14_stage_bd_hypotheses():
         photometric_confidence=out["photometric_confidence"], prob_volume_pre=out["prob_volume_pre"], **wman)
 
 
+@torch.no_grad()
+def f15_stage_other_groups():
+    """StageNet with base_ch != 8 (cost_volume.py:29-49: in_channels = base_ch, CostRegNet(G, G) / CostRegNet3D(G, G), widths 2G / 4G / 8G):
+    G = 4 < C on a CostRegNet stage (D = 16) and on a CostRegNet3D stage (D = 4), G = C = 16 (the per-channel branch :83-85) on D = 4."""
+    for tag, stage_idx, C, G, D, H, W in (("g4_s1", 1, 16, 4, 16, 32, 40), ("g4_s3", 3, 8, 4, 4, 32, 40), ("g16_s2", 2, 16, 16, 4, 16, 24)):
+        torch.manual_seed(70 + G + stage_idx)
+        args = dict(ARGS, base_ch=[G] * 4)
+        net = StageNet(args, D, stage_idx).eval()
+        wman = seed_weights(net, 270 + G + stage_idx)
+        feats, cams, hyp = stage_inputs(C, D, H, W, 3, 70 + G + stage_idx, down=2 ** (3 - stage_idx))
+        cap = {}
+        h = net.cost_reg.register_forward_hook(lambda m, i, o: cap.__setitem__("vol", i[0].detach().clone()))
+        tmp = 5.0 if stage_idx < 3 else 1.0
+        out = net(feats, cams, hyp, tmp=tmp)
+        h.remove()
+        npz("f15_stage_%s.npz" % tag, features=feats, proj=cams, hyp=hyp, tmp=np.float32(tmp), stage_idx=np.int32(stage_idx),
+            base_ch=np.int32(G), volume_mean=cap["vol"], depth=out["depth"], prob_volume=out["prob_volume"],
+            photometric_confidence=out["photometric_confidence"], prob_volume_pre=out["prob_volume_pre"], **wman)
+
+
+@torch.no_grad()
+def f16_regnet_inner():
+    """Regularisers whose in_channels differ from base_channels (the 1x1x1 `inner` convolution, module.py:385-388 / 481-484), other
+    base widths, CostRegNet(last_layer=False) (features out, :406-408) and CostRegNet3D(log_var=True) (two `prob` channels, :486)."""
+    g = torch.Generator().manual_seed(16)
+    cases = (("crn_4_8", lambda: CostRegNet(4, 8), (1, 4, 8, 16, 16)),
+             ("crn_12_4", lambda: CostRegNet(12, 4), (2, 12, 8, 8, 16)),
+             ("crn_8_8_nolast", lambda: CostRegNet(8, 8, last_layer=False), (1, 8, 8, 8, 16)),
+             ("crn3d_12_8", lambda: CostRegNet3D(12, 8), (1, 12, 4, 16, 24)),
+             ("crn3d_6_6", lambda: CostRegNet3D(6, 6), (1, 6, 3, 8, 16)),
+             ("crn3d_8_8_logvar", lambda: CostRegNet3D(8, 8, log_var=True), (1, 8, 4, 8, 16)))
+    arrs = {}
+    for i, (tag, make, shape) in enumerate(cases):
+        torch.manual_seed(160 + i)
+        net = make().eval()
+        arrs.update(seed_weights(net, 160 + i, prefix=tag + ".w."))
+        x = torch.randn(*shape, generator=g)
+        arrs[tag + ".x"] = x
+        arrs[tag + ".y"] = net.forward_once(x)
+    npz("f16_regnet_inner.npz", **arrs)
+
+
 def pin_weights():
     """tests/golden/weights_sha256.json: SHA-256 of every weight set the fixtures regenerate from (manifest, seed) - checked on every load
     (tests/conftest.py golden_weights)."""
@@ -229,6 +271,33 @@ def f5_small_fns():
     arrs["schedule_range_itv"] = itv
     arrs["schedule_range"] = schedule_range(prev_depth, 4, itv, 10, 12)
     npz("f5_small_fns.npz", **arrs)
+
+
+@torch.no_grad()
+def f17_range_variants():
+    """The branches of the range functions no shipped config takes: per-pixel initial ranges [B,H,W,N] (module.py:683-688, 698-703),
+    schedule_inverse_range(shift=True) (:712-715; the DTU-like depths put most pixels below the 0.002 floor, so the branch fires) and
+    per-pixel depth intervals [B,H/2,W/2] in schedule_range (:731-732)."""
+    g = torch.Generator().manual_seed(17)
+    arrs = {}
+    lo = 400 + 100 * torch.rand(2, 5, 6, 1, generator=g)
+    px = torch.cat([lo, lo + 200, lo + 400 + 100 * torch.rand(2, 5, 6, 1, generator=g)], -1).contiguous()      # [B,H,W,3], first < last
+    arrs["pixel_ranges"] = px
+    arrs["init_range_pixel"] = init_range(px, 8, px.device, px.dtype, 5, 6)
+    arrs["init_inverse_range_pixel"] = init_inverse_range(px, 8, px.device, px.dtype, 5, 6)
+    dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None].repeat(2, 1)
+    prev_hyp = init_inverse_range(dv, 8, dv.device, dv.dtype, 5, 6) * (1 + 0.01 * torch.rand(2, 8, 5, 6, generator=g))
+    plane = torch.randint(0, 8, (2, 1, 5, 6), generator=g)                  # a surface anywhere in the range: near planes stay above the floor
+    prev_depth = torch.gather(prev_hyp, 1, plane)[:, 0] * (1 + 0.02 * torch.rand(2, 5, 6, generator=g))
+    arrs["prev_hyp"] = prev_hyp
+    arrs["prev_depth"] = prev_depth
+    arrs["schedule_inverse_range_shift"] = schedule_inverse_range(prev_depth, prev_hyp, 4, 1.0, 10, 12, shift=True)
+    inv_max = 1 / prev_depth - 1.0 * (1. / prev_hyp[:, 2] - 1. / prev_hyp[:, 1])
+    assert 0.2 < float((inv_max < 0.002).float().mean()) < 0.95, "the fixture must exercise both sides of the shift floor"
+    itv = 2.65 * (1 + torch.rand(2, 5, 6, generator=g))
+    arrs["schedule_range_itv_pixel"] = itv
+    arrs["schedule_range_pixel"] = schedule_range(prev_depth, 4, itv, 10, 12)
+    npz("f17_range_variants.npz", **arrs)
 
 
 @torch.no_grad()
@@ -508,4 +577,7 @@ if __name__ == "__main__":
     f12_train_backward()
     f13_train_backward_transformer()
     f14_stage_bd_hypotheses()
+    f15_stage_other_groups()
+    f16_regnet_inner()
+    f17_range_variants()
     pin_weights()

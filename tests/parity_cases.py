@@ -166,6 +166,146 @@ def case_single_layers(device, prec=None):
         assert (y - ref).abs().max() <= lt * max(1.0, float(ref.abs().max())), (cin, cout, sd)
 
 
+# ---------------------------------------------------------------- a7-a9 outside the tuned tables (shape-generic exact-fp32 kernel)
+def case_generic_conv_layers(device):
+    """Conv3d / Deconv3d wrappers on layer shapes NO tuned kernel exists for (other channel counts, 1x1x1 / 3x1x1 / 5x3x3 / even kernels,
+    padding 0, stride 3, no BatchNorm / no ReLU forms) against torch's own fp32 convolution: the shape-generic kernel is exact fp32, the
+    bound is summation-order noise."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(21)
+    convs = ((4, 8, 3, 2, 1, (6, 7, 9), {}), (12, 6, 3, (1, 2, 2), 1, (3, 8, 10), {}), (5, 3, 1, 1, 0, (2, 5, 7), {}),
+             (8, 1, 3, 1, 1, (4, 5, 6), {"bn": False, "relu": False}), (3, 10, (3, 1, 1), 1, (1, 0, 0), (5, 4, 6), {"relu": False}),
+             (6, 7, (5, 3, 3), (1, 3, 2), (2, 0, 1), (7, 9, 8), {}), (16, 16, 2, 2, 0, (4, 6, 8), {"bn": False}),
+             (128, 8, 3, 1, 1, (2, 3, 5), {}), (8, 16, 3, 2, 0, (5, 7, 9), {"bn": False}))
+    for cin, cout, k, st, pad, shape, kw in convs:
+        layer = M.Conv3d(cin, cout, kernel_size=k, stride=st, padding=pad, **kw)
+        layer.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(layer.state_dict()), 5))
+        layer = layer.eval().to(device)
+        assert not layer.is_tuned(), (cin, cout, k, st, pad)
+        x = torch.randn(2, cin, *shape, generator=g)
+        ref = F.conv3d(x, layer.conv.weight.cpu(), None if layer.conv.bias is None else layer.conv.bias.cpu(), stride=st, padding=pad)
+        if layer.bn is not None:
+            ref = F.batch_norm(ref, layer.bn.running_mean.cpu(), layer.bn.running_var.cpu(), layer.bn.weight.cpu(), layer.bn.bias.cpu(), False, 0.1, 1e-5)
+        if layer.relu:
+            ref = F.relu(ref)
+        with torch.no_grad():
+            y = cpu(layer(dev(x, device)))
+        assert y.shape == ref.shape, (y.shape, ref.shape)
+        assert (y - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max())), (cin, cout, k, st, pad, float((y - ref).abs().max()))
+    deconvs = ((8, 4, 3, 2, 1, 1, (3, 4, 5), {}), (6, 10, 3, (1, 2, 2), 1, (0, 1, 1), (3, 4, 6), {}), (4, 4, 2, 2, 0, 0, (3, 3, 4), {"bn": False, "relu": False}),
+               (5, 2, (3, 3, 1), (2, 3, 1), (1, 0, 0), (1, 2, 0), (3, 4, 5), {"relu": False}), (16, 8, 3, 2, 1, 0, (3, 4, 5), {}),
+               (16, 8, 3, 2, 1, 1, (3, 4, 5), {"bn": False}))
+    for cin, cout, k, st, pad, op, shape, kw in deconvs:
+        layer = M.Deconv3d(cin, cout, kernel_size=k, stride=st, padding=pad, output_padding=op, **kw)
+        layer.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(layer.state_dict()), 6))
+        layer = layer.eval().to(device)
+        assert not layer.is_tuned(), (cin, cout, k, st, pad, op)
+        x = torch.randn(2, cin, *shape, generator=g)
+        ref = F.conv_transpose3d(x, layer.conv.weight.cpu(), None if layer.conv.bias is None else layer.conv.bias.cpu(), stride=st, padding=pad,
+                                 output_padding=op)
+        if layer.bn is not None:
+            ref = F.batch_norm(ref, layer.bn.running_mean.cpu(), layer.bn.running_var.cpu(), layer.bn.weight.cpu(), layer.bn.bias.cpu(), False, 0.1, 1e-5)
+        if layer.relu:
+            ref = F.relu(ref)
+        with torch.no_grad():
+            y = cpu(layer(dev(x, device)))
+        assert y.shape == ref.shape, (y.shape, ref.shape)
+        assert (y - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max())), (cin, cout, k, st, pad, op, float((y - ref).abs().max()))
+    # the C ABI refuses output sizes that do not follow from the layer arithmetic, and skip tensors of another shape
+    x = dev(torch.randn(1, 3, 4, 4, 4, generator=g), device)
+    w = dev(torch.randn(27, 4, 5, generator=g), device)
+    for bad in (lambda: ops.conv3d_generic(x.permute(0, 2, 3, 4, 1).contiguous(), w, None, 5, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # Cin mismatch
+                lambda: ops.conv3d_generic(x, w[:, :3].contiguous()[:, :, :4].contiguous(), None, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1),
+                                           skip_cl=x)):                                                                           # skip shape
+        try:
+            bad()
+        except _lib.MvsHipError:
+            pass
+        else:
+            raise AssertionError("a mismatching weight / skip tensor must be refused")
+    xc = dev(torch.randn(1, 4, 4, 4, 3, generator=g), device)
+    y = torch.empty(1, 9, 9, 9, 5, device=xc.device)
+    rc = _lib.lib().mvs_conv3d_generic_fwd(_lib.ptr(xc), _lib.ptr(dev(torch.randn(27, 3, 5, generator=g), device)), None, None, _lib.ptr(y), 1, 3, 5, 4, 4, 4,
+                                           9, 9, 9, 3, 3, 3, 2, 2, 2, 1, 1, 1, 1, 0, None)
+    assert rc == 1, "output size 9 of a stride-2 k3 p1 transposed layer on 4 inputs (valid: 7, 8) must be MVS_ERR_ARG"
+
+
+def case_regnet_generic_golden(device):
+    """Fixture F16 from the reference: regularisers whose in_channels differ from base_channels (`inner` 1x1x1 convolution,
+    module.py:385-388 / 481-484), other base widths, last_layer=False and log_var=True - all on the shape-generic kernel."""
+    fx = load_golden("f16_regnet_inner.npz")
+    made = {"crn_4_8": lambda: M.CostRegNet(4, 8), "crn_12_4": lambda: M.CostRegNet(12, 4), "crn_8_8_nolast": lambda: M.CostRegNet(8, 8, last_layer=False),
+            "crn3d_12_8": lambda: M.CostRegNet3D(12, 8), "crn3d_6_6": lambda: M.CostRegNet3D(6, 6), "crn3d_8_8_logvar": lambda: M.CostRegNet3D(8, 8, log_var=True)}
+    errs = {}
+    for tag, make in made.items():
+        net = make()
+        net.load_state_dict(golden_weights(fx, prefix=tag + ".w."), strict=True)      # reference state-dict names (incl. inner.weight / .bias), strict
+        net = net.eval().to(device)
+        assert net.is_generic, tag
+        with torch.no_grad():
+            y = cpu(net(dev(fx[tag + ".x"], device)))
+        want = fx[tag + ".y"]
+        assert y.shape == want.shape, (tag, y.shape, want.shape)
+        errs[tag] = float((y - want).abs().max()) / max(1.0, float(want.abs().max()))
+        assert errs[tag] <= 2e-5, "generic regulariser %s differs from the reference: %g" % (tag, errs[tag])
+    # a volume whose size the U-Net's skip adds do not fit is refused with the reference's constraint spelled out
+    net = M.CostRegNet(4, 4).eval().to(device)
+    try:
+        with torch.no_grad():
+            net(dev(torch.zeros(1, 4, 8, 12, 16), device))
+    except ValueError as e:
+        assert "divisible by 8" in str(e)
+    else:
+        raise AssertionError("H = 12 cannot pass three stride-2 levels")
+    return errs
+
+
+def case_stage_other_groups_golden(device, tag, prec=None):
+    """Fixture F15 from the reference: StageNet with base_ch != 8 (cost_volume.py:29-49) - the direct gather with G groups, an fp32 volume
+    [B,D,H,W,G], the CostRegNet(G, G) / CostRegNet3D(G, G) of the reference's own widths on the shape-generic kernel.  conv_precision only
+    selects the visibility CNN's format here (its fp16 form shifts the volume by ~1e-4)."""
+    fx = load_golden("f15_stage_%s.npz" % tag)
+    D, G = fx["hyp"].shape[1], int(fx["base_ch"])
+    args = with_prec(dict(ARGS, base_ch=[G] * 4), prec)
+    net = StageNet(args, D, int(fx["stage_idx"]))
+    net.load_state_dict(golden_weights(fx), strict=True)
+    net = net.eval().to(device)
+    assert net._generic_regulariser() and not net._f16_activations() and not net._split_activations()
+    with torch.no_grad():
+        out = net(dev(fx["features"], device), dev(fx["proj"], device), dev(fx["hyp"], device), float(fx["tmp"]))
+    assert set(out) == {"depth", "prob_volume", "photometric_confidence", "depth_values", "prob_volume_pre"}
+    errs = (rel_l1(cpu(out["depth"]), fx["depth"]), float((cpu(out["prob_volume_pre"]) - fx["prob_volume_pre"]).abs().max()),
+            float((cpu(out["prob_volume"]) - fx["prob_volume"]).abs().max()),
+            float((cpu(out["photometric_confidence"]) - fx["photometric_confidence"]).abs().max()))
+    assert errs[0] <= tol(prec, 2e-5, 2e-4), "stage depth vs reference (bar: 1e-3): %g" % errs[0]
+    assert errs[1] <= tol(prec, 5e-4, 1e-2), errs
+    assert errs[2] <= tol(prec, 1e-4, 2e-3) and errs[3] <= tol(prec, 1e-4, 2e-3), errs
+    return errs
+
+
+def case_cascade_other_groups_vs_oracle(device, G=4, prec=None):
+    """A whole 4-stage cascade with base_ch = G != 8 against the oracle (64 x 128, V = 3): hypothesis scheduling, both U-Net kinds and
+    the confidence average downstream of the generic stages."""
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    args = with_prec({"base_ch": [G] * 4, "depth_type": ["ce"] * 4, "fusion_type": "cnn", "cost_reg_type": ["Normal"] * 4, "ndepths": [32, 16, 8, 4],
+                      "depth_interals_ratio": [4.0, 2.67, 1.5, 1.0], "inverse_depth": True}, prec)
+    head = CascadeDepthHead(dict(args))
+    for i, st in enumerate(head.fusions):
+        st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 40 + i), strict=True)
+    head = head.eval()
+    feats, projs, dv = synth.make_cascade_inputs(64, 128, 3, seed=5, rot_deg=1.0)
+    sds = [dict(st.state_dict()) for st in head.fusions]
+    with torch.no_grad():
+        ref = O.cascade_forward(feats, projs, dv, sds, ndepths=args["ndepths"], depth_interals_ratio=args["depth_interals_ratio"], base_ch=args["base_ch"])
+        head = head.to(device)
+        out = head({k: dev(v, device) for k, v in feats.items()}, {k: dev(v, device) for k, v in projs.items()}, dev(dv, device))
+    e = rel_l1(cpu(out["refined_depth"]), ref["refined_depth"])
+    c = float((cpu(out["photometric_confidence"]) - ref["photometric_confidence"]).abs().max())
+    assert e <= tol(prec, 5e-5, 5e-4), "refined depth vs oracle (bar 1e-3): %g" % e
+    assert c <= tol(prec, 2e-3, 5e-2), c
+    return e, c
+
+
 # ---------------------------------------------------------------- a1-a12 one stage
 def make_stage(fx, ndepth, stage_idx, device, depth_type="ce", prec=None):
     args = with_prec(ARGS, prec)
@@ -290,6 +430,28 @@ def case_small_fns(device):
     assert torch.allclose(cpu(got), fx["schedule_inverse_range"], rtol=2e-6, atol=0)
     got = M.schedule_range(dev(fx["prev_depth"], device), 4, dev(fx["schedule_range_itv"], device), 10, 12)
     assert torch.allclose(cpu(got), fx["schedule_range"], rtol=2e-6, atol=0)
+
+
+def case_range_variants(device):
+    """Fixture F17 from the reference: per-pixel initial ranges, schedule_inverse_range(shift=True), per-pixel depth intervals."""
+    fx = load_golden("f17_range_variants.npz")
+    px = dev(fx["pixel_ranges"], device)
+    assert torch.allclose(cpu(M.init_range(px, 8, px.device, px.dtype, 5, 6)), fx["init_range_pixel"], rtol=1e-6, atol=0)
+    assert torch.allclose(cpu(M.init_inverse_range(px, 8, px.device, px.dtype, 5, 6)), fx["init_inverse_range_pixel"], rtol=1e-6, atol=0)
+    pd, ph = dev(fx["prev_depth"], device), dev(fx["prev_hyp"], device)
+    got = cpu(M.schedule_inverse_range(pd, ph, 4, 1.0, 10, 12, shift=True))
+    assert torch.allclose(got, fx["schedule_inverse_range_shift"], rtol=5e-6, atol=0)
+    plain = cpu(M.schedule_inverse_range(pd, ph, 4, 1.0, 10, 12))
+    assert float((got - plain).abs().max()) > 1.0, "shift=True must change the hypotheses of this fixture"
+    got = M.schedule_range(pd, 4, dev(fx["schedule_range_itv_pixel"], device), 10, 12)
+    assert torch.allclose(cpu(got), fx["schedule_range_pixel"], rtol=2e-6, atol=0)
+    for bad in (lambda: M.init_range(px[:, :, :, 0], 8, px.device, px.dtype, 5, 6), lambda: M.init_range(px, 8, px.device, px.dtype, 6, 5)):
+        try:
+            bad()
+        except (ValueError, _lib.MvsHipError):
+            pass
+        else:
+            raise AssertionError("a range tensor of the wrong rank / map size must be refused")
 
 
 def case_generic_shapes(device):

@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol():
     from mvsformerplusplus_amd import build
     path = build.build()                       # hipcc cross-compiles gfx950 without a GPU
     lib = _lib.bind(path)                      # getattr() on every symbol; raises if one is missing
-    assert lib.mvs_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.mvs_abi_version() == _lib.ABI_VERSION == 10
     for name in header_symbols():
         assert hasattr(lib, name)
 

@@ -92,6 +92,27 @@ def _slab_worker(rank, world, port, emu_path, precision, q):
     dist.destroy_process_group()
 
 
+def _other_groups_worker(rank, world, port, emu_path, mode, q):
+    """A stage with base_ch = 4 (fixture F15: the shape-generic regulariser, fp32 partial volumes of 4 groups) sharded over the ranks:
+    all-reduce form and the slab exchange forced on a 32-row map (the halo covers everything: every rank regularises the whole map)."""
+    _setup(rank, world, port, emu_path)
+    from conftest import golden_weights, load_golden
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    fx = load_golden("f15_stage_g4_s3.npz")
+    net = StageNet({"base_ch": [4] * 4, "depth_type": ["ce"] * 4, "conv_precision": "bf16x3"}, fx["hyp"].shape[1], 3)
+    net.load_state_dict(golden_weights(fx), strict=True)
+    net.eval()
+    with torch.no_grad():
+        single = net(fx["features"], fx["proj"], fx["hyp"], 1.0)
+        net.view_group = dist.group.WORLD
+        net.shard_mode = mode
+        sharded = net(fx["features"], fx["proj"], fx["hyp"], 1.0)
+    errs = [float((single[k] - sharded[k]).abs().max() / single[k].abs().max()) for k in ("depth", "photometric_confidence", "prob_volume_pre")]
+    ref = float((sharded["depth"] - fx["depth"]).abs().div(fx["depth"].abs()).mean())
+    q.put((rank, max(max(errs), ref), _agree(sharded["depth"], world)))
+    dist.destroy_process_group()
+
+
 def _cascade_worker(rank, world, port, emu_path, V, mode, q):
     _setup(rank, world, port, emu_path)
     from conftest import golden_weights, load_golden
@@ -156,6 +177,13 @@ def test_slab_mode_matches_single_process(precision, tol):
     for rank, err, same in _run(_slab_worker, 2, precision):
         assert err <= tol, "rank %d: slab-sharded outputs differ from single-process outputs by %g" % (rank, err)
         assert same, "ranks disagree after the slab all-gather"
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "slab"])
+def test_view_sharded_stage_other_base_ch(mode):
+    for rank, err, same in _run(_other_groups_worker, 2, mode):
+        assert err <= 2e-5, "rank %d: sharded base_ch = 4 stage differs from the single-process / reference result by %g" % (rank, err)
+        assert same, "ranks disagree"
 
 
 @pytest.mark.parametrize("world,V,mode", [(4, 10, "auto")])

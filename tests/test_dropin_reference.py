@@ -50,6 +50,41 @@ def test_patch_model_on_the_reference_network(emu, prec):
     assert (out["photometric_confidence"] - ref["photometric_confidence"]).abs().max() <= (5e-3 if prec else 3e-2)
 
 
+def test_patch_model_on_the_reference_network_other_base_ch(emu):
+    """The reference's own network built with base_ch = 4 (not a shipped value) and all-"Normal" regularisers: cost_volume.py:29-49 then
+    builds CostRegNet(4, 4) / CostRegNet3D(4, 4).  patch_model must take the model as it is (strict state-dict load) and reproduce it -
+    the stages run the direct gather with 4 groups and the shape-generic exact-fp32 convolution kernel (ABI v10)."""
+    sys.path.insert(0, REF)
+    try:
+        from models.networks.DINOv2_mvsformer_model import DINOv2MVSNet
+    finally:
+        sys.path.remove(REF)
+    from mvsformerplusplus_amd import patch_model, synth
+    args = json.load(open(os.path.join(REF, "config", "mvsformer++.json")))["arch"]["args"]
+    args["base_ch"] = [4, 4, 4, 4]
+    args["cost_reg_type"] = ["Normal"] * 4
+    torch.manual_seed(0)
+    model = DINOv2MVSNet(args).eval()
+    synth.randomize_bn_(model, seed=4)
+    assert model.fusions[0].cost_reg.conv1.conv.weight.shape[:2] == (8, 4)
+    H, W, V = 64, 128, 3
+    imgs = torch.rand(1, V, 3, H, W, generator=torch.Generator().manual_seed(1))
+    cams = synth.make_cameras(V, H, W, baseline=30.0, rot_deg=1.0, seed=2)
+    projs = synth.stage_proj_matrices(cams, 4)
+    dv = torch.arange(425.0, 2.65 * 191.5 + 425.0, 2.65)[None]
+    with torch.no_grad():
+        ref = model(imgs, projs, dv)
+        patched = patch_model(copy.deepcopy(model), conv_precision="bf16x3")
+        assert all(f._generic_regulariser() for f in patched.fusions)
+        out = patched(imgs, projs, dv)
+    for s in range(1, 5):
+        a, b = out["stage%d" % s]["depth"], ref["stage%d" % s]["depth"]
+        assert float(((a - b).abs() / b.abs()).mean()) <= 2e-4, s
+    r = float(((out["refined_depth"] - ref["refined_depth"]).abs() / ref["refined_depth"].abs()).mean())
+    assert r <= 2e-4, r
+    assert (out["photometric_confidence"] - ref["photometric_confidence"]).abs().max() <= 5e-3
+
+
 def test_patch_model_trains_like_the_reference_network(emu):
     """train.py's use: the reference's whole network in .train() mode with its stages swapped by patch_model.  The stage-1 loss
     (before any argmax-dependent hypothesis scheduling) must give the same gradients for the stage's own parameters AND for the

@@ -31,6 +31,24 @@ def test_regnet_golden(emu, name, prec):
     P.case_regnet_golden(emu, name, prec)
 
 
+def test_generic_conv_layers(emu):
+    P.case_generic_conv_layers(emu)
+
+
+def test_regnet_generic_golden(emu):
+    P.case_regnet_generic_golden(emu)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("tag", ["g4_s1", "g4_s3", "g16_s2"])
+def test_stage_other_groups_golden(emu, tag, prec):
+    P.case_stage_other_groups_golden(emu, tag, prec)
+
+
+def test_cascade_other_groups_vs_oracle(emu):
+    P.case_cascade_other_groups_vs_oracle(emu, G=4, prec="bf16x3")
+
+
 def test_stage_pieces(emu):
     P.case_stage_pieces(emu)
 
@@ -58,6 +76,10 @@ def test_stage_lowp_features(emu, prec):
 
 def test_small_fns(emu):
     P.case_small_fns(emu)
+
+
+def test_range_variants(emu):
+    P.case_range_variants(emu)
 
 
 def test_generic_shapes(emu):

@@ -45,6 +45,25 @@ def test_regnet_golden(name, prec):
     P.case_regnet_golden(DEV, name, prec)
 
 
+def test_generic_conv_layers():
+    P.case_generic_conv_layers(DEV)
+
+
+def test_regnet_generic_golden():
+    P.case_regnet_generic_golden(DEV)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("tag", ["g4_s1", "g4_s3", "g16_s2"])
+def test_stage_other_groups_golden(tag, prec):
+    P.case_stage_other_groups_golden(DEV, tag, prec)
+
+
+@pytest.mark.parametrize("G", [4, 2])
+def test_cascade_other_groups_vs_oracle(G):
+    P.case_cascade_other_groups_vs_oracle(DEV, G=G)
+
+
 def test_stage_pieces():
     P.case_stage_pieces(DEV)
 
@@ -73,6 +92,10 @@ def test_stage_lowp_features(prec):
 
 def test_small_fns():
     P.case_small_fns(DEV)
+
+
+def test_range_variants():
+    P.case_range_variants(DEV)
 
 
 def test_generic_shapes():

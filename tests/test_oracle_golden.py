@@ -53,6 +53,29 @@ def test_f3_regnets(name, fn):
     assert (y - fx["y"]).abs().max() <= 1e-4 * max(1.0, float(fx["y"].abs().max()))
 
 
+@pytest.mark.parametrize("tag", ["g4_s1", "g4_s3", "g16_s2"])
+def test_f15_stage_other_groups(tag):
+    """base_ch != 8 (cost_volume.py:29-49): G groups in the correlation, CostRegNet(G, G) / CostRegNet3D(G, G) widths."""
+    fx = load_golden("f15_stage_%s.npz" % tag)
+    sd = golden_weights(fx)
+    out = O.stage_forward(fx["features"], fx["proj"], fx["hyp"], float(fx["tmp"]), sd, G=int(fx["base_ch"]), return_intermediates=True)
+    assert out["volume_mean"].shape[1] == int(fx["base_ch"])
+    assert (out["volume_mean"] - fx["volume_mean"]).abs().max() <= 1e-5
+    assert (out["prob_volume_pre"] - fx["prob_volume_pre"]).abs().max() <= 1e-4
+    assert (out["prob_volume"] - fx["prob_volume"]).abs().max() <= 1e-5
+    assert rel_l1(out["depth"], fx["depth"]) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["crn_4_8", "crn_12_4", "crn_8_8_nolast", "crn3d_12_8", "crn3d_6_6", "crn3d_8_8_logvar"])
+def test_f16_regnet_inner(tag):
+    """in_channels != base_channels (`inner`, module.py:385-388 / 481-484), last_layer=False, log_var=True."""
+    fx = load_golden("f16_regnet_inner.npz")
+    sd = {"cost_reg." + k: v for k, v in golden_weights(fx, prefix=tag + ".w.").items()}
+    y = (O.cost_regnet3d if "3d" in tag else O.cost_regnet)(fx[tag + ".x"], sd)
+    assert y.shape == fx[tag + ".y"].shape
+    assert (y - fx[tag + ".y"]).abs().max() <= 1e-4 * max(1.0, float(fx[tag + ".y"].abs().max()))
+
+
 def test_f4_cascade():
     fx = load_golden("f4_cascade.npz")
     feats = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
@@ -67,6 +90,17 @@ def test_f4_cascade():
         assert (st["photometric_confidence"] - fx["conf%d" % s]).abs().max() <= 1e-4
     assert rel_l1(out["refined_depth"], fx["refined_depth"]) <= 1e-6
     assert (out["photometric_confidence"] - fx["photometric_confidence"]).abs().max() <= 1e-4
+
+
+def test_f17_range_variants():
+    fx = load_golden("f17_range_variants.npz")
+    px = fx["pixel_ranges"]
+    assert torch.equal(O.init_range(px, 8, 5, 6), fx["init_range_pixel"])
+    assert torch.equal(O.init_inverse_range(px, 8, 5, 6), fx["init_inverse_range_pixel"])
+    got = O.schedule_inverse_range(fx["prev_depth"], fx["prev_hyp"], 4, 1.0, 10, 12, shift=True)
+    assert torch.allclose(got, fx["schedule_inverse_range_shift"], rtol=1e-6, atol=0)
+    got = O.schedule_range(fx["prev_depth"], 4, fx["schedule_range_itv_pixel"], 10, 12)
+    assert torch.allclose(got, fx["schedule_range_pixel"], rtol=1e-6, atol=0)
 
 
 def test_f5_small_fns():
