@@ -154,15 +154,15 @@ int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, con
                                 int V, int C, int G, int D, int H, int W, int view_begin, int view_end, void* stream);
 /* ---- slab exchange of the view-sharded latency mode (no reference counterpart - the reference is
  * single-GPU; the sums follow cost_volume.py:97-101).  Message j = rows [row_begin[j], row_end[j]) of a PARTIAL fp32 volume
- * [B,D,H,W,8] followed by the same rows of the partial visibility sum [B,H,W], i.e. B*D*rows*W*8 + B*rows*W floats.
+ * [B,D,H,W,G] followed by the same rows of the partial visibility sum [B,H,W], i.e. B*D*rows*W*G + B*rows*W floats (G: v10).
  * mvs_slab_pack: one launch writes the messages of all n_ranks destinations (send_host_ptrs[j] = device buffer, NULL = no message).
  * mvs_slab_reduce: slab_out = sum over ranks j = 0 .. n_ranks-1, in that order, of rank j's partial of MY rows [row_begin, row_end):
  * the own slice (j == my_rank) read in place from (volume_cl, vis_sum), the others from recv_host_ptrs[j] (NULL = rank j sent
  * nothing).  The pointer arrays are HOST arrays of device pointers (at most 16 ranks).                                           */
 int mvs_slab_pack(const float* volume_cl, const float* vis_sum, float* const* send_host_ptrs, const int* row_begin, const int* row_end,
-                  int n_ranks, int B, int D, int H, int W, void* stream);
+                  int n_ranks, int B, int D, int H, int W, int G, void* stream);
 int mvs_slab_reduce(const float* volume_cl, const float* vis_sum, float* const* recv_host_ptrs, int n_ranks, int my_rank, float* slab_out,
-                    int row_begin, int row_end, int B, int D, int H, int W, void* stream);
+                    int row_begin, int row_end, int B, int D, int H, int W, int G, void* stream);
 /* volume_cl /= (vis_sum + 1e-6) in place; volume_format = MVS_VOLUME_SPLIT additionally converts it to the split format */
 int mvs_volume_normalise(float* volume_cl, const float* vis_sum, int B, int D, int H, int W, int G, int volume_format, void* stream);
 /* fp32 volume [B,D,H,W,8] (vis_sum != NULL: divided by vis_sum + 1e-6 first) -> fp16 [B,D,H,W,8] in a separate buffer, clamped to the

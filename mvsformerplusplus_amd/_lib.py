@@ -52,8 +52,8 @@ SIGNATURES = {
     "mvs_gather_keeps_correlations": (_i, [_i, _i, _i, _i, _i, _i]),
     "mvs_warp_corr_entropy_keep_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "mvs_corr_aggregate_fwd": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_vp]),
-    "mvs_slab_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "mvs_slab_reduce": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mvs_slab_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mvs_slab_reduce": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mvs_deconv3d_bn_relu_add_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mvs_conv3d_generic_fwd": (_i, [_vp] * 5 + [_i] * 20 + [_vp]),

@@ -436,7 +436,7 @@ __global__ void volume_to_split_kernel(float* __restrict__ vol, const float* __r
 
 // ------------------------------------------------------------------------------------------------
 // Slab exchange of the view-sharded latency mode (no reference counterpart: the reference is single-GPU).
-// A message to / from rank j = the rows [r0_j, r1_j) of a partial volume [B,D,H,W,8] followed by the same rows of the partial
+// A message to / from rank j = the rows [r0_j, r1_j) of a partial volume [B,D,H,W,G] followed by the same rows of the partial
 // visibility sum [B,H,W].  Round 2 built every message with two strided torch copies and summed the received partials with R - 1
 // separate add_ launches; here ONE launch packs the messages of all destinations and ONE launch sums the own slice and every
 // received message (fixed rank order) into the slab the regulariser reads.
@@ -449,8 +449,9 @@ struct SlabMsgs {
 };
 
 // element e of a message over rows [r0, r1): e < nvol -> volume element (b, d, row, x, g), else visibility-sum element (b, row, x)
-__device__ __forceinline__ float slab_src(const float* __restrict__ vol, const float* __restrict__ vsum, size_t e, int r0, int rows, int B, int D, int H, int W) {
-    const size_t rowq = (size_t)W * 8, nvol = (size_t)B * D * rows * rowq;
+__device__ __forceinline__ float slab_src(const float* __restrict__ vol, const float* __restrict__ vsum, size_t e, int r0, int rows, int B, int D, int H, int W,
+                                          int G) {
+    const size_t rowq = (size_t)W * G, nvol = (size_t)B * D * rows * rowq;
     if (e < nvol) {
         const size_t x = e % rowq, t = e / rowq;
         const size_t r = t % rows, bd = t / rows;
@@ -462,22 +463,22 @@ __device__ __forceinline__ float slab_src(const float* __restrict__ vol, const f
 }
 
 // grid = (blocks, destinations)
-__global__ void slab_pack_kernel(const float* __restrict__ vol, const float* __restrict__ vsum, SlabMsgs m, int B, int D, int H, int W) {
+__global__ void slab_pack_kernel(const float* __restrict__ vol, const float* __restrict__ vsum, SlabMsgs m, int B, int D, int H, int W, int G) {
     const int j = (int)blockIdx.y;
     const int r0 = m.r0[j], rows = m.r1[j] - r0;
     if (m.ptr[j] == nullptr || rows <= 0) return;
-    const size_t n = (size_t)B * D * rows * W * 8 + (size_t)B * rows * W;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) m.ptr[j][e] = slab_src(vol, vsum, e, r0, rows, B, D, H, W);
+    const size_t n = (size_t)B * D * rows * W * G + (size_t)B * rows * W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) m.ptr[j][e] = slab_src(vol, vsum, e, r0, rows, B, D, H, W, G);
 }
 
 // out[e] = sum over ranks in rank order of their partial of my slab: the own slice straight from (vol, vsum), the others from their messages
 __global__ void slab_reduce_kernel(const float* __restrict__ vol, const float* __restrict__ vsum, SlabMsgs m, int my_rank, float* __restrict__ out,
-                                   int r0, int r1, int B, int D, int H, int W) {
+                                   int r0, int r1, int B, int D, int H, int W, int G) {
     const int rows = r1 - r0;
-    const size_t n = (size_t)B * D * rows * W * 8 + (size_t)B * rows * W;
+    const size_t n = (size_t)B * D * rows * W * G + (size_t)B * rows * W;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         float acc = 0.0f;
-        for (int j = 0; j < m.n; ++j) acc += (j == my_rank) ? slab_src(vol, vsum, e, r0, rows, B, D, H, W) : (m.ptr[j] != nullptr ? m.ptr[j][e] : 0.0f);
+        for (int j = 0; j < m.n; ++j) acc += (j == my_rank) ? slab_src(vol, vsum, e, r0, rows, B, D, H, W, G) : (m.ptr[j] != nullptr ? m.ptr[j][e] : 0.0f);
         out[e] = acc;
     }
 }
@@ -735,8 +736,8 @@ static int volume_to_split(float* volume_cl, const float* vis_sum, int B, int D,
 }
 
 static bool slab_args(const char* who, const float* volume_cl, const float* vis_sum, float* const* bufs, const int* r0, const int* r1, int n, int B, int D,
-                      int H, int W, SlabMsgs* m) {
-    if (!volume_cl || !vis_sum || !bufs || !r0 || !r1 || n < 1 || n > kMaxShardRanks || B < 1 || D < 1 || H < 1 || W < 1) {
+                      int H, int W, int G, SlabMsgs* m) {
+    if (!volume_cl || !vis_sum || !bufs || !r0 || !r1 || n < 1 || n > kMaxShardRanks || B < 1 || D < 1 || H < 1 || W < 1 || G < 1) {
         set_error("%s: bad arguments (1..%d ranks)", who, kMaxShardRanks);
         return false;
     }
@@ -751,25 +752,25 @@ static bool slab_args(const char* who, const float* volume_cl, const float* vis_
 }
 
 extern "C" int mvs_slab_pack(const float* volume_cl, const float* vis_sum, float* const* send_host_ptrs, const int* row_begin, const int* row_end,
-                             int n_ranks, int B, int D, int H, int W, void* stream) {
+                             int n_ranks, int B, int D, int H, int W, int G, void* stream) {
     SlabMsgs m;
-    if (!slab_args("mvs_slab_pack", volume_cl, vis_sum, send_host_ptrs, row_begin, row_end, n_ranks, B, D, H, W, &m)) return MVS_ERR_ARG;
-    hipLaunchKernelGGL(slab_pack_kernel, dim3(1024, n_ranks), dim3(256), 0, (hipStream_t)stream, volume_cl, vis_sum, m, B, D, H, W);
+    if (!slab_args("mvs_slab_pack", volume_cl, vis_sum, send_host_ptrs, row_begin, row_end, n_ranks, B, D, H, W, G, &m)) return MVS_ERR_ARG;
+    hipLaunchKernelGGL(slab_pack_kernel, dim3(1024, n_ranks), dim3(256), 0, (hipStream_t)stream, volume_cl, vis_sum, m, B, D, H, W, G);
     return check_launch("slab_pack_kernel");
 }
 
 extern "C" int mvs_slab_reduce(const float* volume_cl, const float* vis_sum, float* const* recv_host_ptrs, int n_ranks, int my_rank, float* slab_out,
-                               int row_begin, int row_end, int B, int D, int H, int W, void* stream) {
+                               int row_begin, int row_end, int B, int D, int H, int W, int G, void* stream) {
     int r0[kMaxShardRanks], r1[kMaxShardRanks];
     for (int j = 0; j < kMaxShardRanks; ++j) { r0[j] = row_begin; r1[j] = row_end; }
     SlabMsgs m;
     if (!slab_out || my_rank < 0 || my_rank >= n_ranks || row_begin < 0 || row_end > H || row_end <= row_begin ||
-        !slab_args("mvs_slab_reduce", volume_cl, vis_sum, recv_host_ptrs, r0, r1, n_ranks, B, D, H, W, &m)) {
+        !slab_args("mvs_slab_reduce", volume_cl, vis_sum, recv_host_ptrs, r0, r1, n_ranks, B, D, H, W, G, &m)) {
         if (!slab_out || my_rank < 0 || my_rank >= n_ranks || row_begin < 0 || row_end > H || row_end <= row_begin) set_error("mvs_slab_reduce: bad arguments");
         return MVS_ERR_ARG;
     }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, volume_cl, vis_sum, m, my_rank, slab_out, row_begin, row_end, B, D, H,
-                       W);
+                       W, G);
     return check_launch("slab_reduce_kernel");
 }
 

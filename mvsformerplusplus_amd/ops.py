@@ -264,7 +264,7 @@ def volume_to_f16(vol_cl: torch.Tensor, vis_sum: Optional[torch.Tensor] = None) 
 
 
 def slab_pack(vol_cl: torch.Tensor, vis_sum: torch.Tensor, send_bufs, rows) -> None:
-    """One launch: send_bufs[j] (or None) <- rows[j] = [r0, r1) of the partial volume [B,D,H,W,8] followed by the same rows of the
+    """One launch: send_bufs[j] (or None) <- rows[j] = [r0, r1) of the partial volume [B,D,H,W,G] followed by the same rows of the
     partial visibility sum [B,H,W] (the messages of the slab exchange)."""
     import ctypes as C
     B, D, H, W, G = vol_cl.shape
@@ -273,8 +273,8 @@ def slab_pack(vol_cl: torch.Tensor, vis_sum: torch.Tensor, send_bufs, rows) -> N
     ptrs = (C.c_void_p * n)(*[None if b is None else ptr(b) for b in send_bufs])
     r0 = (C.c_int * n)(*[int(r[0]) for r in rows])
     r1 = (C.c_int * n)(*[int(r[1]) for r in rows])
-    check(fn(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), C.cast(r0, C.c_void_p), C.cast(r1, C.c_void_p), n, B, D, H, W,
-                              stream_of(vol_cl)), "mvs_slab_pack")
+    check(fn(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), C.cast(r0, C.c_void_p), C.cast(r1, C.c_void_p), n, B, D, H, W, G,
+             stream_of(vol_cl)), "mvs_slab_pack")
 
 
 def slab_reduce(vol_cl: torch.Tensor, vis_sum: torch.Tensor, recv_bufs, my_rank: int, out: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
@@ -285,7 +285,7 @@ def slab_reduce(vol_cl: torch.Tensor, vis_sum: torch.Tensor, recv_bufs, my_rank:
     n = len(recv_bufs)
     fn = lib().mvs_slab_reduce        # before the pointer array, see slab_pack
     ptrs = (C.c_void_p * n)(*[None if b is None else ptr(b) for b in recv_bufs])
-    check(fn(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), n, my_rank, ptr(out), r0, r1, B, D, H, W, stream_of(vol_cl)),
+    check(fn(ptr(vol_cl), ptr(vis_sum), C.cast(ptrs, C.c_void_p), n, my_rank, ptr(out), r0, r1, B, D, H, W, G, stream_of(vol_cl)),
           "mvs_slab_reduce")
     return out
 

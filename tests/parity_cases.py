@@ -828,8 +828,13 @@ def case_slab_exchange_kernels(device):
     """mvs_slab_pack / mvs_slab_reduce (the slab exchange of the view-sharded latency mode) against torch slicing: message j = rows
     [r0_j, r1_j) of the partial volume followed by the same rows of the partial visibility sum; the reduction adds the own slice and
     the received messages in rank order (bit-identical to the sequential sum)."""
+    for G in (8, 4, 3):                                              # 8 groups (every shipped config) and the run-time G of ABI v10
+        _slab_exchange(device, G)
+
+
+def _slab_exchange(device, G):
     g = torch.Generator().manual_seed(9)
-    B, D, H, W, G, R = 2, 3, 24, 16, 8, 4
+    B, D, H, W, R = 2, 3, 24, 16, 4
     vol = torch.randn(B, D, H, W, G, generator=g)
     vsum = torch.rand(B, H, W, generator=g)
     rows = [(0, 10), (4, 18), (12, 24), (5, 5)]                      # rank 3 owns nothing
