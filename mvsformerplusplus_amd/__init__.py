@@ -13,9 +13,9 @@ from .module import (Conv3d, ConvBnReLU, CostRegNet, CostRegNet3D, Deconv3d, Pur
 from . import fusion
 from .ops import PackedFeatures, pack_features
 from .position_encoding import get_position_3d
-from .warping import homo_warping_3D_with_mask
+from .warping import diff_homo_warping_3D_with_mask, homo_warping_3D, homo_warping_3D_with_mask
 
 __all__ = ["CascadeDepthHead", "patch_model", "StageNet", "Conv3d", "Deconv3d", "ConvBnReLU", "CostRegNet", "CostRegNet3D",
            "PureTransformerCostReg", "get_position_3d", "fusion", "PackedFeatures", "pack_features",
            "depth_regression", "conf_regression", "init_range", "init_inverse_range", "schedule_inverse_range", "schedule_range",
-           "homo_warping_3D_with_mask"]
+           "homo_warping_3D_with_mask", "homo_warping_3D", "diff_homo_warping_3D_with_mask"]

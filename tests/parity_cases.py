@@ -61,6 +61,24 @@ def case_warp_golden(device, tag):
         assert (w - fx[wk]).abs().mean() <= 2e-6
 
 
+def case_warp_siblings(device):
+    """homo_warping_3D (no mask, warping.py:152-189) and the forward of diff_homo_warping_3D_with_mask (:112-149) against the same F1
+    vectors - the reference computes the three from one formula."""
+    from mvsformerplusplus_amd.warping import diff_homo_warping_3D_with_mask, homo_warping_3D
+    fx = load_golden("f1_warp_b.npz")
+    args = [dev(fx[k], device) for k in ("src_fea", "src_proj", "ref_proj", "dv4")]
+    w = cpu(homo_warping_3D(*args))
+    assert (w - fx["warped4"]).abs().max() <= 2e-4
+    w2, m2 = diff_homo_warping_3D_with_mask(*args)
+    assert torch.equal(cpu(w2), w) and (cpu(m2) != fx["mask4"]).float().mean() <= 2e-3
+    try:
+        diff_homo_warping_3D_with_mask(args[0], args[1], args[2], args[3].clone().requires_grad_(True))
+    except NotImplementedError:
+        pass
+    else:
+        raise AssertionError("the forward-only form must refuse hypotheses that require grad")
+
+
 def case_warp_dtypes(device):
     fx = load_golden("f1_warp_a.npz")
     for dt, tol in ((torch.bfloat16, 1e-6), (torch.float16, 1e-6)):

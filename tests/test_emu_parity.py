@@ -16,6 +16,10 @@ def test_warp_dtypes(emu):
     P.case_warp_dtypes(emu)
 
 
+def test_warp_siblings(emu):
+    P.case_warp_siblings(emu)
+
+
 def test_precisions(emu):
     P.case_precisions(emu)
 

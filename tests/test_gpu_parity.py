@@ -30,6 +30,10 @@ def test_warp_dtypes():
     P.case_warp_dtypes(DEV)
 
 
+def test_warp_siblings():
+    P.case_warp_siblings(DEV)
+
+
 def test_precisions():
     P.case_precisions(DEV)
 
