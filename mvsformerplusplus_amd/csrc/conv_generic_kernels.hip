@@ -45,22 +45,39 @@ __device__ __forceinline__ bool tap_index(int o, int k, int s, int p, int n, int
     return true;
 }
 
-template <int COT, bool TRANSPOSED, bool VEC4>
-__global__ __launch_bounds__(256) void conv3d_generic_kernel(GenericConvArgs a) {
-    const long long nvox = (long long)a.OD * a.OH * a.OW;
-    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (v >= nvox) return;
-    const int co0 = (int)blockIdx.y * COT;
-    const int b = (int)blockIdx.z;
-    const int ox = (int)(v % a.OW);
-    const long long t = v / a.OW;
-    const int oy = (int)(t % a.OH), oz = (int)(t / a.OH);
-    const float* xb = a.x + (size_t)b * a.D * a.H * a.W * a.Cin;
-
-    float acc[COT];
+// one tap's contribution: acc[c] += sum_ci x[ci] * w[ci][co0 + c].  FULL = the block's COT output channels all exist: the weight run
+// w[ci][co0 .. co0 + COT) is contiguous and its address wave-uniform, so the compiler fetches it with wide scalar loads (s_load_dwordx8)
+// instead of one s_load_dword per weight; the tail chunk of Cout reads a clamped (valid) address per channel and never stores those lanes.
+template <int COT, bool VEC4, bool FULL>
+__device__ __forceinline__ void generic_tap(const float* __restrict__ xp, const float* __restrict__ wp, int Cin, int Cout, int nvalid, float* acc) {
+    if (VEC4) {
+        for (int ci = 0; ci < Cin; ci += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + ci);
+            const float* w0 = wp + (size_t)ci * Cout;
 #pragma unroll
-    for (int c = 0; c < COT; ++c) acc[c] = 0.0f;
+            for (int c = 0; c < COT; ++c) {
+                const int cc = FULL ? c : (c < nvalid ? c : 0);
+                acc[c] = fmaf(xv.x, w0[cc], acc[c]);
+                acc[c] = fmaf(xv.y, w0[Cout + cc], acc[c]);
+                acc[c] = fmaf(xv.z, w0[2 * Cout + cc], acc[c]);
+                acc[c] = fmaf(xv.w, w0[3 * Cout + cc], acc[c]);
+            }
+        }
+    } else {
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = xp[ci];
+            const float* w0 = wp + (size_t)ci * Cout;
+#pragma unroll
+            for (int c = 0; c < COT; ++c) {
+                const int cc = FULL ? c : (c < nvalid ? c : 0);
+                acc[c] = fmaf(xv, w0[cc], acc[c]);
+            }
+        }
+    }
+}
 
+template <int COT, bool TRANSPOSED, bool VEC4, bool FULL>
+__device__ __forceinline__ void generic_voxel(const GenericConvArgs& a, const float* __restrict__ xb, int oz, int oy, int ox, int co0, int nvalid, float* acc) {
     for (int kz = 0; kz < a.kd; ++kz) {
         int iz;
         if (!tap_index<TRANSPOSED>(oz, kz, a.sd, a.pd, a.D, &iz)) continue;
@@ -72,38 +89,35 @@ __global__ __launch_bounds__(256) void conv3d_generic_kernel(GenericConvArgs a) 
                 if (!tap_index<TRANSPOSED>(ox, kx, a.sw, a.pw, a.W, &ix)) continue;
                 const float* xp = xb + (((size_t)iz * a.H + iy) * a.W + ix) * a.Cin;
                 const float* wp = a.w + (size_t)((kz * a.kh + ky) * a.kw + kx) * a.Cin * a.Cout + co0;
-                if (VEC4) {
-                    for (int ci = 0; ci < a.Cin; ci += 4) {
-                        const float4 xv = *reinterpret_cast<const float4*>(xp + ci);
-                        const float* w0 = wp + (size_t)ci * a.Cout;
-#pragma unroll
-                        for (int c = 0; c < COT; ++c) {
-                            // the tail chunk of Cout reads a clamped (valid) address; its accumulators are never stored
-                            const int cc = (co0 + c < a.Cout) ? c : 0;
-                            acc[c] = fmaf(xv.x, w0[cc], acc[c]);
-                            acc[c] = fmaf(xv.y, w0[a.Cout + cc], acc[c]);
-                            acc[c] = fmaf(xv.z, w0[2 * a.Cout + cc], acc[c]);
-                            acc[c] = fmaf(xv.w, w0[3 * a.Cout + cc], acc[c]);
-                        }
-                    }
-                } else {
-                    for (int ci = 0; ci < a.Cin; ++ci) {
-                        const float xv = xp[ci];
-                        const float* w0 = wp + (size_t)ci * a.Cout;
-#pragma unroll
-                        for (int c = 0; c < COT; ++c) {
-                            const int cc = (co0 + c < a.Cout) ? c : 0;
-                            acc[c] = fmaf(xv, w0[cc], acc[c]);
-                        }
-                    }
-                }
+                generic_tap<COT, VEC4, FULL>(xp, wp, a.Cin, a.Cout, nvalid, acc);
             }
         }
     }
+}
+
+template <int COT, bool TRANSPOSED, bool VEC4>
+__global__ __launch_bounds__(256) void conv3d_generic_kernel(GenericConvArgs a) {
+    const long long nvox = (long long)a.OD * a.OH * a.OW;
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvox) return;
+    const int co0 = (int)blockIdx.y * COT;
+    const int b = (int)blockIdx.z;
+    const int ox = (int)(v % a.OW);
+    const long long t = v / a.OW;
+    const int oy = (int)(t % a.OH), oz = (int)(t / a.OH);
+    const float* xb = a.x + (size_t)b * a.D * a.H * a.W * a.Cin;
+    const int nvalid = a.Cout - co0 < COT ? a.Cout - co0 : COT;          // block-uniform
+
+    float acc[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[c] = 0.0f;
+    if (nvalid == COT) generic_voxel<COT, TRANSPOSED, VEC4, true>(a, xb, oz, oy, ox, co0, nvalid, acc);
+    else generic_voxel<COT, TRANSPOSED, VEC4, false>(a, xb, oz, oy, ox, co0, nvalid, acc);
+
     const size_t o = ((size_t)b * nvox + (size_t)v) * a.Cout + co0;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
-        if (co0 + c >= a.Cout) break;
+        if (c >= nvalid) break;
         float r = acc[c] + (a.bias ? a.bias[co0 + c] : 0.0f);
         if (a.relu) r = fmaxf(r, 0.0f);
         if (a.skip) r += a.skip[o + c];

@@ -179,7 +179,7 @@ def test_slab_mode_matches_single_process(precision, tol):
         assert same, "ranks disagree after the slab all-gather"
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "slab"])
+@pytest.mark.parametrize("mode", ["slab"])        # the all-reduce form is G-agnostic (one flat buffer); the slab exchange kernels carry G
 def test_view_sharded_stage_other_base_ch(mode):
     for rank, err, same in _run(_other_groups_worker, 2, mode):
         assert err <= 2e-5, "rank %d: sharded base_ch = 4 stage differs from the single-process / reference result by %g" % (rank, err)
