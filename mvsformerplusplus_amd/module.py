@@ -7,6 +7,7 @@ checkpoint loads with ``strict=True`` (SURVEY.md section 8b state-dict contract)
     ConvBnReLU                 module.py:168-197   .conv.weight, .bn.*
     CostRegNet                 module.py:367-408   conv1..6, conv7/9/11 (Deconv3d), prob.weight [1,8,3,3,3]
     CostRegNet3D               module.py:453-504   conv1..6, conv7/9/11 = Sequential(ConvTranspose3d, BatchNorm3d, ReLU), prob.{weight,bias}
+    CostRegNet2D               module.py:411-450   the same names with (1,3,3) strided / transposed layers (dead code in the reference; generic form)
     depth_regression, conf_regression, init_range, init_inverse_range, schedule_inverse_range, schedule_range
 
 The torch sub-modules are parameter containers only: every forward runs hand-written HIP kernels through
@@ -505,6 +506,34 @@ class CostRegNet3D(_RegNetBase):
     @staticmethod
     def _deconv_parts(seq):
         return seq[0], seq[1]
+
+
+class CostRegNet2D(CostRegNet3D):
+    """The reference's third U-Net (module.py:411-450): CostRegNet3D's topology with (1,3,3) kernels in the strided and transposed layers - no
+    mixing along depth there - and a 1x1x1 `prob` with bias.  No shipped config and no caller in the reference tree builds it (SURVEY.md
+    section 8a: dead code); it is here so that every regulariser class of models/module.py has a counterpart with the same constructor and
+    state-dict names.  No tuned kernels exist for its (1,3,3) layers: it always runs the shape-generic exact-fp32 form (`is_generic`)."""
+
+    def __init__(self, in_channels, base_channel=8):
+        nn.Module.__init__(self)
+        self.log_var = False
+        c = base_channel
+        s, k, p = (1, 2, 2), (1, 3, 3), (0, 1, 1)
+        plan = [("conv1", in_channels, 2 * c, True), ("conv2", 2 * c, 2 * c, False), ("conv3", 2 * c, 4 * c, True),
+                ("conv4", 4 * c, 4 * c, False), ("conv5", 4 * c, 8 * c, True), ("conv6", 8 * c, 8 * c, False)]
+        for name, ci, co, strided in plan:
+            setattr(self, name, Conv3d(ci, co, kernel_size=k, stride=s, padding=p) if strided else Conv3d(ci, co, padding=1))
+        for name, ci, co in (("conv7", 8 * c, 4 * c), ("conv9", 4 * c, 2 * c), ("conv11", 2 * c, c)):
+            setattr(self, name, nn.Sequential(
+                nn.ConvTranspose3d(ci, co, kernel_size=k, padding=p, output_padding=(0, 1, 1), stride=s, bias=False),
+                nn.BatchNorm3d(co), nn.ReLU(inplace=True)))
+        self.inner = nn.Identity()                        # the reference adds conv0 itself (module.py:447): in_channels must equal base_channel
+        self.prob = nn.Conv3d(c, 1, 1, stride=1, padding=0)
+        self._cache = _PackedCache()
+
+    @property
+    def is_generic(self) -> bool:
+        return True
 
 
 # --------------------------------------------------------------------------------------------------

@@ -167,6 +167,29 @@ def cost_regnet3d(x: torch.Tensor, sd: SD, prefix: str = "cost_reg") -> torch.Te
     return F.conv3d(x, sd[p + "prob.weight"], sd[p + "prob.bias"], stride=1, padding=0)    # module.py:486
 
 
+def cost_regnet2d(x: torch.Tensor, sd: SD, prefix: str = "cost_reg") -> torch.Tensor:
+    """``CostRegNet2D.forward`` module.py:439-450: CostRegNet3D's topology, (1,3,3) kernels with padding (0,1,1) in the strided and the
+    transposed layers (conv2 / conv4 / conv6 stay 3x3x3), ``conv0`` added as it is (no ``inner``), 1x1x1 prob + bias."""
+    p = prefix + "."
+    s, pad, op = (1, 2, 2), (0, 1, 1), (0, 1, 1)
+
+    def down(t, name):
+        t = F.conv3d(t, sd[p + name + ".conv.weight"], None, stride=s, padding=pad)
+        return F.relu(_bn(t, sd, p + name + ".bn"))
+
+    def up(t, name):
+        t = F.conv_transpose3d(t, sd[p + name + ".0.weight"], None, stride=s, padding=pad, output_padding=op)
+        return F.relu(_bn(t, sd, p + name + ".1"))
+    conv0 = x
+    conv2 = _conv3d_bn_relu(down(conv0, "conv1"), sd, p + "conv2", 1)
+    conv4 = _conv3d_bn_relu(down(conv2, "conv3"), sd, p + "conv4", 1)
+    x = _conv3d_bn_relu(down(conv4, "conv5"), sd, p + "conv6", 1)
+    x = conv4 + up(x, "conv7")
+    x = conv2 + up(x, "conv9")
+    x = conv0 + up(x, "conv11")
+    return F.conv3d(x, sd[p + "prob.weight"], sd[p + "prob.bias"], stride=1, padding=0)
+
+
 def is_regnet3d(sd: SD, prefix: str = "cost_reg") -> bool:
     return (prefix + ".conv7.0.weight") in sd
 

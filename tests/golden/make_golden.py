@@ -24,7 +24,7 @@ sys.dont_write_bytecode = True
 import torch  # noqa: E402
 
 from models.cost_volume import StageNet  # noqa: E402  (reference)
-from models.module import (CostRegNet, CostRegNet3D, conf_regression, depth_regression, init_inverse_range,  # noqa: E402
+from models.module import (CostRegNet, CostRegNet2D, CostRegNet3D, conf_regression, depth_regression, init_inverse_range,  # noqa: E402
                            init_range, schedule_inverse_range, schedule_range)
 from models.warping import homo_warping_3D_with_mask  # noqa: E402
 
@@ -165,6 +165,21 @@ def f16_regnet_inner():
         arrs[tag + ".x"] = x
         arrs[tag + ".y"] = net.forward_once(x)
     npz("f16_regnet_inner.npz", **arrs)
+
+
+@torch.no_grad()
+def f18_costregnet2d():
+    """CostRegNet2D (module.py:411-450; dead code in the reference, kept for class-level API parity): base 8 and base 4."""
+    g = torch.Generator().manual_seed(18)
+    arrs = {}
+    for i, (tag, base, shape) in enumerate((("b8", 8, (1, 8, 4, 16, 24)), ("b4", 4, (2, 4, 3, 8, 16)))):
+        torch.manual_seed(180 + i)
+        net = CostRegNet2D(base, base).eval()
+        arrs.update(seed_weights(net, 180 + i, prefix=tag + ".w."))
+        x = torch.randn(*shape, generator=g)
+        arrs[tag + ".x"] = x
+        arrs[tag + ".y"] = net(x)
+    npz("f18_costregnet2d.npz", **arrs)
 
 
 def pin_weights():
@@ -580,4 +595,5 @@ if __name__ == "__main__":
     f15_stage_other_groups()
     f16_regnet_inner()
     f17_range_variants()
+    f18_costregnet2d()
     pin_weights()

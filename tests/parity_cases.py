@@ -278,6 +278,25 @@ def case_regnet_generic_golden(device):
     return errs
 
 
+def case_costregnet2d_golden(device):
+    """Fixture F18 from the reference: CostRegNet2D (module.py:411-450) at base 8 and 4 - (1,3,3) strided / transposed layers on the
+    shape-generic kernel, strict state-dict load."""
+    fx = load_golden("f18_costregnet2d.npz")
+    errs = {}
+    for tag, base in (("b8", 8), ("b4", 4)):
+        net = M.CostRegNet2D(base, base)
+        net.load_state_dict(golden_weights(fx, prefix=tag + ".w."), strict=True)
+        net = net.eval().to(device)
+        assert net.is_generic
+        with torch.no_grad():
+            y = cpu(net(dev(fx[tag + ".x"], device)))
+        want = fx[tag + ".y"]
+        assert y.shape == want.shape
+        errs[tag] = float((y - want).abs().max()) / max(1.0, float(want.abs().max()))
+        assert errs[tag] <= 2e-5, (tag, errs[tag])
+    return errs
+
+
 def case_stage_other_groups_golden(device, tag, prec=None):
     """Fixture F15 from the reference: StageNet with base_ch != 8 (cost_volume.py:29-49) - the direct gather with G groups, an fp32 volume
     [B,D,H,W,G], the CostRegNet(G, G) / CostRegNet3D(G, G) of the reference's own widths on the shape-generic kernel.  conv_precision only

@@ -57,6 +57,10 @@ def test_regnet_generic_golden():
     P.case_regnet_generic_golden(DEV)
 
 
+def test_costregnet2d_golden():
+    P.case_costregnet2d_golden(DEV)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag", ["g4_s1", "g4_s3", "g16_s2"])
 def test_stage_other_groups_golden(tag, prec):

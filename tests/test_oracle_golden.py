@@ -76,6 +76,15 @@ def test_f16_regnet_inner(tag):
     assert (y - fx[tag + ".y"]).abs().max() <= 1e-4 * max(1.0, float(fx[tag + ".y"].abs().max()))
 
 
+@pytest.mark.parametrize("tag", ["b8", "b4"])
+def test_f18_costregnet2d(tag):
+    fx = load_golden("f18_costregnet2d.npz")
+    sd = {"cost_reg." + k: v for k, v in golden_weights(fx, prefix=tag + ".w.").items()}
+    y = O.cost_regnet2d(fx[tag + ".x"], sd)
+    assert y.shape == fx[tag + ".y"].shape
+    assert (y - fx[tag + ".y"]).abs().max() <= 1e-4 * max(1.0, float(fx[tag + ".y"].abs().max()))
+
+
 def test_f4_cascade():
     fx = load_golden("f4_cascade.npz")
     feats = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
