@@ -354,6 +354,15 @@ int mvs_position3d_fwd(const float* K, const float* hyp, const float* depth_valu
                        int compute_range, float* workspace, size_t workspace_bytes, float* position3d, int B, int D,
                        int H, int W, void* stream);
 
+/* get_position_3d(normalize=False), position_encoding.py:146-149: position3d [B,3,D,H,W] = K^-1 [x, y, 1] * depth, no ranges (v10) */
+int mvs_position3d_raw_fwd(const float* K, const float* hyp, float* position3d, int B, int D, int H, int W, void* stream);
+/* PositionEncoding3D(position3d, C, rescale) as a tensor of its own, position_encoding.py:164-189: position3d [B,3,N] (N = D*H*W) ->
+ * pe [B,3C,N], channel ax*C + 2f = sin(pos_ax * rescale * div_f), + 1 = cos; div_term [C/2] (device) = the frequencies
+ * exp(2f * (-ln 1e4 / C)) as the caller computed them; C even.  The hot path never materialises the encoding (mvs_tr_embed_fwd
+ * evaluates it per token); this is the standalone form for callers of the function (v10)                                        */
+int mvs_position_encoding3d_fwd(const float* position3d, const float* div_term, float* pe, int B, int C, float rescale, long long N,
+                                void* stream);
+
 /* x + pe_proj(PositionEncoding3D(position3d, 8)) (module.py:631-635, position_encoding.py:166-189; skipped when
  * position3d == NULL), `down` = Conv3d(8, 64, kernel = stride = (rd,rh,rw)) + bias + LayerNorm3D(64, eps 1e-6).
  * volume_cl [B,D,H,W,8], pe_w = pe_proj.weight [8][24], pe_div_host = the 4 frequencies exp(2k * -ln(1e4)/8) (HOST

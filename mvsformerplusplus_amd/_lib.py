@@ -89,6 +89,8 @@ SIGNATURES = {
     "mvs_confidence_average": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "mvs_position3d_workspace_bytes": (_sz, []),
     "mvs_position3d_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_position3d_raw_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_position_encoding3d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, C.c_longlong, _vp]),
     "mvs_tr_embed_fwd": (_i, [_vp] * 9 + [_i] * 8 + [_vp]),
     "mvs_tr_linear_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_tr_attention_operand_bytes": (_sz, [_i, _i, _i]),

@@ -546,6 +546,40 @@ __global__ __launch_bounds__(256) void pos3d_write_kernel(const float* __restric
     pb[2 * DHW] = (fminf(fmaxf(Z, dmin), dmax) - dmin) / (dmax - dmin + 1e-5f);
 }
 
+// get_position_3d(normalize=False): the frustum points themselves, K^-1 [x, y, 1] * depth (position_encoding.py:146-149)
+__global__ __launch_bounds__(256) void pos3d_raw_kernel(const float* __restrict__ Km, const float* __restrict__ hyp, float* __restrict__ pos, int B,
+                                                        int D, int H, int W) {
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW, total = (size_t)B * DHW;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t pix = i % HW, r = i % DHW;
+    const int b = (int)(i / DHW);
+    float inv[9];
+    inverse3x3(Km + b * 9, inv);
+    const float x = (float)(pix % W), y = (float)(pix / W), d = hyp[i];
+    float* pb = pos + (size_t)b * 3 * DHW + r;
+    pb[0] = (inv[0] * x + inv[1] * y + inv[2]) * d;
+    pb[DHW] = (inv[3] * x + inv[4] * y + inv[5]) * d;
+    pb[2 * DHW] = (inv[6] * x + inv[7] * y + inv[8]) * d;
+}
+
+// PositionEncoding3D as a tensor of its own (position_encoding.py:164-189; the hot path evaluates it inside the patch embedding and never
+// writes it): pe[b, ax*C + 2f, n] = sin(pos[b, ax, n] * rescale * div[f]), pe[b, ax*C + 2f + 1, n] = cos(...), div[f] = exp(2f * (-ln 1e4 / C))
+__global__ __launch_bounds__(256) void pos_encoding3d_kernel(const float* __restrict__ pos, const float* __restrict__ div_term, float* __restrict__ pe,
+                                                             int C, float rescale, size_t N) {
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int f = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (n >= N) return;
+    const float div = div_term[f];          // the caller's table: the reference's own fp32 values (position_encoding.py:169)
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float ang = pos[((size_t)b * 3 + ax) * N + n] * rescale * div;
+        float* o = pe + ((size_t)b * 3 * C + (size_t)ax * C + 2 * f) * N + n;
+        o[0] = sinf(ang);
+        o[N] = cosf(ang);
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------------
@@ -594,6 +628,21 @@ extern "C" int mvs_position3d_fwd(const float* K, const float* hyp, const float*
 }
 
 extern "C" size_t mvs_position3d_workspace_bytes(void) { return (size_t)1024 * 4 * sizeof(float); }
+
+extern "C" int mvs_position3d_raw_fwd(const float* K, const float* hyp, float* position3d, int B, int D, int H, int W, void* stream) {
+    if (!K || !hyp || !position3d || B < 1 || D < 1 || H < 1 || W < 1) { set_error("mvs_position3d_raw_fwd: bad arguments"); return MVS_ERR_ARG; }
+    const size_t total = (size_t)B * D * H * W;
+    hipLaunchKernelGGL(pos3d_raw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, hyp, position3d, B, D, H, W);
+    return check_launch("pos3d_raw_kernel");
+}
+
+extern "C" int mvs_position_encoding3d_fwd(const float* position3d, const float* div_term, float* pe, int B, int C, float rescale, long long N,
+                                           void* stream) {
+    if (!position3d || !div_term || !pe || B < 1 || B > 65535 || C < 2 || (C & 1) || C / 2 > 65535 || N < 1) { set_error("mvs_position_encoding3d_fwd: bad arguments (C even, >= 2)"); return MVS_ERR_ARG; }
+    hipLaunchKernelGGL(pos_encoding3d_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)(C / 2), (unsigned)B), dim3(256), 0, (hipStream_t)stream, position3d,
+                       div_term, pe, C, rescale, (size_t)N);
+    return check_launch("pos_encoding3d_kernel");
+}
 
 extern "C" int mvs_tr_embed_fwd(const float* volume_cl, const float* position3d, const float* pe_w, const float* pe_div,
                                 const void* w_packed, const float* bias, const float* ln_w, const float* ln_b, float* tokens, int B,

@@ -628,6 +628,32 @@ def position3d(K: torch.Tensor, hyp: torch.Tensor, depth_values: torch.Tensor, p
     return pos, rng
 
 
+def position3d_raw(K: torch.Tensor, hyp: torch.Tensor) -> torch.Tensor:
+    """get_position_3d(normalize=False): K [B,3,3], hyp [B,D,H,W] -> the frustum points [B,3,D,H,W] = K^-1 [x, y, 1] * depth."""
+    Kc, hp = _f32c(K), _f32c(hyp)
+    B, D, H, W = hp.shape
+    pos = torch.empty(B, 3, D, H, W, dtype=torch.float32, device=hp.device)
+    check(lib().mvs_position3d_raw_fwd(ptr(Kc), ptr(hp), ptr(pos), B, D, H, W, stream_of(hp)), "mvs_position3d_raw_fwd")
+    return pos
+
+
+def position_encoding3d(position3d: torch.Tensor, Cc: int, rescale: float = 4.0) -> torch.Tensor:
+    """PositionEncoding3D as a tensor: position3d [B,3,D,H,W] -> [B,3C,D,H,W] (position_encoding.py:164-189)."""
+    pos = _f32c(position3d)
+    B, three, D, H, W = pos.shape
+    if three != 3:
+        raise _lib.MvsHipError("position3d must be [B,3,D,H,W], got %s" % (tuple(pos.shape),))
+    import math
+    if Cc < 2 or Cc % 2:
+        raise _lib.MvsHipError("PositionEncoding3D needs an even channel count, got %d" % Cc)
+    # the frequency table exactly as the reference builds it (fp32 exp of fp32 products, position_encoding.py:169)
+    div = torch.exp(torch.arange(0, Cc, 2).float() * (-math.log(10000.0) / Cc)).to(pos.device)
+    pe = torch.empty(B, 3 * Cc, D, H, W, dtype=torch.float32, device=pos.device)
+    check(lib().mvs_position_encoding3d_fwd(ptr(pos), ptr(div), ptr(pe), B, Cc, float(rescale), D * H * W, stream_of(pos)),
+          "mvs_position_encoding3d_fwd")
+    return pe
+
+
 def tr_embed(volume_cl: torch.Tensor, pos: Optional[torch.Tensor], pe_w, pe_div, w_packed, bias, ln_w, ln_b, rate, precision: int):
     B, D, H, W, Cc = volume_cl.shape
     assert Cc == 8

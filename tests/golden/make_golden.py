@@ -168,6 +168,23 @@ def f16_regnet_inner():
 
 
 @torch.no_grad()
+def f19_position_encoding():
+    """get_position_3d(normalize=True / False) and PositionEncoding3D as a tensor (position_encoding.py:138-189) on a small frustum."""
+    from models.position_encoding import PositionEncoding3D, get_position_3d
+    g = torch.Generator().manual_seed(19)
+    B, D, H, W = 2, 3, 6, 8
+    K = torch.tensor([[[40.0, 0.0, 4.0], [0.0, 42.0, 3.0], [0.0, 0.0, 1.0]]]).repeat(B, 1, 1)
+    K[1, 0, 0] = 36.0
+    hyp = (torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.05 * torch.rand(B, D, H, W, generator=g))).contiguous()
+    pos, hmin, hmax, wmin, wmax = get_position_3d(B, H, W, K, hyp, 425.0, 935.0, None, None, None, None, normalize=True)
+    raw = get_position_3d(B, H, W, K, hyp, 425.0, 935.0, None, None, None, None, normalize=False)[0]
+    arrs = {"K": K, "hyp": hyp, "position3d": pos, "ranges": torch.stack([hmin, hmax, wmin, wmax]), "position3d_raw": raw}
+    for C, rescale in ((8, 4.0), (6, 2.5)):
+        arrs["pe_c%d" % C] = PositionEncoding3D(pos, C, rescale=rescale)
+    npz("f19_position_encoding.npz", **arrs)
+
+
+@torch.no_grad()
 def f18_costregnet2d():
     """CostRegNet2D (module.py:411-450; dead code in the reference, kept for class-level API parity): base 8 and base 4."""
     g = torch.Generator().manual_seed(18)
@@ -596,4 +613,5 @@ if __name__ == "__main__":
     f16_regnet_inner()
     f17_range_variants()
     f18_costregnet2d()
+    f19_position_encoding()
     pin_weights()

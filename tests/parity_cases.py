@@ -278,6 +278,30 @@ def case_regnet_generic_golden(device):
     return errs
 
 
+def case_position_encoding_golden(device):
+    """Fixture F19 from the reference: get_position_3d with and without normalisation, PositionEncoding3D as a tensor of its own."""
+    from mvsformerplusplus_amd import PositionEncoding3D, get_position_3d
+    fx = load_golden("f19_position_encoding.npz")
+    B, D, H, W = fx["hyp"].shape
+    K, hyp = dev(fx["K"], device), dev(fx["hyp"], device)
+    pos, hmin, hmax, wmin, wmax = get_position_3d(B, H, W, K, hyp, 425.0, 935.0, None, None, None, None, normalize=True)
+    assert torch.allclose(cpu(pos), fx["position3d"], rtol=1e-4, atol=2e-6)
+    assert torch.allclose(torch.stack([cpu(hmin), cpu(hmax), cpu(wmin), cpu(wmax)]), fx["ranges"], rtol=1e-5)
+    raw, a, b, c, d = get_position_3d(B, H, W, K, hyp, 425.0, 935.0, None, 1.0, None, None, normalize=False)
+    assert (a, b, c, d) == (None, 1.0, None, None), "normalize=False hands the range arguments back untouched (position_encoding.py:150,163)"
+    assert torch.allclose(cpu(raw), fx["position3d_raw"], rtol=1e-5, atol=1e-4)
+    for C, rescale in ((8, 4.0), (6, 2.5)):
+        pe = cpu(PositionEncoding3D(dev(fx["position3d"], device), C, rescale=rescale))
+        assert pe.shape == fx["pe_c%d" % C].shape
+        assert (pe - fx["pe_c%d" % C]).abs().max() <= 2e-6, (C, float((pe - fx["pe_c%d" % C]).abs().max()))
+    try:
+        PositionEncoding3D(dev(fx["position3d"], device), 5)
+    except _lib.MvsHipError:
+        pass
+    else:
+        raise AssertionError("an odd channel count must be refused")
+
+
 def case_costregnet2d_golden(device):
     """Fixture F18 from the reference: CostRegNet2D (module.py:411-450) at base 8 and 4 - (1,3,3) strided / transposed layers on the
     shape-generic kernel, strict state-dict load."""

@@ -47,6 +47,10 @@ def test_costregnet2d_golden(emu):
     P.case_costregnet2d_golden(emu)
 
 
+def test_position_encoding_golden(emu):
+    P.case_position_encoding_golden(emu)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag", ["g4_s1", "g4_s3", "g16_s2"])
 def test_stage_other_groups_golden(emu, tag, prec):

@@ -61,6 +61,10 @@ def test_costregnet2d_golden():
     P.case_costregnet2d_golden(DEV)
 
 
+def test_position_encoding_golden():
+    P.case_position_encoding_golden(DEV)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag", ["g4_s1", "g4_s3", "g16_s2"])
 def test_stage_other_groups_golden(tag, prec):

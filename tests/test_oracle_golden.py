@@ -85,6 +85,16 @@ def test_f18_costregnet2d(tag):
     assert (y - fx[tag + ".y"]).abs().max() <= 1e-4 * max(1.0, float(fx[tag + ".y"].abs().max()))
 
 
+def test_f19_position_encoding():
+    fx = load_golden("f19_position_encoding.npz")
+    B, D, H, W = fx["hyp"].shape
+    pos, hmin, hmax, wmin, wmax = O.get_position_3d(H, W, fx["K"], fx["hyp"], 425.0, 935.0)
+    assert torch.allclose(pos, fx["position3d"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(torch.stack([hmin, hmax, wmin, wmax]), fx["ranges"], rtol=1e-6)
+    for C, rescale in ((8, 4.0), (6, 2.5)):
+        assert (O.position_encoding_3d(fx["position3d"], C, rescale) - fx["pe_c%d" % C]).abs().max() <= 1e-6
+
+
 def test_f4_cascade():
     fx = load_golden("f4_cascade.npz")
     feats = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
