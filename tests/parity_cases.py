@@ -248,6 +248,55 @@ def case_generic_conv_layers(device):
     assert rc == 1, "output size 9 of a stride-2 k3 p1 transposed layer on 4 inputs (valid: 7, 8) must be MVS_ERR_ARG"
 
 
+def case_generic_conv_fuzz(device, n_cases=60, seed=0):
+    """Seeded random layer shapes through ops.conv3d_generic (both forms, with / without bias, ReLU, skip) against torch's fp32 convolutions:
+    kernel 1..4 per axis, stride 1..3, padding 0..2, output padding < stride, 1..20 channels, ragged sizes.  Runs on the emulator in the CPU
+    suite; it was written after the session's GPU budget was spent, so the -m gpu suite (which must not carry a case that never ran on the
+    MI355X) does not include it yet - `python -c "import parity_cases as P; P.case_generic_conv_fuzz('cuda', 200, 1)"` from tests/ is the GPU run."""
+    import random
+    import torch.nn.functional as F
+    rnd = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    done = 0
+    while done < n_cases:
+        transposed = rnd.random() < 0.5
+        k = tuple(rnd.randint(1, 4) for _ in range(3))
+        st = tuple(rnd.randint(1, 3) for _ in range(3))
+        pad = tuple(rnd.randint(0, min(2, k[i] - 1) if transposed else 2) for i in range(3))
+        op = tuple(rnd.randint(0, st[i] - 1) for i in range(3)) if transposed else (0, 0, 0)
+        cin, cout, B = rnd.randint(1, 20), rnd.choice([1, 2, 3, 4, 5, 8, 9, 16, 17]), rnd.randint(1, 2)
+        size = tuple(rnd.randint(1, 7) for _ in range(3))
+        if not transposed and any(size[i] + 2 * pad[i] < k[i] for i in range(3)):
+            continue
+        x = torch.randn(B, cin, *size, generator=g)
+        bias = torch.randn(cout, generator=g) if rnd.random() < 0.6 else None
+        relu = rnd.random() < 0.5
+        if transposed:
+            if any((size[i] - 1) * st[i] - 2 * pad[i] + k[i] + op[i] < 1 for i in range(3)):
+                continue                                       # no output voxel along an axis: torch refuses the layer too
+            w = torch.randn(cin, cout, *k, generator=g) * 0.3
+            ref = F.conv_transpose3d(x, w, bias, stride=st, padding=pad, output_padding=op)
+            wt = packing.pack_generic_deconv_weights(w)
+        else:
+            w = torch.randn(cout, cin, *k, generator=g) * 0.3
+            ref = F.conv3d(x, w, bias, stride=st, padding=pad)
+            wt = packing.pack_generic_conv_weights(w)
+        if ref.numel() == 0:
+            continue
+        if relu:
+            ref = F.relu(ref)
+        skip = torch.randn(ref.shape, generator=g) if rnd.random() < 0.4 else None
+        if skip is not None:
+            ref = ref + skip
+        cl = lambda t: None if t is None else dev(t.permute(0, 2, 3, 4, 1).contiguous(), device)
+        y = ops.conv3d_generic(cl(x), dev(wt, device), None if bias is None else dev(bias, device), cout, k, st, pad, relu, cl(skip), transposed, op)
+        y = cpu(y).permute(0, 4, 1, 2, 3)
+        assert y.shape == ref.shape, (transposed, k, st, pad, op, y.shape, ref.shape)
+        err = float((y - ref).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (transposed, k, st, pad, op, cin, cout, size, err)
+        done += 1
+
+
 def case_regnet_generic_golden(device):
     """Fixture F16 from the reference: regularisers whose in_channels differ from base_channels (`inner` 1x1x1 convolution,
     module.py:385-388 / 481-484), other base widths, last_layer=False and log_var=True - all on the shape-generic kernel."""

@@ -39,6 +39,10 @@ def test_generic_conv_layers(emu):
     P.case_generic_conv_layers(emu)
 
 
+def test_generic_conv_fuzz(emu):
+    P.case_generic_conv_fuzz(emu, n_cases=60, seed=0)
+
+
 def test_regnet_generic_golden(emu):
     P.case_regnet_generic_golden(emu)
 
