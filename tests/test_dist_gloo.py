@@ -161,7 +161,7 @@ def _run(target, world, *args):
 
 
 @pytest.mark.parametrize("precision,tol", [(None, 5e-4), ("bf16x3", 1e-5)])
-@pytest.mark.parametrize("V", [3, 4, 2])
+@pytest.mark.parametrize("V", [4, 2])        # 3 source views over 2 ranks (2 + 1) and 1 source view (one rank idle); the even 1 + 1 split is inside the cascade tests
 def test_view_sharded_stage_matches_single_process(V, precision, tol):
     """precision None = the product default ("f16x2"): the all-reduced fp32 volume is rounded to fp16 once (mvs_volume_to_f16) where the
     single-process aggregate pass rounds its own sum - the same values up to fp32 summation order, i.e. an fp16 ulp at a few voxels."""
