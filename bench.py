@@ -182,7 +182,7 @@ def main():
                     help="planar: [B,V,C,H,W] as the reference's FPN emits it (headline); tiled: the octet-tiled channel-last hand-off "
                          "layout [B,V,C/8,H,W,8] (SURVEY.md section 8f #4) as a producer-side emitter would hand it over - packed once, "
                          "outside the timed region")
-    ap.add_argument("--view-sharded-timeout", type=int, default=240, help="N > 1: seconds the extra view-sharded latency leg may take")
+    ap.add_argument("--view-sharded-timeout", type=int, default=120, help="N > 1: seconds the extra view-sharded latency leg may take")
     ap.add_argument("--view-sharded-only", action="store_true",
                     help="N > 1: run ONLY the view-sharded latency mode (SURVEY.md section 8e: the source views of ONE reference view over the ranks, "
                          "RCCL all-reduce / slab exchange per stage, BASELINE configs[2]'s V = 10) and print its JSON line: value = reference views "
