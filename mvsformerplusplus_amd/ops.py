@@ -358,8 +358,10 @@ def conv3d_generic(x_cl: torch.Tensor, w_tck: torch.Tensor, bias: Optional[torch
         raise _lib.MvsHipError("the generic convolution takes fp32 activations, got %s" % x_cl.dtype)
     B, D, H, W, cin = x_cl.shape
     k, s, p = tuple(ksize), tuple(stride), tuple(padding)
-    if tuple(w_tck.shape) != (k[0] * k[1] * k[2], cin, cout):
-        raise _lib.MvsHipError("generic convolution weights %s do not match [%d][%d][%d]" % (tuple(w_tck.shape), k[0] * k[1] * k[2], cin, cout))
+    if tuple(w_tck.shape) != (k[0] * k[1] * k[2], cin, cout) or w_tck.dtype != torch.float32:
+        raise _lib.MvsHipError("generic convolution weights %s %s do not match fp32 [%d][%d][%d]" % (tuple(w_tck.shape), w_tck.dtype, k[0] * k[1] * k[2], cin, cout))
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() < cout):
+        raise _lib.MvsHipError("generic convolution bias must be fp32 with at least %d entries, got %s %s" % (cout, bias.dtype, tuple(bias.shape)))
     if transposed:
         out = [(n - 1) * s[i] - 2 * p[i] + k[i] + output_padding[i] for i, n in enumerate((D, H, W))]
     else:
