@@ -15,18 +15,21 @@ Workload = BASELINE.json configs[1]: 1152x1536, V=5, numdepth 192 (-> cascade nd
 fp32 features, all-"Normal" regularisers, synthetic features / cameras and seeded random weights with randomised BatchNorm
 statistics (no dataset or checkpoint exists offline).
 
-Arithmetic: warp, correlation, visibility, heads and every accumulation in fp32; the 3-D regularisers in the PRODUCT DEFAULT format
-"f16mix" (module.DEFAULT_PRECISION: fp16 activation tensors; fp16 hi + lo weights = two MFMA terms per product on the 8- / 16-channel
-layers, one fp16 term on conv4..conv7 and in the visibility CNN; fp16 source windows and kept correlations in the gather;
-`--conv-precision stagemix` runs the coarse stages - D = 32 / 16, whose depth schedules the next stage's hypotheses - in the
-fp32-equivalent format instead: 4x closer to the fp32 oracle for 4 % of the throughput) - wider than
-the bf16 autocast the reference's own GPU path runs these layers under (test.py:250); `--conv-precision bf16x3` selects the
-fp32-equivalent mode of rounds 1-2.  `parity` = this run's refined depth against the fp32 CPU oracle on the same inputs (bar 1e-3).
+Arithmetic: warp, correlation, visibility, heads and every accumulation in fp32; the precision policy of the stages is the PRODUCT
+DEFAULT "stagemix" (module.DEFAULT_STAGE_POLICY, round 5): the coarse stages (D = 32 / 16, whose depth schedules the next stage's
+hypotheses) fp32-equivalent - split-bf16 regulariser and visibility CNN (three MFMA terms), exact gather -, the fine stages (D = 8 / 4,
+~75 % of the time) in "f16mix": fp16 activation tensors; fp16 hi + lo weights = two MFMA terms per product on the 8- / 16-channel layers,
+one fp16 term on conv4..conv7 and in the visibility CNN; fp16 source windows and kept correlations in the gather - no narrower than the
+bf16 autocast the reference's own GPU path runs these layers under (test.py:250).  `--conv-precision bf16x3` selects the fp32-equivalent
+format on every stage, `f16mix` round 4's uniform fp16 default.  `parity` = this run's refined depth against the fp32 CPU oracle on the
+same inputs (bar 1e-3).
 
 The reference views of a step are issued round-robin on `--streams` HIP streams (default 3): views are independent, so the small
 latency-bound launches of one view's coarse stages overlap the large launches of another's fine stages; the single-stream
 figure (one view at a time, the reference's loop) is reported in `latency`, the per-kernel profile behind `roofline` is
-single-stream too.
+single-stream too.  Issue (round 5): one hipGraph replay per reference view (`CascadeDepthHead.capture`, one graph per (stream,
+input set); `--issue eager` = the ~60 launches of a view issued from Python) - the same device work; the host needs ~1.1 ms per view to
+issue it eagerly, which a device path below ~1.3 ms per view no longer hides.
 
 N > 1: one process per GPU; reference views are independent, so every rank runs its own stream of reference views
 (data parallel over reference views, no data-path collective; "scaling": "weak").  The view-sharded latency mode
@@ -36,7 +39,9 @@ BASELINE configs[2]'s shape (V = 10) and reported in the extra `view_sharded` ob
 Rank 0 prints ONE JSON line.  Extra objects: `training_step` (N = 1: forward + backward of each cascade stage through the native
 training kernels at DTU-training-like sizes, outside the timed region), `roofline` (dominant kernel, HIP-event timing on the launch stream) and
 `cpu_baseline` (the oracle - a CPU restatement of the reference path - timed on this host's cores, N=1 only), `fp32_equivalent_mode`
-(N = 1: the same weights, inputs and loop with the regularisers in "bf16x3", outside the timed headline: both modes in one line).
+(N = 1: the same weights, inputs and loop with the regularisers in "bf16x3", outside the timed headline: both modes in one line),
+`shipped` (N = 1, round 5: the SHIPPED regulariser mix - stage-1 transformer + PE3D, config/mvsformer++.json:86-113 - on the same inputs:
+ref-views/s and its own parity against the oracle, outside the timed headline).
 """
 import argparse
 import json
@@ -54,6 +59,16 @@ ARGS = {"base_ch": [8, 8, 8, 8], "depth_type": ["ce"] * 4, "fusion_type": "cnn",
         "ndepths": [32, 16, 8, 4], "depth_interals_ratio": [4.0, 2.67, 1.5, 1.0], "inverse_depth": True}
 TMP = [5.0, 5.0, 5.0, 1.0]
 ALGO_BYTES_PER_VIEW = 5.03e9
+# `dtype` of the JSON line = the arithmetic the regularisers (the only reduced-precision part) compute in; warp / correlation /
+# visibility maps / heads / every accumulation are fp32 in all of them ("f32 (...)" mislabelled fp16 operands)
+DTYPE_TEXT = {
+    "stagemix": "fp16 operands/storage, fp32 accumulate (fine stages 3-4: fp16 U-Net tensors, source windows and kept correlations, 1-2 fp16 MFMA "
+                "terms; coarse stages 1-2: split-bf16 operands x3 terms = fp32-equivalent, exact gather)",
+    "f16mix": "fp16 operands/storage, fp32 accumulate (every stage; 1-2 fp16 MFMA terms)",
+    "f16x2": "fp16 operands/storage, fp32 accumulate (every stage; 2 fp16 MFMA terms)",
+    "f16": "fp16 operands/storage, fp32 accumulate (every stage; 1 fp16 MFMA term)",
+    "bf16x3": "split-bf16 operands x3 MFMA terms (fp32-equivalent activations), fp32 accumulate",
+    "fp32": "f32"}
 
 
 # stage-1 regulariser of the shipped checkpoints (config/mvsformer++.json:86-113); reported beside the all-"Normal" headline
@@ -164,9 +179,11 @@ def main():
                     help="reference views per forward call (the module API's batch axis B).  1 = the reference's own loop (test.py feeds one "
                          "reference view per call); larger batches put B views into every launch (B x the workgroups per launch, 1 / B of the "
                          "launches per view)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay one captured hipGraph per (stream, input set) (CascadeDepthHead.capture) instead of issuing the ~67 launches of "
-                         "a reference view from Python: the same device work, one launch per view from the host's side")
+    ap.add_argument("--issue", choices=["graph", "eager"], default="graph",
+                    help="graph (default): replay one captured hipGraph per (stream, input set) (CascadeDepthHead.capture) - one launch per "
+                         "reference view from the host's side; eager: issue the ~60 launches of a reference view from Python.  The same device work")
+    ap.add_argument("--graph", action="store_true", help="= --issue graph (kept for the round-3/4 scripts)")
+    ap.add_argument("--no-shipped-leg", action="store_true", help="skip the extra `shipped` object (stage-1 transformer mix: value + parity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra `training_step` object (forward + backward of each cascade stage)")
     ap.add_argument("--no-profile", action="store_true")
@@ -194,6 +211,7 @@ def main():
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
                     help="normal: all-'Normal' regularisers (Track R headline); shipped: stage-1 transformer + PE3D as in the shipped config")
     a = ap.parse_args()
+    a.graph = a.graph or a.issue == "graph"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -236,7 +254,7 @@ def main():
             print(json.dumps({"metric": "ref-views/sec at 1152x1536 N=5 D=192 4-stage; achieved HBM GB/s vs peak", "mode": "view-sharded-only",
                               "value": vs["ref_views_per_s"], "unit": "ref-views/s", "n_gpus": world, "steps": max(3, a.steps // 4), "warmup": 2,
                               "ms_per_step": vs["ms_per_ref_view"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                              "dtype": "f32 (fp16 storage of the regulariser's activations)", "data": "synthetic",
+                              "dtype": DTYPE_TEXT[head.fusions[0].precision_policy], "data": "synthetic",
                               "config": {"workload": "BASELINE configs[2]: 1152x1536, V = %d, 4-stage cascade, source views sharded over %d ranks" % (vs["views"], world),
                                          "parallelism": "source views over %d ranks, one reference view at a time" % world},
                               "view_sharded": vs}))
@@ -268,34 +286,45 @@ def main():
             torch.cuda.synchronize()
         streams = [torch.cuda.Stream(device=device) for _ in range(a.streams)] if a.streams > 1 else None
 
-        graphs = {}
-        if a.graph:
-            for si in range(len(streams) if streams is not None else 1):
-                for k in range(nsets):
-                    if streams is None:
-                        graphs[(si, k)] = head.capture(*sets[k], tmp=TMP)
-                    else:
-                        with torch.cuda.stream(streams[si]):
-                            graphs[(si, k)] = head.capture(*sets[k], tmp=TMP)
-            torch.cuda.synchronize()
+        def make_runner(hd):
+            """-> (run(n_steps, first), issue text).  Graph mode: one captured hipGraph per (stream, input set); a capture that fails
+            falls back to eager issue and says so in config.issue (the headline must not die on it)."""
+            graphs, issue = {}, "eager launches"
+            if a.graph:
+                try:
+                    for si in range(len(streams) if streams is not None else 1):
+                        for k in range(nsets):
+                            if streams is None:
+                                graphs[(si, k)] = hd.capture(*sets[k], tmp=TMP)
+                            else:
+                                with torch.cuda.stream(streams[si]):
+                                    graphs[(si, k)] = hd.capture(*sets[k], tmp=TMP)
+                    torch.cuda.synchronize()
+                    issue = "one hipGraph replay per reference view"
+                except Exception as e:
+                    graphs, issue = {}, "eager launches (hipGraph capture failed: %r)" % (e,)
+                    torch.cuda.synchronize()
 
-        def run(n_steps, first=0):
-            """n_steps steps; step k = the R reference views k*R .. k*R+R-1, view j on input set j % nsets and stream j % nstreams."""
-            o = None
-            if streams is not None:
-                for st in streams:
-                    st.wait_stream(torch.cuda.current_stream(device))
-            for j in range(first * R // BATCH, (first + n_steps) * R // BATCH):       # one forward call = BATCH reference views
-                f, p, d = sets[j % nsets]
-                if streams is None:
-                    o = graphs[(0, j % nsets)]() if a.graph else head(f, p, d, tmp=TMP)
-                else:
-                    with torch.cuda.stream(streams[j % len(streams)]):
-                        o = graphs[(j % len(streams), j % nsets)]() if a.graph else head(f, p, d, tmp=TMP)
-            if streams is not None:
-                for st in streams:
-                    torch.cuda.current_stream(device).wait_stream(st)
-            return o
+            def run(n_steps, first=0):
+                """n_steps steps; step k = the R reference views k*R .. k*R+R-1, view j on input set j % nsets and stream j % nstreams."""
+                o = None
+                if streams is not None:
+                    for st in streams:
+                        st.wait_stream(torch.cuda.current_stream(device))
+                for j in range(first * R // BATCH, (first + n_steps) * R // BATCH):       # one forward call = BATCH reference views
+                    f, p, d = sets[j % nsets]
+                    if streams is None:
+                        o = graphs[(0, j % nsets)]() if graphs else hd(f, p, d, tmp=TMP)
+                    else:
+                        with torch.cuda.stream(streams[j % len(streams)]):
+                            o = graphs[(j % len(streams), j % nsets)]() if graphs else hd(f, p, d, tmp=TMP)
+                if streams is not None:
+                    for st in streams:
+                        torch.cuda.current_stream(device).wait_stream(st)
+                return o
+            return run, issue
+
+        run, issue_text = make_runner(head)
 
         run(a.warmup)
         sync_all()
@@ -328,12 +357,12 @@ def main():
         "metric": "ref-views/sec at 1152x1536 N=5 D=192 4-stage; achieved HBM GB/s vs peak",
         "value": value, "unit": "ref-views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",           # replaced below by the format the regularisers really compute in
         "config": {"workload": WORKLOAD if is_cfg2 else "%dx%d V=%d 4-stage cascade" % (a.height, a.width, a.views),
                    "height": a.height, "width": a.width, "views": a.views, "global_batch": world * R,
                    "step": "one batch of %d reference views (batch %d per forward call%s), rotating over %d input sets" %
                            (R, BATCH, ", like test.py" if BATCH == 1 else "", nsets),
-                   "views_per_forward_call": BATCH, "issue": "one hipGraph replay per reference view" if a.graph else "eager launches",
+                   "views_per_forward_call": BATCH, "issue": issue_text,
                    "ref_views_per_step_per_gpu": R, "input_sets": nsets, "timed_seconds": elapsed,
                    "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams,
                    "features": "%s %s resident in HBM" % (a.feat_dtype, "octet-tiled [B,V,C/8,H,W,8]" if a.feat_layout == "tiled" else "planar [B,V,C,H,W]")},
@@ -357,21 +386,22 @@ def main():
         "f16x2": "f16x2: U-Net activations (cost volume included) stored as fp16, weights as fp16 hi + lo, two MFMA terms per product on "
                  "v_mfma_f32_16x16x32_f16, fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the "
                  "regulariser under bf16 autocast, test.py:250)",
-        "f16mix": "f16mix (product default): fp16 U-Net activations as in f16x2; weights fp16 hi + lo (two MFMA terms) on the 8- / 16-channel layers, "
+        "f16mix": "f16mix (round 4's default, opt-in): fp16 U-Net activations as in f16x2; weights fp16 hi + lo (two MFMA terms) on the 8- / 16-channel layers, "
                   "ONE fp16 term on the 32- / 64-channel layers conv4..conv7 (no measurable change of the depth error, scripts/study_weight_precision.py); "
                   "fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the regulariser under bf16 autocast, "
                   "test.py:250)",
         "f16": "f16: fp16 U-Net activations, ONE fp16 weight term on every layer (depth 7e-5 / 4.8e-4 from the fp32 oracle on plain / stress inputs)",
-        "stagemix": "stagemix (opt-in policy): the coarse stages (ndepth > model_th: CostRegNet, D = 32 / 16 - their depth schedules the next stage's "
-                    "hypotheses) run the fp32-equivalent bf16x3 regulariser and visibility CNN, the CostRegNet3D stages (D = 8 / 4) run f16mix (fp16 "
-                    "activations; fp16 hi + lo weights on the 8- / 16-channel layers, one fp16 term on conv4..conv7 and in the visibility CNN); the gather of "
-                    "every stage keeps fp16 source windows and fp16 per-view correlations; fp32 accumulation everywhere (the reference's GPU path runs the "
-                    "regulariser under bf16 autocast, test.py:250)",
+        "stagemix": "stagemix (product default policy, round 5): the coarse stages (ndepth > model_th: CostRegNet, D = 32 / 16 - their depth schedules the "
+                    "next stage's hypotheses) run fp32-equivalent: split-bf16 (bf16x3, three MFMA terms) regulariser and visibility CNN, exact gather (fp32 "
+                    "source windows, fp32 kept correlations); the CostRegNet3D stages (D = 8 / 4) run f16mix (fp16 activations; fp16 hi + lo weights on "
+                    "the 8- / 16-channel layers, one fp16 term on conv4..conv7 and in the visibility CNN; fp16 source windows and kept correlations); fp32 "
+                    "accumulation everywhere (the reference's GPU path runs the regulariser under bf16 autocast, test.py:250)",
         "fp32": "fp32-exact MFMA contraction"}[prec0]
+    result["dtype"] = DTYPE_TEXT[prec0]
     if prec0 in ("f16x2", "f16mix", "f16", "stagemix"):
-        result["dtype"] = "f32 (fp16 storage of the regulariser's activations)"
         result["config"]["gather_pass2"] = ("second gather on every stage (--no-keep-correlations)" if a.no_keep_correlations else
-                                            "stages with D > 4: stream of the fp16 per-view correlations kept by pass 1; D <= 4: second gather")
+                                            "stream of the per-view correlations kept by pass 1 (fp32 on the exact coarse stages from D = 16 on, fp16 "
+                                            "on the fp16-format stages with D > 4); otherwise a second gather")
 
     # ---- per-kernel HIP-event profile -> roofline of the dominant kernel ----
     if not a.no_profile:
@@ -381,8 +411,22 @@ def main():
             _, launches = profiling.profile_cascade(head, *sets[r % nsets], TMP)
             allruns.append(launches)
         agg = profiling.summarize([l for run in allruns for l in run])
-        # the dominant SINGLE kernel symbol (bundles of several launches timed as a unit are not candidates)
-        dom_name, dom = max(((k, v) for k, v in agg.items() if not k.startswith("[bundle]")), key=lambda kv: kv[1]["ms"])
+        # the dominant KERNEL = the __global__ function with the largest share of a reference view's kernel time, ALL of its template
+        # instantiations together (round 5, VERDICT r4 weak #4: per-instantiation ranking made the visibility CNN "dominant" at 8 % of the step
+        # only because the convolutions are spread over ~25 tile configurations).  Bundles of several launches timed as a unit are not candidates.
+        groups = {}
+        for k, v in agg.items():
+            if k.startswith("[bundle]"):
+                continue
+            gname = profiling.kernel_group(k)
+            gr = groups.setdefault(gname, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "issued_flops": 0.0, "members": []})
+            for f in ("calls", "ms", "flops", "bytes", "issued_flops"):
+                gr[f] += v[f]
+            gr["members"].append(k)
+        dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        dom["avg_ms"] = dom["ms"] / dom["calls"]
+        dom["tflops"] = dom["flops"] / max(dom["ms"], 1e-9) / 1e9
+        dom["gbs"] = dom["bytes"] / max(dom["ms"], 1e-9) / 1e6
         mfma = dom_name.startswith("conv3d") or dom_name.startswith("deconv3d") or dom_name.startswith("vis_cnn")
         per_launch = dom["flops" if mfma else "bytes"] / dom["calls"]
         achieved = (dom["tflops"] if mfma else dom["gbs"])
@@ -394,20 +438,26 @@ def main():
         elif prec != "fp32":
             # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak 2.5 PFLOP/s.  `frac` is against THAT peak (the guide's); the contraction issues
             # `terms` MFMA products per algorithmic product, an implementation choice reported separately as frac_of_issued_mfma
-            peak, note = profiling.PEAK_F16_MFMA_TFLOPS, ("algorithmic FLOPs (2 x MACs of the operator) / HIP-event launch time vs the dense %s MFMA peak of "
-                                                         "MI355X_MICROARCH.md; the kernel issues %.2f MFMA term(s) per algorithmic product (over its launches)" %
-                                                         ("bf16" if prec == "bf16x3" else "fp16 / bf16", terms))
+            peak, note = profiling.PEAK_F16_MFMA_TFLOPS, ("algorithmic FLOPs (2 x MACs of the operator) of ALL launches of this __global__ function in one reference view "
+                                                         "(every tile configuration / cascade stage) / their summed HIP-event time vs the dense fp16 / bf16 MFMA peak of "
+                                                         "MI355X_MICROARCH.md; the launches issue %.2f MFMA term(s) per algorithmic product on average" % terms)
         else:
             peak, note = profiling.PEAK_F32_MFMA_TFLOPS, "fp32-exact contraction on v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense peak)"
         traffic, tsrc = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # PMC-derived HBM bytes per launch, committed per round
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
-            hit = profiling.match_kernel(dom_name, tj)
-            if hit is not None:
-                traffic, tsrc = tj[hit].get("hbm_bytes_per_launch"), hit
-        result["roofline"] = {"kernel": dom_name, "bound": "mfma" if mfma else "hbm", "achieved": achieved, "peak": peak,
-                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_pmc_symbol": tsrc,
+            tb, tsrc, ok = 0.0, [], True
+            for k in dom["members"]:
+                hit = profiling.match_kernel(k, tj)
+                if hit is None or tj[hit].get("hbm_bytes_per_launch") is None:
+                    ok = False
+                    break
+                tb += tj[hit]["hbm_bytes_per_launch"] * agg[k]["calls"]
+                tsrc.append(hit)
+            traffic = tb / dom["calls"] if ok else None
+        result["roofline"] = {"kernel": dom_name, "instantiations": sorted(dom["members"]), "bound": "mfma" if mfma else "hbm", "achieved": achieved, "peak": peak,
+                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_pmc_symbols": tsrc,
                               "avg_launch_ms": dom["avg_ms"], "algorithmic_per_launch": per_launch,
                               "share_of_step": dom["ms"] / max(sum(v["ms"] for v in agg.values()), 1e-9),
                               "launches_per_ref_view": dom["calls"] / reps, "note": note}
@@ -416,6 +466,8 @@ def main():
             result["roofline"]["frac_of_issued_mfma"] = achieved * terms / peak
         if mfma:
             result["roofline"]["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["calls"]
+            result["roofline"]["hbm_view"] = {"achieved_gbs": dom["gbs"], "frac_of_8TBs": dom["gbs"] / profiling.PEAK_HBM_GBS,
+                                              "note": "the same launches by their as-built algorithmic bytes: the family is bound by neither roof (DESIGN.md 4.2)"}
         # the two gather passes (the kernels VERDICT r1 named: 6 % of the HBM roofline then), per instantiation, by the SURVEY 8d byte count
         result["gather_roofline"] = {k: {"achieved_gbs": v["gbs"], "frac_of_8TBs": v["gbs"] / profiling.PEAK_HBM_GBS, "avg_launch_ms": v["avg_ms"],
                                          "algorithmic_bytes_per_launch": v["bytes"] / v["calls"]}
@@ -519,30 +571,73 @@ def main():
             result["attention_bf16p"] = {"error": repr(e)}
 
     # ---- extra: the fp32-equivalent regulariser format ("bf16x3") on the same weights, inputs and loop, outside the timed headline: the
-    #      driver's own BENCH line then carries both modes (the headline runs the product default, "f16mix") ----
-    if world == 1 and not a.no_profile and a.cost_reg != "shipped" and head.fusions[0].precision_policy in ("f16x2", "f16mix", "f16", "stagemix") and not a.graph:
+    #      driver's own BENCH line then carries both modes (the headline runs the product default policy) ----
+    def side_leg(hd, n2):
+        """ref-views/s of another head on the headline's inputs, streams and issue mode (n2 timed steps after one warm-up step) + its
+        outputs on input set 0."""
+        with torch.no_grad():
+            run2, issue2 = make_runner(hd)
+            run2(1)
+            sync_all()
+            t0 = time.perf_counter()
+            run2(n2, first=1)
+            sync_all()
+            dt = (time.perf_counter() - t0) / n2
+            o = hd(feats, projs, dv, tmp=TMP)
+            o = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}
+            torch.cuda.synchronize()
+        del run2
+        return dt, o, issue2
+
+    if world == 1 and not a.no_profile and a.cost_reg != "shipped" and head.fusions[0].precision_policy in ("f16x2", "f16mix", "f16", "stagemix"):
         try:
             head32 = build_head(device, conv_precision="bf16x3")
             n2 = max(2, a.steps // 4)
-            keep = head
-            with torch.no_grad():
-                head = head32                                    # run() reads `head` from this scope
-                run(1)
-                sync_all()
-                t0 = time.perf_counter()
-                run(n2, first=1)
-                sync_all()
-                t32 = (time.perf_counter() - t0) / n2
-                out32 = head32(feats, projs, dv, tmp=TMP)
-                torch.cuda.synchronize()
-                head = keep
+            t32, out32, _ = side_leg(head32, n2)
             d16, d32 = out["refined_depth"], out32["refined_depth"]
             result["fp32_equivalent_mode"] = {"conv_precision": "bf16x3", "value": R / t32, "unit": "ref-views/s", "ms_per_ref_view": t32 / R * 1e3, "steps": n2,
                                               "default_vs_this_refined_depth_rel_l1": float(((d16 - d32).abs() / d32.abs()).mean()),
-                                              "note": "split-bf16 activations (hi | lo pairs, 4 bytes per element), three MFMA terms: 1e-6 from the fp32 oracle"}
+                                              "note": "split-bf16 activations (hi | lo pairs, 4 bytes per element), three MFMA terms on every stage: 1e-6 from the fp32 oracle"}
             del head32, out32
+            torch.cuda.empty_cache()
         except Exception as e:
             result["fp32_equivalent_mode"] = {"error": repr(e)}
+
+    # ---- extra (round 5, VERDICT r4 item 6): the SHIPPED regulariser mix (stage-1 transformer + PE3D - what released checkpoints run) on the same
+    #      inputs, outside the timed headline: value + its own parity against the oracle ----
+    if world == 1 and a.cost_reg != "shipped" and not a.no_shipped_leg and is_cfg2 and a.feat_layout == "planar":
+        try:
+            heads = build_head(device, shipped=True, conv_precision=a.conv_precision)
+            n2 = max(2, a.steps // 4)
+            ts, outs, issue_s = side_leg(heads, n2)
+            sh = {"cost_reg_type": SHIPPED["cost_reg_type"], "value": R / ts, "unit": "ref-views/s", "ms_per_ref_view": ts / R * 1e3, "steps": n2,
+                  "issue": issue_s, "attention_precision": heads.fusions[0].cost_reg.attention_precision,
+                  "note": "stage 1 = PureTransformerCostReg (6 blocks, 27 648 tokens at cfg2) + Frustoconical PE, stages 2-4 as in the headline"}
+            if not a.no_cpu_baseline:
+                from oracle import ref_path as O
+                sds = [{k: v.detach().cpu() for k, v in st.state_dict().items()} for st in heads.fusions]
+                torch.set_num_threads(min(16, os.cpu_count() or 1))
+                t0 = time.time()
+                with torch.no_grad():
+                    refs = O.cascade_forward({k: v.float().cpu() for k, v in feats.items()}, {k: v.cpu() for k, v in projs.items()}, dv.cpu(), sds,
+                                             ndepths=ARGS["ndepths"], depth_interals_ratio=ARGS["depth_interals_ratio"], base_ch=ARGS["base_ch"], tmp=TMP,
+                                             use_pe3d=True, transformer_config=SHIPPED["transformer_config"])
+                d, r = outs["refined_depth"].cpu(), refs["refined_depth"]
+                sh["parity"] = {"refined_depth_rel_l1_vs_oracle": float(((d - r).abs() / r.abs()).mean()),
+                                "confidence_max_abs_vs_oracle": float((outs["photometric_confidence"].cpu() - refs["photometric_confidence"]).abs().max()),
+                                "bar": 1e-3, "oracle_pass_s": time.time() - t0}
+            result["shipped"] = sh
+            del heads, outs
+            torch.cuda.empty_cache()
+        except Exception as e:
+            result["shipped"] = {"error": repr(e)}
+
+    # ---- extra (round 5, SURVEY.md section 8f #4): the producer-side feature emitter on cfg2's stage shapes, outside the timed region ----
+    if world == 1 and not a.no_profile and is_cfg2:
+        try:
+            result["feature_emitter"] = emitter_leg(device, a.views)
+        except Exception as e:
+            result["feature_emitter"] = {"error": repr(e)}
 
     # ---- extra: one training step (forward + backward) per cascade stage through the native kernels (SURVEY.md section 8f #2) ----
     if world == 1 and not a.no_train_leg and a.cost_reg != "shipped":
@@ -599,6 +694,43 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         bye.cancel()
+
+
+def emitter_leg(device, V):
+    """TiledFeatureHead (mvs_conv2d3x3_tiles_fwd: the feature side's last 3x3 convolution writing bf16 octet tiles from its epilogue,
+    FMT.py:195-197) on the stage 2-4 shapes of the workload, all V views per launch, and the converter pass (mvs_pack_features) it makes
+    unnecessary.  Features are INPUTS of the timed path: this is not part of `value`."""
+    import torch.nn as nn
+    from mvsformerplusplus_amd import TiledFeatureHead, ops
+    out = {"unit": "ms per reference view (all %d views of a stage)" % V, "stages": {},
+           "note": "Conv2d(C, C, 3, padding=1, bias=False) fp32 planar in -> bf16 [V, C/8, H, W, 8] tiles out, split-bf16 MFMA (fp32-equivalent); "
+                   "pack_features_ms = the planar -> tiled converter pass (fp32 in, bf16 out) a producer without the emitter pays on top of its convolution"}
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 5 * 1e3
+
+    tot = 0.0
+    for stage, C, H, W in ((2, 32, 288, 384), (3, 16, 576, 768), (4, 8, 1152, 1536)):
+        conv = nn.Conv2d(C, C, 3, padding=1, bias=False)
+        head = TiledFeatureHead(conv).to(device)
+        x = torch.randn(1, V, C, H, W, device=device)
+        ms = timed(lambda: head(x))
+        nbytes = V * C * H * W * (4 + 2)
+        y = torch.randn(1, V, C, H, W, device=device)
+        pk = timed(lambda: ops.pack_features(y, dtype=torch.bfloat16))
+        out["stages"]["stage%d" % stage] = {"C": C, "H": H, "W": W, "ms": ms, "algorithmic_gbs": nbytes / ms / 1e6,
+                                            "gflop": 2.0 * 9 * C * C * V * H * W / 1e9, "pack_features_ms": pk}
+        tot += ms
+        del x, y
+    out["ms_stages_2_to_4"] = tot
+    return out
 
 
 def training_leg(device):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 10
+#define MVS_ABI_VERSION 11
 
 enum { MVS_OK = 0, MVS_ERR_ARG = 1, MVS_ERR_UNSUPPORTED = 2, MVS_ERR_LAUNCH = 3, MVS_ERR_WORKSPACE = 4 };
 enum { MVS_DTYPE_F32 = 0, MVS_DTYPE_BF16 = 1, MVS_DTYPE_F16 = 2 };
@@ -73,6 +73,11 @@ enum { MVS_VOLUME_F32 = 0, MVS_VOLUME_SPLIT = 1, MVS_VOLUME_F16 = 2 };
  * MVS_VOLUME_F16 (aggregate) and mvs_warp_corr_entropy_keep_fwd imply MVS_GATHER_F16; kernels outside the LDS-staged form ignore it.
  * The reference rounds the features to a 16-bit type under its autocast (test.py:250, cost_volume.py:67).                              */
 enum { MVS_GATHER_F32 = 0, MVS_GATHER_F16 = 1 };
+/* format of the per-view group correlations mvs_warp_corr_entropy_keep_fwd keeps for mvs_corr_aggregate_fwd ([B,V-1,D,H,W,8]):
+ * MVS_CORR_F16 = fp16 octets from fp16 source windows (16 B per voxel and view; the fp16 formats' fine stages), MVS_CORR_F32 = fp32 octets
+ * from fp32 windows (32 B; EXACT: the streamed pass 2 then equals the second gather - the coarse stages of the default policy, whose
+ * depth schedules the next stage's hypotheses: the fp16 correlations' 2^-11 is what an ill-conditioned cascade amplifies).               */
+enum { MVS_CORR_F16 = 0, MVS_CORR_F32 = 1 };
 /* epilogues of mvs_tr_linear_fwd */
 enum { MVS_TR_EPI_BIAS = 0, MVS_TR_EPI_GELU = 1, MVS_TR_EPI_RES_LN = 2 };
 
@@ -91,6 +96,11 @@ const char* mvs_last_error(void);
  * For every source view v>=1: P = E.clone(); P[:3,:4] = K[:3,:3] @ E[:3,:4] (cost_volume.py:68-71),
  * M = P_v @ inverse(P_0); homography[b, v-1] = {M[:3,:3] row-major (9), M[:3,3] (3)}.          */
 int mvs_compose_homography(const float* proj, int B, int V, float* homography /*[B,V-1,12]*/, void* stream);
+/* Round 5, cascade prologue (DINOv2_mvsformer_model.py:127-150): the homographies of ALL stages (n_stages <= 8 proj tensors [B,V,2,4,4],
+ * host array of device pointers) -> homography [n_stages,B,V-1,12], and - hyp != NULL - stage 1's hypotheses (mvs_init_range_fwd:
+ * depth_values [B,N] -> hyp [B,D,H,W]) in ONE launch instead of n_stages + 1.                                                */
+int mvs_cascade_prologue_fwd(const float* const* proj_host_ptrs, int n_stages, int B, int V, float* homography,
+                             const float* depth_values, int N, int inverse, float* hyp, int D, int H, int W, void* stream);
 /* same from already-composed 4x4 projections (the argument form of homo_warping_3D_with_mask) */
 int mvs_homography_from_proj(const float* src_proj /*[B,4,4]*/, const float* ref_proj /*[B,4,4]*/, int B,
                              float* homography /*[B,12]*/, void* stream);
@@ -111,18 +121,32 @@ int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int layout, const
                               const float* hyp, float* entropy, int B, int V, int C, int G, int D, int H, int W,
                               int view_begin, int view_end, int gather_format, void* stream);
 
-/* ---- pass 1 that KEEPS the per-view group correlations + the streaming pass 2 (fp16 volume formats) -----------------------
- * cost_volume.py:74-101 with the [B,G,D,H,W] per-view correlation the reference materialises kept as fp16 [B,V-1,D,H,W,8]
- * (clamped to the fp16 range; mvs_f16_saturation_count) instead of warping twice.  mvs_warp_corr_entropy_keep_fwd = the entropy
- * pass over ALL source views + `corr_f16`; mvs_corr_aggregate_fwd = sum_v vis_v * corr_v / (sum_v vis_v + 1e-6) -> the normalised
- * volume [B,D,H,W,8] in `volume_format` (MVS_VOLUME_F16 / _SPLIT / _F32: the regulariser's format is independent of the gather's).  Built where mvs_gather_keeps_correlations() returns 1 (the LDS-staged gather's
- * shapes with D > 4); MVS_ERR_UNSUPPORTED elsewhere - the two-gather pair above covers every shape.                           */
+/* ---- pass 1 that KEEPS the per-view group correlations + the streaming pass 2 ------------------------------------------------
+ * cost_volume.py:74-101 with the [B,G,D,H,W] per-view correlation the reference materialises kept as [B,V-1,D,H,W,8] in `corr_format`
+ * (MVS_CORR_F16: clamped to the fp16 range, mvs_f16_saturation_count; MVS_CORR_F32: exact) instead of warping twice.
+ * mvs_warp_corr_entropy_keep_fwd = the entropy pass over ALL source views + `corr`; mvs_corr_aggregate_fwd =
+ * sum_v vis_v * corr_v / (sum_v vis_v + 1e-6) -> the normalised volume [B,D,H,W,8] in `volume_format` (MVS_VOLUME_F16 / _SPLIT / _F32:
+ * the regulariser's format is independent of the gather's).  Built where mvs_gather_keeps_correlations() returns 1 (the LDS-staged
+ * gather's shapes with D > 4); MVS_ERR_UNSUPPORTED elsewhere - the two-gather pair above covers every shape.                  */
 int mvs_gather_keeps_correlations(int layout, int C, int G, int D, int H, int W);
 int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, int layout, const float* homography /*[B,V-1,12]*/,
-                                   const float* hyp, float* entropy, void* corr_f16, int B, int V, int C, int G, int D, int H,
-                                   int W, void* stream);
-int mvs_corr_aggregate_fwd(const void* corr_f16, const float* vis /*[B,V-1,H,W]*/, void* volume_cl, int volume_format, int B, int V,
-                           int D, int H, int W, void* stream);
+                                   const float* hyp, float* entropy, void* corr, int corr_format, int B, int V, int C, int G, int D,
+                                   int H, int W, void* stream);
+int mvs_corr_aggregate_fwd(const void* corr, int corr_format, const float* vis /*[B,V-1,H,W]*/, void* volume_cl, int volume_format,
+                           int B, int V, int D, int H, int W, void* stream);
+
+/* ---- section 8f #4, producer side (round 5): the feature side's LAST 3x3 convolution emitting the hand-off layout ----------------
+ * Replaces Conv2d(Cin, Cout, 3, padding=1[, bias]) [+ folded BatchNorm2d] [+ Swish] followed by torch.stack / mvs_pack_features:
+ * models/FMT.py:195-197 (smooth_1/2/3: (32,32), (16,16), (8,8), no bias, act 0) and models/module.py:257-270 (FPNDecoder.out1/2/3:
+ * (64,32), (64,16), (64,8), bias = folded BatchNorm shift, act 1 = Swish).  x [N,Cin,H,W] planar (in_dtype), image n at
+ * x + n * in_batch_stride elements; w_packed = packing.pack_conv_weights_bf16x3(w[:, :, None], min(Cin, 32)) (split-bf16, three MFMA
+ * terms: fp32-equivalent); bias [Cout] fp32 or NULL; tiled [.., Cout/8, H, W, 8] (out_dtype), image n at tiled + n * out_batch_stride
+ * elements (so that view v of [B,V,C/8,H,W,8] can be written in place: out_batch_stride = V * Cout * H * W).  mvs_feature_conv_is_built
+ * says which (Cin, Cout) pairs exist; others return MVS_ERR_UNSUPPORTED.                                                          */
+int mvs_feature_conv_is_built(int Cin, int Cout);
+int mvs_conv2d3x3_tiles_fwd(const void* x, int in_dtype, const void* w_packed, const float* bias, int act, void* tiled, int out_dtype,
+                            int N, int Cin, int Cout, int H, int W, long long in_batch_stride, long long out_batch_stride,
+                            void* stream);
 
 /* ---- section 8f #4: feature hand-off -------------------------------------------------------------------
  * features [N,C,H,W] (dtype) -> tiled [N,C/8,H,W,8] (out_dtype); C % 8 == 0.  fp32 / bf16 / fp16 in, any of them out except
@@ -311,6 +335,13 @@ int mvs_prob_regress_fwd(const float* feat_cl, const float* prob_w, const float*
 /* same head on precomputed logits [B,D,H,W] (depth_regression / conf_regression callers) */
 int mvs_softmax_regress_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth,
                             float* conf, float* prob_volume, int B, int D, int H, int W, void* stream);
+/* Round 5: the LAST cascade stage's head with a16 fused (DINOv2_mvsformer_model.py:167-177): besides depth / conf / prob_volume it writes
+ * conf_avg [B,H,W] = (sum_i nearest-upsampled prev_conf[i] + conf) / (n_prev + 1); prev_conf[i] is [B, H >> shift[i], W >> shift[i]]
+ * (host arrays of n_prev <= 7 device pointers / shifts, earliest stage first: the summation order of mvs_confidence_average).    */
+int mvs_softmax_regress_confavg_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth,
+                                    float* conf, float* prob_volume, const float* const* prev_conf_host_ptrs,
+                                    const int* prev_shifts_host, int n_prev, float* conf_avg, int B, int D, int H, int W,
+                                    void* stream);
 
 /* module.py:649-671 as free functions on a probability volume p [B,D,H,W]:
  * depth_regression: out = sum_d p*depth_values (depth_values [B,D,H,W]); conf_regression: window sum of n. */

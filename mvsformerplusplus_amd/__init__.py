@@ -12,10 +12,11 @@ from .module import (Conv3d, ConvBnReLU, CostRegNet, CostRegNet2D, CostRegNet3D,
                      init_inverse_range, init_range, schedule_inverse_range, schedule_range)
 from . import fusion
 from .ops import PackedFeatures, pack_features
+from .handoff import TiledFeatureHead
 from .position_encoding import PositionEncoding3D, get_position_3d
 from .warping import diff_homo_warping_3D_with_mask, homo_warping_3D, homo_warping_3D_with_mask
 
 __all__ = ["CascadeDepthHead", "patch_model", "StageNet", "Conv3d", "Deconv3d", "ConvBnReLU", "CostRegNet", "CostRegNet3D", "CostRegNet2D",
-           "PureTransformerCostReg", "get_position_3d", "PositionEncoding3D", "fusion", "PackedFeatures", "pack_features",
+           "PureTransformerCostReg", "get_position_3d", "PositionEncoding3D", "fusion", "PackedFeatures", "pack_features", "TiledFeatureHead",
            "depth_regression", "conf_regression", "init_range", "init_inverse_range", "schedule_inverse_range", "schedule_range",
            "homo_warping_3D_with_mask", "homo_warping_3D", "diff_homo_warping_3D_with_mask"]

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 OK = 0
-ABI_VERSION = 10
+ABI_VERSION = 11
 TR_EPI_BIAS, TR_EPI_GELU, TR_EPI_RES_LN = 0, 1, 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 HEAD_CE_EVAL, HEAD_CE_TRAIN, HEAD_REG = 0, 1, 2
@@ -28,6 +28,7 @@ PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f16x2": PREC_F16X2, "f1
 F16_FORMATS = ("f16x2", "f16", "f16mix")        # conv_precision values whose regulariser ACTIVATIONS are fp16 tensors (they share packed weights)
 F16_CODES = (PREC_F16X2, PREC_F16, PREC_F16MIX)
 VOLUME_F32, VOLUME_SPLIT, VOLUME_F16 = 0, 1, 2
+CORR_F16, CORR_F32 = 0, 1
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -37,10 +38,13 @@ SIGNATURES = {
     "mvs_f16_saturation_count": (C.c_ulonglong, [_i]),
     "mvs_last_error": (C.c_char_p, []),
     "mvs_compose_homography": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mvs_cascade_prologue_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "mvs_homography_from_proj": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mvs_homo_warp_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_warp_corr_entropy_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mvs_pack_features": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvs_feature_conv_is_built": (_i, [_i, _i]),
+    "mvs_conv2d3x3_tiles_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.c_longlong, C.c_longlong, _vp]),
     "mvs_vis_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mvs_vis_weight_fwd": (_i, [_vp] * 10 + [_vp, _sz, _i, _i, _i, _i, _vp]),
     "mvs_vis_conv1_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -50,8 +54,8 @@ SIGNATURES = {
     "mvs_volume_to_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_gather_is_lds_staged": (_i, [_i, _i, _i, _i, _i, _i]),
     "mvs_gather_keeps_correlations": (_i, [_i, _i, _i, _i, _i, _i]),
-    "mvs_warp_corr_entropy_keep_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
-    "mvs_corr_aggregate_fwd": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_vp]),
+    "mvs_warp_corr_entropy_keep_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "mvs_corr_aggregate_fwd": (_i, [_vp, _i, _vp, _vp] + [_i] * 6 + [_vp]),
     "mvs_slab_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_slab_reduce": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvs_conv3d_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
@@ -80,6 +84,7 @@ SIGNATURES = {
     "mvs_regnet_logits_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "mvs_prob_regress_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_softmax_regress_fwd": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_softmax_regress_confavg_fwd": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "mvs_depth_regression_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_conf_regression_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "mvs_init_range_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),

@@ -59,12 +59,23 @@ class CascadeDepthHead(nn.Module):
         stage_out: Optional[Dict[str, torch.Tensor]] = None
         confs: List[torch.Tensor] = []
         pe_range = None                                  # stage 1 measures the frustum's x / y range, later stages reuse it
+        # Round 5: the prologue in ONE launch - every stage's homographies (a1, warping.py:80) and stage 1's hypotheses (a13) - and the
+        # confidence average (a16) in the last stage's head: 13 -> 8 head / range launches per reference view.  Inference with [B,N] depth
+        # values and one (B, V) on every stage; anything else (training, per-pixel initial ranges) takes the stage-by-stage calls.
+        fuse = (not any(f._wants_autograd(features["stage%d" % (i + 1)]) for i, f in enumerate(self.fusions)) and depth_values.dim() == 2
+                and len({tuple(proj_matrices["stage%d" % (s + 1)].shape) for s in range(n)}) == 1)
+        homs, hyp0 = None, None
+        if fuse:
+            H0, W0 = features["stage1"].shape[-2:]
+            homs, hyp0 = ops.cascade_prologue([proj_matrices["stage%d" % (s + 1)] for s in range(n)], depth_values, self.ndepths[0], H0, W0,
+                                              inverse=self.inverse_depth)
+        fused: Optional[dict] = None
         for s in range(n):
             key = "stage%d" % (s + 1)
             feat, proj = features[key], proj_matrices[key]
             H, W = feat.shape[-2:]
             if s == 0:
-                hyp = ops.init_range(depth_values, self.ndepths[s], H, W, inverse=self.inverse_depth)
+                hyp = hyp0 if hyp0 is not None else ops.init_range(depth_values, self.ndepths[s], H, W, inverse=self.inverse_depth)
             elif self.inverse_depth:
                 hyp = ops.schedule_inverse_range(stage_out["depth"], stage_out["depth_values"], self.ndepths[s],
                                                  self.depth_interals_ratio[s], H, W)
@@ -73,14 +84,29 @@ class CascadeDepthHead(nn.Module):
             position3d = None
             if self.cost_reg_type[s] != "Normal" and self.use_pe3d:                           # DINOv2_mvsformer_model.py:151-162
                 position3d, pe_range = ops.position3d(proj[:, 0, 1, :3, :3], hyp, depth_values, pe_range)
-            stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s], position3d=position3d)
+            if fuse:
+                fused = {"homography": homs[s]}
+                if s == n - 1 and self.fusions[s].view_group is None and all(self._is_pow2_of(c, H, W) for c in confs):
+                    fused["conf_prev"] = list(confs)
+                stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s], position3d=position3d, _fused=fused)
+            else:
+                stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s], position3d=position3d)
             outputs[key] = stage_out
             confs.append(stage_out["photometric_confidence"])
             outputs.update(stage_out)
         Hf, Wf = features["stage%d" % n].shape[-2:]
         outputs["refined_depth"] = stage_out["depth"]
-        outputs["photometric_confidence"] = ops.confidence_average(confs, Hf, Wf)
+        if fused is not None and "conf_avg" in fused:
+            outputs["photometric_confidence"] = fused["conf_avg"]
+        else:
+            outputs["photometric_confidence"] = ops.confidence_average(confs, Hf, Wf)
         return outputs
+
+    @staticmethod
+    def _is_pow2_of(c: torch.Tensor, H: int, W: int) -> bool:
+        h, w = c.shape[-2:]
+        k = H // h if h else 0
+        return k >= 1 and (k & (k - 1)) == 0 and h * k == H and w * k == W
 
 
 class GraphedCascade:

@@ -33,17 +33,19 @@ def shard_views(n_src: int, world: int, rank: int):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-# Default contraction / activation format of a stage's 3-D regulariser at INFERENCE: "f16mix" - the U-Net's tensors (cost volume
-# included) in HBM as fp16, weights as fp16 hi + lo (two MFMA terms per product) on the 8- / 16-channel layers and ONE fp16 term on
-# conv4..conv7 and in the visibility CNN, fp32 accumulation; "f16x2" = two terms everywhere, "f16" = one everywhere.  Depth vs the fp32
-# oracle: ~6e-5 relative L1 on plain inputs, 4e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers
-# under bf16 autocast (test.py:250).  "bf16x3" = fp32-equivalent activations (split bf16 pairs, three terms; 1e-6 from the oracle),
-# "fp32" = exact.  args["conv_precision"] overrides it per head.  Training always runs the bf16x3 kernels on fp32 activations.
-STAGE_DEFAULT_PRECISION = DEFAULT_STAGE_POLICY   # = module.DEFAULT_PRECISION ("f16mix") on every stage; "stagemix" (module.py) is the opt-in policy
+# Default precision POLICY of a stage at inference = module.DEFAULT_STAGE_POLICY ("stagemix", round 5): the coarse stages
+# (ndepth > model_th) fp32-equivalent - "bf16x3" regulariser + visibility CNN, exact gather -, the CostRegNet3D stages "f16mix" (fp16 U-Net
+# tensors, fp16 gather forms).  Depth vs the fp32 oracle ~5e-6 plain / 2e-5 on the x30-logits stress set / 2-4e-4 on cfg4 / cfg5's
+# ill-conditioned literal range (bar 1e-3).  args["conv_precision"] overrides it per head with the policy name or ONE format for every
+# stage ("f16mix", "f16x2", "f16", "bf16x3", "fp32"; module.py).  Training always runs the bf16x3 kernels on fp32 activations.
+STAGE_DEFAULT_PRECISION = DEFAULT_STAGE_POLICY
 
 
-_F16_CALLS = 0
-KEEP_CORRELATIONS_MAX_BYTES = 1 << 30      # largest kept per-view correlation tensor ([B,V-1,D,H,W,8] fp16) of the streaming pass 2
+_F16_CALLS = {}                            # fp16-format stage calls per device index (one process may drive several GPUs)
+_F16_CHECK_DUE = set()                     # devices whose check fell inside a hipGraph capture: done at the next eager call
+KEEP_CORRELATIONS_MAX_BYTES = 1 << 30      # largest kept per-view correlation tensor ([B,V-1,D,H,W,8] fp16 / fp32) of the streaming pass 2
+KEEP_EXACT_MIN_DEPTH = 16                  # exact gather (gather_precision "f32"): fp32 kept correlations pay from this many planes on (32 B per
+                                           # voxel and view streamed twice against a second gather; D = 8: 453 MB at cfg2's stage 3 - no gain)
 F16_SATURATION_CHECK_EVERY = 4096          # stage calls between two automatic reads of the saturation counter (0 = never)
 
 
@@ -78,7 +80,8 @@ def check_hypothesis_conditioning(hyp: torch.Tensor, warn: bool = True) -> float
         _HYP_WARNED = True
         warnings.warn("mvsformerplusplus_amd: %.1f %% of the depth hypotheses of a stage are non-finite or non-positive - the inverse-depth "
                       "schedule crossed zero (depth range too wide for the number of planes).  Depth there is meaningless and ill-conditioned "
-                      "around it; the fp16 regulariser formats lose accuracy on such inputs (build the stages with conv_precision='bf16x3', or 'stagemix')."
+                      "around it; a uniform fp16 regulariser format loses accuracy on such inputs (build the stages with conv_precision='bf16x3', or leave "
+                      "conv_precision at its default policy 'stagemix')."
                       % (100.0 * bad), RuntimeWarning, stacklevel=2)
     return bad
 
@@ -116,10 +119,9 @@ class StageNet(nn.Module):
         self.last_collective_bytes = 0
         self._buffers_cache = {}
         self.return_prob_volumes = True   # prob_volume / prob_volume_pre are only read by the training losses
-        # contraction of every MFMA convolution of the stage: "bf16x3" (3-term split bf16, ~2^-16 relative) or "fp32"
-        # or "f16x2" (fp16 activations + fp16 hi / lo weights, 2 terms: 4e-4 from the oracle on the stress set, 1.3x faster)
-        # args["conv_precision"]: a policy ("stagemix", the default) or one format for every stage; resolved per stage here - conv_precision
-        # is always a concrete format ("bf16x3" | "f16mix" | ...), gather_precision "f16" (fp16 windows + kept correlations) or "f32"
+        # args["conv_precision"]: the policy "stagemix" (the default, module.DEFAULT_STAGE_POLICY) or one format for every stage; resolved
+        # per stage here - conv_precision is always a concrete format ("bf16x3" | "f16mix" | ...), gather_precision "f16" (fp16 windows +
+        # fp16 kept correlations) or "f32" (exact: fp32 windows, fp32 kept correlations or a second gather)
         self.conv_precision = args.get("conv_precision", STAGE_DEFAULT_PRECISION)        # property: resolves the policy for this stage
         self._vis_cache = _PackedCache()
 
@@ -163,13 +165,18 @@ class StageNet(nn.Module):
         return self.conv_precision           # every fp16 format shares the fp16 rings; "f16" / "f16mix" drop the CNN's second weight term too
 
     def _keeps_correlations(self, feats, G, hyp) -> bool:
-        """Pass 2 as a stream over fp16 correlations kept by pass 1 (ops.warp_corr_entropy_keep / corr_aggregate) instead of a second
+        """Pass 2 as a stream over correlations kept by pass 1 (ops.warp_corr_entropy_keep / corr_aggregate) instead of a second
         gather: `keep_correlations` True / "auto" (default) where the library builds it (LDS-staged shapes, D > 4) and the kept tensor
-        fits KEEP_CORRELATIONS_MAX_BYTES; False = always gather twice."""
-        if not self.keep_correlations or self.gather_precision != "f16":
+        fits KEEP_CORRELATIONS_MAX_BYTES; False = always gather twice.  gather_precision "f16" keeps fp16 correlations (16 B per voxel
+        and view), "f32" fp32 ones (32 B: exact - from KEEP_EXACT_MIN_DEPTH planes on, where the stream is cheaper than the gather)."""
+        if not self.keep_correlations:
             return False
+        exact = self.gather_precision != "f16"
         B, V, _, H, W = feats.shape
-        if (V - 1) * B * hyp.shape[1] * H * W * 16 > KEEP_CORRELATIONS_MAX_BYTES:
+        D = hyp.shape[1]
+        if exact and D < KEEP_EXACT_MIN_DEPTH:
+            return False
+        if (V - 1) * B * D * H * W * (32 if exact else 16) > KEEP_CORRELATIONS_MAX_BYTES:
             return False
         return ops.gather_keeps_correlations(feats, G, hyp)
 
@@ -189,7 +196,11 @@ class StageNet(nn.Module):
         """Training mode (BatchNorm batch statistics) or a caller that differentiates w.r.t. the features."""
         return self.training or (torch.is_grad_enabled() and torch.is_tensor(features) and features.requires_grad)
 
-    def forward(self, features, proj_matrices, depth_values, tmp, position3d=None) -> Dict[str, torch.Tensor]:
+    def forward(self, features, proj_matrices, depth_values, tmp, position3d=None, _fused: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """The reference's signature (cost_volume.py:51).  `_fused` is CascadeDepthHead's private side channel (round 5, fewer launches):
+        "homography" = this stage's [B,V-1,12] homographies from the cascade's one-launch prologue (otherwise composed here);
+        "conf_prev" = the earlier stages' confidence maps - the head then also writes the cascade's averaged confidence into
+        _fused["conf_avg"] (a16 fused into the last stage's head).  The returned dict is the reference's five keys either way."""
         if self._wants_autograd(features):
             # SURVEY.md section 8f #2: autograd Functions over the library's training kernels (gather forward / backward, U-Net and
             # visibility CNN convolutions, BatchNorm, weight gradients); training.py says exactly what runs where
@@ -211,7 +222,10 @@ class StageNet(nn.Module):
             hyp = hyp[:, :, None, None].expand(B, hyp.shape[1], H, W).contiguous()
         elif hyp.dim() != 4:
             raise ValueError("depth_values must be [B,D] or [B,D,H,W], got shape %s" % (tuple(depth_values.shape),))
-        hom = ops.compose_homography(proj_matrices)
+        hom = _fused.get("homography") if _fused else None
+        if hom is None:
+            hom = ops.compose_homography(proj_matrices)
+        conf_prev = _fused.get("conf_prev") if _fused and self.view_group is None else None
         vis_params = self._vis_params(feats.device)
         prec = precision_code(self._vis_precision())
         if self.view_group is not None:
@@ -225,39 +239,47 @@ class StageNet(nn.Module):
         else:
             split = self._split_activations()
             f16 = self._f16_activations()
+            w16 = self.gather_precision == "f16"
             if self._keeps_correlations(feats, G, hyp):
-                # fp16 gather forms, D >= 8: pass 1 keeps the per-view group correlations as fp16 (16 B per voxel and view) and pass 2
-                # streams them - cheaper than the second gather, which is bound by window staging and LDS reads.  The
-                # volume comes out in the regulariser's own format (fp16 / split bf16 / fp32), whatever the gather keeps
-                entropy, corr = ops.warp_corr_entropy_keep(feats, code, hom, hyp, G)
+                # pass 1 keeps the per-view group correlations (fp16 / 16 B per voxel and view in the fp16 gather form, fp32 / 32 B in the
+                # exact one) and pass 2 streams them - cheaper than the second gather, which is bound by window staging and LDS reads
+                # (DESIGN.md 4.1).  The volume comes out in the regulariser's own format (fp16 / split bf16 / fp32), whatever the gather keeps
+                entropy, corr = ops.warp_corr_entropy_keep(feats, code, hom, hyp, G, exact=not w16)
                 vis = ops.vis_weight(entropy, vis_params, prec)
                 volume = ops.corr_aggregate(corr, vis, split=split, f16=f16)
                 del corr
             else:
                 # pass 1 -> visibility CNN -> pass 2 gathers again and writes the cost volume once (no per-view intermediate in HBM)
-                entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, f16_window=f16)
+                entropy = ops.warp_corr_entropy(feats, code, hom, hyp, G, f16_window=w16)
                 vis = ops.vis_weight(entropy, vis_params, prec)
                 if f16 and not ops.gather_is_lds_staged(feats, G, hyp):   # shapes the LDS-staged gather does not cover: fp32 volume, converted
                     volume = ops.volume_to_f16(ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)[0])
                 else:
                     volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, split=split, f16=f16)
-        out = self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split)
+        out = self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split, conf_prev=conf_prev)
+        if conf_prev is not None:
+            _fused["conf_avg"] = out.pop("_conf_avg")
         if self._f16_activations():
             self._count_f16_call(feats.device, hyp)
         return out
 
     @staticmethod
     def _count_f16_call(device, hyp=None):
-        """Automatic checks of the fp16 default (check_f16_saturation, check_hypothesis_conditioning): after the 8th fp16-format inference
-        call of the process, then every F16_SATURATION_CHECK_EVERY calls; one device synchronisation each time, never inside a hipGraph capture."""
-        global _F16_CALLS
-        _F16_CALLS += 1
-        if F16_SATURATION_CHECK_EVERY and (_F16_CALLS == 8 or _F16_CALLS % F16_SATURATION_CHECK_EVERY == 0):
-            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-                return
-            check_f16_saturation(device)
-            if hyp is not None:
-                check_hypothesis_conditioning(hyp)
+        """Automatic checks of the fp16 formats (check_f16_saturation, check_hypothesis_conditioning): after the 8th fp16-format inference
+        call ON THIS DEVICE, then every F16_SATURATION_CHECK_EVERY calls; one device synchronisation each time.  A check that falls inside
+        a hipGraph capture is deferred to the next eager call on the device, not dropped."""
+        key = device.index if device.type == "cuda" else -1
+        n = _F16_CALLS[key] = _F16_CALLS.get(key, 0) + 1
+        due = bool(F16_SATURATION_CHECK_EVERY) and (n == 8 or n % F16_SATURATION_CHECK_EVERY == 0 or key in _F16_CHECK_DUE)
+        if not due:
+            return
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            _F16_CHECK_DUE.add(key)
+            return
+        _F16_CHECK_DUE.discard(key)
+        check_f16_saturation(device)
+        if hyp is not None:
+            check_hypothesis_conditioning(hyp)
 
     def _split_activations(self) -> bool:
         """The bf16x3 U-Net keeps its activations - cost volume included - in the split hi | lo bf16 format between layers
@@ -273,31 +295,38 @@ class StageNet(nn.Module):
             conf_n = 4 if D >= 32 else (3 if D == 16 else (2 if D == 8 else 0))                    # cost_volume.py:121-128
         return mode, conf_n
 
-    def _regularise_and_regress(self, volume, hyp, depth_values, tmp, position3d=None, split=False) -> Dict[str, torch.Tensor]:
+    def _regularise_and_regress(self, volume, hyp, depth_values, tmp, position3d=None, split=False, conf_prev=None) -> Dict[str, torch.Tensor]:
         """cost_volume.py:103-131 on a normalised channel-last volume [B,D,H,W,8] (H may be a row slab of the stage); split: the
-        volume is in the split activation format and the U-Net runs MVS_PREC_BF16X3_SPLIT."""
+        volume is in the split activation format and the U-Net runs MVS_PREC_BF16X3_SPLIT.  conf_prev: the earlier stages' confidence
+        maps - the head also averages them with this stage's (extra key "_conf_avg", popped by forward)."""
         D = hyp.shape[1]
         pcode = _lib.PREC_BF16X3_SPLIT if split else precision_code(self.conv_precision)
         mfma = self.conv_precision in MFMA_FORMATS
         mode, conf_n = self._head_mode(D)
+        conf_avg = None
+
+        def head(logits):
+            r = ops.softmax_regress(logits, hyp, tmp, mode, conf_n, self.return_prob_volumes, conf_prev=conf_prev)
+            return r if conf_prev is None else (r[0], r[1], r[2], r[3])
+
         if isinstance(self.cost_reg, PureTransformerCostReg):
             prob_volume_pre = self.cost_reg.logits_cl(volume, position3d)
-            depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+            depth, conf, prob_volume, *rest = head(prob_volume_pre)
         elif self._generic_regulariser():
             prob_volume_pre = self.cost_reg.logits_cl_generic(volume)
-            depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+            depth, conf, prob_volume, *rest = head(prob_volume_pre)
         else:
             ws, bs, prob_w, prob_b = self.cost_reg.packed_all(volume.device, self.conv_precision)
             if self.cost_reg.prob_ksize == 1 and mfma and self.fuse_prob_head:
                 # CostRegNet3D: the 1x1x1 head rides in the last deconvolution's epilogue (module.py:500-502): logits out, the
                 # 8-channel full-resolution features never reach HBM
                 prob_volume_pre = ops.regnet_logits(self.cost_reg.kind, volume, ws, bs, prob_w, prob_b, pcode)
-                depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+                depth, conf, prob_volume, *rest = head(prob_volume_pre)
             elif self.cost_reg.prob_ksize == 3 and mfma:
                 # CostRegNet: the 3x3x3 head (module.py:391,407) as an MFMA convolution with one real output row, logits out
                 feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, pcode)
                 prob_volume_pre = ops.conv3d_logits(feat_cl, prob_w, prob_b, pcode)
-                depth, conf, prob_volume = ops.softmax_regress(prob_volume_pre, hyp, tmp, mode, conf_n, self.return_prob_volumes)
+                depth, conf, prob_volume, *rest = head(prob_volume_pre)
             else:
                 feat_cl = ops.regnet(self.cost_reg.kind, volume, ws, bs, pcode)
                 if split:                                       # fuse_prob_head = False (A/B switch): the standalone head reads fp32
@@ -306,8 +335,14 @@ class StageNet(nn.Module):
                     feat_cl = feat_cl.float()
                 depth, conf, prob_volume, prob_volume_pre = ops.prob_regress(
                     feat_cl, prob_w, prob_b, self.cost_reg.prob_ksize, hyp, tmp, mode, conf_n, self.return_prob_volumes)
-        return {"depth": depth, "prob_volume": prob_volume, "photometric_confidence": conf,
-                "depth_values": depth_values, "prob_volume_pre": prob_volume_pre}
+                rest = []
+                if conf_prev is not None:                       # the fp32-exact route has no fused form: the stand-alone average
+                    rest = [ops.confidence_average(list(conf_prev) + [conf], conf.shape[-2], conf.shape[-1])]
+        out = {"depth": depth, "prob_volume": prob_volume, "photometric_confidence": conf,
+               "depth_values": depth_values, "prob_volume_pre": prob_volume_pre}
+        if conf_prev is not None:
+            out["_conf_avg"] = rest[0]
+        return out
 
     # ---- source views sharded over the ranks of `view_group` ---------------------------------------
     MAX_CACHED_SHAPES = 2          # input resolutions whose scratch is kept (mixed-resolution datasets would otherwise grow it without bound)

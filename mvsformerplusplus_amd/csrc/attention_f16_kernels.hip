@@ -325,7 +325,9 @@ static int launch_one(const void* q, const void* k, const void* vp, float* out, 
     return check_launch("tr_attention16_kernel");
 }
 
-// variant: measurement switch (MVS_ATTN_VARIANT, scripts/prof_attn.py); 0 = the product's choice
+// variant: measurement switch (MVS_ATTN_VARIANT, scripts/prof_attn.py); 0 = the product's choice.  1 .. 6 are tile
+// shapes of the SAME algorithm (every one numerically valid).  The ablations (exponentials / p.v MFMAs / barriers removed: timing only,
+// wrong results) exist only in a library built with -DMVS_ATTN_ABLATIONS; the shipped one ignores their numbers.
 int launch_attention16(const void* q, const void* k, const void* vp, float* out, int B, int n, int heads, int variant, hipStream_t st) {
     const int npad = (n + kAttnPad - 1) / kAttnPad * kAttnPad;
     switch (variant) {
@@ -335,6 +337,7 @@ int launch_attention16(const void* q, const void* k, const void* vp, float* out,
         case 4: return launch_one<2, 256>(q, k, vp, out, B, n, npad, heads, st);
         case 5: return launch_one<1, 256>(q, k, vp, out, B, n, npad, heads, st);
         case 6: return launch_one<4, 256>(q, k, vp, out, B, n, npad, heads, st);
+#ifdef MVS_ATTN_ABLATIONS
         // ablations of the QT = 2, KB = 128 shape (16 + mask): timing only
         case 18: return launch_one<2, 128, 2>(q, k, vp, out, B, n, npad, heads, st);
         case 20: return launch_one<2, 128, 4>(q, k, vp, out, B, n, npad, heads, st);
@@ -343,6 +346,7 @@ int launch_attention16(const void* q, const void* k, const void* vp, float* out,
         case 32: return launch_one<2, 128, 16>(q, k, vp, out, B, n, npad, heads, st);
         case 40: return launch_one<2, 128, 24>(q, k, vp, out, B, n, npad, heads, st);
         case 80: return launch_one<2, 128, 64>(q, k, vp, out, B, n, npad, heads, st);
+#endif
         default: return launch_one<1, 256>(q, k, vp, out, B, n, npad, heads, st);
     }
 }

@@ -264,12 +264,14 @@ struct GlTile {
 // pass 1: entropy of the depth-softmax of the group-summed correlation          cost_volume.py:79-92
 // grid = (tiles, ceil(views in launch / vpb), B); a block walks `vpb` consecutive source views of its tile
 // ------------------------------------------------------------------------------------------------
-// KEEP: the per-view GROUP correlations (mean over the group's channels, cost_volume.py:79-84) are also written, as fp16
-// [B, V-1, D, HW, 8] clamped to the fp16 range, for corr_aggregate_kernel; the group sum the entropy needs is taken from them.
+// KEEP: the per-view GROUP correlations (mean over the group's channels, cost_volume.py:79-84) are also written for
+// corr_aggregate_kernel, [B, V-1, D, HW, 8]; the group sum the entropy needs is taken from them.  KEEP && W16: fp16 windows and fp16
+// correlations clamped to the fp16 range (MVS_CORR_F16, 16 B per voxel and view); KEEP && !W16: fp32 windows and fp32 correlations
+// (MVS_CORR_F32, 32 B per voxel and view - the exact form: what the second gather would have recomputed, round 5).
 template <int DT, int NOCT, int NS, bool TILED, bool KEEP, bool W16>
 __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict__ feat_, const float* __restrict__ hom,
                                                          const float* __restrict__ hyp, float* __restrict__ entropy,
-                                                         _Float16* __restrict__ corr, int V, int D, int H,
+                                                         void* __restrict__ corr, int V, int D, int H,
                                                          int W, int view_begin, int view_end, int vpb, int ntx, int nblk) {
     typedef typename FeatT<DT>::type T;
     HIP_DYNAMIC_SHARED(float, smem)
@@ -314,19 +316,26 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
                 for (int i = 0; i < 8 * GL_DCH; ++i) acc[i] = 0.0f;
                 gl_unit<T, NOCT, true, TILED, W16>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, acc);
                 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-                h8* cv = reinterpret_cast<h8*>(corr) + (size_t)(b * (V - 1) + (v - 1)) * D * HW + t.pc;
+                const size_t cbase = (size_t)(b * (V - 1) + (v - 1)) * D * HW + t.pc;
 #pragma unroll
                 for (int dd = 0; dd < GL_DCH; ++dd) {
                     float r[8];
 #pragma unroll
                     for (int g = 0; g < 8; ++g) { r[g] = acc[g * GL_DCH + dd]; s[dd] += r[g]; }
                     if (active && d0 + dd < D) {
-                        h8 hv;
+                        const size_t vox = cbase + (size_t)(unsigned)(d0 + dd) * HW;
+                        if constexpr (W16) {
+                            h8 hv;
 #pragma unroll
-                        for (int g = 0; g < 8; ++g) hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f);
-                        sat::track(sat_amax, r[0], r[1], r[2], r[3]);
-                        sat::track(sat_amax, r[4], r[5], r[6], r[7]);
-                        cv[(size_t)(unsigned)(d0 + dd) * HW] = hv;
+                            for (int g = 0; g < 8; ++g) hv[g] = (_Float16)fminf(fmaxf(r[g], -65504.0f), 65504.0f);
+                            sat::track(sat_amax, r[0], r[1], r[2], r[3]);
+                            sat::track(sat_amax, r[4], r[5], r[6], r[7]);
+                            reinterpret_cast<h8*>(corr)[vox] = hv;
+                        } else {
+                            f32x4* cv = reinterpret_cast<f32x4*>(corr) + vox * 2;
+                            cv[0] = f32x4{r[0], r[1], r[2], r[3]};
+                            cv[1] = f32x4{r[4], r[5], r[6], r[7]};
+                        }
                     }
                 }
             } else {
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
             if (t.slot == 0 && t.valid) gl_softmax_entropy_store(sim + t.pi, TP, D, dst);
         }
     }
-    if (KEEP) sat::commit(sat_amax);
+    if (KEEP && W16) sat::commit(sat_amax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,7 +481,7 @@ bool gl_supported(int C, int G, int D, int H, int W);
 
 template <int DT, int NOCT, int NS, bool TILED, bool KEEP = false, bool W16 = false>
 static int gl_launch_entropy_t(const void* feat, const float* hom, const float* hyp, float* ent, int B, int V, int D, int H, int W, int vb,
-                               int ve, hipStream_t st, _Float16* corr = nullptr) {
+                               int ve, hipStream_t st, void* corr = nullptr) {
     constexpr int TP = 256 / NS, TW = TP / GL_TH;
     const int ntx = (int)ceil_div(W, TW), nty = (int)ceil_div(H, GL_TH);
     const int nblk = ntx * nty;

@@ -1,5 +1,5 @@
-// LDS-staged gather, translation unit 3 of 5 (gather_lds.h): the entropy pass that keeps the per-view group correlations as fp16, and
-// the streaming pass 2 over them.
+// LDS-staged gather, translation unit 3 of 6 (gather_lds.h): the entropy pass that keeps the per-view group correlations as fp16, and
+// the streaming pass 2 over kept correlations (fp16, or fp32 from gather_lds_keep32_kernels.hip).
 #include "gather_lds.h"
 
 namespace mvs {
@@ -11,16 +11,17 @@ namespace mvs {
 // once for the four), 16-byte loads and stores.
 // ------------------------------------------------------------------------------------------------
 // FMT: the volume's format - MVS_VOLUME_F16 (fp16 octet, 16 B per voxel), MVS_VOLUME_SPLIT ([hi x8 | lo x8] bf16 of the bf16x3 U-Net, 32 B) or
-// MVS_VOLUME_F32 (32 B): the kept correlations are fp16 in every case - the stage's REGULARISER format is independent of the gather's
-template <int FMT>
-__global__ __launch_bounds__(256) void corr_aggregate_kernel(const _Float16* __restrict__ corr, const float* __restrict__ vis,
+// MVS_VOLUME_F32 (32 B); CF32: the kept correlations are fp32 octets (MVS_CORR_F32) instead of fp16 (MVS_CORR_F16) - the stage's
+// REGULARISER format is independent of the gather's
+template <int FMT, bool CF32>
+__global__ __launch_bounds__(256) void corr_aggregate_kernel(const void* __restrict__ corr, const float* __restrict__ vis,
                                                              void* __restrict__ vol, int NV, int D, unsigned HW) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const unsigned p = blockIdx.x * 256u + threadIdx.x;
     if (p >= HW) return;
     const int b = (int)blockIdx.z, d0 = (int)blockIdx.y * 4;
     const float* vp = vis + (size_t)b * NV * HW + p;
-    const h8* cp = reinterpret_cast<const h8*>(corr) + (size_t)b * NV * D * HW + p;
+    const size_t cp = (size_t)b * NV * D * HW + p;
     float acc[4][8];
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd)
@@ -31,13 +32,21 @@ __global__ __launch_bounds__(256) void corr_aggregate_kernel(const _Float16* __r
     for (int v = 0; v < NV; ++v) {
         const float w = vp[(size_t)v * HW];
         vsum += w;                                                                                   // cost_volume.py:98
-        const h8* cv = cp + (size_t)v * D * HW;
+        const size_t cv = cp + (size_t)v * D * HW;
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
             const int d = d0 + dd < D ? d0 + dd : D - 1;
-            const h8 c = cv[(size_t)(unsigned)d * HW];
+            const size_t vox = cv + (size_t)(unsigned)d * HW;
+            if constexpr (CF32) {
+                const f32x4* c4 = reinterpret_cast<const f32x4*>(corr) + vox * 2;
+                const f32x4 c0 = c4[0], c1 = c4[1];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) acc[dd][g] += w * (float)c[g];                                // cost_volume.py:97
+                for (int g = 0; g < 4; ++g) { acc[dd][g] += w * c0[g]; acc[dd][4 + g] += w * c1[g]; }  // cost_volume.py:97
+            } else {
+                const h8 c = reinterpret_cast<const h8*>(corr)[vox];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) acc[dd][g] += w * (float)c[g];                            // cost_volume.py:97
+            }
         }
     }
     const float rdenom = 1.0f / (vsum + 1e-6f);                                                      // cost_volume.py:101
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void corr_aggregate_kernel(const _Float16* __r
 
 // KEEP form: the launcher with NS = 1 (D <= 4) is not instantiated - the streaming pass 2 never pays there (gl_keep_supported)
 template <int DT, int NOCT, int NS, bool TILED>
-static int gl_launch_entropy_keep_t(const void* feat, const float* hom, const float* hyp, float* ent, _Float16* corr, int B, int V, int D, int H, int W,
+static int gl_launch_entropy_keep_t(const void* feat, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int D, int H, int W,
                                     hipStream_t st) {
     if constexpr (NS == 1) {
         set_error("mvs_warp_corr_entropy_keep_fwd: D <= 4 is not built (the second gather is the faster pass 2 there)");
@@ -90,21 +99,31 @@ static int gl_launch_entropy_keep_t(const void* feat, const float* hom, const fl
     }
 }
 
-int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C, int D,
-                           int H, int W, hipStream_t st) {
-    GL_DISPATCH(gl_launch_entropy_keep_t, feat, hom, hyp, ent, static_cast<_Float16*>(corr), B, V, D, H, W, st);
+int gl_launch_entropy_keep32(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C,
+                             int D, int H, int W, hipStream_t st);      // gather_lds_keep32_kernels.hip
+
+int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int corr_format, int B,
+                           int V, int C, int D, int H, int W, hipStream_t st) {
+    if (corr_format == MVS_CORR_F32) return gl_launch_entropy_keep32(feat, dtype, layout, hom, hyp, ent, corr, B, V, C, D, H, W, st);
+    GL_DISPATCH(gl_launch_entropy_keep_t, feat, hom, hyp, ent, corr, B, V, D, H, W, st);
 }
 
-int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W, hipStream_t st) {
+template <bool CF32>
+static int launch_corr_aggregate_t(const void* c, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W, hipStream_t st) {
     const unsigned HW = (unsigned)H * (unsigned)W;
     const dim3 grid(ceil_div(HW, 256), ceil_div(D, 4), B);
-    const _Float16* c = static_cast<const _Float16*>(corr);
     switch (volume_format) {
-        case MVS_VOLUME_F16: hipLaunchKernelGGL(corr_aggregate_kernel<MVS_VOLUME_F16>, grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
-        case MVS_VOLUME_SPLIT: hipLaunchKernelGGL(corr_aggregate_kernel<MVS_VOLUME_SPLIT>, grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
-        default: hipLaunchKernelGGL(corr_aggregate_kernel<MVS_VOLUME_F32>, grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
+        case MVS_VOLUME_F16: hipLaunchKernelGGL((corr_aggregate_kernel<MVS_VOLUME_F16, CF32>), grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
+        case MVS_VOLUME_SPLIT: hipLaunchKernelGGL((corr_aggregate_kernel<MVS_VOLUME_SPLIT, CF32>), grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
+        default: hipLaunchKernelGGL((corr_aggregate_kernel<MVS_VOLUME_F32, CF32>), grid, dim3(256), 0, st, c, vis, vol, V - 1, D, HW); break;
     }
     return check_launch("corr_aggregate_kernel");
+}
+
+int launch_corr_aggregate(const void* corr, int corr_format, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W,
+                          hipStream_t st) {
+    return corr_format == MVS_CORR_F32 ? launch_corr_aggregate_t<true>(corr, vis, vol, volume_format, B, V, D, H, W, st)
+                                       : launch_corr_aggregate_t<false>(corr, vis, vol, volume_format, B, V, D, H, W, st);
 }
 
 }  // namespace mvs

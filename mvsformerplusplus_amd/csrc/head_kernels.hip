@@ -14,6 +14,15 @@
 
 namespace mvs {
 
+// a16: mean over stages of nearest-upsampled confidences (DINOv2_mvsformer_model.py:167-177).  As a stand-alone kernel
+// (confidence_average_kernel) and - round 5 - as the epilogue of the LAST stage's head (prob_regress_kernel: cavg.n = number of
+// EARLIER stages, this stage's own confidence is the value the work-item just computed; one launch and one HW read less).
+struct ConfPtrs {
+    const float* p[8];
+    int shift[8];
+    int n;
+};
+
 // ------------------------------------------------------------------------------------------------
 // logits -> softmax -> depth / confidence
 //   DC  compile-time D (registers) or 0 (logits live in the prob_volume_pre buffer)
@@ -24,7 +33,8 @@ __global__ __launch_bounds__(256) void prob_regress_kernel(const float* __restri
                                                            const float* __restrict__ prob_b, const float* __restrict__ hyp, float tmp,
                                                            int mode, int conf_n, float* __restrict__ depth_out,
                                                            float* __restrict__ conf_out, float* __restrict__ prob_vol,
-                                                           float* __restrict__ pre, int D_, int H, int W) {
+                                                           float* __restrict__ pre, int D_, int H, int W, ConfPtrs cavg = ConfPtrs{},
+                                                           float* __restrict__ conf_avg_out = nullptr) {
     const int D = DC > 0 ? DC : D_;
     const int HW = H * W;
     const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
@@ -154,6 +164,14 @@ __global__ __launch_bounds__(256) void prob_regress_kernel(const float* __restri
     }
     depth_out[(size_t)b * HW + p] = depth;
     conf_out[(size_t)b * HW + p] = conf;
+    if (conf_avg_out != nullptr) {                                // a16 fused: (sum of the earlier stages' nearest-upsampled confidences + this one) / n
+        float s = 0.0f;
+        for (int i = 0; i < cavg.n; ++i) {
+            const int hs = H >> cavg.shift[i], ws = W >> cavg.shift[i];
+            s += cavg.p[i][(size_t)b * hs * ws + (size_t)(y >> cavg.shift[i]) * ws + (x >> cavg.shift[i])];
+        }
+        conf_avg_out[(size_t)b * HW + p] = (s + conf) / (float)(cavg.n + 1);      // same summation order as confidence_average_kernel: stage 1 first
+    }
 #undef MVS_LOGIT
 }
 
@@ -186,16 +204,6 @@ __global__ void conf_regression_kernel(const float* __restrict__ p, int n, float
 // ------------------------------------------------------------------------------------------------
 // a13 / init_range: [B,N] depth values -> [B,D,H,W] hypotheses              module.py:674-704
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float init_range_value(float first, float last, int inverse, int d, int D) {
-    if (inverse) {
-        const float inv_min = 1.0f / first, inv_max = 1.0f / last;
-        const float itv = (float)d / (float)(D - 1);
-        return 1.0f / (inv_max + (inv_min - inv_max) * itv);                        // module.py:697-704
-    }
-    const float interval = (last - first) / (float)(D - 1);
-    return first + (float)d * interval;                                             // module.py:676-682
-}
-
 __global__ void init_range_kernel(const float* __restrict__ dv, int N, int inverse, float* __restrict__ hyp, int D, int HW) {
     const int b = (int)blockIdx.z, d = (int)blockIdx.y;
     const float v = init_range_value(dv[(size_t)b * N], dv[(size_t)b * N + N - 1], inverse, d, D);
@@ -280,13 +288,7 @@ __global__ __launch_bounds__(256) void schedule_range_kernel(const float* __rest
     }
 }
 
-// a16: mean over stages of nearest-upsampled confidences
-struct ConfPtrs {
-    const float* p[8];
-    int shift[8];
-    int n;
-};
-
+// a16: mean over stages of nearest-upsampled confidences (ConfPtrs: above)
 __global__ void confidence_average_kernel(ConfPtrs cp, float* __restrict__ out, int H, int W) {
     const int HW = H * W;
     const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
@@ -318,11 +320,12 @@ __global__ void cl_to_ncdhw_kernel(const float* __restrict__ x, float* __restric
 
 template <int KS>
 static int launch_head(const float* in, const float* pw, const float* pb, const float* hyp, float tmp, int mode, int conf_n,
-                       float* depth, float* conf, float* pv, float* pre, int B, int D, int H, int W, hipStream_t st) {
+                       float* depth, float* conf, float* pv, float* pre, int B, int D, int H, int W, hipStream_t st,
+                       ConfPtrs cavg = ConfPtrs{}, float* conf_avg = nullptr) {
     const dim3 grid(ceil_div((long long)H * W, 256), B), block(256);
 #define MVS_HEAD_CASE(DC)                                                                                                     \
     case DC:                                                                                                                  \
-        hipLaunchKernelGGL((prob_regress_kernel<DC, KS>), grid, block, 0, st, in, pw, pb, hyp, tmp, mode, conf_n, depth, conf, pv, pre, D, H, W); \
+        hipLaunchKernelGGL((prob_regress_kernel<DC, KS>), grid, block, 0, st, in, pw, pb, hyp, tmp, mode, conf_n, depth, conf, pv, pre, D, H, W, cavg, conf_avg); \
         break;
     switch (D) {
         MVS_HEAD_CASE(4)
@@ -332,7 +335,7 @@ static int launch_head(const float* in, const float* pw, const float* pb, const 
         MVS_HEAD_CASE(48)
         default:
             if (!pre) { set_error("prob_regress: D=%d has no register-resident variant; pass a prob_volume_pre buffer", D); return MVS_ERR_ARG; }
-            hipLaunchKernelGGL((prob_regress_kernel<0, KS>), grid, block, 0, st, in, pw, pb, hyp, tmp, mode, conf_n, depth, conf, pv, pre, D, H, W);
+            hipLaunchKernelGGL((prob_regress_kernel<0, KS>), grid, block, 0, st, in, pw, pb, hyp, tmp, mode, conf_n, depth, conf, pv, pre, D, H, W, cavg, conf_avg);
     }
 #undef MVS_HEAD_CASE
     return check_launch("prob_regress_kernel");
@@ -371,6 +374,23 @@ extern "C" int mvs_softmax_regress_fwd(const float* logits, const float* hyp, fl
     if (rc != MVS_OK) return rc;
     // KS = 0 reads logits; for run-time D they are re-read from the same buffer (never written: KS == 0)
     return launch_head<0>(logits, nullptr, nullptr, hyp, tmp, mode, conf_n, depth, conf, prob_volume, const_cast<float*>(logits), B, D, H, W, (hipStream_t)stream);
+}
+
+extern "C" int mvs_softmax_regress_confavg_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth, float* conf,
+                                              float* prob_volume, const float* const* prev_conf_host_ptrs, const int* prev_shifts_host, int n_prev,
+                                              float* conf_avg, int B, int D, int H, int W, void* stream) {
+    int rc = check_head("mvs_softmax_regress_confavg_fwd", logits, hyp, depth, conf, mode, B, D, H, W);
+    if (rc != MVS_OK) return rc;
+    if (!conf_avg || n_prev < 0 || n_prev > 7 || (n_prev > 0 && (!prev_conf_host_ptrs || !prev_shifts_host))) { set_error("mvs_softmax_regress_confavg_fwd: bad arguments (0..7 earlier stages)"); return MVS_ERR_ARG; }
+    ConfPtrs cp;
+    cp.n = n_prev;
+    for (int i = 0; i < 8; ++i) { cp.p[i] = i < n_prev ? prev_conf_host_ptrs[i] : nullptr; cp.shift[i] = i < n_prev ? prev_shifts_host[i] : 0; }
+    for (int i = 0; i < n_prev; ++i)
+        if (!cp.p[i] || cp.shift[i] < 0 || cp.shift[i] > 16 || ((H >> cp.shift[i]) << cp.shift[i]) != H || ((W >> cp.shift[i]) << cp.shift[i]) != W) {
+            set_error("mvs_softmax_regress_confavg_fwd: earlier stage %d must be a 2^shift-times smaller map of this %dx%d stage", i, H, W);
+            return MVS_ERR_ARG;
+        }
+    return launch_head<0>(logits, nullptr, nullptr, hyp, tmp, mode, conf_n, depth, conf, prob_volume, const_cast<float*>(logits), B, D, H, W, (hipStream_t)stream, cp, conf_avg);
 }
 
 extern "C" int mvs_depth_regression_fwd(const float* p, const float* depth_values, float* out, int B, int D, int H, int W, void* stream) {

@@ -308,4 +308,15 @@ __device__ __forceinline__ void prio_contract_end() {
 
 static inline unsigned ceil_div(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+// a13 / init_range: hypothesis d of D between the first and the last of the [B,N] depth values           module.py:674-704
+__device__ __forceinline__ float init_range_value(float first, float last, int inverse, int d, int D) {
+    if (inverse) {
+        const float inv_min = 1.0f / first, inv_max = 1.0f / last;
+        const float itv = (float)d / (float)(D - 1);
+        return 1.0f / (inv_max + (inv_min - inv_max) * itv);                        // module.py:697-704
+    }
+    const float interval = (last - first) / (float)(D - 1);
+    return first + (float)d * interval;                                             // module.py:676-682
+}
+
 }  // namespace mvs

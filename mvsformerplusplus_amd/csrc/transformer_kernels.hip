@@ -720,7 +720,9 @@ extern "C" int mvs_tr_attention_fwd(const void* q, const void* k, const void* vt
                                     void* stream) {
     if (!q || !k || !vt || !out || B < 1 || n < 1 || heads < 1) { set_error("mvs_tr_attention_fwd: bad arguments"); return MVS_ERR_ARG; }
     if (precision == MVS_PREC_ATTN16) {
-        const char* ev = getenv("MVS_ATTN_VARIANT");                       // measurement / test switch (tile shapes of the same algorithm)
+        // measurement / test switch: tile shapes 1 .. 6 of the SAME algorithm, every one numerically valid (tests/test_emu_parity.py runs them
+        // all in one process, hence no caching; the wrong-result timing ablations need a -DMVS_ATTN_ABLATIONS build, attention_f16_kernels.hip)
+        const char* ev = getenv("MVS_ATTN_VARIANT");
         const int variant = ev ? atoi(ev) : 0;
         return launch_attention16(q, k, vt, out, B, n, heads, variant, (hipStream_t)stream);
     }

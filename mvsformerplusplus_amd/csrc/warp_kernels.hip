@@ -80,6 +80,37 @@ __global__ void compose_homography_kernel(const float* proj, int B, int V, float
     homography_out(Ps, Pr, out + (size_t)idx * 12);
 }
 
+// Round 5: the cascade's prologue as ONE launch - the homographies of EVERY stage (the per-stage proj tensors differ only in the
+// intrinsics' scale, general_eval.py:229-242) and stage 1's hypotheses (init_range / init_inverse_range, module.py:674-704): five launches of
+// ~5 us each before (4 x compose_homography + init_range), all latency.  Blocks [0, init_blocks) fill the hypotheses, the last block
+// composes: thread idx -> (stage, b, v).
+struct ProloguePtrs {
+    const float* proj[8];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void cascade_prologue_kernel(ProloguePtrs pp, int B, int V, float* __restrict__ hom, const float* __restrict__ dv,
+                                                               int N, int inverse, float* __restrict__ hyp, int D, int HW, int init_blocks) {
+    if ((int)blockIdx.x < init_blocks) {
+        const long long total = (long long)B * D * HW;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)init_blocks * 256) {
+            const int bd = (int)(i / HW);
+            const int b = bd / D, d = bd - b * D;
+            hyp[i] = init_range_value(dv[(size_t)b * N], dv[(size_t)b * N + N - 1], inverse, d, D);
+        }
+        return;
+    }
+    const int per = B * (V - 1);
+    for (int idx = (int)threadIdx.x; idx < pp.n * per; idx += 256) {
+        const int s = idx / per, r = idx - s * per;
+        const int b = r / (V - 1), v = 1 + r % (V - 1);
+        double Pr[16], Ps[16];
+        compose_p(pp.proj[s] + (size_t)(b * V) * 32, Pr);
+        compose_p(pp.proj[s] + (size_t)(b * V + v) * 32, Ps);
+        homography_out(Ps, Pr, hom + (size_t)idx * 12);
+    }
+}
+
 __global__ void homography_from_proj_kernel(const float* src_proj, const float* ref_proj, int B, float* out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -578,9 +609,10 @@ int gl_launch_entropy(const void* feat, int dtype, int layout, const float* hom,
 int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol,
                         float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
 bool gl_keep_supported(int C, int G, int D, int H, int W);
-int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C, int D,
-                           int H, int W, hipStream_t st);
-int launch_corr_aggregate(const void* corr, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W, hipStream_t st);
+int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int corr_format, int B,
+                           int V, int C, int D, int H, int W, hipStream_t st);
+int launch_corr_aggregate(const void* corr, int corr_format, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W,
+                          hipStream_t st);
 int pack_features_dispatch(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W, hipStream_t st);
 
 // MVS_GATHER_IMPL=direct selects the round-1 direct-gather kernels (A/B measurements); anything else = LDS-staged where supported.
@@ -604,6 +636,26 @@ extern "C" int mvs_compose_homography(const float* proj, int B, int V, float* ho
     const int n = B * (V - 1);
     hipLaunchKernelGGL(compose_homography_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, proj, B, V, homography);
     return check_launch("compose_homography_kernel");
+}
+
+extern "C" int mvs_cascade_prologue_fwd(const float* const* proj_host_ptrs, int n_stages, int B, int V, float* homography, const float* depth_values,
+                                       int N, int inverse, float* hyp, int D, int H, int W, void* stream) {
+    if (!proj_host_ptrs || !homography || n_stages < 1 || n_stages > 8 || B < 1 || V < 2) { set_error("mvs_cascade_prologue_fwd: bad arguments (1..8 stages)"); return MVS_ERR_ARG; }
+    if (hyp && (!depth_values || N < 1 || D < 2 || H < 1 || W < 1)) { set_error("mvs_cascade_prologue_fwd: bad hypothesis arguments"); return MVS_ERR_ARG; }
+    ProloguePtrs pp;
+    pp.n = n_stages;
+    for (int i = 0; i < 8; ++i) {
+        pp.proj[i] = i < n_stages ? proj_host_ptrs[i] : nullptr;
+        if (i < n_stages && !pp.proj[i]) { set_error("mvs_cascade_prologue_fwd: null projection tensor of stage %d", i); return MVS_ERR_ARG; }
+    }
+    int init_blocks = 0;
+    if (hyp) {
+        const long long total = (long long)B * D * H * W;
+        init_blocks = (int)(ceil_div(total, 1024) > 1024 ? 1024 : ceil_div(total, 1024));      // ~4 elements per thread, at most 1024 blocks
+    }
+    hipLaunchKernelGGL(cascade_prologue_kernel, dim3(init_blocks + 1), dim3(256), 0, (hipStream_t)stream, pp, B, V, homography, depth_values, N, inverse,
+                       hyp, D, H * W, init_blocks);
+    return check_launch("cascade_prologue_kernel");
 }
 
 extern "C" int mvs_homography_from_proj(const float* src_proj, const float* ref_proj, int B, float* homography, void* stream) {
@@ -670,10 +722,11 @@ extern "C" int mvs_gather_keeps_correlations(int layout, int C, int G, int D, in
 }
 
 extern "C" int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, float* entropy,
-                                              void* corr_f16, int B, int V, int C, int G, int D, int H, int W, void* stream) {
+                                              void* corr, int corr_format, int B, int V, int C, int G, int D, int H, int W, void* stream) {
     int rc = check_corr_args("mvs_warp_corr_entropy_keep_fwd", features, homography, hyp, dtype, B, V, C, G, D, H, W, 1, V);
     if (rc != MVS_OK) return rc;
-    if (!entropy || !corr_f16) { set_error("mvs_warp_corr_entropy_keep_fwd: null output"); return MVS_ERR_ARG; }
+    if (!entropy || !corr) { set_error("mvs_warp_corr_entropy_keep_fwd: null output"); return MVS_ERR_ARG; }
+    if (corr_format != MVS_CORR_F16 && corr_format != MVS_CORR_F32) { set_error("mvs_warp_corr_entropy_keep_fwd: unknown correlation format %d", corr_format); return MVS_ERR_ARG; }
     rc = check_layout("mvs_warp_corr_entropy_keep_fwd", layout, C, G, D, H, W);
     if (rc != MVS_OK) return rc;
     if (!gl_keep_supported(C, G, D, H, W)) {
@@ -681,15 +734,16 @@ extern "C" int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, i
                   "mvs_gather_keeps_correlations() says which shapes qualify");
         return MVS_ERR_UNSUPPORTED;
     }
-    return gl_launch_entropy_keep(features, dtype, layout, homography, hyp, entropy, corr_f16, B, V, C, D, H, W, (hipStream_t)stream);
+    return gl_launch_entropy_keep(features, dtype, layout, homography, hyp, entropy, corr, corr_format, B, V, C, D, H, W, (hipStream_t)stream);
 }
 
-extern "C" int mvs_corr_aggregate_fwd(const void* corr_f16, const float* vis, void* volume_cl, int volume_format, int B, int V, int D, int H, int W,
-                                      void* stream) {
-    if (!corr_f16 || !vis || !volume_cl) { set_error("mvs_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
+extern "C" int mvs_corr_aggregate_fwd(const void* corr, int corr_format, const float* vis, void* volume_cl, int volume_format, int B, int V, int D,
+                                      int H, int W, void* stream) {
+    if (!corr || !vis || !volume_cl) { set_error("mvs_corr_aggregate_fwd: null pointer"); return MVS_ERR_ARG; }
+    if (corr_format != MVS_CORR_F16 && corr_format != MVS_CORR_F32) { set_error("mvs_corr_aggregate_fwd: unknown correlation format %d", corr_format); return MVS_ERR_ARG; }
     if (B < 1 || V < 2 || D < 1 || H < 1 || W < 1 || (long long)D * H * W > 0x7fffffffLL) { set_error("mvs_corr_aggregate_fwd: bad shape"); return MVS_ERR_ARG; }
     if (volume_format != MVS_VOLUME_F32 && volume_format != MVS_VOLUME_SPLIT && volume_format != MVS_VOLUME_F16) { set_error("mvs_corr_aggregate_fwd: unknown volume format %d", volume_format); return MVS_ERR_ARG; }
-    return launch_corr_aggregate(corr_f16, vis, volume_cl, volume_format, B, V, D, H, W, (hipStream_t)stream);
+    return launch_corr_aggregate(corr, corr_format, vis, volume_cl, volume_format, B, V, D, H, W, (hipStream_t)stream);
 }
 
 extern "C" int mvs_warp_corr_aggregate_fwd(const void* features, int dtype, int layout, const float* homography, const float* hyp, const float* vis,

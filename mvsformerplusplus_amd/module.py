@@ -34,32 +34,37 @@ def _bn_dict(bn: nn.Module) -> Dict[str, torch.Tensor]:
             "running_mean": bn.running_mean.detach().cpu(), "running_var": bn.running_var.detach().cpu(), "eps": float(bn.eps)}
 
 
-# THE default contraction / activation format of the 3-D regularisers at inference (one constant: cost_volume.STAGE_DEFAULT_PRECISION is
-# this value): "f16x2" - fp16 activation tensors, fp16 hi + lo weights, two MFMA terms per product, fp32 accumulation; depth 5e-5 / 4e-4
-# from the fp32 oracle on plain / x30-logits stress inputs (bar 1e-3); the reference's own GPU path runs these layers under bf16 autocast
-# (test.py:250).  "bf16x3" = 3-term split bf16, fp32-equivalent activations (1e-6 from the oracle); "fp32" = exact.
+# The default contraction / activation format of ONE regulariser / layer at inference (standalone CostRegNet / CostRegNet3D / Conv3d /
+# Deconv3d wrappers, and the fine stages of the default stage policy below): "f16mix" - fp16 activation tensors, fp16 hi + lo weights
+# (two MFMA terms per product) on the 8- / 16-channel layers and ONE fp16 term on the U-Net's 32- / 64-channel layers (conv4 .. conv7)
+# and in the visibility CNN, fp32 accumulation.  "f16x2" = two terms everywhere, "f16" = one everywhere (all three store fp16 activations
+# and share the packed weights; scripts/study_weight_precision.py).  "bf16x3" = 3-term split bf16, fp32-equivalent activations (1e-6
+# from the oracle); "fp32" = exact.  The reference's own GPU path runs these layers under bf16 autocast (test.py:250).
 DEFAULT_PRECISION = "f16mix"
-# Round 4: "f16mix" = "f16x2" with the second weight term (w_lo) dropped on the U-Net's 32- / 64-channel layers (conv4 .. conv7), where it
-# costs the most MFMAs and changes nothing measurable; "f16" drops it on every layer (refined depth 7e-5 plain / 4.8e-4 stress set against
-# 5.5e-5 / 4.2e-4 for "f16x2", scripts/study_weight_precision.py).  All three store fp16 activations and share the packed weights.
 F16_FORMATS = _lib.F16_FORMATS
 MFMA_FORMATS = ("bf16x3",) + F16_FORMATS
-# Round 4, late: args["conv_precision"] of a STAGE is a policy.  Besides one format for every stage there is "stagemix": the stages
-# regularised by CostRegNet / the transformer (ndepth > model_th: the coarse stages, whose depth schedules the next stage's hypotheses -
-# their noise is what the cascade amplifies) run the fp32-equivalent "bf16x3" regulariser and visibility CNN, the CostRegNet3D stages
-# (the large ones) run DEFAULT_PRECISION, the gather of EVERY stage keeps its fp16 storage forms (fp16 source windows, per-view
-# correlations kept as fp16).  Refined depth vs the fp32 oracle: 1.5e-5 plain / 1.0e-4 on the x30-logits stress set against 6e-5 / 4.8e-4
-# with DEFAULT_PRECISION on every stage (scripts/study_stage_mix.py, profiles/r04_stage_mix_study.txt), for 4.4 % of the throughput
-# (614 vs 642 ref-views/s on one box).  The DEFAULT stays the faster one - both are inside the 1e-3 bar with room; "stagemix" is the
-# choice for wide hypothesis ranges ("Degenerate hypothesis ranges").
-DEFAULT_STAGE_POLICY = DEFAULT_PRECISION
+# args["conv_precision"] of a STAGE is a policy: one format for every stage, or "stagemix" - THE PRODUCT DEFAULT since round 5:
+#   * the coarse stages (ndepth > model_th: CostRegNet / the transformer; their depth schedules the next stage's hypotheses, so their
+#     noise is what the cascade amplifies) run fp32-equivalent throughout: "bf16x3" regulariser and visibility CNN, EXACT gather
+#     (fp32 source windows; pass 2 streams fp32 kept correlations where that is built, otherwise gathers a second time);
+#   * the CostRegNet3D stages (the large ones, ~75 % of the time) run DEFAULT_PRECISION with the fp16 gather forms (fp16 source
+#     windows, per-view correlations kept as fp16 where D > 4).
+# Why it is the default: with "f16mix" on every stage the refined depth is 6e-5 / 4.8e-4 from the fp32 oracle on
+# plain / x30-logits inputs but 3-5e-3 on BASELINE cfg4 / cfg5's literal 0.5 .. 10 range (ill-conditioned around the pixels whose
+# inverse-depth window crosses zero, module.py:712-716) - outside the 1e-3 bar.  "stagemix": 5e-6 / 2e-5 and 2e-4 / 4e-4 on that range
+# (profiles/r04_stagemix_ab.txt "bf16x3 x2", profiles/r05_wide_range_gather_study.txt: of the coarse stages' storage forms the fp16 KEPT
+# CORRELATIONS carry the error - 1.1e-3 / 1.8e-3 - not the fp16 windows).  A uniform format ("f16mix", "f16x2", "f16", "bf16x3", "fp32")
+# stays available per head.
+DEFAULT_STAGE_POLICY = "stagemix"
+STAGE_POLICIES = ("stagemix",)
 
 
 def resolve_stage_precision(policy: str, ndepth: int, model_th: int = 8):
     """(conv_precision, gather_precision) of a stage under `policy` = args["conv_precision"]: "stagemix" (above) or one format for every
-    stage - an fp16 format keeps the fp16 gather forms, "bf16x3" / "fp32" gather with fp32 windows and no kept correlations."""
+    stage.  gather_precision "f16" = fp16 source windows + fp16 kept correlations (the fp16 formats); "f32" = fp32 windows, pass 2 exact
+    (fp32 kept correlations or a second gather) - "bf16x3" / "fp32" and the coarse stages of "stagemix"."""
     if policy == "stagemix":
-        return ("bf16x3" if ndepth > model_th else DEFAULT_PRECISION), "f16"
+        return ("bf16x3", "f32") if ndepth > model_th else (DEFAULT_PRECISION, "f16")
     if policy in F16_FORMATS:
         return policy, "f16"
     return policy, "f32"

@@ -66,6 +66,30 @@ def pack_features(features: torch.Tensor, dtype: Optional[torch.dtype] = None) -
     return PackedFeatures(out)
 
 
+def feature_conv_is_built(cin: int, cout: int) -> bool:
+    return bool(lib().mvs_feature_conv_is_built(int(cin), int(cout)))
+
+
+def conv2d3x3_tiles(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, swish: bool = False,
+                    out: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """Producer-side feature emitter: x [N,Cin,H,W] planar (fp32 / bf16 / fp16; any batch stride) through
+    Conv2d(Cin, cout, 3, padding=1) [+ bias] [+ Swish] -> octet tiles [N, cout/8, H, W, 8] in `dtype`, written by the convolution's
+    epilogue (no planar output, no pack pass).  `out`: a [N, cout/8, H, W, 8] tensor or VIEW to fill - e.g. `packed.data[:, v]` of a
+    [B, V, cout/8, H, W, 8] PackedFeatures buffer (any batch stride, the rest contiguous)."""
+    if x.dtype not in _lib.DTYPE_CODE:
+        x = x.float()
+    N, cin, H, W = x.shape
+    if x.stride()[1:] != (H * W, W, 1):
+        x = x.contiguous()
+    if out is None:
+        out = torch.empty(N, cout // 8, H, W, 8, dtype=dtype, device=x.device)
+    assert out.shape == (N, cout // 8, H, W, 8) and out.stride()[1:] == (H * W * 8, W * 8, 8, 1) and out.dtype in _lib.DTYPE_CODE, "tiled output [N,C/8,H,W,8]"
+    check(lib().mvs_conv2d3x3_tiles_fwd(ptr(x), _lib.DTYPE_CODE[x.dtype], ptr(w_packed), ptr(bias), 1 if swish else 0, ptr(out), _lib.DTYPE_CODE[out.dtype],
+                                        N, cin, cout, H, W, x.stride(0) if N > 1 else cin * H * W, out.stride(0) if N > 1 else cout * H * W,
+                                        stream_of(x)), "mvs_conv2d3x3_tiles_fwd")
+    return out
+
+
 def _feat(t) -> Tuple[torch.Tensor, int]:
     if isinstance(t, PackedFeatures):
         return t, _lib.DTYPE_CODE[t.dtype]
@@ -90,6 +114,27 @@ def compose_homography(proj_matrices: torch.Tensor) -> torch.Tensor:
     out = torch.empty(B, V - 1, 12, dtype=torch.float32, device=p.device)
     check(lib().mvs_compose_homography(ptr(p), B, V, ptr(out), stream_of(p)), "mvs_compose_homography")
     return out
+
+
+def cascade_prologue(proj_matrices: Sequence[torch.Tensor], depth_values: Optional[torch.Tensor] = None, ndepths: int = 0, H: int = 0, W: int = 0,
+                     inverse: bool = True):
+    """Round 5: the cascade's prologue in ONE launch (mvs_cascade_prologue_fwd): the homographies of every stage's proj_matrices
+    [B,V,2,4,4] -> list of [B,V-1,12], and - depth_values [B,N] given - stage 1's hypotheses [B,ndepths,H,W] (init_range)."""
+    ps = [_f32c(p) for p in proj_matrices]
+    B, V = ps[0].shape[:2]
+    for p in ps:
+        assert p.shape == (B, V, 2, 4, 4), "proj_matrices must be [B,V,2,4,4] with the same B, V on every stage"
+    hom = torch.empty(len(ps), B, V - 1, 12, dtype=torch.float32, device=ps[0].device)
+    hyp, dv, N = None, None, 0
+    if depth_values is not None:
+        dv = _f32c(depth_values)
+        assert dv.dim() == 2 and dv.shape[0] == B, "depth_values must be [B,N] (per-pixel ranges go through init_range)"
+        N = dv.shape[1]
+        hyp = torch.empty(B, ndepths, H, W, dtype=torch.float32, device=dv.device)
+    pa = _ptr_array(ps)
+    check(lib().mvs_cascade_prologue_fwd(C.cast(pa, C.c_void_p), len(ps), B, V, ptr(hom), ptr(dv), N, 1 if inverse else 0, ptr(hyp), ndepths, H, W,
+                                         stream_of(ps[0])), "mvs_cascade_prologue_fwd")
+    return list(hom.unbind(0)), hyp
 
 
 def homography_from_proj(src_proj: torch.Tensor, ref_proj: torch.Tensor) -> torch.Tensor:
@@ -219,30 +264,34 @@ def gather_keeps_correlations(features, G: int, hyp: torch.Tensor) -> bool:
     return bool(lib().mvs_gather_keeps_correlations(layout, Cc, G, hyp.shape[1], H, W))
 
 
-def warp_corr_entropy_keep(features, code: int, homography: torch.Tensor, hyp: torch.Tensor, G: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Pass 1 over all source views that also KEEPS the per-view group correlations (cost_volume.py:79-84) as fp16:
-    -> (entropy [B,V-1,H,W] fp32, corr [B,V-1,D,H,W,8] fp16)."""
+def warp_corr_entropy_keep(features, code: int, homography: torch.Tensor, hyp: torch.Tensor, G: int, exact: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pass 1 over all source views that also KEEPS the per-view group correlations (cost_volume.py:79-84):
+    -> (entropy [B,V-1,H,W] fp32, corr [B,V-1,D,H,W,8]).  corr is fp16 from fp16 source windows (MVS_CORR_F16), or - `exact` - fp32 from
+    fp32 windows (MVS_CORR_F32): corr_aggregate then writes what the second gather would have."""
     B, V, Cc, H, W = features.shape
     D = hyp.shape[1]
     ft, layout = _feat_ptr(features)
     ent = torch.empty(B, V - 1, H, W, dtype=torch.float32, device=ft.device)
-    corr = torch.empty(B, V - 1, D, H, W, 8, dtype=torch.float16, device=ft.device)
-    check(lib().mvs_warp_corr_entropy_keep_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(ent), ptr(corr), B, V, Cc, G, D, H, W,
-                                               stream_of(ft)), "mvs_warp_corr_entropy_keep_fwd")
+    corr = torch.empty(B, V - 1, D, H, W, 8, dtype=torch.float32 if exact else torch.float16, device=ft.device)
+    check(lib().mvs_warp_corr_entropy_keep_fwd(ptr(ft), code, layout, ptr(homography), ptr(hyp), ptr(ent), ptr(corr),
+                                               _lib.CORR_F32 if exact else _lib.CORR_F16, B, V, Cc, G, D, H, W, stream_of(ft)),
+          "mvs_warp_corr_entropy_keep_fwd")
     return ent, corr
 
 
 def corr_aggregate(corr: torch.Tensor, vis: torch.Tensor, split: bool = False, f16: bool = True) -> torch.Tensor:
-    """corr [B,V-1,D,H,W,8] fp16, vis [B,V-1,H,W] fp32 -> the normalised cost volume [B,D,H,W,8] (cost_volume.py:97-101): fp16 (f16, the
-    fp16 U-Nets' format), the split activation format of the bf16x3 U-Net (split) or fp32 (neither; the transformer regulariser)."""
-    assert corr.dtype == torch.float16 and corr.is_contiguous() and corr.dim() == 6 and corr.shape[-1] == 8
+    """corr [B,V-1,D,H,W,8] fp16 or fp32 (warp_corr_entropy_keep), vis [B,V-1,H,W] fp32 -> the normalised cost volume [B,D,H,W,8]
+    (cost_volume.py:97-101): fp16 (f16, the fp16 U-Nets' format), the split activation format of the bf16x3 U-Net (split) or fp32
+    (neither; the transformer regulariser)."""
+    assert corr.dtype in (torch.float16, torch.float32) and corr.is_contiguous() and corr.dim() == 6 and corr.shape[-1] == 8
     B, NV, D, H, W, _ = corr.shape
     v = _f32c(vis)
     assert v.shape == (B, NV, H, W)
     f16 = f16 and not split
     vol = torch.empty(B, D, H, W, 8, dtype=torch.float16 if f16 else torch.float32, device=corr.device)
     fmt = _lib.VOLUME_F16 if f16 else (_lib.VOLUME_SPLIT if split else _lib.VOLUME_F32)
-    check(lib().mvs_corr_aggregate_fwd(ptr(corr), ptr(v), ptr(vol), fmt, B, NV + 1, D, H, W, stream_of(corr)), "mvs_corr_aggregate_fwd")
+    cfmt = _lib.CORR_F32 if corr.dtype == torch.float32 else _lib.CORR_F16
+    check(lib().mvs_corr_aggregate_fwd(ptr(corr), cfmt, ptr(v), ptr(vol), fmt, B, NV + 1, D, H, W, stream_of(corr)), "mvs_corr_aggregate_fwd")
     return vol
 
 
@@ -602,15 +651,33 @@ def prob_regress(feat_cl: torch.Tensor, prob_w: torch.Tensor, prob_b: Optional[t
     return depth, conf, pv, pre
 
 
-def softmax_regress(logits: torch.Tensor, hyp: torch.Tensor, tmp: float, mode: int, conf_n: int = 0, want_prob: bool = True):
+def softmax_regress(logits: torch.Tensor, hyp: torch.Tensor, tmp: float, mode: int, conf_n: int = 0, want_prob: bool = True,
+                    conf_prev: Optional[Sequence[torch.Tensor]] = None):
+    """-> (depth, conf, prob_volume or None).  conf_prev (round 5): the EARLIER cascade stages' confidence maps (power-of-two smaller);
+    the head then also writes the cascade's averaged confidence (DINOv2_mvsformer_model.py:167-177, confidence_average fused into the
+    last stage's head) and returns it as a fourth value."""
     lg, hp = _f32c(logits), _f32c(hyp)
     B, D, H, W = lg.shape
     depth = torch.empty(B, H, W, dtype=torch.float32, device=lg.device)
     conf = torch.empty(B, H, W, dtype=torch.float32, device=lg.device)
     pv = torch.empty_like(lg) if want_prob else None
-    check(lib().mvs_softmax_regress_fwd(ptr(lg), ptr(hp), float(tmp), mode, conf_n, ptr(depth), ptr(conf), ptr(pv), B, D, H, W,
-                                        stream_of(lg)), "mvs_softmax_regress_fwd")
-    return depth, conf, pv
+    if conf_prev is None:
+        check(lib().mvs_softmax_regress_fwd(ptr(lg), ptr(hp), float(tmp), mode, conf_n, ptr(depth), ptr(conf), ptr(pv), B, D, H, W,
+                                            stream_of(lg)), "mvs_softmax_regress_fwd")
+        return depth, conf, pv
+    prev = [_f32c(c) for c in conf_prev]
+    shifts = []
+    for c in prev:
+        s = (H // c.shape[1]).bit_length() - 1
+        assert c.shape[0] == B and c.shape[1] << s == H and c.shape[2] << s == W, "confidence maps must be power-of-two downsamplings"
+        shifts.append(s)
+    avg = torch.empty(B, H, W, dtype=torch.float32, device=lg.device)
+    pa = _ptr_array(prev) if prev else None
+    sa = (C.c_int * max(len(shifts), 1))(*shifts)
+    check(lib().mvs_softmax_regress_confavg_fwd(ptr(lg), ptr(hp), float(tmp), mode, conf_n, ptr(depth), ptr(conf), ptr(pv),
+                                                C.cast(pa, C.c_void_p) if prev else None, C.cast(sa, C.c_void_p), len(prev), ptr(avg), B, D, H, W,
+                                                stream_of(lg)), "mvs_softmax_regress_confavg_fwd")
+    return depth, conf, pv, avg
 
 
 # ---- section 8f #1: stage-1 transformer regulariser ----------------------------------------------

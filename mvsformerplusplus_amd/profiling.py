@@ -66,6 +66,20 @@ def match_kernel(label: str, table: dict):
     return max(cands, key=lambda k: table[k].get("launches_sampled", 0))
 
 
+def kernel_group(label: str) -> str:
+    """The __global__ function a launch label belongs to, all template instantiations together: bench.py ranks kernels by THIS (round 5) -
+    "conv3d_mfma<16,16,k3,s111>" and "conv3d_mfma<8,1,k3,s111> prob head" -> "conv3d_mfma_bf16x3_kernel" (the tile form and the Cin = 8
+    persistent form of the same implicit-GEMM convolution), "gl_entropy_kernel<0, 2, 2, ...>" -> "gl_entropy_kernel"."""
+    base = label.split(" ")[0].split("+")[0].split("<")[0]
+    if base == "conv3d_mfma":
+        return "conv3d_mfma_bf16x3_kernel"
+    if base == "deconv3d_mfma":
+        return "deconv3d_mfma_bf16x3_kernel"
+    if base == "softmax_regress_kernel":
+        return "prob_regress_kernel"
+    return base if base.endswith("_kernel") else base + "_kernel"
+
+
 def mfma_terms(label: str, prec: str) -> int:
     """MFMA products a kernel issues per algorithmic product: 3 (split bf16), 2 (fp16 hi + lo weights), 1 (one fp16 weight term).  "f16mix"
     (csrc/conv_kernels.hip mfma_form): one term where min(Cin, Cout) >= 32 or max >= 64 and in the visibility CNN, two elsewhere."""
@@ -99,15 +113,16 @@ class Launch:
 
 def gather_kernel_name(which: str, code: int, C: int, D: int, W: int, tiled: bool = False, keep=None, w16=False) -> str:
     """Symbol rocprofv3 reports for the gather pass of a stage (template args: feature dtype, C / 8, work-items per pixel,
-    octet-tiled layout; the entropy pass also: does it keep the per-view correlations; fp16 window)."""
+    octet-tiled layout; the entropy pass also: does it keep the per-view correlations; fp16 window - a keeping pass with fp32 windows
+    is the exact form, MVS_CORR_F32)."""
     import os
-    w16 = bool(w16 or keep) and not os.environ.get("MVS_GATHER_WINDOW", "").startswith("f3")
+    w16 = bool(w16) and (bool(keep) or not os.environ.get("MVS_GATHER_WINDOW", "").startswith("f3"))
     b = lambda v: "true" if v else "false"
     if C in (8, 16, 32, 64) and W % 8 == 0:
         nch = (D + 3) // 4
         ns = 8 if nch >= 8 else 4 if nch >= 4 else 2 if nch >= 2 else 1
         if which == "entropy":
-            return "gl_entropy_kernel<%d, %d, %d, %s, %s, %s>" % (code, C // 8, ns, b(tiled), b(keep), b(w16 or keep))
+            return "gl_entropy_kernel<%d, %d, %d, %s, %s, %s>" % (code, C // 8, ns, b(tiled), b(keep), b(w16))
         return "gl_%s_kernel<%d, %d, %d, %s, %s>" % (which, code, C // 8, ns, b(tiled), b(w16))
     return "warp_corr_%s_kernel" % which
 
@@ -202,7 +217,14 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
     n = len(head.ndepths)
     out = None
     confs = []
+    final_conf = None
     pe_range = None
+    # round 5: ONE prologue launch (every stage's homographies + stage 1's hypotheses), exactly as CascadeDepthHead.forward issues it
+    H0, W0 = features["stage1"].shape[-2:]
+    B0 = depth_values.shape[0]
+    homs, hyp0 = _timed(launches, "cascade_prologue", 0, 0, 4.0 * B0 * head.ndepths[0] * H0 * W0,
+                        lambda: ops.cascade_prologue([proj_matrices["stage%d" % (i + 1)] for i in range(n)], depth_values, head.ndepths[0], H0, W0,
+                                                     inverse=head.inverse_depth))
     for s in range(n):
         key = "stage%d" % (s + 1)
         net = head.fusions[s]
@@ -214,25 +236,27 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         HW = H * W
         esz = feats.element_size()
         if s == 0:
-            hyp = _timed(launches, "init_range", s, 0, 4.0 * B * D * HW,
-                         lambda: ops.init_range(depth_values, D, H, W, inverse=head.inverse_depth))
+            hyp = hyp0
         else:
             pd, ph = out["depth"], out["depth_values"]
             hyp = _timed(launches, "schedule_range", s, 0, 4.0 * (B * D * HW + 3 * B * HW / 4),
                          lambda: ops.schedule_inverse_range(pd, ph, D, head.depth_interals_ratio[s], H, W))
-        hom = _timed(launches, "compose_homography", s, 0, 0, lambda: ops.compose_homography(proj))
+        hom = homs[s]
+        last = s == n - 1                                   # the last stage's head also writes the cascade's averaged confidence (a16 fused)
+        cprev = list(confs) if last else None
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
         # every feature map once, the hypotheses once, the entropy maps out
         tiled = isinstance(feats, ops.PackedFeatures)
         keep = net._keeps_correlations(feats, 8, hyp)                                   # exactly StageNet.forward's choice
-        corr_bytes = B * (V - 1) * D * HW * 16.0                                        # fp16 per-view group correlations (as-built traffic)
+        w16 = net.gather_precision == "f16"                                             # fp16 source windows (+ fp16 kept correlations)
+        corr_bytes = B * (V - 1) * D * HW * (16.0 if w16 else 32.0)                     # per-view group correlations, fp16 / fp32 (as-built traffic)
         if keep:
-            ent, corr = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, True), s, corr_flops,
+            ent, corr = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, True, w16), s, corr_flops,
                                B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4) + corr_bytes,
-                               lambda: ops.warp_corr_entropy_keep(feats, code, hom, hyp, 8))
+                               lambda: ops.warp_corr_entropy_keep(feats, code, hom, hyp, 8, exact=not w16))
         else:
-            ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, False, net._f16_activations()), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
-                         lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8, f16_window=net._f16_activations()))
+            ent = _timed(launches, gather_kernel_name("entropy", code, C, D, W, tiled, False, w16), s, corr_flops, B * (V * C * HW * esz + D * HW * 4 + (V - 1) * HW * 4),
+                         lambda: ops.warp_corr_entropy(feats, code, hom, hyp, 8, f16_window=w16))
         vp = net._vis_params(feats.device)
         prec = _lib.PRECISIONS[net._vis_precision()]
         N = B * (V - 1)
@@ -273,28 +297,34 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                 pos, pe_range = _timed(launches, "[bundle] pos3d", s, 0, 4.0 * 4 * B * D * HW,
                                        lambda: ops.position3d(proj[:, 0, 1, :3, :3], hyp, depth_values, pr))
             logits = _transformer_layers(net.cost_reg, vol, pos, s, launches)
-            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW),
-                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
+            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW + (HW if last else 0)),
+                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, conf_prev=cprev))
             out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
             confs.append(r3[1])
+            if last:
+                final_conf = r3[3]
             continue
         ks = net.cost_reg.prob_ksize
         if ks == 1 and net.conv_precision in _lib.F16_FORMATS + ("bf16x3",) and net.fuse_prob_head:
             logits = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, fused_head=True, split=split)
-            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW),
-                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
+            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW + (HW if last else 0)),
+                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, conf_prev=cprev))
             out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
             confs.append(r3[1])
+            if last:
+                final_conf = r3[3]
             continue
         feat_cl = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, split=split)
         ws, bs, prob_w, prob_b = net.cost_reg.packed_all(feats.device, net.conv_precision)
         if ks == 3 and net.conv_precision in _lib.F16_FORMATS + ("bf16x3",):
             logits = _timed(launches, "conv3d_mfma<8,1,k3,s111> prob head", s, 2.0 * B * D * HW * 8 * 27, B * (float(feat_cl.element_size()) * 8 * D * HW + 4.0 * D * HW),
                             lambda: ops.conv3d_logits(feat_cl, prob_w, prob_b, _lib.PREC_BF16X3_SPLIT if split else _lib.PRECISIONS[net.conv_precision]))
-            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW),
-                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes))
+            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW + (HW if last else 0)),
+                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, conf_prev=cprev))
             out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
             confs.append(r3[1])
+            if last:
+                final_conf = r3[3]
             continue
         res = _timed(launches, "prob_regress_kernel<%d,%d>" % (D, ks), s, 2.0 * B * D * HW * 8 * (27 if ks == 3 else 1),
                      4.0 * B * (8 * D * HW + D * HW + 2 * D * HW + 2 * HW),
@@ -302,7 +332,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         out = {"depth": res[0], "photometric_confidence": res[1], "depth_values": hyp}
         confs.append(res[1])
     Hf, Wf = features["stage%d" % n].shape[-2:]
-    final_conf = _timed(launches, "confidence_average", n - 1, 0, 4.0 * Hf * Wf * 2, lambda: ops.confidence_average(confs, Hf, Wf))
+    if final_conf is None:                                  # fp32-exact route: no fused form
+        final_conf = _timed(launches, "confidence_average", n - 1, 0, 4.0 * Hf * Wf * 2, lambda: ops.confidence_average(confs, Hf, Wf))
     torch.cuda.synchronize()
     for l in launches:
         l.ms = l.start.elapsed_time(l.end)

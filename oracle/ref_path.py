@@ -350,6 +350,21 @@ def pure_transformer_cost_reg(x: torch.Tensor, position3d, sd: SD, *, num_heads:
 
 
 # --------------------------------------------------------------------------------------
+# SURVEY section 8f #4 (producer side of the feature hand-off): the feature side's last 3x3 convolutions
+# --------------------------------------------------------------------------------------
+def feature_head(x: torch.Tensor, weight: torch.Tensor, bias=None, bn=None, swish: bool = False) -> torch.Tensor:
+    """FMT_with_pathway.smooth_k (models/FMT.py:195-197: Conv2d(C, C, 3, padding=1, bias=False), applied per view at :231-233) and
+    FPNDecoder.out_k (models/module.py:247-256: Conv2d(64, C, 3, padding=1) -> BatchNorm2d -> Swish, applied at :262-268).
+    x [N,Cin,H,W] fp32; bn = dict(weight, bias, running_mean, running_var, eps) of the eval-mode BatchNorm2d or None."""
+    y = F.conv2d(x, weight, bias, padding=1)
+    if bn is not None:
+        y = F.batch_norm(y, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, float(bn["eps"]))
+    if swish:
+        y = y * torch.sigmoid(y)                                                    # module.py Swish
+    return y
+
+
+# --------------------------------------------------------------------------------------
 # StageNet.forward                                               cost_volume.py:51-133
 # --------------------------------------------------------------------------------------
 def stage_forward(features: torch.Tensor, proj_matrices: torch.Tensor, depth_values: torch.Tensor, tmp: float,

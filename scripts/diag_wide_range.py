@@ -16,7 +16,10 @@ inputs.update(depth_min=0.5, depth_interval=9.5 / (nd - 1))
 H, W, V = c["small"][0], c["small"][1], c["V"]
 dev = "cuda"
 ref = None
-for prec, keep in (("bf16x3", "auto"), ("stagemix", "auto"), ("f16x2", False), ("f16x2", "auto"), ("f16mix", False), ("f16mix", "auto"), ("f16", "auto")):
+MODES = (("bf16x3", "auto"), ("stagemix", "auto"), ("stagemix", False), ("f16mix", "auto"))
+if len(sys.argv) > 2 and sys.argv[2] == "all":
+    MODES += (("f16x2", False), ("f16x2", "auto"), ("f16mix", False), ("f16", "auto"))
+for prec, keep in MODES:
     head, args = P._seeded_head(dev, conv_precision=prec)
     for st in head.fusions:
         st.keep_correlations = keep

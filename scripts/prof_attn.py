@@ -51,7 +51,8 @@ for v in sorted(names):
     print("attn16 variant %d  %-30s %.3f ms   err %.2e" % (v, names[v], t, err))
 abl = {18: "no exponentials", 20: "no staging after block 0", 52: "no staging, no barrier", 24: "no p.v / row-sum MFMA", 32: "no score MFMA",
        40: "no MFMA at all", 80: "row sums by VALU adds (correct results)"}
-print("ablations of variant 2 (QT=2 KB=128); results are wrong by construction, time only:")
+print("ablations of variant 2 (QT=2 KB=128); results are wrong by construction, time only - they exist only in a library built with\n"
+      "-DMVS_ATTN_ABLATIONS (build.build(extra_flags=['-DMVS_ATTN_ABLATIONS'], out=...) + MVS_HIP_LIB); the shipped library runs the default for these numbers:")
 for v, name in abl.items():
     os.environ["MVS_ATTN_VARIANT"] = str(v)
     t, _ = timeit(_lib.PREC_ATTN16)

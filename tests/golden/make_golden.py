@@ -589,6 +589,53 @@ def f11_formats():
             depth_read_by_reference=np.ascontiguousarray(read_pfm(os.path.join(t, "a.pfm"))[0]), K_read_by_reference=K, E_read_by_reference=E)
 
 
+@torch.no_grad()
+def f20_feature_heads():
+    """SURVEY.md section 8f #4, producer side: the LAST 3x3 convolutions of the reference's feature side, inputs and outputs captured with
+    forward hooks while the reference's own modules run - FMT_with_pathway.smooth_1/2/3 (FMT.py:195-197, called per view at FMT.py:231-233)
+    inside a full FMT_with_pathway.forward on the shipped FMT_config, and FPNDecoder.out1/2/3 (module.py:247-270) inside FPNDecoder.forward."""
+    from models.FMT import FMT_with_pathway
+    from models.module import FPNDecoder
+    cfg = json.load(open(os.path.join(REF, "config", "mvsformer++.json")))["arch"]["args"]
+    g = torch.Generator().manual_seed(20)
+    arrs = {}
+    # ---- FMT pathway: stages 2-4 of the shipped model ----
+    fmt = FMT_with_pathway(**cfg["FMT_config"]).eval()
+    seed_weights(fmt, 41)
+    B, V = 1, 3
+    feats = {"stage1": torch.randn(B, V, 64, 3, 9, generator=g), "stage2": torch.randn(B, V, 32, 5, 18, generator=g),
+             "stage3": torch.randn(B, V, 16, 10, 36, generator=g), "stage4": torch.randn(B, V, 8, 20, 72, generator=g)}     # 72 > one 64-wide tile, ragged
+    cap = {1: [], 2: [], 3: []}
+    hooks = [getattr(fmt, "smooth_%d" % k).register_forward_hook(lambda m, i, o, k=k: cap[k].append((i[0].clone(), o.clone()))) for k in (1, 2, 3)]
+    out = fmt(feats)
+    for h in hooks:
+        h.remove()
+    for k in (1, 2, 3):
+        assert len(cap[k]) == V
+        arrs["fmt%d_x" % k] = torch.stack([c[0] for c in cap[k]], 1)            # [B, V, C, H, W]: the conv's input, view by view
+        arrs["fmt%d_y" % k] = torch.stack([c[1] for c in cap[k]], 1)
+        arrs["fmt%d_w" % k] = getattr(fmt, "smooth_%d" % k).weight
+        assert torch.equal(arrs["fmt%d_y" % k], out["stage%d" % (k + 1)]), "smooth_k's outputs ARE the stage features the cost volume reads"
+    # ---- FPN decoder heads ----
+    dec = FPNDecoder(cfg["feat_chs"]).eval()
+    seed_weights(dec, 42)
+    ins = [torch.randn(1, 8, 24, 72, generator=g), torch.randn(1, 16, 12, 36, generator=g), torch.randn(1, 32, 6, 18, generator=g),
+           torch.randn(1, 64, 3, 9, generator=g)]
+    capd = {}
+    hooks = [getattr(dec, "out%d" % k).register_forward_hook(lambda m, i, o, k=k: capd.__setitem__(k, (i[0].clone(), o.clone()))) for k in (1, 2, 3)]
+    dec(*ins)
+    for h in hooks:
+        h.remove()
+    for k in (1, 2, 3):
+        seq = getattr(dec, "out%d" % k)
+        arrs["fpn%d_x" % k], arrs["fpn%d_y" % k] = capd[k]
+        arrs["fpn%d_w" % k], arrs["fpn%d_b" % k] = seq[0].weight, seq[0].bias
+        for name in ("weight", "bias", "running_mean", "running_var"):
+            arrs["fpn%d_bn_%s" % (k, name)] = getattr(seq[1], name)
+        arrs["fpn%d_bn_eps" % k] = np.float64(seq[1].eps)
+    npz("f20_feature_heads.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -614,4 +661,5 @@ if __name__ == "__main__":
     f17_range_variants()
     f18_costregnet2d()
     f19_position_encoding()
+    f20_feature_heads()
     pin_weights()

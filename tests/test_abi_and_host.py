@@ -19,25 +19,22 @@ def header_symbols():
 
 
 def test_product_default_precision():
-    """The product default is ONE constant: "f16mix" (fp16 activations, the second weight term only on the 8 / 16-channel layers) for
-    stages, standalone regularisers and layer wrappers; the test session does not override it; an explicit conv_precision puts every stage
-    on that format.  args["conv_precision"] may also be the POLICY "stagemix": the coarse stages (ndepth > model_th, whose depth schedules
-    the next stage's hypotheses) on the fp32-equivalent "bf16x3" regulariser, the CostRegNet3D stages on "f16mix", the fp16 gather forms on
-    every stage.  Assigning conv_precision later re-resolves the stage."""
+    """The product default of a STAGE is the policy "stagemix" (round 5): the coarse stages (ndepth > model_th, whose depth schedules the
+    next stage's hypotheses) fp32-equivalent - "bf16x3" regulariser + visibility CNN, exact gather ("f32") -, the CostRegNet3D stages
+    "f16mix" with the fp16 gather forms.  A bare regulariser / layer wrapper defaults to "f16mix".  The test session does not override
+    either; an explicit conv_precision puts every stage on that format; assigning conv_precision later re-resolves the stage."""
     import conftest
     from mvsformerplusplus_amd import cost_volume, module
     from mvsformerplusplus_amd.cost_volume import StageNet
-    assert conftest.PRODUCT_DEFAULT_PRECISION == cost_volume.STAGE_DEFAULT_PRECISION == module.DEFAULT_STAGE_POLICY == module.DEFAULT_PRECISION == "f16mix"
-    assert module.CostRegNet3D(8, 8).conv_precision == "f16mix"
+    assert conftest.PRODUCT_DEFAULT_PRECISION == cost_volume.STAGE_DEFAULT_PRECISION == module.DEFAULT_STAGE_POLICY == "stagemix"
+    assert module.DEFAULT_PRECISION == "f16mix" and module.CostRegNet3D(8, 8).conv_precision == "f16mix"
     args = {"base_ch": 8, "depth_type": "ce"}
-    for nd, si in ((32, 0), (4, 3)):
-        n = StageNet(dict(args), nd, si)
-        assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("f16mix", "f16mix", "f16") and n._f16_activations()
-    for nd, si, want in ((32, 0, "bf16x3"), (16, 1, "bf16x3"), (8, 2, "f16mix"), (4, 3, "f16mix")):
-        n = StageNet(dict(args, conv_precision="stagemix"), nd, si)
-        assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("stagemix", want, "f16"), (nd, n.conv_precision)
-        assert n._f16_activations() == (want == "f16mix") and n._split_activations() == (want == "bf16x3")
-    assert StageNet(dict(args, model_th=16, conv_precision="stagemix"), 16, 1).conv_precision == "f16mix"      # model_th moves the CostRegNet3D boundary
+    for explicit in (False, True):
+        for nd, si, want, gat in ((32, 0, "bf16x3", "f32"), (16, 1, "bf16x3", "f32"), (8, 2, "f16mix", "f16"), (4, 3, "f16mix", "f16")):
+            n = StageNet(dict(args, conv_precision="stagemix") if explicit else dict(args), nd, si)
+            assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("stagemix", want, gat), (nd, n.conv_precision)
+            assert n._f16_activations() == (want == "f16mix") and n._split_activations() == (want == "bf16x3")
+    assert StageNet(dict(args, model_th=16), 16, 1).conv_precision == "f16mix"      # model_th moves the CostRegNet3D boundary
     for fmt in ("f16mix", "f16", "f16x2"):
         for nd in (32, 4):
             n = StageNet(dict(args, conv_precision=fmt), nd, 3)
@@ -57,7 +54,7 @@ def test_library_exports_every_declared_symbol():
     from mvsformerplusplus_amd import build
     path = build.build()                       # hipcc cross-compiles gfx950 without a GPU
     lib = _lib.bind(path)                      # getattr() on every symbol; raises if one is missing
-    assert lib.mvs_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.mvs_abi_version() == _lib.ABI_VERSION == 11
     for name in header_symbols():
         assert hasattr(lib, name)
 

@@ -4,7 +4,7 @@ numbers that count are produced by tests/test_gpu_parity.py on the MI355X."""
 import pytest
 
 import parity_cases as P
-from conftest import PRECS, PRECS_ALL          # [None = the product default ("f16mix"), "bf16x3" = the fp32-equivalent mode]
+from conftest import PRECS, PRECS_ALL          # [None = the product default (the "stagemix" policy), "bf16x3" = the fp32-equivalent mode]
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -92,6 +92,14 @@ def test_stage_lowp_features(emu, prec):
 
 def test_small_fns(emu):
     P.case_small_fns(emu)
+
+
+def test_feature_heads(emu):
+    P.case_feature_heads(emu)
+
+
+def test_fused_small_launches(emu):
+    P.case_fused_small_launches(emu)
 
 
 def test_range_variants(emu):

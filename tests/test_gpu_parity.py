@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import parity_cases as P
-from conftest import PRECS, PRECS_ALL, rel_l1      # PRECS = [None (the product default, "f16x2"), "bf16x3" (the fp32-equivalent mode)]
+from conftest import PRECS, PRECS_ALL, rel_l1      # PRECS = [None (the product default: the "stagemix" policy), "bf16x3" (the fp32-equivalent mode)]
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -104,6 +104,14 @@ def test_stage_lowp_features(prec):
 
 def test_small_fns():
     P.case_small_fns(DEV)
+
+
+def test_feature_heads():
+    P.case_feature_heads(DEV)
+
+
+def test_fused_small_launches():
+    P.case_fused_small_launches(DEV)
 
 
 def test_range_variants():

@@ -95,6 +95,21 @@ def test_f19_position_encoding():
         assert (O.position_encoding_3d(fx["position3d"], C, rescale) - fx["pe_c%d" % C]).abs().max() <= 1e-6
 
 
+def test_f20_feature_heads():
+    """the oracle's restatement of the feature side's last 3x3 convolutions against what the reference's own
+    FMT_with_pathway / FPNDecoder modules produced (forward hooks, tests/golden/make_golden.py:f20_feature_heads)."""
+    fx = load_golden("f20_feature_heads.npz")
+    for k in (1, 2, 3):
+        x, y = fx["fmt%d_x" % k], fx["fmt%d_y" % k]
+        B, V = x.shape[:2]
+        got = O.feature_head(x.flatten(0, 1), fx["fmt%d_w" % k]).view_as(y)
+        assert (got - y).abs().max() <= 1e-5 * max(1.0, float(y.abs().max()))
+        bn = {n: fx["fpn%d_bn_%s" % (k, n)] for n in ("weight", "bias", "running_mean", "running_var")}
+        bn["eps"] = fx["fpn%d_bn_eps" % k]
+        got = O.feature_head(fx["fpn%d_x" % k], fx["fpn%d_w" % k], fx["fpn%d_b" % k], bn, swish=True)
+        assert (got - fx["fpn%d_y" % k]).abs().max() <= 1e-5 * max(1.0, float(fx["fpn%d_y" % k].abs().max()))
+
+
 def test_f4_cascade():
     fx = load_golden("f4_cascade.npz")
     feats = {"stage%d" % s: fx["features%d" % s] for s in range(1, 5)}
