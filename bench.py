@@ -206,6 +206,8 @@ def main():
                          "per second of the whole group, scaling 'strong'.  For a first RCCL contact without the data-parallel headline in front of it")
     ap.add_argument("--conv-precision", choices=["stagemix", "bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
                     help="contraction / activation format of the 3-D regularisers (default: the package default, cost_volume.STAGE_DEFAULT_PRECISION)")
+    ap.add_argument("--keep-exact-min-depth", type=int, default=None,
+                    help="A/B: cost_volume.KEEP_EXACT_MIN_DEPTH (planes from which the exact coarse-stage gather keeps fp32 correlations instead of gathering twice)")
     ap.add_argument("--no-keep-correlations", action="store_true",
                     help="A/B: pass 2 of every stage gathers again instead of streaming the fp16 correlations kept by pass 1 (StageNet.keep_correlations)")
     ap.add_argument("--cost-reg", choices=["normal", "shipped"], default="normal",
@@ -235,6 +237,9 @@ def main():
             dist.init_process_group(backend)
 
     from mvsformerplusplus_amd import profiling, synth
+    if a.keep_exact_min_depth is not None:
+        from mvsformerplusplus_amd import cost_volume as _cvm
+        _cvm.KEEP_EXACT_MIN_DEPTH = a.keep_exact_min_depth
     head = build_head(device, shipped=a.cost_reg == "shipped", conv_precision=a.conv_precision)
     if a.no_keep_correlations:
         for st in head.fusions:

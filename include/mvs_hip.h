@@ -335,6 +335,13 @@ int mvs_prob_regress_fwd(const float* feat_cl, const float* prob_w, const float*
 /* same head on precomputed logits [B,D,H,W] (depth_regression / conf_regression callers) */
 int mvs_softmax_regress_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth,
                             float* conf, float* prob_volume, int B, int D, int H, int W, void* stream);
+/* Round 5: a stage's head fused with the NEXT stage's inverse-depth schedule (mvs_softmax_regress_fwd + mvs_schedule_inverse_range_fwd with
+ * shift = 0 in one launch; DINOv2_mvsformer_model.py:133-148 + cost_volume.py:105-131): besides depth / conf / prob_volume it writes
+ * next_hyp [B,next_D,2H,2W] from this stage's depth and hypotheses (module.py:707-724, `ratio` = the next stage's depth_interals_ratio).
+ * depth / conf / prob_volume are bit-identical to mvs_softmax_regress_fwd's, next_hyp to the stand-alone schedule's.                  */
+int mvs_softmax_regress_schedule_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth, float* conf,
+                                     float* prob_volume, float ratio, float* next_hyp, int next_D, int B, int D, int H, int W,
+                                     void* stream);
 /* Round 5: the LAST cascade stage's head with a16 fused (DINOv2_mvsformer_model.py:167-177): besides depth / conf / prob_volume it writes
  * conf_avg [B,H,W] = (sum_i nearest-upsampled prev_conf[i] + conf) / (n_prev + 1); prev_conf[i] is [B, H >> shift[i], W >> shift[i]]
  * (host arrays of n_prev <= 7 device pointers / shifts, earliest stage first: the summation order of mvs_confidence_average).    */

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mvs_regnet_logits_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "mvs_prob_regress_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_softmax_regress_fwd": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvs_softmax_regress_schedule_fwd": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvs_softmax_regress_confavg_fwd": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "mvs_depth_regression_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvs_conf_regression_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),

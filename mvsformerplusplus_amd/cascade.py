@@ -60,7 +60,8 @@ class CascadeDepthHead(nn.Module):
         confs: List[torch.Tensor] = []
         pe_range = None                                  # stage 1 measures the frustum's x / y range, later stages reuse it
         # Round 5: the prologue in ONE launch - every stage's homographies (a1, warping.py:80) and stage 1's hypotheses (a13) - and the
-        # confidence average (a16) in the last stage's head: 13 -> 8 head / range launches per reference view.  Inference with [B,N] depth
+        # confidence average (a16) in the last stage's head, each stage's head also scheduling the next stage's hypotheses (a14): 13 -> 5 head /
+        # range launches per reference view (prologue + four heads).  Inference with [B,N] depth
         # values and one (B, V) on every stage; anything else (training, per-pixel initial ranges) takes the stage-by-stage calls.
         fuse = (not any(f._wants_autograd(features["stage%d" % (i + 1)]) for i, f in enumerate(self.fusions)) and depth_values.dim() == 2
                 and len({tuple(proj_matrices["stage%d" % (s + 1)].shape) for s in range(n)}) == 1)
@@ -76,6 +77,8 @@ class CascadeDepthHead(nn.Module):
             H, W = feat.shape[-2:]
             if s == 0:
                 hyp = hyp0 if hyp0 is not None else ops.init_range(depth_values, self.ndepths[s], H, W, inverse=self.inverse_depth)
+            elif fused is not None and "next_hyp" in fused:
+                hyp = fused["next_hyp"]                      # written by the previous stage's head (a14 fused)
             elif self.inverse_depth:
                 hyp = ops.schedule_inverse_range(stage_out["depth"], stage_out["depth_values"], self.ndepths[s],
                                                  self.depth_interals_ratio[s], H, W)
@@ -88,6 +91,8 @@ class CascadeDepthHead(nn.Module):
                 fused = {"homography": homs[s]}
                 if s == n - 1 and self.fusions[s].view_group is None and all(self._is_pow2_of(c, H, W) for c in confs):
                     fused["conf_prev"] = list(confs)
+                elif s < n - 1 and self.inverse_depth and tuple(features["stage%d" % (s + 2)].shape[-2:]) == (2 * H, 2 * W):
+                    fused["next"] = (self.ndepths[s + 1], self.depth_interals_ratio[s + 1])
                 stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s], position3d=position3d, _fused=fused)
             else:
                 stage_out = self.fusions[s](feat, proj, hyp, tmp=tmp[s], position3d=position3d)

@@ -200,7 +200,9 @@ class StageNet(nn.Module):
         """The reference's signature (cost_volume.py:51).  `_fused` is CascadeDepthHead's private side channel (round 5, fewer launches):
         "homography" = this stage's [B,V-1,12] homographies from the cascade's one-launch prologue (otherwise composed here);
         "conf_prev" = the earlier stages' confidence maps - the head then also writes the cascade's averaged confidence into
-        _fused["conf_avg"] (a16 fused into the last stage's head).  The returned dict is the reference's five keys either way."""
+        _fused["conf_avg"] (a16 fused into the last stage's head); "next" = (ndepth, ratio) of the NEXT stage - the head then also writes
+        that stage's inverse-depth hypotheses [B,ndepth,2H,2W] into _fused["next_hyp"] (a14 fused, module.py:707-724).  The returned dict
+        is the reference's five keys either way."""
         if self._wants_autograd(features):
             # SURVEY.md section 8f #2: autograd Functions over the library's training kernels (gather forward / backward, U-Net and
             # visibility CNN convolutions, BatchNorm, weight gradients); training.py says exactly what runs where
@@ -226,6 +228,7 @@ class StageNet(nn.Module):
         if hom is None:
             hom = ops.compose_homography(proj_matrices)
         conf_prev = _fused.get("conf_prev") if _fused and self.view_group is None else None
+        nxt = _fused.get("next") if _fused and self.view_group is None and conf_prev is None and hyp.shape[1] >= 3 else None
         vis_params = self._vis_params(feats.device)
         prec = precision_code(self._vis_precision())
         if self.view_group is not None:
@@ -256,9 +259,11 @@ class StageNet(nn.Module):
                     volume = ops.volume_to_f16(ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True)[0])
                 else:
                     volume, _ = ops.warp_corr_aggregate(feats, code, hom, hyp, vis, G, normalise=True, split=split, f16=f16)
-        out = self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split, conf_prev=conf_prev)
+        out = self._regularise_and_regress(volume, hyp, depth_values, float(tmp), position3d, split=split, conf_prev=conf_prev, nxt=nxt)
         if conf_prev is not None:
             _fused["conf_avg"] = out.pop("_conf_avg")
+        if "_next_hyp" in out:
+            _fused["next_hyp"] = out.pop("_next_hyp")
         if self._f16_activations():
             self._count_f16_call(feats.device, hyp)
         return out
@@ -295,10 +300,11 @@ class StageNet(nn.Module):
             conf_n = 4 if D >= 32 else (3 if D == 16 else (2 if D == 8 else 0))                    # cost_volume.py:121-128
         return mode, conf_n
 
-    def _regularise_and_regress(self, volume, hyp, depth_values, tmp, position3d=None, split=False, conf_prev=None) -> Dict[str, torch.Tensor]:
+    def _regularise_and_regress(self, volume, hyp, depth_values, tmp, position3d=None, split=False, conf_prev=None, nxt=None) -> Dict[str, torch.Tensor]:
         """cost_volume.py:103-131 on a normalised channel-last volume [B,D,H,W,8] (H may be a row slab of the stage); split: the
         volume is in the split activation format and the U-Net runs MVS_PREC_BF16X3_SPLIT.  conf_prev: the earlier stages' confidence
-        maps - the head also averages them with this stage's (extra key "_conf_avg", popped by forward)."""
+        maps - the head also averages them with this stage's (extra key "_conf_avg", popped by forward); nxt = (ndepth, ratio): the head
+        also schedules the next stage's hypotheses (extra key "_next_hyp")."""
         D = hyp.shape[1]
         pcode = _lib.PREC_BF16X3_SPLIT if split else precision_code(self.conv_precision)
         mfma = self.conv_precision in MFMA_FORMATS
@@ -306,8 +312,9 @@ class StageNet(nn.Module):
         conf_avg = None
 
         def head(logits):
-            r = ops.softmax_regress(logits, hyp, tmp, mode, conf_n, self.return_prob_volumes, conf_prev=conf_prev)
-            return r if conf_prev is None else (r[0], r[1], r[2], r[3])
+            if nxt is not None:
+                return ops.softmax_regress_schedule(logits, hyp, tmp, mode, conf_n, self.return_prob_volumes, int(nxt[0]), float(nxt[1]))
+            return ops.softmax_regress(logits, hyp, tmp, mode, conf_n, self.return_prob_volumes, conf_prev=conf_prev)
 
         if isinstance(self.cost_reg, PureTransformerCostReg):
             prob_volume_pre = self.cost_reg.logits_cl(volume, position3d)
@@ -342,6 +349,8 @@ class StageNet(nn.Module):
                "depth_values": depth_values, "prob_volume_pre": prob_volume_pre}
         if conf_prev is not None:
             out["_conf_avg"] = rest[0]
+        elif nxt is not None and rest:
+            out["_next_hyp"] = rest[0]
         return out
 
     # ---- source views sharded over the ranks of `view_group` ---------------------------------------

@@ -206,12 +206,24 @@ struct BfConv {
 // overlap (scripts/ubench/overlap.hip: MFMA || VALU on one SIMD takes the SUM of the two).  A work-item's runs are 256 / OPT
 // voxels apart: the walk advances (dz, dy, dx) by compile-time steps with at most one carry each and the byte offset by three
 // wave-uniform constants; out-of-volume runs are fetched through a buffer descriptor at an out-of-range offset (the hardware
-// returns zeros: no select on the data).  Offsets are 32-bit: one batch item of the input must stay below 2 GB (dispatch checks).
+// returns zeros: no select on the data).  Offsets are 32-bit, relative to the tile's first in-volume input plane (round 5,
+// bf_make_rsrc_z: the descriptor is re-based per tile, a block-uniform 64-bit add), so only the <= 12 planes a tile spans have to stay
+// below 2 GB - not the whole batch item (rounds 1-4; Track S's D = 192 at 1152 x 1536 is an 11 GB volume).
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned BF_OOB = 0x80000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// descriptor over the input from plane max(z0, 0) on; zrel = z0 relative to that plane (-1 or 0 for a tile that starts in the z halo, else 0):
+// BfTileWalk takes zrel for its offsets, inside() keeps the absolute z0.  The range is clamped below BF_OOB (valid offsets of a tile are
+// far smaller: dispatch checks 12 planes < 2 GB).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_make_rsrc_z(const char* xb, int z0, int D, int H, int W, unsigned vstride, int& zrel) {
+    const int zb = z0 > 0 ? z0 : 0;
+    const size_t plane = (size_t)H * (size_t)W * vstride;
+    const size_t rem = (size_t)(D - zb) * plane;
+    zrel = z0 - zb;
+    return bf_make_rsrc(xb + (size_t)zb * plane, rem > 0x7fffffffull ? 0x7fffffffu : (unsigned)rem);
 }
 __device__ __forceinline__ float4 bf_buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + (unsigned)imm), 0, 0));
@@ -489,9 +501,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
     // p + 1 are issued before the contraction of pass p.
     constexpr int NITEM = Cfg::NVOX * OPT, NIT = (NITEM + 255) / 256;
     float4 su[NIT], sv[NIT];
-    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
+    int zrel;
+    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc_z(xb, iz0, D, H, W, (unsigned)(CIN * EB), zrel);
     auto issue = [&](int pass) {
-        BfTileWalk<IW, IH, OPT, RUNB> wk(tid, iz0, iy0, ix0, H, W, CIN * EB, (unsigned)(pass * CH * EB));
+        BfTileWalk<IW, IH, OPT, RUNB> wk(tid, zrel, iy0, ix0, H, W, CIN * EB, (unsigned)(pass * CH * EB));
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it > 0) wk.advance();
@@ -530,7 +543,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_kernel(const float* __
         if constexpr (UNROLLED) {
             commit();
         } else {
-            BfTileWalk<IW, IH, OPT, RUNB> wk(tid, iz0, iy0, ix0, H, W, CIN * EB, (unsigned)(pass * CH * EB));
+            BfTileWalk<IW, IH, OPT, RUNB> wk(tid, zrel, iy0, ix0, H, W, CIN * EB, (unsigned)(pass * CH * EB));
             int ldso = (tid / OPT) * SB + (tid % OPT) * BfConv<Cfg>::PLANE;
 #pragma unroll 1
             for (int e = tid; e < NITEM; e += 256) {
@@ -688,13 +701,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_bf16x3_persist_kernel(const f
     constexpr int NITEM = Cfg::NVOX * OPT, NIT = (NITEM + 255) / 256;
     // MVS_PERSIST_PFD register sets: the loads of tile t + PFD are issued while tile t is contracted
     float4 su0[NIT], sv0[NIT], su1[NIT], sv1[NIT];
-    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
     auto issue = [&](int tile, float4* su, float4* sv) {
         const int tx = tile % tiles_x;
         const int t1 = tile / tiles_x;
         const int ty = t1 % tiles_y, tz = t1 / tiles_y;
         const int iz0 = tz * TD * SD - Cfg::PD, iy0 = ty * TH * SH - 1, ix0 = tx * 16 * SW - 1;
-        BfTileWalk<IW, IH, OPT, RUNB> wk(tid, iz0, iy0, ix0, H, W, CIN * EB, 0u);
+        int zrel;
+        const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc_z(xb, iz0, D, H, W, (unsigned)(CIN * EB), zrel);
+        BfTileWalk<IW, IH, OPT, RUNB> wk(tid, zrel, iy0, ix0, H, W, CIN * EB, 0u);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it > 0) wk.advance();
@@ -1009,8 +1023,9 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_kernel(const float* 
     constexpr int EB = F16 ? 2 : 4, RUNB = BfDeconv<Cfg>::RUNB;
     const char* xb = reinterpret_cast<const char*>(x) + (size_t)b * D * H * W * CIN * EB;
     {
-        const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
-        BfTileWalk<LW, LH, OPT, RUNB> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * EB, 0u);
+        int zrel;
+        const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc_z(xb, mz0 - Cfg::ZO, D, H, W, (unsigned)(CIN * EB), zrel);
+        BfTileWalk<LW, LH, OPT, RUNB> wk(tid, zrel, my0, mx0, H, W, CIN * EB, 0u);
         int ldso = (tid / OPT) * SB + (tid % OPT) * BfDeconv<Cfg>::PLANE;
         for (int e = tid; e < Cfg::NVOX * OPT; e += 256) {
             const bool ok = MVS_ABL != 1 && wk.inside(mz0 - Cfg::ZO, my0, mx0, D, H, W);
@@ -1290,13 +1305,14 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_bf16x3_persist_kernel(const
 
     constexpr int NITEM = Cfg::NVOX * OPT, NITX = (NITEM + 255) / 256;
     float4 su[NITX], sv[NITX];
-    const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc(xb, (unsigned)D * (unsigned)H * (unsigned)W * (unsigned)(CIN * EB));
     auto issue_x = [&](int tile) {
         const int tx = tile % tiles_x;
         const int t1 = tile / tiles_x;
         const int ty = t1 % tiles_y, tz = t1 / tiles_y;
         const int mz0 = tz * TDM, my0 = ty * THM, mx0 = tx * 16;
-        BfTileWalk<LW, LH, OPT, P::RUNB> wk(tid, mz0 - Cfg::ZO, my0, mx0, H, W, CIN * EB, 0u);
+        int zrel;
+        const __amdgpu_buffer_rsrc_t xrs = bf_make_rsrc_z(xb, mz0 - Cfg::ZO, D, H, W, (unsigned)(CIN * EB), zrel);
+        BfTileWalk<LW, LH, OPT, P::RUNB> wk(tid, zrel, my0, mx0, H, W, CIN * EB, 0u);
 #pragma unroll
         for (int it = 0; it < NITX; ++it) {
             if (it > 0) wk.advance();
@@ -1502,11 +1518,13 @@ static int launch_deconv_bf(const float* x, const void* wp, const float* bias, c
     return check_launch("deconv3d_mfma_bf16x3_kernel");
 }
 
-// the staging loops address one batch item of the input through 32-bit byte offsets and a buffer descriptor
+// the staging loops address the input planes of ONE TILE through 32-bit byte offsets and a buffer descriptor re-based per tile
+// (bf_make_rsrc_z): a tile spans at most (TD - 1) * SD + 3 <= 9 input planes; 12 of them must stay below 2 GB.  The volume itself may
+// be any size (round 5: rounds 1-4 required the whole batch item below 2 GB, which refused Track S's D = 192 at 1152 x 1536).
 static bool bf_input_fits(const char* who, int Cin, int D, int H, int W, int split) {
-    const long long bytes = (long long)D * H * W * Cin * (split >= 2 ? 2 : 4);
+    const long long bytes = 12LL * H * W * Cin * (split >= 2 ? 2 : 4);
     if (bytes < (1LL << 31)) return true;
-    set_error("%s: one batch item of the input is %lld bytes; the MFMA convolutions address it with 32-bit offsets (< 2 GB)", who, bytes);
+    set_error("%s: twelve z-planes of the input are %lld bytes; the MFMA convolutions address a tile's planes with 32-bit offsets (< 2 GB)", who, bytes);
     return false;
 }
 

@@ -14,6 +14,60 @@
 
 namespace mvs {
 
+// softmax over depth + depth regression / argmax / plain regression + confidence of ONE pixel (cost_volume.py:105-128, module.py:649-671).
+// l: the D logits in registers (DC > 0) or, DC == 0, read from lg[d * HW]; hp / pv: this pixel's hypothesis / probability columns
+// (stride HW; pv may be null).  Shared by prob_regress_kernel and the schedule-fused head (round 5) so that both give the same bits.
+template <int DC>
+__device__ __forceinline__ void head_from_logits(const float* l, const float* lg, const float* hp, size_t HW, int D, float tmp, int mode, int conf_n,
+                                                 float* pv, float& depth, float& conf) {
+#define HL(d) (DC > 0 ? l[(DC > 0 ? (d) : 0)] : lg[(size_t)(d) * HW])
+    // ---- softmax over depth (cost_volume.py:106) ----
+    float m = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < D; ++d) m = fmaxf(m, HL(d));
+    float den = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) den += expf(HL(d) - m);
+
+    depth = 0.0f;
+    conf = 0.0f;
+    if (mode == MVS_HEAD_CE_EVAL) {
+        // depth_regression(softmax(pre * tmp), depth_values)  cost_volume.py:115
+        float m2 = -INFINITY;
+#pragma unroll
+        for (int d = 0; d < D; ++d) m2 = fmaxf(m2, HL(d) * tmp);
+        float den2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) den2 += expf(HL(d) * tmp - m2);
+#pragma unroll
+        for (int d = 0; d < D; ++d) depth += (expf(HL(d) * tmp - m2) / den2) * hp[(size_t)d * HW];
+    }
+    float best = -1.0f, idxf = 0.0f;
+    int best_i = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float pr = expf(HL(d) - m) / den;
+        if (pv) pv[(size_t)d * HW] = pr;
+        if (pr > best) { best = pr; best_i = d; }                 // first maximum, like torch.max
+        if (mode == MVS_HEAD_REG) { depth += pr * hp[(size_t)d * HW]; idxf += pr * (float)d; }
+    }
+    conf = best;                                                  // prob_volume.max(1)[0]  cost_volume.py:117
+    if (mode == MVS_HEAD_CE_TRAIN) depth = hp[(size_t)best_i * HW];   // cost_volume.py:109-112
+    if (mode == MVS_HEAD_REG && conf_n > 0) {
+        // conf_regression module.py:658-671: window sum of n probabilities around floor(sum p*idx)
+        int idx = (int)idxf;
+        idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
+        const int lo = (conf_n & 1) ? idx - conf_n / 2 : idx - (conf_n / 2 - 1);
+        const int hi = idx + conf_n / 2;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d >= lo && d <= hi) s += expf(HL(d) - m) / den;
+        conf = s;
+    }
+#undef HL
+}
+
 // a16: mean over stages of nearest-upsampled confidences (DINOv2_mvsformer_model.py:167-177).  As a stand-alone kernel
 // (confidence_average_kernel) and - round 5 - as the epilogue of the LAST stage's head (prob_regress_kernel: cavg.n = number of
 // EARLIER stages, this stage's own confidence is the value the work-item just computed; one launch and one HW read less).
@@ -119,49 +173,8 @@ __global__ __launch_bounds__(256) void prob_regress_kernel(const float* __restri
     }
     }
 
-    // ---- softmax over depth (cost_volume.py:106) ----
-    float m = -INFINITY;
-#pragma unroll
-    for (int d = 0; d < D; ++d) m = fmaxf(m, MVS_LOGIT(d));
-    float den = 0.0f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) den += expf(MVS_LOGIT(d) - m);
-
-    float depth = 0.0f, conf = 0.0f;
-    if (mode == MVS_HEAD_CE_EVAL) {
-        // depth_regression(softmax(pre * tmp), depth_values)  cost_volume.py:115
-        float m2 = -INFINITY;
-#pragma unroll
-        for (int d = 0; d < D; ++d) m2 = fmaxf(m2, MVS_LOGIT(d) * tmp);
-        float den2 = 0.0f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) den2 += expf(MVS_LOGIT(d) * tmp - m2);
-#pragma unroll
-        for (int d = 0; d < D; ++d) depth += (expf(MVS_LOGIT(d) * tmp - m2) / den2) * hp[(size_t)d * HW];
-    }
-    float best = -1.0f, idxf = 0.0f;
-    int best_i = 0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float pr = expf(MVS_LOGIT(d) - m) / den;
-        if (prob_vol) prob_vol[((size_t)b * D + d) * HW + p] = pr;
-        if (pr > best) { best = pr; best_i = d; }                 // first maximum, like torch.max
-        if (mode == MVS_HEAD_REG) { depth += pr * hp[(size_t)d * HW]; idxf += pr * (float)d; }
-    }
-    conf = best;                                                  // prob_volume.max(1)[0]  cost_volume.py:117
-    if (mode == MVS_HEAD_CE_TRAIN) depth = hp[(size_t)best_i * HW];   // cost_volume.py:109-112
-    if (mode == MVS_HEAD_REG && conf_n > 0) {
-        // conf_regression module.py:658-671: window sum of n probabilities around floor(sum p*idx)
-        int idx = (int)idxf;
-        idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
-        const int lo = (conf_n & 1) ? idx - conf_n / 2 : idx - (conf_n / 2 - 1);
-        const int hi = idx + conf_n / 2;
-        float s = 0.0f;
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d >= lo && d <= hi) s += expf(MVS_LOGIT(d) - m) / den;
-        conf = s;
-    }
+    float depth, conf;
+    head_from_logits<DC>(l, prep, hp, (size_t)HW, D, tmp, mode, conf_n, prob_vol ? prob_vol + (size_t)b * D * HW + p : nullptr, depth, conf);
     depth_out[(size_t)b * HW + p] = depth;
     conf_out[(size_t)b * HW + p] = conf;
     if (conf_avg_out != nullptr) {                                // a16 fused: (sum of the earlier stages' nearest-upsampled confidences + this one) / n
@@ -288,6 +301,83 @@ __global__ __launch_bounds__(256) void schedule_range_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 5: a stage's head FUSED with the next stage's inverse-depth schedule (a10-a12 + a14 in one launch instead of two).
+// The schedule is a 2x bilinear (align_corners=True) upsample of per-pixel (1/depth -/+ ratio * itv) followed by a linspace and a
+// reciprocal (module.py:707-724): an output pixel (Y, X) reads the source pixels floor(Y r), floor(Y r) + 1 with r = (H-1)/(2H-1) < 1/2,
+// so the 2 SH x 2 SW outputs [2 y0, 2 y0 + 2 SH) x [2 x0, 2 x0 + 2 SW) of the source tile [y0, y0 + SH) x [x0, x0 + SW) need the source rows
+// y0 - 1 .. y0 + SH and columns x0 - 1 .. x0 + SW: a one-pixel ring.  A workgroup therefore runs the head for its 8 x 32 tile (writing
+// depth / confidence / probabilities for it) AND for the ring (84 pixels, nothing written: the neighbour tiles own them and compute the
+// same bits), keeps (inv_max, inv_min - inv_max) of the 10 x 34 region in LDS, and writes the next stage's hypotheses of its 16 x 64
+// outputs - the arithmetic of schedule_range_kernel (variant 0), statement for statement.  33 % more head work (logits and hypotheses of
+// the ring come from L2) against a launch and a [B,H,W] + 2 [B,H,W] re-read less.  KS = 0 (logits given) only.
+// ------------------------------------------------------------------------------------------------
+constexpr int HS_SH = 8, HS_SW = 32, HS_RH = HS_SH + 2, HS_RW = HS_SW + 2, HS_NREG = HS_RH * HS_RW;
+
+template <int DC>
+__global__ __launch_bounds__(256) void prob_regress_sched_kernel(const float* __restrict__ logits, const float* __restrict__ hyp, float tmp, int mode,
+                                                                 int conf_n, float* __restrict__ depth_out, float* __restrict__ conf_out,
+                                                                 float* __restrict__ prob_vol, int D_, int H, int W, float ratio,
+                                                                 float* __restrict__ next_hyp, int Dn, int tiles_x) {
+    __shared__ float s_lo[HS_NREG], s_span[HS_NREG];
+    const int D = DC > 0 ? DC : D_;
+    const size_t HW = (size_t)H * W;
+    const int b = (int)blockIdx.y;
+    const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+    const int y0 = ty * HS_SH, x0 = tx * HS_SW;
+    for (int task = (int)threadIdx.x; task < HS_NREG; task += 256) {
+        const int ry = task / HS_RW, rx = task - ry * HS_RW;
+        const int y = y0 - 1 + ry, x = x0 - 1 + rx;
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;       // outside the image: never referenced (the bilinear taps are clamped)
+        const bool owner = ry >= 1 && ry <= HS_SH && rx >= 1 && rx <= HS_SW;
+        const size_t p = (size_t)y * W + x;
+        const float* lg = logits + (size_t)b * D * HW + p;
+        const float* hp = hyp + (size_t)b * D * HW + p;
+        float l[DC > 0 ? DC : 1];
+        if (DC > 0) {
+#pragma unroll
+            for (int d = 0; d < (DC > 0 ? DC : 1); ++d) l[d] = lg[(size_t)d * HW];
+        }
+        float depth, conf;
+        head_from_logits<DC>(l, lg, hp, HW, D, tmp, mode, conf_n, (owner && prob_vol) ? prob_vol + (size_t)b * D * HW + p : nullptr, depth, conf);
+        if (owner) {
+            depth_out[(size_t)b * HW + p] = depth;
+            conf_out[(size_t)b * HW + p] = conf;
+        }
+        const float h1 = hp[HW], h2 = hp[2 * HW];
+        const float last_itv = 1.0f / h2 - 1.0f / h1;                                // module.py:708
+        const float inv_min = 1.0f / depth + ratio * last_itv;
+        const float inv_max = 1.0f / depth - ratio * last_itv;
+        s_lo[task] = inv_max;
+        s_span[task] = inv_min - inv_max;
+    }
+    __syncthreads();
+    const int Hn = 2 * H, Wn = 2 * W;
+    const size_t HWn = (size_t)Hn * Wn;
+    for (int o = (int)threadIdx.x; o < 4 * HS_SH * HS_SW; o += 256) {
+        const int oy = o / (2 * HS_SW), ox = o - oy * (2 * HS_SW);
+        const int Y = 2 * y0 + oy, X = 2 * x0 + ox;
+        if (Y >= Hn || X >= Wn) continue;
+        int ya, yb, xa, xb;
+        float ly0, ly1, lx0, lx1;
+        lin_coord(Y, H, Hn, &ya, &yb, &ly0, &ly1);
+        lin_coord(X, W, Wn, &xa, &xb, &lx0, &lx1);
+        const int r0 = (ya - (y0 - 1)) * HS_RW, r1 = (yb - (y0 - 1)) * HS_RW, c0 = xa - (x0 - 1), c1 = xb - (x0 - 1);
+        const int q[4] = {r0 + c0, r0 + c1, r1 + c0, r1 + c1};
+        float lo[4], span[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo[k] = s_lo[q[k]]; span[k] = s_span[q[k]]; }
+        float* dst = next_hyp + (size_t)b * Dn * HWn + (size_t)Y * Wn + X;
+        for (int d = 0; d < Dn; ++d) {
+            float c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = lo[k] + span[k] * ((float)d / (float)(Dn - 1));
+            const float v = ly0 * (lx0 * c[0] + lx1 * c[1]) + ly1 * (lx0 * c[2] + lx1 * c[3]);
+            dst[(size_t)d * HWn] = 1.0f / v;
+        }
+    }
+}
+
 // a16: mean over stages of nearest-upsampled confidences (ConfPtrs: above)
 __global__ void confidence_average_kernel(ConfPtrs cp, float* __restrict__ out, int H, int W) {
     const int HW = H * W;
@@ -391,6 +481,33 @@ extern "C" int mvs_softmax_regress_confavg_fwd(const float* logits, const float*
             return MVS_ERR_ARG;
         }
     return launch_head<0>(logits, nullptr, nullptr, hyp, tmp, mode, conf_n, depth, conf, prob_volume, const_cast<float*>(logits), B, D, H, W, (hipStream_t)stream, cp, conf_avg);
+}
+
+extern "C" int mvs_softmax_regress_schedule_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth, float* conf,
+                                               float* prob_volume, float ratio, float* next_hyp, int next_D, int B, int D, int H, int W, void* stream) {
+    int rc = check_head("mvs_softmax_regress_schedule_fwd", logits, hyp, depth, conf, mode, B, D, H, W);
+    if (rc != MVS_OK) return rc;
+    if (!next_hyp || next_D < 2 || D < 3 || H < 2 || W < 2) { set_error("mvs_softmax_regress_schedule_fwd: bad arguments (needs D >= 3 hypotheses, module.py:708, and next_D >= 2)"); return MVS_ERR_ARG; }
+    const int tiles_x = (int)ceil_div(W, HS_SW), tiles_y = (int)ceil_div(H, HS_SH);
+    const dim3 grid(tiles_x * tiles_y, B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MVS_HS_CASE(DC)                                                                                                                   \
+    case DC:                                                                                                                              \
+        hipLaunchKernelGGL((prob_regress_sched_kernel<DC>), grid, block, 0, st, logits, hyp, tmp, mode, conf_n, depth, conf, prob_volume, D, H, W, ratio, \
+                           next_hyp, next_D, tiles_x);                                                                                    \
+        break;
+    switch (D) {
+        MVS_HS_CASE(4)
+        MVS_HS_CASE(8)
+        MVS_HS_CASE(16)
+        MVS_HS_CASE(32)
+        MVS_HS_CASE(48)
+        default:
+            hipLaunchKernelGGL((prob_regress_sched_kernel<0>), grid, block, 0, st, logits, hyp, tmp, mode, conf_n, depth, conf, prob_volume, D, H, W, ratio,
+                               next_hyp, next_D, tiles_x);
+    }
+#undef MVS_HS_CASE
+    return check_launch("prob_regress_sched_kernel");
 }
 
 extern "C" int mvs_depth_regression_fwd(const float* p, const float* depth_values, float* out, int B, int D, int H, int W, void* stream) {

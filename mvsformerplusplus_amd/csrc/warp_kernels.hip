@@ -91,15 +91,16 @@ struct ProloguePtrs {
 
 __global__ __launch_bounds__(256) void cascade_prologue_kernel(ProloguePtrs pp, int B, int V, float* __restrict__ hom, const float* __restrict__ dv,
                                                                int N, int inverse, float* __restrict__ hyp, int D, int HW, int init_blocks) {
+    // grid = (init_blocks + 1, D or 1, B or 1): blocks x < init_blocks fill plane (b, d) of the hypotheses (grid-stride over HW, no divisions);
+    // block (init_blocks, 0, 0) composes the homographies; the other x == init_blocks blocks have nothing to do
     if ((int)blockIdx.x < init_blocks) {
-        const long long total = (long long)B * D * HW;
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)init_blocks * 256) {
-            const int bd = (int)(i / HW);
-            const int b = bd / D, d = bd - b * D;
-            hyp[i] = init_range_value(dv[(size_t)b * N], dv[(size_t)b * N + N - 1], inverse, d, D);
-        }
+        const int b = (int)blockIdx.z, d = (int)blockIdx.y;
+        const float v = init_range_value(dv[(size_t)b * N], dv[(size_t)b * N + N - 1], inverse, d, D);
+        float* o = hyp + ((size_t)b * D + d) * HW;
+        for (int p = (int)blockIdx.x * 256 + (int)threadIdx.x; p < HW; p += init_blocks * 256) o[p] = v;
         return;
     }
+    if (blockIdx.y != 0 || blockIdx.z != 0) return;
     const int per = B * (V - 1);
     for (int idx = (int)threadIdx.x; idx < pp.n * per; idx += 256) {
         const int s = idx / per, r = idx - s * per;
@@ -649,11 +650,13 @@ extern "C" int mvs_cascade_prologue_fwd(const float* const* proj_host_ptrs, int 
         if (i < n_stages && !pp.proj[i]) { set_error("mvs_cascade_prologue_fwd: null projection tensor of stage %d", i); return MVS_ERR_ARG; }
     }
     int init_blocks = 0;
+    dim3 grid(1, 1, 1);
     if (hyp) {
-        const long long total = (long long)B * D * H * W;
-        init_blocks = (int)(ceil_div(total, 1024) > 1024 ? 1024 : ceil_div(total, 1024));      // ~4 elements per thread, at most 1024 blocks
+        const int HW = H * W;
+        init_blocks = (int)(ceil_div(HW, 1024) > 64 ? 64 : ceil_div(HW, 1024));      // ~4 elements per thread and plane, at most 64 blocks per plane
+        grid = dim3(init_blocks + 1, D, B);
     }
-    hipLaunchKernelGGL(cascade_prologue_kernel, dim3(init_blocks + 1), dim3(256), 0, (hipStream_t)stream, pp, B, V, homography, depth_values, N, inverse,
+    hipLaunchKernelGGL(cascade_prologue_kernel, grid, dim3(256), 0, (hipStream_t)stream, pp, B, V, homography, depth_values, N, inverse,
                        hyp, D, H * W, init_blocks);
     return check_launch("cascade_prologue_kernel");
 }

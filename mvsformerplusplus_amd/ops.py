@@ -680,6 +680,20 @@ def softmax_regress(logits: torch.Tensor, hyp: torch.Tensor, tmp: float, mode: i
     return depth, conf, pv, avg
 
 
+def softmax_regress_schedule(logits: torch.Tensor, hyp: torch.Tensor, tmp: float, mode: int, conf_n: int, want_prob: bool, next_D: int, ratio: float):
+    """Round 5: softmax_regress + schedule_inverse_range(shift=False) of the NEXT stage in one launch
+    -> (depth, conf, prob_volume or None, next_hyp [B,next_D,2H,2W])."""
+    lg, hp = _f32c(logits), _f32c(hyp)
+    B, D, H, W = lg.shape
+    depth = torch.empty(B, H, W, dtype=torch.float32, device=lg.device)
+    conf = torch.empty(B, H, W, dtype=torch.float32, device=lg.device)
+    pv = torch.empty_like(lg) if want_prob else None
+    nxt = torch.empty(B, next_D, 2 * H, 2 * W, dtype=torch.float32, device=lg.device)
+    check(lib().mvs_softmax_regress_schedule_fwd(ptr(lg), ptr(hp), float(tmp), mode, conf_n, ptr(depth), ptr(conf), ptr(pv), float(ratio), ptr(nxt), next_D,
+                                                 B, D, H, W, stream_of(lg)), "mvs_softmax_regress_schedule_fwd")
+    return depth, conf, pv, nxt
+
+
 # ---- section 8f #1: stage-1 transformer regulariser ----------------------------------------------
 def position3d(K: torch.Tensor, hyp: torch.Tensor, depth_values: torch.Tensor, pe_range: Optional[torch.Tensor] = None):
     """get_position_3d(normalize=True): K [B,3,3], hyp [B,D,H,W], depth_values [B,n] -> (position3d [B,3,D,H,W],

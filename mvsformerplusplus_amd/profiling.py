@@ -237,6 +237,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         esz = feats.element_size()
         if s == 0:
             hyp = hyp0
+        elif out.get("next_hyp") is not None:
+            hyp = out["next_hyp"]                            # scheduled by the previous stage's head (round 5)
         else:
             pd, ph = out["depth"], out["depth_values"]
             hyp = _timed(launches, "schedule_range", s, 0, 4.0 * (B * D * HW + 3 * B * HW / 4),
@@ -244,6 +246,17 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         hom = homs[s]
         last = s == n - 1                                   # the last stage's head also writes the cascade's averaged confidence (a16 fused)
         cprev = list(confs) if last else None
+        # ... and every other stage's head the next stage's hypotheses (a14 fused), exactly when CascadeDepthHead.forward asks for it
+        sched = (not last and head.inverse_depth and D >= 3 and tuple(features["stage%d" % (s + 2)].shape[-2:]) == (2 * H, 2 * W))
+        Dn = head.ndepths[s + 1] if not last else 0
+        rn = head.depth_interals_ratio[s + 1] if not last else 0.0
+
+        def run_head(lg):
+            if sched:
+                return ops.softmax_regress_schedule(lg, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, Dn, rn)
+            return ops.softmax_regress(lg, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, conf_prev=cprev)
+        head_label = "prob_regress_sched_kernel" if sched else "softmax_regress_kernel"
+        head_bytes = 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW + (HW if last else 0) + (4 * Dn * HW if sched else 0))
         corr_flops = 2.0 * (V - 1) * B * D * HW * C * 5          # 4-tap bilinear + correlation MAC per channel
         # every feature map once, the hypotheses once, the entropy maps out
         tiled = isinstance(feats, ops.PackedFeatures)
@@ -297,9 +310,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
                 pos, pe_range = _timed(launches, "[bundle] pos3d", s, 0, 4.0 * 4 * B * D * HW,
                                        lambda: ops.position3d(proj[:, 0, 1, :3, :3], hyp, depth_values, pr))
             logits = _transformer_layers(net.cost_reg, vol, pos, s, launches)
-            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW + (HW if last else 0)),
-                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, conf_prev=cprev))
-            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
+            r3 = _timed(launches, head_label, s, 0, head_bytes, lambda: run_head(logits))
+            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp, "next_hyp": r3[3] if sched else None}
             confs.append(r3[1])
             if last:
                 final_conf = r3[3]
@@ -307,9 +319,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         ks = net.cost_reg.prob_ksize
         if ks == 1 and net.conv_precision in _lib.F16_FORMATS + ("bf16x3",) and net.fuse_prob_head:
             logits = _regnet_layers(net.cost_reg, vol, s, launches, net.conv_precision, fused_head=True, split=split)
-            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW + (HW if last else 0)),
-                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, conf_prev=cprev))
-            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
+            r3 = _timed(launches, head_label, s, 0, head_bytes, lambda: run_head(logits))
+            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp, "next_hyp": r3[3] if sched else None}
             confs.append(r3[1])
             if last:
                 final_conf = r3[3]
@@ -319,9 +330,8 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
         if ks == 3 and net.conv_precision in _lib.F16_FORMATS + ("bf16x3",):
             logits = _timed(launches, "conv3d_mfma<8,1,k3,s111> prob head", s, 2.0 * B * D * HW * 8 * 27, B * (float(feat_cl.element_size()) * 8 * D * HW + 4.0 * D * HW),
                             lambda: ops.conv3d_logits(feat_cl, prob_w, prob_b, _lib.PREC_BF16X3_SPLIT if split else _lib.PRECISIONS[net.conv_precision]))
-            r3 = _timed(launches, "softmax_regress_kernel", s, 0, 4.0 * B * ((2 + int(bool(net.return_prob_volumes))) * D * HW + 2 * HW + (HW if last else 0)),
-                        lambda: ops.softmax_regress(logits, hyp, tmp[s], _lib.HEAD_CE_EVAL, 0, net.return_prob_volumes, conf_prev=cprev))
-            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp}
+            r3 = _timed(launches, head_label, s, 0, head_bytes, lambda: run_head(logits))
+            out = {"depth": r3[0], "photometric_confidence": r3[1], "depth_values": hyp, "next_hyp": r3[3] if sched else None}
             confs.append(r3[1])
             if last:
                 final_conf = r3[3]

@@ -56,7 +56,8 @@ MODES = [("fp16 default on every stage", yes, yes, yes),
          ("coarse: exact reg, fp16 kept corr only", fine, fine, yes),
          ("coarse: exact reg, fp16 windows + kept corr (stagemix)", fine, yes, yes),
          ("stage 1 exact all; stage 2 exact reg + fp16 gather", fine, lambda D: D <= 16, lambda D: D <= 16),
-         ("coarse: fp16 reg, exact gather", yes, fine, fine)]
+         ("coarse: fp16 reg, exact gather", yes, fine, fine),
+         ("coarse exact reg + gather, fp16 (one-term) vis CNN", fine, fine, fine, yes)]
 
 for name in (sys.argv[1:] or ["cfg4"]):
     c = P.BASELINE_CFGS[name]
@@ -79,8 +80,8 @@ for name in (sys.argv[1:] or ["cfg4"]):
             good = (torch.isfinite(hyp) & (hyp > lo) & (hyp < hi)).all(1) & torch.isfinite(ref["stage%d" % s]["depth"])
             ok = ok & F.interpolate(good[:, None].float(), size=(H, W), mode="nearest")[:, 0].bool()
         print("%s wide range: finite fraction %.2f" % (name, float(ok.float().mean())), flush=True)
-        for mname, rf, wf, cf in MODES:
-            install(rf, wf, cf)
+        for mname, rf, wf, cf, *vf in MODES:
+            install(rf, wf, cf, *vf)
             try:
                 res = run()
             finally:

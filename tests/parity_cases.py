@@ -625,6 +625,16 @@ def case_fused_small_launches(device):
             assert torch.equal(cpu(avg), cpu(ops.confidence_average(prev + [c0], H, W))), ("fused confidence average", D, mode)
         d1, c1, _, avg = ops.softmax_regress(logits, hyp, 1.0, _lib.HEAD_CE_EVAL, 0, False, conf_prev=[])      # a one-stage cascade
         assert torch.equal(cpu(avg), cpu(c1))
+    # head + the next stage's schedule in one launch == head, then schedule_inverse_range: tiles with ragged edges, several D, odd sizes
+    for D, Dn, (H, W), ratio in ((32, 16, (16, 40), 2.67), (8, 4, (9, 70), 1.0), (6, 5, (20, 33), 1.5), (16, 8, (8, 32), 1.5)):
+        logits = dev(torch.randn(B, D, H, W, generator=g) * 3.0, device)
+        hyp = dev((torch.linspace(900, 450, D)[None, :, None, None] * (1 + 0.02 * torch.rand(B, D, H, W, generator=g))).contiguous(), device)
+        for mode, conf_n, wp in ((_lib.HEAD_CE_EVAL, 0, True), (_lib.HEAD_REG, 2, False)):
+            d0, c0, p0 = ops.softmax_regress(logits, hyp, 5.0, mode, conf_n, wp)
+            d1, c1, p1, nh = ops.softmax_regress_schedule(logits, hyp, 5.0, mode, conf_n, wp, Dn, ratio)
+            assert torch.equal(cpu(d0), cpu(d1)) and torch.equal(cpu(c0), cpu(c1)) and (p0 is None or torch.equal(cpu(p0), cpu(p1))), ("fused head", D, H, W)
+            want = cpu(ops.schedule_inverse_range(d0, hyp, Dn, ratio, 2 * H, 2 * W))
+            assert nh.shape == want.shape and rel_l1(cpu(nh), want) <= 1e-7 and (cpu(nh) - want).abs().max() <= 2e-6 * float(want.abs().max()), ("fused schedule", D, H, W)
     # the whole cascade: fused driver vs the stage-by-stage calls of the reference's loop
     head, args = _seeded_head(device)
     feats, projm, dvs = synth.make_cascade_inputs(64, 128, 3, seed=4, rot_deg=1.0)
@@ -1273,6 +1283,52 @@ def case_baseline_cfg1(device, prec=None):
     pe = float((cpu(out["prob_volume"]) - ref["prob_volume"]).abs().max())
     assert pe <= tol(prec, 2e-3, 2e-2), pe
     return r, pe
+
+
+def case_track_s_d192(device, H=1152, W=1536, D=192, V=3):
+    """SURVEY section 8d Track S, literal D: ONE StageNet (stage_idx 3: C = G = 8) at 1152 x 1536 with 192 hypotheses - a 340-Mvoxel volume,
+    10.9 GB in the coarse-stage (split-bf16) format, which rounds 1-4 refused (32-bit byte offsets over a whole batch item; round 5 re-bases
+    the staging descriptor per tile, conv_bf16x3_kernels.hip bf_make_rsrc_z).  The oracle cannot run this size; the check is a CROP
+    cross-check: the same stage on a 256 x 512 window of the same inputs (principal point shifted by the window origin; every tensor of that
+    run is far below 2 GB) must reproduce the full run on the window's interior - the pixels whose U-Net receptive field (+-40) and
+    source taps (disparity <= 131 px at depth 425) stay inside the window.  A wrong plane / row offset anywhere beyond 2 GB shows up here.
+    Plus the size-independent properties: finite outputs, probabilities sum to 1, depth inside the hypothesis range."""
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    st = StageNet(dict(ARGS), D, 3)
+    assert st.conv_precision == "bf16x3"                                       # D > model_th: the policy's exact form
+    st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 5), strict=True)
+    st = st.eval().to(device)
+    cams = synth.make_cameras(V, H, W, baseline=20.0, seed=0)
+    proj = synth.stage_proj_matrices(cams, 1)["stage1"]
+    g = torch.Generator().manual_seed(12)
+    feats = torch.randn(1, V, 8, H, W, generator=g)
+    dvals = torch.linspace(425.0, 935.0, D)
+    with torch.no_grad():
+        hyp = dev(dvals.view(1, D, 1, 1), device).expand(1, D, H, W).contiguous()
+        out = st(dev(feats, device), dev(proj, device), hyp, tmp=1.0)
+        depth, conf = cpu(out["depth"]), cpu(out["photometric_confidence"])
+        assert torch.isfinite(depth).all() and torch.isfinite(conf).all()
+        assert float(depth.min()) >= 425.0 - 1e-2 and float(depth.max()) <= 935.0 + 1e-2
+        psum = out["prob_volume"].sum(1)
+        assert float((psum - 1.0).abs().max()) <= 1e-4, "softmax over 192 planes"
+        del psum
+        y0, x0, hc, wc = 448, 512, 256, 512                                     # window origin multiples of 64: same tile phases as the full run
+        pc = proj.clone()
+        pc[:, :, 1, 0, 2] -= x0
+        pc[:, :, 1, 1, 2] -= y0
+        fc = feats[..., y0:y0 + hc, x0:x0 + wc].contiguous()
+        hc_ = dev(dvals.view(1, D, 1, 1), device).expand(1, D, hc, wc).contiguous()
+        full_pre = cpu(out["prob_volume_pre"][..., y0:y0 + hc, x0:x0 + wc])
+        del out
+        oc = st(dev(fc, device), dev(pc, device), hc_, tmp=1.0)
+    my, mx = 48, 131 + 48
+    a = depth[:, y0 + my:y0 + hc - my, x0 + mx:x0 + wc - mx]
+    b = cpu(oc["depth"])[:, my:hc - my, mx:wc - mx]
+    r = rel_l1(b, a)
+    assert r <= 2e-5, "full-size D = 192 run vs the same stage on a window: depth rel-L1 %g" % r
+    pa, pb = full_pre[:, :, my:hc - my, mx:wc - mx], cpu(oc["prob_volume_pre"])[:, :, my:hc - my, mx:wc - mx]
+    assert (pa - pb).abs().max() <= 2e-4 * max(1.0, float(pa.abs().max())), "logits, every one of the 192 planes"
+    return r
 
 
 def case_baseline_cfg_small(device, name, conv_precision=None):

@@ -198,6 +198,12 @@ def test_cascade_fullsize_properties(prec):
     P.case_cascade_fullsize_properties(DEV, conv_precision=prec)
 
 
+
+def test_track_s_d192_fullsize():
+    """SURVEY 8d Track S at its literal size (1152 x 1536, D = 192: an 11 GB volume) - round 5 lifted the 2 GB ceiling of the MFMA convolutions."""
+    r = P.case_track_s_d192(DEV)
+    print("Track S D=192 1152x1536: full run vs window run, depth rel-L1 %.2e" % r)
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_baseline_cfg1_stage4_d48(prec):
     """BASELINE configs[0]: 640x512, V=3, D=48, stage-4-only StageNet (CostRegNet + the 3x3x3 head) vs the oracle."""
