@@ -388,6 +388,10 @@ class StageNet(nn.Module):
         vol = flat[:nvol].view(B, D, H, W, G)
         vsum = flat[nvol:].view(B, H, W)
         if ve > vb:
+            # The sharded passes ALWAYS gather with fp32 source windows and sum fp32 partial volumes (no kept correlations: pass 2 must
+            # produce the un-normalised per-rank partial sum), whatever gather_precision says - on the fp16-format stages a sharded head is
+            # therefore slightly MORE exact than the single-GPU one (fp16 windows / fp16 kept correlations there): they agree to an fp16 ulp
+            # of the volume, not bit for bit (tests/test_dist_gloo.py asserts that bound).  ADVICE r4.
             # entropy / visibility maps are indexed by absolute view; only this rank's views are written and read
             entropy = self._buffer("entropy", (B, V - 1, H, W), feats.device)
             ops.warp_corr_entropy(feats, code, hom, hyp, G, vb, ve, out=entropy)

@@ -1,6 +1,7 @@
 // Helpers shared by the two LDS-staged forms of the gather passes (gather_lds_kernels.hip: block-level windows, round 2;
 // gather_wave_kernels.hip: wave-autonomous windows, round 3).
 #pragma once
+#include <type_traits>
 #include "mvs_common.h"
 
 namespace mvs {

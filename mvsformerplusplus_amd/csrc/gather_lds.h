@@ -123,6 +123,12 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             for (int i = tid; i < n; i += 256) {
                 const int row = (int)(((float)i + 0.5f) * inv_ww);
                 const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;    // (ymin+row)*W + wx0 + (i - row*ww)
+                if constexpr (W16 && TILED && std::is_same<T, _Float16>::value) {
+                    // fp16 octet tiles (what a producer-side emitter hands over, mvs_conv2d3x3_tiles_fwd with out_dtype fp16): the window
+                    // position IS the 16-byte run in HBM - staging is a copy, no conversion, no clamp (round 5)
+                    win16[i] = *(reinterpret_cast<const h8*>(so) + g);
+                    continue;
+                }
                 float v[8];
                 gl_load8<TILED, T>(so, HW, g, v);
                 if (W16) {

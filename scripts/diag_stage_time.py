@@ -6,12 +6,14 @@ import torch, bench
 from mvsformerplusplus_amd import synth, ops
 dev = torch.device("cuda:0")
 feats, projs, dv = synth.make_cascade_inputs(1152, 1536, 5, seed=0, device=dev)
-for pol in ("stagemix", "f16mix", "bf16x3"):
+for pol in (sys.argv[1:] or ["stagemix", "f16mix", "bf16x3"]):
     head = bench.build_head(dev, conv_precision=pol)
     n = len(head.ndepths)
     with torch.no_grad():
         out = head(feats, projs, dv)
         hyps = [out["stage%d" % (s + 1)]["depth_values"] for s in range(n)]
+        from mvsformerplusplus_amd import cost_volume as _cv
+        _cv.F16_SATURATION_CHECK_EVERY = 0                  # no synchronising self-check inside the timed loops
         ts = []
         for s in range(n):
             st = head.fusions[s]

@@ -822,6 +822,17 @@ def case_gather_variants(device, quick=False):
                 assert (vol_s - vol_f).abs().max() <= 2e-5 * scale, (C, D, "streamed volume, split out")
                 vol16 = cpu(ops.warp_corr_aggregate(fk, ops._feat(fk)[1], hom, hd, dev(vis, device), G, f16=True)[0]).float().permute(0, 4, 1, 2, 3)
                 assert (vol_k - vol16).abs().max() <= 1.2e-3 * scale, (C, D, "streamed vs gathered fp16 volume")
+                if dt == torch.float32 and fk is not f:
+                    # fp16 octet tiles (the producer-side emitter's other hand-off dtype): the fp16 window is staged by a pure 16-byte copy
+                    # (gather_lds.h) - the same bits as planar fp16 features, whose staging converts fp16 -> fp32 -> fp16
+                    fh = dev(feats.half(), device)
+                    e_p, c_p = ops.warp_corr_entropy_keep(fh, ops._feat(fh)[1], hom, hd, G)
+                    ft16 = ops.pack_features(fh)
+                    e_t, c_t = ops.warp_corr_entropy_keep(ft16, ops._feat(ft16)[1], hom, hd, G)
+                    assert ft16.dtype == torch.float16 and torch.equal(cpu(e_p), cpu(e_t)) and torch.equal(cpu(c_p), cpu(c_t)), (C, D, "fp16 tiles: copy staging")
+                    v_p = ops.warp_corr_aggregate(fh, ops._feat(fh)[1], hom, hd, dev(vis, device), G, f16=True)[0]
+                    v_t = ops.warp_corr_aggregate(ft16, ops._feat(ft16)[1], hom, hd, dev(vis, device), G, f16=True)[0]
+                    assert torch.equal(cpu(v_p), cpu(v_t)), (C, D, "fp16 tiles: copy staging, pass 2")
                 # round 5: the EXACT keeping pass (MVS_CORR_F32: fp32 windows, fp32 kept correlations - the coarse stages of the default
                 # policy): entropy == the plain pass 1, kept correlations == the oracle's, streamed volume == the second gather's
                 ent_x, corr_x = ops.warp_corr_entropy_keep(fk, ops._feat(fk)[1], hom, hd, G, exact=True)
