@@ -60,31 +60,43 @@ def run():
               ("prob head 8->1 st2", "h", 8, 1, (1, 1, 1), 16, 288, 384), ("prob head 8->1 st1", "h", 8, 1, (1, 1, 1), 32, 144, 192),
               ("conv 64->64 s111 st1", "c", 64, 64, (1, 1, 1), 4, 18, 24), ("conv 32->64 s222 st1", "c", 32, 64, (2, 2, 2), 8, 36, 48),
               ("deconv 64->32 s222 st1", "d", 64, 32, 2, 4, 18, 24), ("conv 32->32 s111 st1", "c", 32, 32, (1, 1, 1), 8, 36, 48)]
+    PREC, conv_in = 1, (lambda t: t.to(dev))
+    if os.environ.get("ABL_SET") == "coarse":
+        # round 5: the ten U-Net launches of the COARSE stages (stage 1: [32,144,192], stage 2: [16,288,384]) in the format the default
+        # policy runs them in - split bf16 (MVS_PREC_BF16X3_SPLIT): what are these latency-bound launches made of?
+        layers = []
+        for st, (D0, H0, W0) in (("st1", (32, 144, 192)), ("st2", (16, 288, 384))):
+            layers += [("conv1 8->16 s222 " + st, "c", 8, 16, (2, 2, 2), D0, H0, W0), ("conv2 16->16 " + st, "c", 16, 16, (1, 1, 1), D0 // 2, H0 // 2, W0 // 2),
+                       ("conv3 16->32 s222 " + st, "c", 16, 32, (2, 2, 2), D0 // 2, H0 // 2, W0 // 2), ("conv4 32->32 " + st, "c", 32, 32, (1, 1, 1), D0 // 4, H0 // 4, W0 // 4),
+                       ("conv5 32->64 s222 " + st, "c", 32, 64, (2, 2, 2), D0 // 4, H0 // 4, W0 // 4), ("conv6 64->64 " + st, "c", 64, 64, (1, 1, 1), D0 // 8, H0 // 8, W0 // 8),
+                       ("conv7 deconv 64->32 " + st, "d", 64, 32, 2, D0 // 8, H0 // 8, W0 // 8), ("conv9 deconv 32->16 " + st, "d", 32, 16, 2, D0 // 4, H0 // 4, W0 // 4),
+                       ("conv11 deconv 16->8 " + st, "d", 16, 8, 2, D0 // 2, H0 // 2, W0 // 2), ("prob head 8->1 " + st, "h", 8, 1, (1, 1, 1), D0, H0, W0)]
+        PREC, conv_in = _lib.PREC_BF16X3_SPLIT, (lambda t: ops.to_split(t.to(dev)))
     res = {}
     for k in VARIANTS:
         _lib._LIB = _lib.bind(os.path.join(OUT, "libmvs_abl%s.so" % _tag(k)))
         for name, kind, cin, cout, stride, D, H, W in layers:
-            x = torch.randn(1, D, H, W, cin, generator=g).to(dev)
+            x = conv_in(torch.randn(1, D, H, W, cin, generator=g))
             if kind == "h":
                 w16 = torch.zeros(16, 8, 3, 3, 3)
                 w16[0] = torch.randn(8, 3, 3, 3, generator=g) * 0.05
                 wp = packing.pack_conv_weights_bf16x3(w16, 8).to(dev)
                 bias = torch.zeros(16, device=dev)
-                f = lambda: ops.conv3d_logits(x, wp, bias, 1)
+                f = lambda: ops.conv3d_logits(x, wp, bias, PREC)
             elif kind == "c":
                 w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05
                 wp = packing.pack_conv_weights_bf16x3(w, _ch_of(cin, cout, stride)).to(dev)
                 bias = torch.zeros(cout, device=dev)
-                f = lambda: ops.conv3d_bn_relu(x, wp, bias, cout, 3, stride, True, 1)
+                f = lambda: ops.conv3d_bn_relu(x, wp, bias, cout, 3, stride, True, PREC)
             else:
                 w = torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.05
                 wp = packing.pack_deconv_weights_bf16x3(w, stride).to(dev)
                 bias = torch.zeros(cout, device=dev)
-                skip = torch.randn(1, D * stride, 2 * H, 2 * W, cout, generator=g).to(dev)
-                f = lambda: ops.deconv3d_bn_relu_add(x, wp, bias, cout, stride, skip, 1)
+                skip = conv_in(torch.randn(1, D * stride, 2 * H, 2 * W, cout, generator=g))
+                f = lambda: ops.deconv3d_bn_relu_add(x, wp, bias, cout, stride, skip, PREC)
                 if kind == "p":
                     pw, pb = torch.randn(8, device=dev), torch.zeros(1, device=dev)
-                    f = lambda: ops.deconv3d_prob(x, wp, bias, stride, skip, pw, pb, 1)
+                    f = lambda: ops.deconv3d_prob(x, wp, bias, stride, skip, pw, pb, PREC)
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
