@@ -40,6 +40,7 @@ Rank 0 prints ONE JSON line.  Extra objects: `training_step` (N = 1: forward + b
 training kernels at DTU-training-like sizes, outside the timed region), `roofline` (dominant kernel, HIP-event timing on the launch stream) and
 `cpu_baseline` (the oracle - a CPU restatement of the reference path - timed on this host's cores, N=1 only), `fp32_equivalent_mode`
 (N = 1: the same weights, inputs and loop with the regularisers in "bf16x3", outside the timed headline: both modes in one line),
+`uniform_f16mix_mode` (N = 1, round 5: the same with rounds 3-4's uniform fp16 format - what the default policy's exact coarse stages cost),
 `shipped` (N = 1, round 5: the SHIPPED regulariser mix - stage-1 transformer + PE3D, config/mvsformer++.json:86-113 - on the same inputs:
 ref-views/s and its own parity against the oracle, outside the timed headline).
 """
@@ -206,6 +207,8 @@ def main():
                          "per second of the whole group, scaling 'strong'.  For a first RCCL contact without the data-parallel headline in front of it")
     ap.add_argument("--conv-precision", choices=["stagemix", "bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
                     help="contraction / activation format of the 3-D regularisers (default: the package default, cost_volume.STAGE_DEFAULT_PRECISION)")
+    ap.add_argument("--keep-min-depth", type=int, default=None,
+                    help="A/B: cost_volume.KEEP_MIN_DEPTH (planes from which the fp16 gather form keeps fp16 correlations; 1 = stage 4's D = 4 too)")
     ap.add_argument("--keep-exact-min-depth", type=int, default=None,
                     help="A/B: cost_volume.KEEP_EXACT_MIN_DEPTH (planes from which the exact coarse-stage gather keeps fp32 correlations instead of gathering twice)")
     ap.add_argument("--no-keep-correlations", action="store_true",
@@ -237,9 +240,12 @@ def main():
             dist.init_process_group(backend)
 
     from mvsformerplusplus_amd import profiling, synth
-    if a.keep_exact_min_depth is not None:
+    if a.keep_exact_min_depth is not None or a.keep_min_depth is not None:
         from mvsformerplusplus_amd import cost_volume as _cvm
-        _cvm.KEEP_EXACT_MIN_DEPTH = a.keep_exact_min_depth
+        if a.keep_exact_min_depth is not None:
+            _cvm.KEEP_EXACT_MIN_DEPTH = a.keep_exact_min_depth
+        if a.keep_min_depth is not None:
+            _cvm.KEEP_MIN_DEPTH = a.keep_min_depth
     head = build_head(device, shipped=a.cost_reg == "shipped", conv_precision=a.conv_precision)
     if a.no_keep_correlations:
         for st in head.fusions:
@@ -451,16 +457,7 @@ def main():
         traffic, tsrc = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # PMC-derived HBM bytes per launch, committed per round
         if os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            tb, tsrc, ok = 0.0, [], True
-            for k in dom["members"]:
-                hit = profiling.match_kernel(k, tj)
-                if hit is None or tj[hit].get("hbm_bytes_per_launch") is None:
-                    ok = False
-                    break
-                tb += tj[hit]["hbm_bytes_per_launch"] * agg[k]["calls"]
-                tsrc.append(hit)
-            traffic = tb / dom["calls"] if ok else None
+            traffic, tsrc = profiling.group_pmc_traffic(dom_name, json.load(open(tfile)))
         result["roofline"] = {"kernel": dom_name, "instantiations": sorted(dom["members"]), "bound": "mfma" if mfma else "hbm", "achieved": achieved, "peak": peak,
                               "unit": "TFLOP/s" if mfma else "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_pmc_symbols": tsrc,
                               "avg_launch_ms": dom["avg_ms"], "algorithmic_per_launch": per_launch,
@@ -539,7 +536,7 @@ def main():
                         miss.append(k)
                     else:
                         pm += tj[hit]["hbm_bytes_per_launch"] * v["calls"] / reps
-                if "_whole_path" in tj and a.cost_reg != "shipped" and prec in ("f16x2", "f16mix"):
+                if "_whole_path" in tj and a.cost_reg != "shipped" and a.conv_precision is None:      # the PMC run is the default policy's
                     pm, miss = tj["_whole_path"]["hbm_bytes_per_ref_view"], []       # every launch of the PMC run / its reference views
                 wp["pmc_bytes_per_ref_view"] = pm
                 wp["frac_pmc"] = pm * vps / 8.0e12
@@ -607,6 +604,21 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             result["fp32_equivalent_mode"] = {"error": repr(e)}
+        # ... and rounds 3-4's default, the uniform fp16 format on every stage (opt-in since round 5: it leaves the 1e-3 bar on ill-conditioned
+        # depth ranges) - what the exact coarse stages of the default policy cost on this workload
+        if head.fusions[0].precision_policy == "stagemix":
+            try:
+                head16 = build_head(device, conv_precision="f16mix")
+                n2 = max(2, a.steps // 4)
+                t16, out16, _ = side_leg(head16, n2)
+                result["uniform_f16mix_mode"] = {"conv_precision": "f16mix", "value": R / t16, "unit": "ref-views/s", "ms_per_ref_view": t16 / R * 1e3, "steps": n2,
+                                                 "default_vs_this_refined_depth_rel_l1": float(((out["refined_depth"] - out16["refined_depth"]).abs() / out16["refined_depth"].abs()).mean()),
+                                                 "note": "fp16 U-Net tensors, source windows and kept correlations on EVERY stage (rounds 3-4's default): 4.7e-5 from the fp32 oracle at cfg2, "
+                                                         "4e-3 on BASELINE cfg4 / cfg5's literal depth range - opt-in (conv_precision='f16mix')"}
+                del head16, out16
+                torch.cuda.empty_cache()
+            except Exception as e:
+                result["uniform_f16mix_mode"] = {"error": repr(e)}
 
     # ---- extra (round 5): the SHIPPED regulariser mix (stage-1 transformer + PE3D - what released checkpoints run) on the same
     #      inputs, outside the timed headline: value + its own parity against the oracle ----

@@ -127,7 +127,8 @@ int mvs_warp_corr_entropy_fwd(const void* features, int dtype, int layout, const
  * mvs_warp_corr_entropy_keep_fwd = the entropy pass over ALL source views + `corr`; mvs_corr_aggregate_fwd =
  * sum_v vis_v * corr_v / (sum_v vis_v + 1e-6) -> the normalised volume [B,D,H,W,8] in `volume_format` (MVS_VOLUME_F16 / _SPLIT / _F32:
  * the regulariser's format is independent of the gather's).  Built where mvs_gather_keeps_correlations() returns 1 (the LDS-staged
- * gather's shapes with D > 4); MVS_ERR_UNSUPPORTED elsewhere - the two-gather pair above covers every shape.                  */
+ * gather's shapes; MVS_CORR_F32 additionally needs D > 4); MVS_ERR_UNSUPPORTED elsewhere - the two-gather pair above covers every
+ * shape.  Whether the stream pays (16 / 32 B per voxel and view written and read against a second gather) is the caller's policy.   */
 int mvs_gather_keeps_correlations(int layout, int C, int G, int D, int H, int W);
 int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, int layout, const float* homography /*[B,V-1,12]*/,
                                    const float* hyp, float* entropy, void* corr, int corr_format, int B, int V, int C, int G, int D,

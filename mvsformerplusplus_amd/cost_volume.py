@@ -44,6 +44,7 @@ STAGE_DEFAULT_PRECISION = DEFAULT_STAGE_POLICY
 _F16_CALLS = {}                            # fp16-format stage calls per device index (one process may drive several GPUs)
 _F16_CHECK_DUE = set()                     # devices whose check fell inside a hipGraph capture: done at the next eager call
 KEEP_CORRELATIONS_MAX_BYTES = 1 << 30      # largest kept per-view correlation tensor ([B,V-1,D,H,W,8] fp16 / fp32) of the streaming pass 2
+KEEP_MIN_DEPTH = 5                         # fp16 gather form: pass 1 keeps fp16 correlations from this many planes on (D <= 4: see StageNet.keep_min_depth)
 KEEP_EXACT_MIN_DEPTH = 16                  # exact gather (gather_precision "f32"): fp32 kept correlations pay from this many planes on (32 B per
                                            # voxel and view streamed twice against a second gather; D = 8: 453 MB at cfg2's stage 3 - no gain)
 F16_SATURATION_CHECK_EVERY = 4096          # stage calls between two automatic reads of the saturation counter (0 = never)
@@ -114,7 +115,8 @@ class StageNet(nn.Module):
         # "auto": all-reduce of the partial volumes on coarse stages, H-slab exchange + 1/R of the regulariser where a slab is
         # at least one halo tall; "allreduce" / "slab" force one form
         self.shard_mode = "auto"
-        self.keep_correlations = "auto"   # fp16 formats, D > 4: pass 1 keeps fp16 per-view correlations, pass 2 streams them (_keeps_correlations)
+        self.keep_correlations = "auto"   # pass 1 keeps per-view correlations, pass 2 streams them (_keeps_correlations)
+        self.keep_min_depth = None        # None = KEEP_MIN_DEPTH / KEEP_EXACT_MIN_DEPTH; fewer planes gather twice
         self.fuse_prob_head = True        # CostRegNet3D + bf16x3: `prob` applied in the last deconvolution's epilogue
         self.last_collective_bytes = 0
         self._buffers_cache = {}
@@ -174,7 +176,8 @@ class StageNet(nn.Module):
         exact = self.gather_precision != "f16"
         B, V, _, H, W = feats.shape
         D = hyp.shape[1]
-        if exact and D < KEEP_EXACT_MIN_DEPTH:
+        dmin = self.keep_min_depth if self.keep_min_depth is not None else (KEEP_EXACT_MIN_DEPTH if exact else KEEP_MIN_DEPTH)
+        if D < dmin or (exact and D <= 4):
             return False
         if (V - 1) * B * D * H * W * (32 if exact else 16) > KEEP_CORRELATIONS_MAX_BYTES:
             return False

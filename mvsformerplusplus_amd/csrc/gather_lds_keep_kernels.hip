@@ -87,16 +87,12 @@ __global__ __launch_bounds__(256) void corr_aggregate_kernel(const void* __restr
     if constexpr (FMT == MVS_VOLUME_F16) sat::commit(sat_amax);
 }
 
-// KEEP form: the launcher with NS = 1 (D <= 4) is not instantiated - the streaming pass 2 never pays there (gl_keep_supported)
+// KEEP form, fp16 correlations: every depth-chunk geometry (round 5 instantiates NS = 1, D <= 4, too: whether the streamed pass 2 pays there -
+// 16 B per voxel and view written and read against a second gather - is the CALLER's policy, StageNet.keep_min_depth)
 template <int DT, int NOCT, int NS, bool TILED>
 static int gl_launch_entropy_keep_t(const void* feat, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int D, int H, int W,
                                     hipStream_t st) {
-    if constexpr (NS == 1) {
-        set_error("mvs_warp_corr_entropy_keep_fwd: D <= 4 is not built (the second gather is the faster pass 2 there)");
-        return MVS_ERR_UNSUPPORTED;
-    } else {
-        return gl_launch_entropy_t<DT, NOCT, NS, TILED, true, true>(feat, hom, hyp, ent, B, V, D, H, W, 1, V, st, corr);
-    }
+    return gl_launch_entropy_t<DT, NOCT, NS, TILED, true, true>(feat, hom, hyp, ent, B, V, D, H, W, 1, V, st, corr);
 }
 
 int gl_launch_entropy_keep32(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int B, int V, int C,

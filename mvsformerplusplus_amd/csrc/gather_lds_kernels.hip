@@ -16,7 +16,9 @@ bool gl_supported(int C, int G, int D, int H, int W) {
     return (size_t)D * (256 / gl_slots(D)) * sizeof(float) <= 64 * 1024;
 }
 
-bool gl_keep_supported(int C, int G, int D, int H, int W) { return gl_supported(C, G, D, H, W) && D > GL_DCH; }
+// the fp16-correlation keeping pass exists for every LDS-staged shape; the fp32-correlation (exact) one for D > GL_DCH only
+bool gl_keep_supported(int C, int G, int D, int H, int W) { return gl_supported(C, G, D, H, W); }
+bool gl_keep32_supported(int C, int G, int D, int H, int W) { return gl_supported(C, G, D, H, W) && D > GL_DCH; }
 
 
 int gl_launch_entropy_w16(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, int B, int V, int C, int D, int H, int W,

@@ -610,6 +610,7 @@ int gl_launch_entropy(const void* feat, int dtype, int layout, const float* hom,
 int gl_launch_aggregate(const void* feat, int dtype, int layout, const float* hom, const float* hyp, const float* vis, float* vol,
                         float* vis_sum, int normalise, int B, int V, int C, int D, int H, int W, int vb, int ve, hipStream_t st);
 bool gl_keep_supported(int C, int G, int D, int H, int W);
+bool gl_keep32_supported(int C, int G, int D, int H, int W);
 int gl_launch_entropy_keep(const void* feat, int dtype, int layout, const float* hom, const float* hyp, float* ent, void* corr, int corr_format, int B,
                            int V, int C, int D, int H, int W, hipStream_t st);
 int launch_corr_aggregate(const void* corr, int corr_format, const float* vis, void* vol, int volume_format, int B, int V, int D, int H, int W,
@@ -732,8 +733,8 @@ extern "C" int mvs_warp_corr_entropy_keep_fwd(const void* features, int dtype, i
     if (corr_format != MVS_CORR_F16 && corr_format != MVS_CORR_F32) { set_error("mvs_warp_corr_entropy_keep_fwd: unknown correlation format %d", corr_format); return MVS_ERR_ARG; }
     rc = check_layout("mvs_warp_corr_entropy_keep_fwd", layout, C, G, D, H, W);
     if (rc != MVS_OK) return rc;
-    if (!gl_keep_supported(C, G, D, H, W)) {
-        set_error("mvs_warp_corr_entropy_keep_fwd: built for the LDS-staged gather with D > 4 (G == 8, C in {8,16,32,64}, W %% 8 == 0); "
+    if (!gl_keep_supported(C, G, D, H, W) || (corr_format == MVS_CORR_F32 && !gl_keep32_supported(C, G, D, H, W))) {
+        set_error("mvs_warp_corr_entropy_keep_fwd: built for the LDS-staged gather (G == 8, C in {8,16,32,64}, W %% 8 == 0; MVS_CORR_F32: D > 4 as well); "
                   "mvs_gather_keeps_correlations() says which shapes qualify");
         return MVS_ERR_UNSUPPORTED;
     }

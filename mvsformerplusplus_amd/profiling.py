@@ -80,6 +80,25 @@ def kernel_group(label: str) -> str:
     return base if base.endswith("_kernel") else base + "_kernel"
 
 
+def group_pmc_traffic(group: str, table: dict):
+    """HBM bytes per launch of a kernel GROUP (kernel_group) from profiles/pmc_traffic.json: the launch-weighted mean over every
+    symbol of that __global__ function the PMC run sampled (all tile configurations and activation formats; the forward convolution's
+    tile and persistent forms together), or None."""
+    stems = {"conv3d_mfma_bf16x3_kernel": ("conv3d_mfma_bf16x3_kernel<", "conv3d_mfma_bf16x3_persist_kernel<"),
+             "deconv3d_mfma_bf16x3_kernel": ("deconv3d_mfma_bf16x3_kernel<", "deconv3d_mfma_bf16x3_persist_kernel<"),
+             "prob_regress_kernel": ("prob_regress_kernel<",)}.get(group, (group + "<", group))
+    tot, n, used = 0.0, 0, []
+    for k, v in table.items():
+        if k.startswith("_") or not isinstance(v, dict) or v.get("hbm_bytes_per_launch") is None:
+            continue
+        if any(k.startswith(st) or k == st for st in stems):
+            c = v.get("launches_sampled", 0)
+            tot += v["hbm_bytes_per_launch"] * c
+            n += c
+            used.append(k)
+    return (tot / n, used) if n else (None, [])
+
+
 def mfma_terms(label: str, prec: str) -> int:
     """MFMA products a kernel issues per algorithmic product: 3 (split bf16), 2 (fp16 hi + lo weights), 1 (one fp16 weight term).  "f16mix"
     (csrc/conv_kernels.hip mfma_form): one term where min(Cin, Cout) >= 32 or max >= 64 and in the visibility CNN, two elsewhere."""

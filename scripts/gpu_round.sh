@@ -3,7 +3,7 @@
 # Usage: gpurun --timeout 1800 -- 'bash scripts/gpu_round.sh <tag>'
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r04}
+ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r05}
 mkdir -p $OUT
 export PYTHONDONTWRITEBYTECODE=1
 echo "== pytest -m gpu =="
@@ -13,8 +13,8 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | 
 # PMC first: bench.py's roofline.traffic / whole_path.frac_pmc read profiles/pmc_traffic.json, which must describe THIS build's kernels
 (cd /tmp && export TMPDIR=/tmp
 echo "== PMC: HBM traffic of every kernel (separate passes) =="
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_f.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_w.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/f -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --issue eager --no-shipped-leg --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_f.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_$TAG/w -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --views-per-step 4 --issue eager --no-shipped-leg --no-cpu-baseline --no-profile --no-train-leg > $ROOT/$OUT/pmc_w.log 2>&1
 )
 mkdir -p $OUT/profiles_$TAG
 python scripts/pmc_traffic.py $OUT/pmc_$TAG $OUT/profiles_$TAG/pmc_traffic.json $OUT/profiles_$TAG/${TAG}_pmc_fetch_write_raw.json
@@ -26,12 +26,14 @@ python - <<'PY'
 import json
 r = json.loads(open('gpurun_out/bench.json').read().strip().splitlines()[-1])
 print({k: r[k] for k in ('value', 'ms_per_step', 'ms_per_ref_view') if k in r})
-for k in ('latency', 'whole_path', 'roofline', 'cpu_baseline', 'parity'):
+for k in ('latency', 'whole_path', 'roofline', 'cpu_baseline', 'parity', 'fp32_equivalent_mode', 'uniform_f16mix_mode', 'shipped', 'feature_emitter'):
     print(k, r.get(k))
 print('gather', r.get('gather_roofline', {}).get('all_passes'))
 PY
+echo "== randomised cascades in the product default vs the oracle (scripts/fuzz_cascade_gpu.py 60 0) =="
+timeout 600 python scripts/fuzz_cascade_gpu.py 60 0 2>&1 | grep -v amdgpu.ids > $OUT/fuzz_cascade.log; tail -3 $OUT/fuzz_cascade.log
 echo "== bench, shipped regulariser mix (stage-1 transformer + PE3D) =="
-timeout 900 python bench.py --steps 6 --warmup 2 --profile-table --cost-reg shipped > $OUT/bench_shipped.json 2> $OUT/bench_shipped.err
+timeout 900 python bench.py --steps 6 --warmup 2 --profile-table --cost-reg shipped --issue eager > $OUT/bench_shipped.json 2> $OUT/bench_shipped.err
 grep -v "amdgpu.ids" $OUT/bench_shipped.err | grep -E "tr_|pos3d|softmax_regress|sum of"
 python - <<'PY'
 import json
@@ -60,11 +62,11 @@ except Exception as e:
 PY
 echo "== rocprofv3 kernel trace (same bench command, 5 steps) =="
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --issue eager --no-shipped-leg --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof.log 2>&1
 tail -2 $ROOT/$OUT/rocprof.log
 # the same with ONE stream: kernels of different reference views do not overlap, so the average durations are the launches' own
 # (what bench.py's HIP-event table and its `roofline` object measure); with 3 streams co-running kernels stretch each other
-timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --streams 1 --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof1.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --streams 1 --issue eager --no-shipped-leg --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof1.log 2>&1
 cd $ROOT
 DB=$(find $OUT/prof_$TAG -name '*.db' | head -1)
 if [ -n "$DB" ]; then
@@ -72,10 +74,13 @@ if [ -n "$DB" ]; then
   python scripts/rocpd_stats.py $DB "mvs::" > $OUT/profiles_$TAG/${TAG}_kernel_stats_3streams.csv
   DB1=$(find $OUT/prof1_$TAG -name '*.db' | head -1)
   python scripts/rocpd_stats.py $DB1 "mvs::" > $OUT/profiles_$TAG/${TAG}_kernel_stats.csv
+  python scripts/group_kernel_stats.py $OUT/profiles_$TAG/${TAG}_kernel_stats.csv > $OUT/profiles_$TAG/${TAG}_kernel_stats_by_function.csv
+  head -8 $OUT/profiles_$TAG/${TAG}_kernel_stats_by_function.csv
   head -14 $OUT/profiles_$TAG/${TAG}_kernel_stats.csv | cut -c1-150
 else
   echo "no rocpd database under $OUT/prof_$TAG"; find $OUT/prof_$TAG | head
 fi
+cp $OUT/fuzz_cascade.log $OUT/profiles_$TAG/${TAG}_fuzz_cascade_default_gpu.log
 cp $OUT/bench.json $OUT/profiles_$TAG/${TAG}_bench_1gpu.json
 cp $OUT/bench_shipped.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_shipped.json
 cp $OUT/bench_n2.json $OUT/profiles_$TAG/${TAG}_bench_n2_flow_check_one_gpu_gloo.json
@@ -86,7 +91,7 @@ grep -v "amdgpu.ids" $OUT/bench.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_tab
 grep -v "amdgpu.ids" $OUT/bench_shipped.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_shipped.txt
 rm -rf $OUT/prof_$TAG $OUT/prof1_$TAG $OUT/pmc_$TAG
 echo "== PMC pipe utilisation per kernel (three counter passes over a short bench run) =="
-bash scripts/gpu_pmc_bench.sh $TAG --no-train-leg --views-per-step 8 > $OUT/pmc_pipe.log 2>&1
+bash scripts/gpu_pmc_bench.sh $TAG --no-train-leg --no-shipped-leg --issue eager --views-per-step 8 > $OUT/pmc_pipe.log 2>&1
 cp $OUT/pmc_$TAG/summary.txt $OUT/profiles_$TAG/${TAG}_pmc_pipe_utilisation.txt
 cp $OUT/pmc_$TAG/table.txt $OUT/profiles_$TAG/${TAG}_pmc_pipe_table_raw.txt
 head -30 $OUT/profiles_$TAG/${TAG}_pmc_pipe_utilisation.txt | cut -c1-200

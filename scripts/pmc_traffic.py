@@ -43,8 +43,10 @@ for k in sorted(set(f) | set(w)):
     rawd[k] = {"calls": max(fc, wc), "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa}
     short = re.sub(r"<.*$", "", k) if k.startswith("warp_corr") or k.startswith("weighted") else k
     res[short] = {"hbm_bytes_per_launch": (2 * fa + wa) * 1024, "fetch_size_kb": fa, "write_size_kb": wa, "launches_sampled": max(fc, wc)}
-# whole path: every library kernel of the run / the reference views of the run (confidence_average_kernel runs once per view)
-views = max(f.get("confidence_average_kernel", [0])[0], w.get("confidence_average_kernel", [0])[0])
+# whole path: every library kernel of the run / the reference views of the run (one cascade_prologue_kernel launch per view since round 5;
+# confidence_average_kernel - once per view through round 4 - is fused into the last stage's head now)
+views = max(f.get(k, [0])[0] for k in ("cascade_prologue_kernel", "confidence_average_kernel"))
+views = max(views, max(w.get(k, [0])[0] for k in ("cascade_prologue_kernel", "confidence_average_kernel")))
 if views:
     tot = sum((2 * f.get(k, [0, 0.0])[1] / max(f.get(k, [1])[0], 1) * max(f.get(k, [0])[0], w.get(k, [0])[0]) +
                w.get(k, [0, 0.0])[1] / max(w.get(k, [1])[0], 1) * max(f.get(k, [0])[0], w.get(k, [0])[0])) * 1024 for k in rawd
