@@ -62,11 +62,11 @@ except Exception as e:
 PY
 echo "== rocprofv3 kernel trace (same bench command, 5 steps) =="
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --issue eager --no-shipped-leg --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --issue eager --no-shipped-leg --no-train-leg --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof.log 2>&1
 tail -2 $ROOT/$OUT/rocprof.log
 # the same with ONE stream: kernels of different reference views do not overlap, so the average durations are the launches' own
 # (what bench.py's HIP-event table and its `roofline` object measure); with 3 streams co-running kernels stretch each other
-timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --streams 1 --issue eager --no-shipped-leg --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof1.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 1 --streams 1 --issue eager --no-shipped-leg --no-train-leg --no-cpu-baseline --no-profile > $ROOT/$OUT/rocprof1.log 2>&1
 cd $ROOT
 DB=$(find $OUT/prof_$TAG -name '*.db' | head -1)
 if [ -n "$DB" ]; then
