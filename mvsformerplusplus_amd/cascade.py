@@ -134,7 +134,9 @@ class GraphedCascade:
                 head(features, proj_matrices, depth_values, tmp=tmp)
             torch.cuda.current_stream(depth_values.device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # capture_error_mode "thread_local": only THIS thread's calls are policed during the capture - a torch.distributed process group's
+            # watchdog thread (bench.py --gpus N captures with RCCL initialised) may query its events meanwhile without invalidating it
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.outputs = head(features, proj_matrices, depth_values, tmp=tmp)
 
     def __call__(self) -> Dict[str, torch.Tensor]:
