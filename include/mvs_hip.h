@@ -57,11 +57,13 @@ enum { MVS_REG_COSTREGNET = 0, MVS_REG_COSTREGNET3D = 1 };
  *                    float*; 2 bytes per element), weights packed as fp16 hi + lo, two MFMA terms w_hi.x + w_lo.x on
  *                    v_mfma_f32_16x16x32_f16, fp32 accumulation, fp32 logits.  Final depth vs the fp32 oracle: 5.5e-5 relative L1 on plain
  *                    inputs, 4.2e-4 on the x30-logits stress set (bar 1e-3); the reference's own GPU path runs these layers under bf16
- *                    autocast (test.py:250).  Values beyond +-65504 overflow: the aggregate pass clamps the volume it writes.            *   MVS_PREC_F16     as MVS_PREC_F16X2 with ONE fp16 term per weight (w_lo never read: half the MFMAs, half the weight bytes); the packed
+ *                    autocast (test.py:250).  Values beyond +-65504 overflow: the aggregate pass clamps the volume it writes.
+ *   MVS_PREC_F16     as MVS_PREC_F16X2 with ONE fp16 term per weight (w_lo never read: half the MFMAs, half the weight bytes); the packed
  *                    weights are the MVS_PREC_F16X2 ones.  Depth error vs the fp32 oracle: 7e-5 plain / 4.8e-4 on the x30-logits stress set
  *                    (F16X2: 5.5e-5 / 4.2e-4; scripts/study_weight_precision.py).  mvs_conv3d_logits_fwd keeps both terms.
- *   MVS_PREC_F16MIX  the product default: one term on the layers with >= 32 channels on both sides or 64 on one (the U-Net's conv4 .. conv7),
- *                    two on the others - indistinguishable from MVS_PREC_F16X2 in the error study.
+ *   MVS_PREC_F16MIX  one term on the layers with >= 32 channels on both sides or 64 on one (the U-Net's conv4 .. conv7), two on the others -
+ *                    indistinguishable from MVS_PREC_F16X2 in the error study.  The format of the fine stages (ndepth <= model_th) under the
+ *                    host mirror's default policy "stagemix" (round 5; its coarse stages run MVS_PREC_BF16X3_SPLIT), and of a bare regulariser.
  */
 enum { MVS_PREC_FP32 = 0, MVS_PREC_BF16X3 = 1, MVS_PREC_BF16P = 2, MVS_PREC_BF16X3_SPLIT = 3, MVS_PREC_F16X2 = 4, MVS_PREC_ATTN16 = 5, MVS_PREC_F16 = 6, MVS_PREC_F16MIX = 7 };
 /* format of the cost volume mvs_warp_corr_aggregate_fwd / mvs_volume_normalise leave behind: fp32 [B,D,H,W,8], the split activation

@@ -149,7 +149,7 @@ def patch_model(model: nn.Module, conv_precision: Optional[str] = None, attentio
 
     Parameters are carried over with ``load_state_dict(strict=True)``; device and train/eval mode are preserved.
     The rest of the reference model (backbone, FMT, cascade loop) keeps calling ``fusions[i].forward(...)`` as before.
-    ``conv_precision`` / ``attention_precision``: None = the product defaults ("f16mix" regulariser format, "attn16" attention
+    ``conv_precision`` / ``attention_precision``: None = the product defaults (the "stagemix" precision policy - fp32-equivalent coarse stages, "f16mix" fine stages -, "attn16" attention
     operands - both at least as wide as the bf16 autocast / flash-attn the reference's own GPU path uses); "bf16x3" for either selects
     the fp32-equivalent form.
     """

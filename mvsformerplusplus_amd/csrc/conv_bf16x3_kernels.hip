@@ -16,7 +16,7 @@
 //
 // Three activation formats share these kernels (C ABI precision codes): MVS_PREC_BF16X3 (fp32 tensors, split while staging),
 // MVS_PREC_BF16X3_SPLIT (tensors stored as hi | lo bf16 pairs: template parameter SPLIT) and MVS_PREC_F16X2 (fp16 tensors, fp16 hi + lo
-// weights, two MFMA terms: tile configurations wrapped in F16Cfg, below) - the product default at inference.
+// weights, two MFMA terms: tile configurations wrapped in F16Cfg, below) - the format of the CostRegNet3D stages under the default policy (round 5; every stage in rounds 3-4).
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -64,7 +64,7 @@ struct F16Cfg : Base { static constexpr int ACT_F16 = 1; };
 // ONE fp16 term per weight (round 4, MVS_PREC_F16 / _F16MIX): the lo half of the packed weights is never read - half the MFMAs, half the
 // weight bytes.  Error study on the oracle (scripts/study_weight_precision.py): refined depth 5.5e-5 -> 7.0e-5 on plain inputs and
 // 4.2e-4 -> 4.8e-4 on the x30-logits stress set when EVERY layer drops w_lo; no measurable change when only the 32- and 64-channel
-// layers do (MVS_PREC_F16MIX, the product default).
+// layers do (MVS_PREC_F16MIX: the fine stages of the default policy).
 template <class Base>
 struct F16x1Cfg : Base { static constexpr int ACT_F16 = 2; };
 template <class Cfg, class = void> struct CfgFmt { static constexpr bool F16 = false, ONE = false; };

@@ -1164,7 +1164,7 @@ def _seeded_head(device, seed=11, peaky=False, conv_precision=None):
 
 
 def case_cascade_vs_oracle(device, H, W, V, peaky=False, conv_precision=None, **inputs):
-    """conv_precision "f16x2" (the product default): the same 1e-3 depth bar; the confidence (max softmax probability - not part of
+    """Any precision policy / format (None = the product default): the same 1e-3 depth bar; the confidence (max softmax probability - not part of
     the north-star bar) is allowed 1e-2 mean absolute error on the x30-logits stress set (bf16x3: 1e-3)."""
     head, args = _seeded_head(device, peaky=peaky, conv_precision=conv_precision)
     feats, projs, dv = synth.make_cascade_inputs(H, W, V, seed=2, rot_deg=1.0, **inputs)
@@ -1424,7 +1424,7 @@ def case_stage_transformer_golden(device, attention_precision=None):
 
 def case_cascade_shipped_golden(device, conv_precision=None, attention_precision=None):
     """Shipped regulariser mix (stage-1 transformer + Frustoconical PE, CostRegNet / CostRegNet3D after it) on the f4 inputs.
-    conv_precision "f16x2" (product default): the three U-Net stages and all four visibility CNNs in the fp16 form; 3e-4 instead of 1e-4.
+    conv_precision "f16x2" (round 3's default, opt-in): the three U-Net stages and all four visibility CNNs in the fp16 form; 3e-4 instead of 1e-4.
     attention_precision None = the module default ("attn16")."""
     from mvsformerplusplus_amd.cascade import CascadeDepthHead
     fx, f4 = load_golden("f9_cascade_shipped.npz"), load_golden("f4_cascade.npz")

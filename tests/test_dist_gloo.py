@@ -163,7 +163,7 @@ def _run(target, world, *args):
 @pytest.mark.parametrize("precision,tol", [(None, 5e-4), ("bf16x3", 1e-5)])
 @pytest.mark.parametrize("V", [4, 2])        # 3 source views over 2 ranks (2 + 1) and 1 source view (one rank idle); the even 1 + 1 split is inside the cascade tests
 def test_view_sharded_stage_matches_single_process(V, precision, tol):
-    """precision None = the product default ("f16x2"): the all-reduced fp32 volume is rounded to fp16 once (mvs_volume_to_f16) where the
+    """precision None = the product default (policy "stagemix": this D = 4 stage runs "f16mix"): the all-reduced fp32 volume is rounded to fp16 once (mvs_volume_to_f16) where the
     single-process aggregate pass rounds its own sum - the same values up to fp32 summation order, i.e. an fp16 ulp at a few voxels."""
     for rank, err, same in _run(_stage_worker, 2, V, precision):
         assert err <= tol, "rank %d: sharded depth differs from single-process depth by %g" % (rank, err)
@@ -172,7 +172,7 @@ def test_view_sharded_stage_matches_single_process(V, precision, tol):
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), (None, 2e-3)])
 def test_slab_mode_matches_single_process(precision, tol):
-    """None = f16x2 (the product default): the sharded path rounds the SUMMED partial volume to fp16 once (mvs_volume_to_f16), the single-process
+    """None = the product default (an fp16-format stage here): the sharded path rounds the SUMMED partial volume to fp16 once (mvs_volume_to_f16), the single-process
     path rounds in the aggregate pass - the same values up to fp32 summation order, i.e. an fp16 ulp (5e-4) at a few voxels."""
     for rank, err, same in _run(_slab_worker, 2, precision):
         assert err <= tol, "rank %d: slab-sharded outputs differ from single-process outputs by %g" % (rank, err)

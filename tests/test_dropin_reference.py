@@ -16,7 +16,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "models")), 
 
 @pytest.mark.parametrize("prec", [None, "bf16x3"])
 def test_patch_model_on_the_reference_network(emu, prec):
-    """prec None = the product defaults (fp16 regulariser activations, 16-bit attention operands): 5e-4 on depth; "bf16x3" = the
+    """prec None = the product defaults (policy "stagemix": fp32-equivalent coarse stages, fp16 regulariser activations on the fine ones; 16-bit attention operands): 5e-4 on depth; "bf16x3" = the
     fp32-equivalent forms of both: 2e-4 (the residue is the feature extractor's own fp32 summation order)."""
     sys.path.insert(0, REF)
     try:

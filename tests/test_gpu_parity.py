@@ -228,7 +228,7 @@ def test_baseline_cfgs_wide_range_vs_oracle(name, prec):
 @pytest.mark.parametrize("prec", PRECS)         # full size: the product default and the fp32-equivalent format (28 s each, most of it the CPU oracle);
 def test_cfg2_fullsize_vs_oracle(prec):         # "f16x2" / "f16" run the same comparison at 384x512 (test_cascade_midsize_vs_oracle)
     """BASELINE configs[1] at full size against the oracle (refined depth within 1e-3 relative L1, every stage too): the north-star bar
-    itself, in the product default format (measured ~5e-5) and in the fp32-equivalent one (~1e-6)."""
+    itself, in the product default (measured 2.4e-6 since round 5's exact coarse stages; 4.7e-5 in round 4's uniform fp16) and in the fp32-equivalent format (~1e-6)."""
     r = P.case_cfg2_fullsize_vs_oracle(DEV, conv_precision=prec)
     assert r <= P.tol(prec, 1e-5, 3e-4), r
 
@@ -254,7 +254,7 @@ def test_stage_transformer_golden(attn):
 
 @pytest.mark.parametrize("prec,attn", [(None, None), ("bf16x3", "bf16x3"), (None, "bf16x3")])
 def test_cascade_shipped_golden(prec, attn):
-    """The shipped regulariser mix (cost_reg_type of config/mvsformer++.json) end to end vs fixture f9: product defaults (fp16 U-Nets,
+    """The shipped regulariser mix (cost_reg_type of config/mvsformer++.json) end to end vs fixture f9: product defaults (policy "stagemix": fp16 U-Nets on the fine stages,
     16-bit attention), everything fp32-equivalent, and the mixed case."""
     P.case_cascade_shipped_golden(DEV, conv_precision=prec, attention_precision=attn)
 
