@@ -24,7 +24,8 @@ bf16 autocast the reference's own GPU path runs these layers under (test.py:250)
 format on every stage, `f16mix` round 4's uniform fp16 default.  `parity` = this run's refined depth against the fp32 CPU oracle on the
 same inputs (bar 1e-3).
 
-The reference views of a step are issued round-robin on `--streams` HIP streams (default 3): views are independent, so the small
+The reference views of a step are issued round-robin on `--streams` HIP streams (default 4 since round 5 - graph replay and the default
+policy's launch-bound coarse stages moved the optimum from 3: 606 vs 595 ref-views/s, three alternations on one box): views are independent, so the small
 latency-bound launches of one view's coarse stages overlap the large launches of another's fine stages; the single-stream
 figure (one view at a time, the reference's loop) is reported in `latency`, the per-kernel profile behind `roofline` is
 single-stream too.  Issue (round 5): one hipGraph replay per reference view (`CascadeDepthHead.capture`, one graph per (stream,
@@ -189,7 +190,7 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra `training_step` object (forward + backward of each cascade stage)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the reference views of a step are issued on round-robin (independent views overlap: the small "
                          "coarse-stage launches of one view run beside the large fine-stage launches of another, SURVEY.md section 8e); "
                          "the single-stream latency is reported beside it")

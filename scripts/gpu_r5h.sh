@@ -1,0 +1,9 @@
+#!/bin/bash
+# Round 5, evidence visit: randomised differential runs on the final code - single stages (80), cascades (a second seed, 60), training path (40)
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out; mkdir -p $OUT
+export PYTHONDONTWRITEBYTECODE=1
+timeout 900 python scripts/fuzz_gpu.py 80 5 2>&1 | grep -v amdgpu.ids > $OUT/fuzz_stage.log; tail -2 $OUT/fuzz_stage.log
+timeout 900 python scripts/fuzz_cascade_gpu.py 60 1 2>&1 | grep -v amdgpu.ids > $OUT/fuzz_cascade_seed1.log; tail -2 $OUT/fuzz_cascade_seed1.log
+timeout 900 python scripts/fuzz_train_gpu.py 40 2>&1 | grep -v amdgpu.ids > $OUT/fuzz_train.log; tail -2 $OUT/fuzz_train.log
