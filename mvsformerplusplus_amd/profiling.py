@@ -238,6 +238,13 @@ def profile_cascade(head: CascadeDepthHead, features, proj_matrices, depth_value
     confs = []
     final_conf = None
     pe_range = None
+    # Round 5: let the host run AHEAD of the device for the whole pass.  Issuing one reference view's ~60 launches + 120 events from Python takes
+    # longer (~2 ms) than the device needs for the short launches, so an idle device used to wait for the host between a start event and its
+    # kernel - the "~8 us of event overhead" rounds 3-4 reported on every sub-20-us launch (bench.py's avg_launch_ms 28 us against rocprofv3's
+    # 23 us for the same convolutions).  A spin kernel at the head of the stream (torch.cuda._sleep, ~10 ms) lets the whole pass queue up behind
+    # it: the events then bracket back-to-back device work.
+    if depth_values.is_cuda:
+        torch.cuda._sleep(int(2.0e7))
     # round 5: ONE prologue launch (every stage's homographies + stage 1's hypotheses), exactly as CascadeDepthHead.forward issues it
     H0, W0 = features["stage1"].shape[-2:]
     B0 = depth_values.shape[0]
