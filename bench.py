@@ -197,10 +197,12 @@ def main():
     ap.add_argument("--feat-dtype", choices=["fp32", "bf16", "fp16"], default="fp32",
                     help="dtype of the feature maps handed to the path (the reference's FPN emits bf16 under test.py:250's autocast and "
                          "StageNet upcasts per view, cost_volume.py:67); the headline keeps fp32")
-    ap.add_argument("--feat-layout", choices=["planar", "tiled"], default="planar",
+    ap.add_argument("--feat-layout", choices=["planar", "tiled", "emitted"], default="planar",
                     help="planar: [B,V,C,H,W] as the reference's FPN emits it (headline); tiled: the octet-tiled channel-last hand-off "
-                         "layout [B,V,C/8,H,W,8] (SURVEY.md section 8f #4) as a producer-side emitter would hand it over - packed once, "
-                         "outside the timed region")
+                         "layout [B,V,C/8,H,W,8] (SURVEY.md section 8f #4) packed once by mvs_pack_features, outside the timed region; "
+                         "emitted: stages 2-4 come out of the producer-side emitter itself (TiledFeatureHead = mvs_conv2d3x3_tiles_fwd, the feature "
+                         "side's last 3x3 convolution writing bf16 octet tiles from its epilogue, FMT.py:195-197) applied to the synthetic maps - "
+                         "mvs_pack_features never runs in the process; stage 1 (the FMT's own output in the reference, no convolution) stays planar")
     ap.add_argument("--view-sharded-timeout", type=int, default=120, help="N > 1: seconds the extra view-sharded latency leg may take")
     ap.add_argument("--view-sharded-only", action="store_true",
                     help="N > 1: run ONLY the view-sharded latency mode (SURVEY.md section 8e: the source views of ONE reference view over the ranks, "
@@ -279,6 +281,17 @@ def main():
     if a.feat_layout == "tiled":
         from mvsformerplusplus_amd import ops
         sets = [({k: ops.pack_features(v) for k, v in f.items()}, p, d) for f, p, d in sets]
+    elif a.feat_layout == "emitted":
+        import torch.nn as nn
+        from mvsformerplusplus_amd import TiledFeatureHead
+        heads_e = {}
+        for k, C in (("stage2", 32), ("stage3", 16), ("stage4", 8)):
+            conv = nn.Conv2d(C, C, 3, padding=1, bias=False)
+            with torch.no_grad():                             # identity + a small random 3x3 part: the views stay correlated, the convolution is real work
+                conv.weight.mul_(0.1)
+                conv.weight[torch.arange(C), torch.arange(C), 1, 1] += 1.0
+            heads_e[k] = TiledFeatureHead(conv, dtype=torch.bfloat16).to(device)
+        sets = [({k: (heads_e[k](v.float()) if k in heads_e else v) for k, v in f.items()}, p, d) for f, p, d in sets]
     feats, projs, dv = sets[0]
     R = max(1, a.views_per_step)
     torch.cuda.synchronize()
@@ -377,7 +390,8 @@ def main():
                    "views_per_forward_call": BATCH, "issue": issue_text,
                    "ref_views_per_step_per_gpu": R, "input_sets": nsets, "timed_seconds": elapsed,
                    "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams,
-                   "features": "%s %s resident in HBM" % (a.feat_dtype, "octet-tiled [B,V,C/8,H,W,8]" if a.feat_layout == "tiled" else "planar [B,V,C,H,W]")},
+                   "features": "%s %s resident in HBM" % (a.feat_dtype, {"tiled": "octet-tiled [B,V,C/8,H,W,8]", "planar": "planar [B,V,C,H,W]",
+                                                                           "emitted": "planar stage 1 + bf16 octet tiles written by the producer-side emitter (stages 2-4)"}[a.feat_layout])},
         "ms_per_ref_view": ms_per_step / R,
         "latency": {"single_stream_ms_per_ref_view": latency_ms, "single_stream_ref_views_per_s": 1e3 / latency_ms,
                     "note": "one reference view at a time on one stream (the reference's loop, test.py:238-252), same rotating inputs"},
