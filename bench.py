@@ -208,7 +208,7 @@ def main():
                     help="N > 1: run ONLY the view-sharded latency mode (SURVEY.md section 8e: the source views of ONE reference view over the ranks, "
                          "RCCL all-reduce / slab exchange per stage, BASELINE configs[2]'s V = 10) and print its JSON line: value = reference views "
                          "per second of the whole group, scaling 'strong'.  For a first RCCL contact without the data-parallel headline in front of it")
-    ap.add_argument("--conv-precision", choices=["stagemix", "bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
+    ap.add_argument("--conv-precision", choices=["stagemix", "auto", "bf16x3", "f16x2", "f16mix", "f16", "fp32"], default=None,
                     help="contraction / activation format of the 3-D regularisers (default: the package default, cost_volume.STAGE_DEFAULT_PRECISION)")
     ap.add_argument("--keep-min-depth", type=int, default=None,
                     help="A/B: cost_volume.KEEP_MIN_DEPTH (planes from which the fp16 gather form keeps fp16 correlations; 1 = stage 4's D = 4 too)")
@@ -424,6 +424,9 @@ def main():
                     "accumulation everywhere (the reference's GPU path runs the regulariser under bf16 autocast, test.py:250)",
         "fp32": "fp32-exact MFMA contraction"}[prec0]
     result["dtype"] = DTYPE_TEXT[prec0]
+    if a.conv_precision == "auto":
+        result["config"]["conv_precision"] = ("auto (opt-in): chose '%s' for this workload's depth range (depth_max / depth_min = 2.2 against the critical 12.6); " % prec0
+                                              + result["config"]["conv_precision"])
     if prec0 in ("f16x2", "f16mix", "f16", "stagemix"):
         result["config"]["gather_pass2"] = ("second gather on every stage (--no-keep-correlations)" if a.no_keep_correlations else
                                             "stream of the per-view correlations kept by pass 1 (fp32 on the exact coarse stages from D = 16 on, fp16 "

@@ -35,6 +35,8 @@ class CascadeDepthHead(nn.Module):
         self.cost_reg_type = list(args.get("cost_reg_type", ["Normal"] * len(self.ndepths)))
         self.use_pe3d = args.get("use_pe3d", False)
         self.fusions = nn.ModuleList([StageNet(args, self.ndepths[i], i) for i in range(len(self.ndepths))])
+        self._auto = args.get("conv_precision") == "auto"
+        self._auto_cache: Dict[tuple, str] = {}
 
     def set_view_group(self, group, shard_mode: str = "auto") -> None:
         """Shard source views over the ranks of `group`.  shard_mode: "allreduce" = one all-reduce of the
@@ -43,6 +45,37 @@ class CascadeDepthHead(nn.Module):
         for f in self.fusions:
             f.view_group = group
             f.shard_mode = shard_mode
+
+    # conv_precision="auto" (opt-in): the uniform fp16 format where the depth range makes it safe, the exact coarse stages elsewhere.
+    AUTO_SAFETY = 0.5          # fraction of the critical range ratio up to which "f16mix" is chosen
+
+    def _auto_policy(self, depth_values: torch.Tensor) -> str:
+        """The reference's inverse-depth schedule (module.py:707-724) takes 1/depth -/+ r2 * itv with itv = stage 1's inverse spacing: for
+        depth_max / depth_min >= (ndepths[0] - 1) / r2 + 1 (12.6 in the shipped configs) the window of far pixels crosses zero, and well before
+        that the hypotheses around such pixels amplify whatever noise the coarse stages carry (fp16 coarse stages reach
+        3-5e-3 at ratio 20, 1.5e-4 at ratio 6, 6e-5 at DTU's 2.2).  "auto" = "f16mix" on every stage while the ratio stays below AUTO_SAFETY x
+        that critical value, "stagemix" otherwise (and always for the linear schedule, which was not studied).  The ratio is read from the
+        DEVICE tensor - one small synchronising copy the first time a depth_values tensor (identity + version) is seen, cached after that;
+        inside a hipGraph capture an unseen tensor raises (capture() warms up on the same tensors first, so this does not happen there)."""
+        import math
+        key = (depth_values.data_ptr(), depth_values._version, tuple(depth_values.shape), str(depth_values.device))
+        hit = self._auto_cache.get(key)
+        if hit is None:
+            if depth_values.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("conv_precision='auto' has to read the depth range of a depth_values tensor it has not seen before; call the head "
+                                   "once on these tensors before capturing (CascadeDepthHead.capture does)")
+            dv = depth_values.detach().float()
+            if dv.dim() == 2 and self.inverse_depth and len(self.ndepths) > 1:
+                a, b = dv[:, 0], dv[:, -1]
+                ratio = float((torch.maximum(a, b) / torch.minimum(a, b)).max())          # the one synchronisation
+                crit = (self.ndepths[0] - 1) / float(self.depth_interals_ratio[1]) + 1.0
+                hit = "f16mix" if (math.isfinite(ratio) and ratio >= 1.0 and ratio <= self.AUTO_SAFETY * crit) else "stagemix"
+            else:
+                hit = "stagemix"
+            if len(self._auto_cache) >= 256:
+                self._auto_cache.clear()
+            self._auto_cache[key] = hit
+        return hit
 
     def capture(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
                 tmp: Sequence[float] = (5.0, 5.0, 5.0, 1.0)) -> "GraphedCascade":
@@ -54,6 +87,11 @@ class CascadeDepthHead(nn.Module):
     def forward(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
                 tmp: Sequence[float] = (5.0, 5.0, 5.0, 1.0)) -> Dict[str, torch.Tensor]:
         n = len(self.ndepths)
+        if self._auto:
+            pol = self._auto_policy(depth_values)
+            for f in self.fusions:
+                if f.precision_policy != pol:
+                    f.conv_precision = pol                    # re-resolves the stage (packed weights are cached per format)
         depth_interval = depth_values[:, 1] - depth_values[:, 0]
         outputs: Dict[str, torch.Tensor] = {}
         stage_out: Optional[Dict[str, torch.Tensor]] = None

@@ -56,14 +56,17 @@ MFMA_FORMATS = ("bf16x3",) + F16_FORMATS
 # CORRELATIONS carry the error - 1.1e-3 / 1.8e-3 - not the fp16 windows).  A uniform format ("f16mix", "f16x2", "f16", "bf16x3", "fp32")
 # stays available per head.
 DEFAULT_STAGE_POLICY = "stagemix"
-STAGE_POLICIES = ("stagemix",)
+# "auto" (opt-in, round 5): CascadeDepthHead decides per call between "stagemix" and the uniform "f16mix" from the depth range it is
+# handed (cascade.CascadeDepthHead._auto_policy: depth_max / depth_min against the ratio at which the inverse-depth schedule degenerates);
+# a StageNet used on its own (patch_model: the reference's loop hands it hypotheses, not the range) resolves "auto" like "stagemix".
+STAGE_POLICIES = ("stagemix", "auto")
 
 
 def resolve_stage_precision(policy: str, ndepth: int, model_th: int = 8):
     """(conv_precision, gather_precision) of a stage under `policy` = args["conv_precision"]: "stagemix" (above) or one format for every
     stage.  gather_precision "f16" = fp16 source windows + fp16 kept correlations (the fp16 formats); "f32" = fp32 windows, pass 2 exact
     (fp32 kept correlations or a second gather) - "bf16x3" / "fp32" and the coarse stages of "stagemix"."""
-    if policy == "stagemix":
+    if policy in ("stagemix", "auto"):
         return ("bf16x3", "f32") if ndepth > model_th else (DEFAULT_PRECISION, "f16")
     if policy in F16_FORMATS:
         return policy, "f16"

@@ -527,6 +527,31 @@ def case_stage_lowp_features(device, prec=None):
 
 
 # ---------------------------------------------------------------- a10-a15 small functions
+def case_auto_policy(device, quick=False):
+    """conv_precision="auto" (opt-in, round 5): CascadeDepthHead picks the uniform "f16mix" format while depth_max / depth_min stays below half the
+    ratio at which the inverse-depth schedule degenerates ((ndepths[0] - 1) / ratio[1] + 1 = 12.6), the default policy's exact coarse stages
+    otherwise - per call, from the depth_values it is handed (cached per tensor).  Bit-identical to the explicitly configured head either way."""
+    def head_of(policy):
+        h, _ = _seeded_head(device, conv_precision=policy)
+        return h
+    auto = head_of("auto")
+    assert [f.precision_policy for f in auto.fusions] == ["auto"] * 4 and auto.fusions[0].conv_precision == "bf16x3"     # unresolved: the safe form
+    for inputs, want in ((dict(), "f16mix"), (dict(numdepth=64, depth_min=0.5, depth_interval=9.5 / 63, baseline=0.03), "stagemix"),
+                         (dict(numdepth=64, depth_min=0.5, depth_interval=2.5 / 63, baseline=0.03), "f16mix"))[:2 if quick else 3]:
+        feats, projs, dv = synth.make_cascade_inputs(64, 64, 3, seed=3, rot_deg=1.0, **inputs)
+        fd, pd, dd = {k: dev(v, device) for k, v in feats.items()}, {k: dev(v, device) for k, v in projs.items()}, dev(dv, device)
+        with torch.no_grad():
+            out = auto(fd, pd, dd)
+            assert [f.precision_policy for f in auto.fusions] == [want] * 4, (inputs, [f.precision_policy for f in auto.fusions])
+            ref = head_of(want)(fd, pd, dd)
+            again = out if quick else auto(fd, pd, dd)       # cached decision: no second read of the range
+        for k in ("refined_depth", "photometric_confidence"):
+            assert torch.equal(cpu(out[k]), cpu(ref[k])) and torch.equal(cpu(out[k]), cpu(again[k])), (want, k)
+    # a StageNet on its own (the reference's loop hands it hypotheses, not the range) resolves "auto" like the default policy
+    st = StageNet(dict(ARGS, conv_precision="auto"), 32, 0)
+    assert (st.conv_precision, st.gather_precision) == ("bf16x3", "f32")
+
+
 def case_feature_heads(device):
     """SURVEY section 8f #4, producer side (round 5): TiledFeatureHead - the feature side's last 3x3 convolution emitting the octet-tiled
     hand-off layout from its epilogue - against fixture F20 (inputs / outputs of the reference's own FMT_with_pathway.smooth_k and

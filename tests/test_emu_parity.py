@@ -94,6 +94,10 @@ def test_small_fns(emu):
     P.case_small_fns(emu)
 
 
+def test_auto_policy(emu):
+    P.case_auto_policy(emu, quick=True)
+
+
 def test_feature_heads(emu):
     P.case_feature_heads(emu)
 

@@ -106,6 +106,10 @@ def test_small_fns():
     P.case_small_fns(DEV)
 
 
+def test_auto_policy():
+    P.case_auto_policy(DEV)
+
+
 def test_feature_heads():
     P.case_feature_heads(DEV)
 
