@@ -46,6 +46,31 @@ def test_product_default_precision():
     assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("stagemix", "f16mix", "f16")
 
 
+def test_auto_policy_decisions():
+    """conv_precision="auto" (opt-in): the decision rule of CascadeDepthHead._auto_policy on host tensors (no kernel runs): uniform "f16mix" while
+    depth_max / depth_min <= half the critical ratio (ndepths[0] - 1) / ratio[1] + 1, "stagemix" beyond it, for the linear schedule, for
+    per-pixel ranges and for non-finite / non-positive values; cached per tensor identity and version."""
+    import torch
+    from mvsformerplusplus_amd.cascade import CascadeDepthHead
+    args = {"base_ch": [8] * 4, "depth_type": ["ce"] * 4, "ndepths": [32, 16, 8, 4], "depth_interals_ratio": [4.0, 2.67, 1.5, 1.0],
+            "inverse_depth": True, "conv_precision": "auto"}
+    h = CascadeDepthHead(dict(args))
+    crit = 31 / 2.67 + 1
+    assert h._auto_policy(torch.linspace(425.0, 931.0, 192)[None]) == "f16mix"                       # DTU: ratio 2.2
+    assert h._auto_policy(torch.linspace(0.5, 0.5 * 0.49 * crit, 64)[None]) == "f16mix"
+    assert h._auto_policy(torch.linspace(0.5, 0.5 * 0.51 * crit, 64)[None]) == "stagemix"
+    assert h._auto_policy(torch.linspace(0.5, 10.0, 256)[None]) == "stagemix"                       # BASELINE cfg4's literal range: ratio 20
+    assert h._auto_policy(torch.linspace(10.0, 0.5, 256)[None]) == "stagemix"                       # either order
+    assert h._auto_policy(torch.stack([torch.linspace(425.0, 931.0, 8), torch.linspace(0.5, 10.0, 8)])) == "stagemix"     # worst batch item decides
+    assert h._auto_policy(torch.tensor([[0.0, 1.0, 2.0]])) == "stagemix" and h._auto_policy(torch.tensor([[1.0, float("nan")]])) == "stagemix"
+    assert h._auto_policy(torch.rand(1, 4, 6, 8) + 1.0) == "stagemix"                               # per-pixel ranges: not analysed
+    t = torch.linspace(425.0, 931.0, 192)[None].clone()
+    assert h._auto_policy(t) == "f16mix"
+    t[:, -1] = 9000.0                                                                               # in-place change = a new version = a new decision
+    assert h._auto_policy(t) == "stagemix"
+    assert CascadeDepthHead(dict(args, inverse_depth=False))._auto_policy(torch.linspace(425.0, 931.0, 192)[None]) == "stagemix"
+
+
 def test_header_matches_binding_table():
     assert header_symbols() == sorted(_lib.SIGNATURES)
 
