@@ -203,6 +203,10 @@ def main():
                          "emitted: stages 2-4 come out of the producer-side emitter itself (TiledFeatureHead = mvs_conv2d3x3_tiles_fwd, the feature "
                          "side's last 3x3 convolution writing bf16 octet tiles from its epilogue, FMT.py:195-197) applied to the synthetic maps - "
                          "mvs_pack_features never runs in the process; stage 1 (the FMT's own output in the reference, no convolution) stays planar")
+    ap.add_argument("--emit-dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="--feat-layout emitted: dtype of the emitter's octet tiles.  fp16 tiles are what the fp16 gather forms hold in LDS anyway "
+                         "(same values as fp32 features rounded once); with them the fine stages' gather needs no window at all - a tap of 8 channels "
+                         "is one 16-byte run, four buffer loads per plane straight from HBM / L2 (gather_lds.h, MVS_GL_DIRECT16)")
     ap.add_argument("--view-sharded-timeout", type=int, default=120, help="N > 1: seconds the extra view-sharded latency leg may take")
     ap.add_argument("--view-sharded-only", action="store_true",
                     help="N > 1: run ONLY the view-sharded latency mode (SURVEY.md section 8e: the source views of ONE reference view over the ranks, "
@@ -290,7 +294,7 @@ def main():
             with torch.no_grad():                             # identity + a small random 3x3 part: the views stay correlated, the convolution is real work
                 conv.weight.mul_(0.1)
                 conv.weight[torch.arange(C), torch.arange(C), 1, 1] += 1.0
-            heads_e[k] = TiledFeatureHead(conv, dtype=torch.bfloat16).to(device)
+            heads_e[k] = TiledFeatureHead(conv, dtype=torch.float16 if a.emit_dtype == "fp16" else torch.bfloat16).to(device)
         sets = [({k: (heads_e[k](v.float()) if k in heads_e else v) for k, v in f.items()}, p, d) for f, p, d in sets]
     feats, projs, dv = sets[0]
     R = max(1, a.views_per_step)
@@ -311,7 +315,7 @@ def main():
             torch.cuda.synchronize()
         streams = [torch.cuda.Stream(device=device) for _ in range(a.streams)] if a.streams > 1 else None
 
-        def make_runner(hd):
+        def make_runner(hd, sets=sets):
             """-> (run(n_steps, first), issue text).  Graph mode: one captured hipGraph per (stream, input set); a capture that fails
             falls back to eager issue and says so in config.issue (the headline must not die on it)."""
             graphs, issue = {}, "eager launches"
@@ -391,7 +395,7 @@ def main():
                    "ref_views_per_step_per_gpu": R, "input_sets": nsets, "timed_seconds": elapsed,
                    "parallelism": "dp%d over reference views" % world, "streams_per_gpu": a.streams,
                    "features": "%s %s resident in HBM" % (a.feat_dtype, {"tiled": "octet-tiled [B,V,C/8,H,W,8]", "planar": "planar [B,V,C,H,W]",
-                                                                           "emitted": "planar stage 1 + bf16 octet tiles written by the producer-side emitter (stages 2-4)"}[a.feat_layout])},
+                                                                           "emitted": "planar stage 1 + %s octet tiles written by the producer-side emitter (stages 2-4)" % a.emit_dtype}[a.feat_layout])},
         "ms_per_ref_view": ms_per_step / R,
         "latency": {"single_stream_ms_per_ref_view": latency_ms, "single_stream_ref_views_per_s": 1e3 / latency_ms,
                     "note": "one reference view at a time on one stream (the reference's loop, test.py:238-252), same rotating inputs"},
@@ -592,18 +596,18 @@ def main():
 
     # ---- extra: the fp32-equivalent regulariser format ("bf16x3") on the same weights, inputs and loop, outside the timed headline: the
     #      driver's own BENCH line then carries both modes (the headline runs the product default policy) ----
-    def side_leg(hd, n2):
-        """ref-views/s of another head on the headline's inputs, streams and issue mode (n2 timed steps after one warm-up step) + its
-        outputs on input set 0."""
+    def side_leg(hd, n2, use_sets=None):
+        """ref-views/s of another head on the headline's inputs (or `use_sets`), streams and issue mode (n2 timed steps after one warm-up step)
+        + its outputs on input set 0."""
         with torch.no_grad():
-            run2, issue2 = make_runner(hd)
+            run2, issue2 = make_runner(hd) if use_sets is None else make_runner(hd, use_sets)
             run2(1)
             sync_all()
             t0 = time.perf_counter()
             run2(n2, first=1)
             sync_all()
             dt = (time.perf_counter() - t0) / n2
-            o = hd(feats, projs, dv, tmp=TMP)
+            o = hd(feats, projs, dv, tmp=TMP) if use_sets is None else hd(*use_sets[0], tmp=TMP)
             o = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}
             torch.cuda.synchronize()
         del run2
@@ -637,6 +641,25 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 result["uniform_f16mix_mode"] = {"error": repr(e)}
+            # ... and the default policy fed with the hand-off a producer-side emitter gives it: the SAME features of
+            # stages 3-4 (the fp16 gather forms) as fp16 octet tiles, where a tap of 8 channels is one 16-byte run and the gather needs no LDS
+            # window (gather_lds.h, MVS_GL_DIRECT16); packed here by mvs_pack_features outside the timed region, like every input
+            if a.feat_layout == "planar" and a.feat_dtype == "fp32":
+                try:
+                    from mvsformerplusplus_amd import ops as _ops
+                    sets_t = [({k: (_ops.pack_features(v, torch.float16) if k in ("stage3", "stage4") else v) for k, v in f.items()}, p, d) for f, p, d in sets]
+                    n2 = max(2, a.steps // 4)
+                    tt, outt, _ = side_leg(head, n2, use_sets=sets_t)
+                    result["fp16_tiles_handoff_mode"] = {"features": "stages 3-4 as fp16 octet tiles [B,V,C/8,H,W,8] (TiledFeatureHead / mvs_conv2d3x3_tiles_fwd with fp16 output, or "
+                                                                     "mvs_pack_features), stages 1-2 as in the headline", "value": R / tt, "unit": "ref-views/s",
+                                                         "ms_per_ref_view": tt / R * 1e3, "steps": n2,
+                                                         "default_vs_this_refined_depth_rel_l1": float(((out["refined_depth"] - outt["refined_depth"]).abs() / outt["refined_depth"].abs()).mean()),
+                                                         "note": "same arithmetic as the headline (its fp16 windows hold exactly these values): the gather of stages 3-4 reads "
+                                                                 "the taps straight from the tiles, four 16-byte buffer loads per plane and octet, no bounding box / window / barrier"}
+                    del sets_t, outt
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    result["fp16_tiles_handoff_mode"] = {"error": repr(e)}
 
     # ---- extra (round 5): the SHIPPED regulariser mix (stage-1 transformer + PE3D - what released checkpoints run) on the same
     #      inputs, outside the timed headline: value + its own parity against the oracle ----

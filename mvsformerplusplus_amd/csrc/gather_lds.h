@@ -56,6 +56,16 @@ constexpr int GL_TH = 4;           // tile height in pixels
 //   (exact for fp16 / in-range bf16 features) and nothing else changes.  The fp16 volume formats use it (MVS_GATHER_F16).
 __device__ __forceinline__ float gl_round_f16(float v) { return (float)(_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
 
+// DIRECT (round 5, MVS_GL_DIRECT16): with fp16 octet tiles in HBM (the producer-side emitter's fp16 hand-off, mvs_conv2d3x3_tiles_fwd) a bilinear
+// tap of 8 channels IS one 16-byte run - the four taps of a plane are four buffer_load_dwordx4 with ONE 32-bit offset register (the right
+// column through the instruction's immediate offset, the lower row through a wave-uniform soffset), so the unit needs no bounding box, no
+// window, no barrier and no LDS at all.  Same fp16 values, same v_fma_mix order as the fp16 window path: bit-identical results.
+#ifndef MVS_GL_DIRECT16
+#define MVS_GL_DIRECT16 1
+#endif
+template <typename T, bool TILED, bool W16>
+constexpr bool gl_direct_v = (MVS_GL_DIRECT16 != 0) && W16 && TILED && std::is_same<T, _Float16>::value;
+
 template <typename T, int NOCT, bool KEEP_GROUPS, bool TILED, bool W16>
 __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __restrict__ ref, const Homography& hm, float fx, float fy,
                                         const float* depth, bool active, int H, int W, unsigned HW, unsigned pc, f32x4* win,
@@ -77,6 +87,85 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             mn = __builtin_elementwise_min(mn, gl_as_vec(tp[dd].pk));
             mx = __builtin_elementwise_max(mx, gl_as_vec(tp[dd].pk));
         }
+    }
+    if constexpr (gl_direct_v<T, TILED, W16>) {
+        if (!active) return;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        unsigned tofs[GL_DCH];
+#pragma unroll
+        for (int dd = 0; dd < GL_DCH; ++dd) {
+            const unsigned pk = tp[dd].pk;
+            tofs[dd] = pk == GL_NONE ? 0u : ((pk >> 16) * (unsigned)W + (pk & 0xffffu)) * 16u;
+        }
+        const int rowb = W * 16;                                 // wave-uniform: the lower tap row through soffset
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) {
+            unsigned oofs = gl_octet_offset(o, HW);
+            asm volatile("" : "+" MVS_OPAQUE_SREG(oofs));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src + oofs), 0, (int)(HW * 16u), 0x00020000);
+            float rf[8];
+            if (NOCT > 1) {
+                gl_load8<TILED, T>(ref + oofs, HW, pc, rf);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rf[c] = rf_in[c];
+            }
+            u32x4 t[GL_DCH][4];
+#pragma unroll
+            for (int dd = 0; dd < GL_DCH; ++dd) {
+#if MVS_GL_DIRECT16 == 3      // ablation (scripts/prof_gather_direct.py): no loads
+                (void)rs; (void)rowb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[dd][k] = u32x4{tofs[dd], tofs[dd] + (unsigned)k, tofs[dd] ^ 0x3c003c00u, 0x3c003c00u};
+#else
+                t[dd][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], 0, 0);
+                t[dd][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), 0, 0);
+                t[dd][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], rowb, 0);
+                t[dd][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), rowb, 0);
+#endif
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rf[c] *= wscale;
+#pragma unroll
+            for (int dd = 0; dd < GL_DCH; ++dd) {
+                float wv[8];
+#if MVS_GL_DIRECT16 == 2      // ablation: the loads are consumed by one xor each, no interpolation
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned x = t[dd][0][j] ^ t[dd][1][j] ^ t[dd][2][j] ^ t[dd][3][j];
+                    wv[2 * j] = __builtin_bit_cast(float, x & 0x3fffffffu);
+                    wv[2 * j + 1] = tp[dd].w00;
+                }
+#else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = MVS_FMA_MIX_LO(t[dd][0][j], tp[dd].w00, 0.0f);
+                    a = MVS_FMA_MIX_LO(t[dd][1][j], tp[dd].w01, a);
+                    a = MVS_FMA_MIX_LO(t[dd][2][j], tp[dd].w10, a);
+                    wv[2 * j] = MVS_FMA_MIX_LO(t[dd][3][j], tp[dd].w11, a);
+                    float b = MVS_FMA_MIX_HI(t[dd][0][j], tp[dd].w00, 0.0f);
+                    b = MVS_FMA_MIX_HI(t[dd][1][j], tp[dd].w01, b);
+                    b = MVS_FMA_MIX_HI(t[dd][2][j], tp[dd].w10, b);
+                    wv[2 * j + 1] = MVS_FMA_MIX_HI(t[dd][3][j], tp[dd].w11, b);
+                }
+#endif
+                if (KEEP_GROUPS) {
+#pragma unroll
+                    for (int j = 0; j < GPO; ++j) {
+                        float s = out[(o * GPO + j) * GL_DCH + dd];
+#pragma unroll
+                        for (int c = 0; c < CPG; ++c) s += rf[j * CPG + c] * wv[j * CPG + c];
+                        out[(o * GPO + j) * GL_DCH + dd] = s;
+                    }
+                } else {
+                    float s = out[dd];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) s += rf[c] * wv[c];
+                    out[dd] = s;
+                }
+            }
+        }
+        return;
     }
     mn = gl_wave_reduce<false>(mn);                               // lane 63 holds the wave's result
     mx = gl_wave_reduce<true>(mx);
@@ -377,6 +466,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
             __syncthreads();
             // the next view's first sim store comes after its unit's barrier (A): no second barrier needed here
             if (t.slot == 0 && t.valid) gl_softmax_entropy_store(sim + t.pi, TP, D, dst);
+            if constexpr (gl_direct_v<T, TILED, W16>) __syncthreads();   // no barrier (A) in the direct unit: the next view's sim stores wait here
         }
     }
     if (KEEP && W16) sat::commit(sat_amax);

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void pack_features_kernel(const TI* __restrict
     to8 v;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const float f = to_f32(src[(size_t)c * HW]);
+        float f = to_f32(src[(size_t)c * HW]);
+        // narrowing to fp16: clamped to the fp16 range, like the fp16 windows' staging (gather_lds.h) and the emitter's epilogue - the same values
+        if (std::is_same<TO, _Float16>::value && !std::is_same<TI, _Float16>::value) f = fminf(fmaxf(f, -65504.0f), 65504.0f);
         if (sizeof(TI) == 2 && sizeof(TO) == 2) v[c] = *reinterpret_cast<const TO*>(&src[(size_t)c * HW]);      // same 2-byte type: bit copy
         else v[c] = from_f32<TO>(f);
     }

@@ -523,6 +523,16 @@ def case_stage_lowp_features(device, prec=None):
             out = net(dev(f, device), dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
         errs.append(rel_l1(cpu(out["depth"]), ref["depth"]))
         assert errs[-1] <= tol(prec, 2e-5, 2e-4), errs      # fp16: measured 4.8e-5
+        if dt == torch.float16:
+            # the same features handed over as fp16 octet tiles (the emitter's fp16 hand-off): in the fp16 gather forms the taps are read straight
+            # from the tiles (gather_lds.h, MVS_GL_DIRECT16 - no window) - the same values in the same order: every output bit for bit
+            with torch.no_grad():
+                out_t = net(ops.pack_features(dev(f, device)), dev(fx["proj"], device), dev(fx["hyp"], device), 1.0)
+            same = all(torch.equal(cpu(out[k]), cpu(out_t[k])) for k in ("depth", "photometric_confidence", "prob_volume"))
+            if net.gather_precision == "f16":
+                assert same, "fp16 tiles (direct gather) must reproduce planar fp16 features (fp16 windows) bit for bit"
+            else:
+                assert rel_l1(cpu(out_t["depth"]), cpu(out["depth"])) <= 1e-6
     return errs
 
 
@@ -858,6 +868,9 @@ def case_gather_variants(device, quick=False):
                     v_p = ops.warp_corr_aggregate(fh, ops._feat(fh)[1], hom, hd, dev(vis, device), G, f16=True)[0]
                     v_t = ops.warp_corr_aggregate(ft16, ops._feat(ft16)[1], hom, hd, dev(vis, device), G, f16=True)[0]
                     assert torch.equal(cpu(v_p), cpu(v_t)), (C, D, "fp16 tiles: copy staging, pass 2")
+                    w_p = ops.warp_corr_entropy(fh, ops._feat(fh)[1], hom, hd, G, f16_window=True)
+                    w_t = ops.warp_corr_entropy(ft16, ops._feat(ft16)[1], hom, hd, G, f16_window=True)
+                    assert torch.equal(cpu(w_p), cpu(w_t)), (C, D, "fp16 tiles: plain pass 1")
                 if D <= 4:
                     continue
                 # round 5: the EXACT keeping pass (MVS_CORR_F32: fp32 windows, fp32 kept correlations - the coarse stages of the default
