@@ -63,10 +63,14 @@ __device__ __forceinline__ float gl_round_f16(float v) { return (float)(_Float16
 #ifndef MVS_GL_DIRECT16
 #define MVS_GL_DIRECT16 1
 #endif
-template <typename T, bool TILED, bool W16>
-constexpr bool gl_direct_v = (MVS_GL_DIRECT16 != 0) && W16 && TILED && std::is_same<T, _Float16>::value;
+// Where it is used is a measured choice (profiles/r05_gather_direct_pmc.txt): the direct form is bound by the vector-memory return path (~25-33 TD
+// cycles per 16-byte-per-lane load), which grows with the octet count, while the window form amortises its bounding box over the octets - C = 8 (one
+// octet) wins in every pass (-16 % pass 2, -8 % pass 1), C = 16 wins only in the keeping pass 1 (-3.5 %) and loses 5-17 % in the plain passes; C >= 32 keeps
+// the windows.
+template <typename T, bool TILED, bool W16, int NOCT, bool KEEPPASS>
+constexpr bool gl_direct_v = (MVS_GL_DIRECT16 != 0) && W16 && TILED && std::is_same<T, _Float16>::value && (NOCT == 1 || (NOCT == 2 && KEEPPASS));
 
-template <typename T, int NOCT, bool KEEP_GROUPS, bool TILED, bool W16>
+template <typename T, int NOCT, bool KEEP_GROUPS, bool TILED, bool W16, bool DIRECT = false>
 __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __restrict__ ref, const Homography& hm, float fx, float fy,
                                         const float* depth, bool active, int H, int W, unsigned HW, unsigned pc, f32x4* win,
                                         unsigned* red, int unit, float wscale, const float* rf_in, float* out) {
@@ -88,7 +92,8 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             mx = __builtin_elementwise_max(mx, gl_as_vec(tp[dd].pk));
         }
     }
-    if constexpr (gl_direct_v<T, TILED, W16>) {
+    if constexpr (DIRECT) {
+        static_assert(W16 && TILED && std::is_same<T, _Float16>::value, "the direct form reads fp16 octet tiles");
         if (!active) return;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         unsigned tofs[GL_DCH];
@@ -369,6 +374,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
                                                          void* __restrict__ corr, int V, int D, int H,
                                                          int W, int view_begin, int view_end, int vpb, int ntx, int nblk) {
     typedef typename FeatT<DT>::type T;
+    constexpr bool DIRECT = gl_direct_v<T, TILED, W16, NOCT, KEEP>;
     HIP_DYNAMIC_SHARED(float, smem)
     f32x4* win = reinterpret_cast<f32x4*>(smem);
     unsigned* red = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem) + GL_WIN_BYTES);
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
                 float acc[8 * GL_DCH];
 #pragma unroll
                 for (int i = 0; i < 8 * GL_DCH; ++i) acc[i] = 0.0f;
-                gl_unit<T, NOCT, true, TILED, W16>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, acc);
+                gl_unit<T, NOCT, true, TILED, W16, DIRECT>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, acc);
                 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
                 const size_t cbase = (size_t)(b * (V - 1) + (v - 1)) * D * HW + t.pc;
 #pragma unroll
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
                     }
                 }
             } else {
-                gl_unit<T, NOCT, false, TILED, W16>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, s);   // sum_g mean_c = (1/cpg) sum_c
+                gl_unit<T, NOCT, false, TILED, W16, DIRECT>(src, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg, rf0, s);   // sum_g mean_c = (1/cpg) sum_c
             }
             if (NS > 1 || niter > 1) {
                 if (chunk < nch) {
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256) void gl_entropy_kernel(const void* __restrict_
             __syncthreads();
             // the next view's first sim store comes after its unit's barrier (A): no second barrier needed here
             if (t.slot == 0 && t.valid) gl_softmax_entropy_store(sim + t.pi, TP, D, dst);
-            if constexpr (gl_direct_v<T, TILED, W16>) __syncthreads();   // no barrier (A) in the direct unit: the next view's sim stores wait here
+            if constexpr (DIRECT) __syncthreads();   // no barrier (A) in the direct unit: the next view's sim stores wait here
         }
     }
     if (KEEP && W16) sat::commit(sat_amax);
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256) void gl_aggregate_kernel(const void* __restric
     for (int v = view_begin; v < view_end; ++v, ++unit) {
         const Homography hm = gl_load_homography(hom + (size_t)(b * (V - 1) + (v - 1)) * 12);
         const float w = vp[(unsigned)(v - 1) * HW];                                               // cost_volume.py:97
-        gl_unit<T, NOCT, true, TILED, W16>(feat + (size_t)v * C * HW, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg * w, rf0, acc);
+        gl_unit<T, NOCT, true, TILED, W16, gl_direct_v<T, TILED, W16, NOCT, false>>(feat + (size_t)v * C * HW, ref, hm, t.fx, t.fy, depth, active, H, W, HW, t.pc, win, red, unit, inv_cpg * w, rf0, acc);
     }
     if (active) {
         float* vb = vol + (size_t)b * D * HW * 8;
