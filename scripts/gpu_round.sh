@@ -26,7 +26,7 @@ python - <<'PY'
 import json
 r = json.loads(open('gpurun_out/bench.json').read().strip().splitlines()[-1])
 print({k: r[k] for k in ('value', 'ms_per_step', 'ms_per_ref_view') if k in r})
-for k in ('latency', 'whole_path', 'roofline', 'cpu_baseline', 'parity', 'fp32_equivalent_mode', 'uniform_f16mix_mode', 'shipped', 'feature_emitter'):
+for k in ('latency', 'whole_path', 'roofline', 'cpu_baseline', 'parity', 'fp32_equivalent_mode', 'uniform_f16mix_mode', 'fp16_tiles_handoff_mode', 'shipped', 'feature_emitter'):
     print(k, r.get(k))
 print('gather', r.get('gather_roofline', {}).get('all_passes'))
 PY
@@ -48,6 +48,10 @@ echo "== bench, bf16 features in the octet-tiled hand-off layout =="
 timeout 600 python bench.py --steps 6 --warmup 2 --no-profile --no-cpu-baseline --feat-layout tiled --feat-dtype bf16 > $OUT/bench_tiled_bf16.json 2>/dev/null
 python -c "
 import json; r = json.loads(open('gpurun_out/bench_tiled_bf16.json').read().strip().splitlines()[-1]); print('tiled bf16', r['value'], r['ms_per_ref_view'])"
+echo "== bench, stages 2-4 fed by the producer-side emitter's fp16 octet tiles (no pack pass in the process; direct gather at stages 3-4) =="
+timeout 600 python bench.py --steps 10 --warmup 3 --no-profile --no-train-leg --no-shipped-leg --feat-layout emitted --emit-dtype fp16 > $OUT/bench_emitted.json 2>/dev/null
+python -c "
+import json; r = json.loads(open('gpurun_out/bench_emitted.json').read().strip().splitlines()[-1]); print('emitted fp16 tiles', r['value'], r['ms_per_ref_view'], r.get('parity'))"
 echo "== N = 2 flow of bench.py on this one-GPU box (both ranks on the device, gloo): code path check, not a measurement =="
 MVS_BENCH_ONE_DEVICE=1 MVS_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
   --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --views-per-step 4 --no-profile > $OUT/bench_n2.raw 2> $OUT/bench_n2.err
@@ -86,6 +90,7 @@ cp $OUT/bench_shipped.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_shipped.json
 cp $OUT/bench_n2.json $OUT/profiles_$TAG/${TAG}_bench_n2_flow_check_one_gpu_gloo.json
 cp $OUT/bench_tiled_bf16.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_tiled_bf16.json
 cp $OUT/bench_bf16x3.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_bf16x3.json
+cp $OUT/bench_emitted.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_emitted.json
 grep -v "amdgpu.ids" $OUT/bench_bf16x3.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_bf16x3.txt
 grep -v "amdgpu.ids" $OUT/bench.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table.txt
 grep -v "amdgpu.ids" $OUT/bench_shipped.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_shipped.txt

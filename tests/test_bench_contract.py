@@ -39,6 +39,9 @@ def test_committed_bench_line(name):
         assert len(ro["instantiations"]) > 1 and ro["kernel"].endswith("_kernel")
         assert r["families"]["heads_and_ranges"]["launches_per_ref_view"] <= 6
         assert "feature_emitter" in r and "stages" in r["feature_emitter"]
+        # last session: the same policy fed with fp16 octet tiles at the fine stages (direct gather) - same arithmetic, reported beside the headline
+        ft = r["fp16_tiles_handoff_mode"]
+        assert ft["value"] > r["value"] and ft["default_vs_this_refined_depth_rel_l1"] <= 1e-5
     if name.startswith("r04") or name.startswith("r05"):
         # the round-4 record: counter traffic present, the fraction against the guide's dense MFMA peak, no per-kernel
         # bandwidth above the 8 TB/s roof, the whole path with its three fractions
