@@ -13,6 +13,7 @@ bool gl_supported(int C, int G, int D, int H, int W) {
     if (G != 8 || !(C == 8 || C == 16 || C == 32 || C == 64)) return false;
     if (W % GL_XALIGN != 0 || W < GL_XALIGN || H < 2 || W > 65535 || H > 65535) return false;
     if ((long long)D * H * W > 0x7fffffffLL) return false;                    // 32-bit voxel offsets inside one batch item
+    if ((long long)H * W >= (1LL << 28)) return false;                        // 32-bit BYTE offsets of 16-byte positions (the direct form's buffer loads)
     return (size_t)D * (256 / gl_slots(D)) * sizeof(float) <= 64 * 1024;
 }
 
