@@ -63,12 +63,13 @@ __device__ __forceinline__ float gl_round_f16(float v) { return (float)(_Float16
 #ifndef MVS_GL_DIRECT16
 #define MVS_GL_DIRECT16 1
 #endif
-// Where it is used is a measured choice (profiles/r05_gather_direct_pmc.txt): the direct form is bound by the vector-memory return path (~25-33 TD
-// cycles per 16-byte-per-lane load), which grows with the octet count, while the window form amortises its bounding box over the octets - C = 8 (one
-// octet) wins in every pass (-16 % pass 2, -8 % pass 1), C = 16 wins only in the keeping pass 1 (-3.5 %) and loses 5-17 % in the plain passes; C >= 32 keeps
-// the windows.
+// Where it is used is a measured choice (profiles/r05_gather_direct_pmc.txt, r05_gather_direct_ab.txt): the direct form is bound by the vector-memory
+// return path (~25-33 TD cycles per 16-byte-per-lane load), which grows with the octet count, while the window form amortises its bounding box over the
+// octets - C = 8 (one octet) wins in every pass on every box measured (-12 ... -16 % pass 2, -8 ... -12 % pass 1); C = 16 loses 5-17 % in the plain passes and
+// is box-dependent in the keeping pass 1 (-3.5 ... -6 % on two boxes, +9 % on two others): C >= 16 keeps the windows.  KEEPPASS stays a parameter of the
+// choice for that reason.
 template <typename T, bool TILED, bool W16, int NOCT, bool KEEPPASS>
-constexpr bool gl_direct_v = (MVS_GL_DIRECT16 != 0) && W16 && TILED && std::is_same<T, _Float16>::value && (NOCT == 1 || (NOCT == 2 && KEEPPASS));
+constexpr bool gl_direct_v = (MVS_GL_DIRECT16 != 0) && W16 && TILED && std::is_same<T, _Float16>::value && NOCT == 1;
 
 template <typename T, int NOCT, bool KEEP_GROUPS, bool TILED, bool W16, bool DIRECT = false>
 __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __restrict__ ref, const Homography& hm, float fx, float fy,
@@ -94,7 +95,6 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
     }
     if constexpr (DIRECT) {
         static_assert(W16 && TILED && std::is_same<T, _Float16>::value, "the direct form reads fp16 octet tiles");
-        if (!active) return;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         unsigned tofs[GL_DCH];
 #pragma unroll
@@ -103,6 +103,18 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             tofs[dd] = pk == GL_NONE ? 0u : ((pk >> 16) * (unsigned)W + (pk & 0xffffu)) * 16u;
         }
         const int rowb = W * 16;                                 // wave-uniform: the lower tap row through soffset
+#if MVS_GL_DIRECT16 == 4
+        // Column sharing (measurement variant): where the next lane's left column IS this lane's right column (tofs[lane + 1] == tofs + 16 - the
+        // usual case at a view scale near 1), the right column comes from that lane's registers (DPP wave_shl:1) and only the remaining lanes
+        // load it (the masked load overwrites the shifted values in place).  Every lane of the wave takes part in the shifts: no early return;
+        // lanes without work hold valid taps of a clamped pixel.
+        bool share[GL_DCH];
+#pragma unroll
+        for (int dd = 0; dd < GL_DCH; ++dd)
+            share[dd] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)tofs[dd], 0x130, 0xf, 0xf, true) == tofs[dd] + 16u;
+#else
+        if (!active) return;
+#endif
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) {
             unsigned oofs = gl_octet_offset(o, HW);
@@ -122,6 +134,9 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 (void)rs; (void)rowb;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[dd][k] = u32x4{tofs[dd], tofs[dd] + (unsigned)k, tofs[dd] ^ 0x3c003c00u, 0x3c003c00u};
+#elif MVS_GL_DIRECT16 == 4
+                t[dd][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], 0, 0);
+                t[dd][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], rowb, 0);
 #else
                 t[dd][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], 0, 0);
                 t[dd][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), 0, 0);
@@ -129,6 +144,21 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 t[dd][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), rowb, 0);
 #endif
             }
+#if MVS_GL_DIRECT16 == 4
+#pragma unroll
+            for (int dd = 0; dd < GL_DCH; ++dd) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[dd][1][j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t[dd][0][j], 0x130, 0xf, 0xf, true);
+                    t[dd][3][j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t[dd][2][j], 0x130, 0xf, 0xf, true);
+                }
+                if (!share[dd]) {
+                    t[dd][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), 0, 0);
+                    t[dd][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), rowb, 0);
+                }
+            }
+            if (!active) continue;
+#endif
 #pragma unroll
             for (int c = 0; c < 8; ++c) rf[c] *= wscale;
 #pragma unroll

@@ -270,7 +270,7 @@ static inline unsigned short hipemu_raw_buffer_load_b16(__amdgpu_buffer_rsrc_t r
 #define __builtin_amdgcn_raw_buffer_load_b32 hipemu_raw_buffer_load_b32
 #define __builtin_amdgcn_raw_buffer_load_b16 hipemu_raw_buffer_load_b16
 
-// DPP (gfx9 controls used by the kernels): quad_perm 0x00-0xFF, row_shr:n 0x111-0x11F, wave_shr:1 0x138, row_mirror 0x140,
+// DPP (gfx9 controls used by the kernels): quad_perm 0x00-0xFF, row_shr:n 0x111-0x11F, wave_shl:1 0x130, wave_shr:1 0x138, row_mirror 0x140,
 // row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.  A lane whose row / bank is masked off, or whose source
 // lane does not exist, keeps `old` (bound_ctrl:0 would give 0 for a missing source).
 static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
@@ -282,6 +282,7 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, in
     int from = -1;
     if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
     else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; from = in_row >= n ? l - n : -1; }
+    else if (ctrl == 0x130) from = l < 63 ? l + 1 : -1;
     else if (ctrl == 0x138) from = l > 0 ? l - 1 : -1;
     else if (ctrl == 0x140) from = (l & ~15) | (15 - in_row);
     else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
