@@ -1220,6 +1220,15 @@ def case_cascade_vs_oracle(device, H, W, V, peaky=False, conv_precision=None, **
     # into a visible probability difference at isolated pixels, so the check is on the mean (the max is only reported)
     dconf = (cpu(out["photometric_confidence"]) - ref["photometric_confidence"]).abs()
     assert float(dconf.mean()) <= tol(conv_precision, 1e-3, 1e-2), "confidence mean abs error %g" % float(dconf.mean())
+    if conv_precision is None and feats["stage4"].dtype in (torch.float32, torch.float16):
+        # the product default fed with the producer-side emitter's hand-off for the fine stages: stages 3-4 as fp16 octet tiles -
+        # the gather reads its taps straight from the tiles where C = 8 (gather_lds.h, MVS_GL_DIRECT16): the same bar against the same oracle
+        with torch.no_grad():
+            ft = {k: (ops.pack_features(dev(v, device), torch.float16) if k in ("stage3", "stage4") else dev(v, device)) for k, v in feats.items()}
+            out_t = head(ft, {k: dev(v, device) for k, v in projs.items()}, dev(dv, device))
+        rt = rel_l1(cpu(out_t["refined_depth"]), ref["refined_depth"])
+        assert rt <= 1e-3, "fp16-tile hand-off: refined depth rel-L1 %g > 1e-3" % rt
+        assert rel_l1(cpu(out_t["refined_depth"]), cpu(out["refined_depth"])) <= 1e-4, "fp16-tile hand-off vs planar features"
     return r
 
 
