@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="= --issue graph (kept for the round-3/4 scripts)")
     ap.add_argument("--no-shipped-leg", action="store_true", help="skip the extra `shipped` object (stage-1 transformer mix: value + parity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-composite-baseline", action="store_true", help="skip the torch-ROCm composite baseline leg (the oracle's tensors on cuda:0)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra `training_step` object (forward + backward of each cascade stage)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel table to stderr")
@@ -654,7 +655,8 @@ def main():
                                                                      "mvs_pack_features), stages 1-2 as in the headline", "value": R / tt, "unit": "ref-views/s",
                                                          "ms_per_ref_view": tt / R * 1e3, "steps": n2,
                                                          "default_vs_this_refined_depth_rel_l1": float(((out["refined_depth"] - outt["refined_depth"]).abs() / outt["refined_depth"].abs()).mean()),
-                                                         "note": "same arithmetic as the headline (its fp16 windows hold exactly these values): the gather of stages 3-4 reads "
+                                                         "note": "same source-window values as the headline (its fp16 windows hold exactly these values); the REFERENCE view's features are "
+                                                                 "additionally rounded to fp16 here (planar fp32 keeps them fp32: ~3e-6 depth difference); the gather of stages 3-4 reads "
                                                                  "the taps straight from the tiles, four 16-byte buffer loads per plane and octet, no bounding box / window / barrier"}
                     del sets_t, outt
                     torch.cuda.empty_cache()
@@ -731,6 +733,16 @@ def main():
         if guard is not None:
             guard.disarm()
 
+    # ---- torch-ROCm composite baseline: the op-for-op restatement of the reference's
+    #      PyTorch path (oracle/ref_path.py = cost_volume.py:51-133 through F.grid_sample / conv3d / conv_transpose3d / batch_norm) with its
+    #      tensors on THIS GPU - what a user who runs the reference on stock PyTorch-ROCm gets - outside the timed region, N = 1 only ----
+    if world == 1 and not a.no_cpu_baseline and not a.no_composite_baseline:
+        try:
+            result["torch_rocm_composite"] = composite_baseline(head, feats, projs, dv, out, shipped=a.cost_reg == "shipped")
+        except Exception as e:
+            result["torch_rocm_composite"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) + a parity read-out ----
     if world == 1 and not a.no_cpu_baseline:
         planar = {k: (v.unpack() if hasattr(v, "unpack") else v) for k, v in feats.items()}
@@ -752,6 +764,43 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         bye.cancel()
+
+
+def composite_baseline(head, feats, projs, dv, out, shipped=False):
+    """The reference's own composite PyTorch path on the MI355X: oracle.ref_path.cascade_forward (op-for-op the reference's
+    StageNet / CostRegNet / cascade loop, fp32, no autocast) with every tensor on cuda:0 - stock PyTorch-ROCm kernels (MIOpen
+    convolutions, ATen grid_sample).  One warm-up pass (MIOpen's find step), then the median of three; the HIP path's output is
+    compared with it as a second parity read-out (same device, other kernels)."""
+    from oracle import ref_path as O
+    dev = dv.device
+    sds = [{k: v.detach().to(dev) for k, v in st.state_dict().items()} for st in head.fusions]
+    f = {k: (v.unpack() if hasattr(v, "unpack") else v).float() for k, v in feats.items()}
+
+    def one():
+        with torch.no_grad():
+            return O.cascade_forward(f, projs, dv, sds, ndepths=ARGS["ndepths"], depth_interals_ratio=ARGS["depth_interals_ratio"],
+                                     base_ch=ARGS["base_ch"], tmp=TMP, use_pe3d=shipped,
+                                     transformer_config=SHIPPED["transformer_config"] if shipped else None)
+    t0 = time.perf_counter()
+    o = one()
+    torch.cuda.synchronize()
+    warm = time.perf_counter() - t0
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = one()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[1]
+    d, r = out["refined_depth"], o["refined_depth"]
+    return {"value": 1.0 / med, "unit": "ref-views/s", "ms_per_ref_view": med * 1e3, "kind": "port",
+            "sample": "1 reference view of the bench workload per pass (full 4-stage cascade, fp32, batch 1, one stream); warm-up pass %.2f s, "
+                      "then the median of three passes: %s ms" % (warm, " / ".join("%.1f" % (t * 1e3) for t in ts)),
+            "peak_memory_gb": torch.cuda.max_memory_allocated() / 1e9,
+            "hip_path_vs_this_refined_depth_rel_l1": float(((d - r).abs() / r.abs()).mean()),
+            "note": "oracle/ref_path.py (the CPU restatement of models/cost_volume.py:51-133 + module.py regularisers + the cascade loop) with its "
+                    "tensors on cuda:0: stock PyTorch-ROCm composite kernels, the baseline a patch_model user starts from"}
 
 
 def emitter_leg(device, V):

@@ -341,7 +341,8 @@ int mvs_softmax_regress_fwd(const float* logits, const float* hyp, float tmp, in
 /* Round 5: a stage's head fused with the NEXT stage's inverse-depth schedule (mvs_softmax_regress_fwd + mvs_schedule_inverse_range_fwd with
  * shift = 0 in one launch; DINOv2_mvsformer_model.py:133-148 + cost_volume.py:105-131): besides depth / conf / prob_volume it writes
  * next_hyp [B,next_D,2H,2W] from this stage's depth and hypotheses (module.py:707-724, `ratio` = the next stage's depth_interals_ratio).
- * depth / conf / prob_volume are bit-identical to mvs_softmax_regress_fwd's, next_hyp to the stand-alone schedule's.                  */
+ * depth / conf / prob_volume are bit-identical to mvs_softmax_regress_fwd's; next_hyp equals the stand-alone schedule's up to FMA
+ * contraction of the two translation units (<= 2e-6 of its range; bit-identical on the shipped build).                               */
 int mvs_softmax_regress_schedule_fwd(const float* logits, const float* hyp, float tmp, int mode, int conf_n, float* depth, float* conf,
                                      float* prob_volume, float ratio, float* next_hyp, int next_D, int B, int D, int H, int W,
                                      void* stream);

@@ -36,7 +36,7 @@ class CascadeDepthHead(nn.Module):
         self.use_pe3d = args.get("use_pe3d", False)
         self.fusions = nn.ModuleList([StageNet(args, self.ndepths[i], i) for i in range(len(self.ndepths))])
         self._auto = args.get("conv_precision") == "auto"
-        self._auto_cache: Dict[tuple, str] = {}
+        self._auto_last: Optional[str] = None          # decision of the last eager call (what a capture inherits)
 
     def set_view_group(self, group, shard_mode: str = "auto") -> None:
         """Shard source views over the ranks of `group`.  shard_mode: "allreduce" = one all-reduce of the
@@ -55,26 +55,26 @@ class CascadeDepthHead(nn.Module):
         that the hypotheses around such pixels amplify whatever noise the coarse stages carry (fp16 coarse stages reach
         3-5e-3 at ratio 20, 1.5e-4 at ratio 6, 6e-5 at DTU's 2.2).  "auto" = "f16mix" on every stage while the ratio stays below AUTO_SAFETY x
         that critical value, "stagemix" otherwise (and always for the linear schedule, which was not studied).  The ratio is read from the
-        DEVICE tensor - one small synchronising copy the first time a depth_values tensor (identity + version) is seen, cached after that;
-        inside a hipGraph capture an unseen tensor raises (capture() warms up on the same tensors first, so this does not happen there)."""
+        VALUES of the device tensor on every eager call - one small synchronising copy of the two endpoints per call (round 6, ADVICE r5: a
+        cache keyed on the tensor's address / version handed a new scene the stale decision of a freed tensor whose address the allocator had
+        reused).  Inside a hipGraph capture nothing can be read: the call takes the decision of the last eager call, which capture() has just
+        made on the same tensors in its warm-up; a graph's policy is therefore fixed at capture time (its launches are fixed anyway)."""
         import math
-        key = (depth_values.data_ptr(), depth_values._version, tuple(depth_values.shape), str(depth_values.device))
-        hit = self._auto_cache.get(key)
-        if hit is None:
-            if depth_values.is_cuda and torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("conv_precision='auto' has to read the depth range of a depth_values tensor it has not seen before; call the head "
-                                   "once on these tensors before capturing (CascadeDepthHead.capture does)")
-            dv = depth_values.detach().float()
-            if dv.dim() == 2 and self.inverse_depth and len(self.ndepths) > 1:
-                a, b = dv[:, 0], dv[:, -1]
-                ratio = float((torch.maximum(a, b) / torch.minimum(a, b)).max())          # the one synchronisation
-                crit = (self.ndepths[0] - 1) / float(self.depth_interals_ratio[1]) + 1.0
-                hit = "f16mix" if (math.isfinite(ratio) and ratio >= 1.0 and ratio <= self.AUTO_SAFETY * crit) else "stagemix"
-            else:
-                hit = "stagemix"
-            if len(self._auto_cache) >= 256:
-                self._auto_cache.clear()
-            self._auto_cache[key] = hit
+        if depth_values.is_cuda and torch.cuda.is_current_stream_capturing():
+            if self._auto_last is None:
+                raise RuntimeError("conv_precision='auto' has to read the depth range before a capture; call the head once on these tensors "
+                                   "first (CascadeDepthHead.capture does)")
+            return self._auto_last
+        dv = depth_values.detach()
+        hit = "stagemix"
+        if dv.dim() == 2 and self.inverse_depth and len(self.ndepths) > 1:
+            ends = torch.stack((dv[:, 0], dv[:, -1]), 1).float().cpu()                    # the one synchronisation: 2 B values
+            a, b = ends[:, 0], ends[:, 1]
+            ratio = float((torch.maximum(a, b) / torch.minimum(a, b)).max())
+            crit = (self.ndepths[0] - 1) / float(self.depth_interals_ratio[1]) + 1.0
+            if math.isfinite(ratio) and ratio >= 1.0 and ratio <= self.AUTO_SAFETY * crit:
+                hit = "f16mix"
+        self._auto_last = hit
         return hit
 
     def capture(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
@@ -176,9 +176,24 @@ class GraphedCascade:
             # watchdog thread (bench.py --gpus N captures with RCCL initialised) may query its events meanwhile without invalidating it
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.outputs = head(features, proj_matrices, depth_values, tmp=tmp)
+        self._replays = 0
+        self._f16_stages = ["stage%d" % (i + 1) for i, f in enumerate(head.fusions) if f._f16_activations()]
 
+    # fp16-format monitoring under replay (round 6): StageNet.forward never runs eagerly in a replay-only process, so the replays are
+    # counted here and the saturation counter is read OUTSIDE the graph after the 8th replay, then every F16_SATURATION_CHECK_EVERY replays - the
+    # schedule the eager path follows (one device synchronisation each time); the hypothesis-conditioning check reads the replay's own hypotheses.
     def __call__(self) -> Dict[str, torch.Tensor]:
         self.graph.replay()
+        if self._f16_stages:
+            self._replays += 1
+            from . import cost_volume as CV
+            every = CV.F16_SATURATION_CHECK_EVERY
+            if every and (self._replays == 8 or self._replays % every == 0):
+                dev = self.depth_values.device
+                CV._F16_CHECK_DUE.discard(dev.index)
+                CV.check_f16_saturation(dev)
+                for k in self._f16_stages:
+                    CV.check_hypothesis_conditioning(self.outputs[k]["depth_values"])
         return self.outputs
 
 

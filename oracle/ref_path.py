@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure, NOT the product) - CPU restatement of MVSFormer++'s depth hot path.
 
-Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-this module.  The product package ``mvsformerplusplus_amd`` never does: it fails loudly when its
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s baseline legs (``cpu_baseline``, and
+``torch_rocm_composite`` = this same restatement with its tensors on cuda:0, both outside the timed
+region) may import this module.  The product package ``mvsformerplusplus_amd`` never does: it fails loudly when its
 HIP library is missing.
 
 Every function restates, op for op and in fp32, one piece of the reference
@@ -210,7 +211,7 @@ def conf_regression(p: torch.Tensor, n: int = 4) -> torch.Tensor:
     else:
         pad = [0, 0, 0, 0, n // 2 - 1, n // 2]
     s = n * F.avg_pool3d(F.pad(p.unsqueeze(1), pad=pad), (n, 1, 1), stride=1, padding=0).squeeze(1)
-    idx = depth_regression(p, torch.arange(ndepths, dtype=torch.float)).long().clamp(min=0, max=ndepths - 1)
+    idx = depth_regression(p, torch.arange(ndepths, dtype=torch.float, device=p.device)).long().clamp(min=0, max=ndepths - 1)
     return torch.gather(s, 1, idx.unsqueeze(1)).squeeze(1)
 
 
@@ -222,16 +223,16 @@ def init_range(cur_depth, ndepths, H, W):
     if cur_depth.dim() == 2:
         dmin, dmax = cur_depth[:, 0], cur_depth[:, -1]
         itv = ((dmax - dmin) / (ndepths - 1))[:, None, None]
-        s = dmin.unsqueeze(1) + torch.arange(0, ndepths, dtype=dtype).reshape(1, -1) * itv.squeeze(1)
+        s = dmin.unsqueeze(1) + torch.arange(0, ndepths, dtype=dtype, device=cur_depth.device).reshape(1, -1) * itv.squeeze(1)
         return s.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, H, W)
     dmin, dmax = cur_depth[..., 0], cur_depth[..., -1]
     itv = (dmax - dmin) / (ndepths - 1)
-    return dmin.unsqueeze(1) + torch.arange(0, ndepths, dtype=dtype).reshape(1, -1, 1, 1) * itv.unsqueeze(1)
+    return dmin.unsqueeze(1) + torch.arange(0, ndepths, dtype=dtype, device=cur_depth.device).reshape(1, -1, 1, 1) * itv.unsqueeze(1)
 
 
 def init_inverse_range(cur_depth, ndepths, H, W):
     dtype = cur_depth.dtype
-    itv = torch.arange(0, ndepths, dtype=dtype).reshape(1, -1, 1, 1).repeat(1, 1, H, W) / (ndepths - 1)
+    itv = torch.arange(0, ndepths, dtype=dtype, device=cur_depth.device).reshape(1, -1, 1, 1).repeat(1, 1, H, W) / (ndepths - 1)
     if cur_depth.dim() == 2:
         inv_min = 1.0 / cur_depth[:, 0]
         inv_max = 1.0 / cur_depth[:, -1]
@@ -251,7 +252,7 @@ def schedule_inverse_range(depth, depth_hypo, ndepths, split_itv, H, W, shift=Fa
         is_neg = (inv_max < 0.002).float()
         inv_max = inv_max - (inv_max - 0.002) * is_neg
         inv_min = inv_min - (inv_max - 0.002) * is_neg
-    itv = torch.arange(0, ndepths, dtype=inv_min.dtype).reshape(1, -1, 1, 1).repeat(1, 1, H // 2, W // 2) / (ndepths - 1)
+    itv = torch.arange(0, ndepths, dtype=inv_min.dtype, device=inv_min.device).reshape(1, -1, 1, 1).repeat(1, 1, H // 2, W // 2) / (ndepths - 1)
     hypo = inv_max[:, None] + (inv_min - inv_max)[:, None] * itv
     hypo = F.interpolate(hypo.unsqueeze(1), [ndepths, H, W], mode="trilinear", align_corners=True).squeeze(1)   # :723
     return 1.0 / hypo
@@ -259,13 +260,13 @@ def schedule_inverse_range(depth, depth_hypo, ndepths, split_itv, H, W, shift=Fa
 
 def schedule_range(cur_depth, ndepth, depth_interval_pixel, H, W):
     if not torch.is_tensor(depth_interval_pixel):
-        depth_interval_pixel = torch.tensor(depth_interval_pixel, dtype=cur_depth.dtype)
+        depth_interval_pixel = torch.tensor(depth_interval_pixel, dtype=cur_depth.dtype, device=cur_depth.device)
     if depth_interval_pixel.dim() != 3:
         depth_interval_pixel = depth_interval_pixel.reshape(-1)[:, None, None]
     dmin = torch.clamp_min(cur_depth - ndepth / 2 * depth_interval_pixel, 0.001)
     dmax = cur_depth + ndepth / 2 * depth_interval_pixel
     itv = (dmax - dmin) / (ndepth - 1)
-    s = dmin.unsqueeze(1) + torch.arange(0, ndepth, dtype=cur_depth.dtype).reshape(1, -1, 1, 1) * itv.unsqueeze(1)
+    s = dmin.unsqueeze(1) + torch.arange(0, ndepth, dtype=cur_depth.dtype, device=cur_depth.device).reshape(1, -1, 1, 1) * itv.unsqueeze(1)
     return F.interpolate(s.unsqueeze(1), [ndepth, H, W], mode="trilinear", align_corners=True).squeeze(1)
 
 
@@ -278,8 +279,9 @@ def get_position_3d(H: int, W: int, K: torch.Tensor, depth_values: torch.Tensor,
                     height_min=None, height_max=None, width_min=None, width_max=None):
     """position_encoding.py:138-163 (normalize=True).  K [B,3,3]; depth_values [B,D,H,W] -> ([B,3,D,H,W], 4 range scalars)."""
     B, D = depth_values.shape[:2]
-    y, x = torch.meshgrid([torch.arange(0, H, dtype=torch.float32), torch.arange(0, W, dtype=torch.float32)], indexing="ij")
-    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(H * W)))[None].repeat(B, 1, 1)
+    dev = depth_values.device
+    y, x = torch.meshgrid([torch.arange(0, H, dtype=torch.float32, device=dev), torch.arange(0, W, dtype=torch.float32, device=dev)], indexing="ij")
+    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(H * W, device=dev)))[None].repeat(B, 1, 1)
     xyz = torch.matmul(torch.inverse(K), xyz)                                               # :147
     pos = xyz.unsqueeze(2).repeat(1, 1, D, 1) * depth_values.reshape(B, 1, D, -1)            # :149
     if height_min is None or height_max is None or width_min is None or width_max is None:
@@ -295,10 +297,10 @@ def position_encoding_3d(position3d: torch.Tensor, C: int, rescale: float = 4.0)
     """position_encoding.py:166-189: per axis C channels sin/cos interleaved -> [B,3C,D,H,W]."""
     import math
     B, _, D, H, W = position3d.shape
-    div = torch.exp(torch.arange(0, C, 2).float() * (-math.log(10000.0) / C))[None, :, None]
+    div = torch.exp(torch.arange(0, C, 2, device=position3d.device).float() * (-math.log(10000.0) / C))[None, :, None]
     parts = []
     for a in range(3):
-        pe = torch.zeros(B, C, D * H * W, dtype=torch.float32)
+        pe = torch.zeros(B, C, D * H * W, dtype=torch.float32, device=position3d.device)
         pos = position3d[:, a].reshape(B, 1, D * H * W)
         pe[:, 0::2] = torch.sin(pos * rescale * div)
         pe[:, 1::2] = torch.cos(pos * rescale * div)
@@ -441,7 +443,7 @@ def cascade_forward(features: Dict[str, torch.Tensor], proj_matrices: Dict[str, 
     B = f_last.shape[0]
     Hf, Wf = full_hw if full_hw is not None else f_last.shape[-2:]
     depth_interval = depth_values[:, 1] - depth_values[:, 0]
-    prob_maps = torch.zeros(B, Hf, Wf, dtype=torch.float32)
+    prob_maps = torch.zeros(B, Hf, Wf, dtype=torch.float32, device=f_last.device)
     outputs: Dict[str, torch.Tensor] = {}
     st = None
     pe_range = [None, None, None, None]                      # height_min, height_max, width_min, width_max  (:154-160)

@@ -685,7 +685,10 @@ def case_fused_small_launches(device):
             so = head.fusions[s](feats[key], projm[key], hyp, tmp=[5.0, 5.0, 5.0, 1.0][s])
             assert set(so) == {"depth", "prob_volume", "photometric_confidence", "depth_values", "prob_volume_pre"}
             assert set(out[key]) == set(so), "the fused driver must return the reference's five keys per stage"
-            assert torch.equal(cpu(so["depth"]), cpu(out[key]["depth"])), ("stage depth, fused vs stage-by-stage", s)
+            # stage 1 has no fused input: bit-equal.  Later stages consume next_hyp, which the header (mvs_hip.h, mvs_softmax_regress_schedule_fwd)
+            # only promises up to FMA contraction (<= 2e-6 of its range, asserted above): the same bar here
+            assert torch.equal(cpu(so["depth"]), cpu(out[key]["depth"])) or (s > 0 and rel_l1(cpu(out[key]["depth"]), cpu(so["depth"])) <= 1e-6), \
+                ("stage depth, fused vs stage-by-stage", s)
             confs.append(so["photometric_confidence"])
         assert torch.equal(cpu(out["photometric_confidence"]), cpu(ops.confidence_average(confs, *feats["stage4"].shape[-2:])))
 
