@@ -36,7 +36,7 @@ class CascadeDepthHead(nn.Module):
         self.use_pe3d = args.get("use_pe3d", False)
         self.fusions = nn.ModuleList([StageNet(args, self.ndepths[i], i) for i in range(len(self.ndepths))])
         self._auto = args.get("conv_precision") == "auto"
-        self._auto_last: Optional[str] = None          # decision of the last eager call (what a capture inherits)
+        self._auto_seen: Dict[int, tuple] = {}         # id(tensor) -> (weakref, version, decision)
 
     def set_view_group(self, group, shard_mode: str = "auto") -> None:
         """Shard source views over the ranks of `group`.  shard_mode: "allreduce" = one all-reduce of the
@@ -55,16 +55,23 @@ class CascadeDepthHead(nn.Module):
         that the hypotheses around such pixels amplify whatever noise the coarse stages carry (fp16 coarse stages reach
         3-5e-3 at ratio 20, 1.5e-4 at ratio 6, 6e-5 at DTU's 2.2).  "auto" = "f16mix" on every stage while the ratio stays below AUTO_SAFETY x
         that critical value, "stagemix" otherwise (and always for the linear schedule, which was not studied).  The ratio is read from the
-        VALUES of the device tensor on every eager call - one small synchronising copy of the two endpoints per call (round 6, ADVICE r5: a
-        cache keyed on the tensor's address / version handed a new scene the stale decision of a freed tensor whose address the allocator had
-        reused).  Inside a hipGraph capture nothing can be read: the call takes the decision of the last eager call, which capture() has just
-        made on the same tensors in its warm-up; a graph's policy is therefore fixed at capture time (its launches are fixed anyway)."""
+        VALUES of the device tensor - one small synchronising copy of the two endpoints - the first time a tensor OBJECT is seen; the
+        decision is remembered per object (weak reference + in-place version: round 6, ADVICE r5 - the round-5 cache was keyed on the
+        tensor's address, which the allocator hands to the next scene's tensor).  An eval loop that builds a new depth_values tensor per
+        sample pays one read per sample; a loop that refills one tensor in place pays it when the version changes.  Inside a hipGraph capture
+        nothing can be read: an unseen tensor raises (capture() warms up on the same tensors first); a graph's policy is fixed at capture."""
         import math
+        import weakref
+        try:
+            ver = depth_values._version
+        except RuntimeError:                           # inference tensors carry no version counter: never cached
+            ver = None
+        ent = self._auto_seen.get(id(depth_values))
+        if ent is not None and ent[0]() is depth_values and ver is not None and ent[1] == ver:
+            return ent[2]
         if depth_values.is_cuda and torch.cuda.is_current_stream_capturing():
-            if self._auto_last is None:
-                raise RuntimeError("conv_precision='auto' has to read the depth range before a capture; call the head once on these tensors "
-                                   "first (CascadeDepthHead.capture does)")
-            return self._auto_last
+            raise RuntimeError("conv_precision='auto' has to read the depth range of a depth_values tensor it has not seen before; call the head "
+                               "once on these tensors before capturing (CascadeDepthHead.capture does)")
         dv = depth_values.detach()
         hit = "stagemix"
         if dv.dim() == 2 and self.inverse_depth and len(self.ndepths) > 1:
@@ -74,7 +81,13 @@ class CascadeDepthHead(nn.Module):
             crit = (self.ndepths[0] - 1) / float(self.depth_interals_ratio[1]) + 1.0
             if math.isfinite(ratio) and ratio >= 1.0 and ratio <= self.AUTO_SAFETY * crit:
                 hit = "f16mix"
-        self._auto_last = hit
+        if ver is not None:
+            if len(self._auto_seen) >= 64:             # drop the entries whose tensors are gone
+                self._auto_seen = {k: v for k, v in self._auto_seen.items() if v[0]() is not None}
+                if len(self._auto_seen) >= 64:
+                    self._auto_seen.clear()
+            key = id(depth_values)
+            self._auto_seen[key] = (weakref.ref(depth_values), ver, hit)
         return hit
 
     def capture(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,

@@ -71,6 +71,37 @@ __device__ __forceinline__ float gl_round_f16(float v) { return (float)(_Float16
 template <typename T, bool TILED, bool W16, int NOCT, bool KEEPPASS>
 constexpr bool gl_direct_v = (MVS_GL_DIRECT16 != 0) && W16 && TILED && std::is_same<T, _Float16>::value && NOCT == 1;
 
+// Round 6 instruction diet of the unit (ISA census in DESIGN.md section 4.1, scripts/isa_census.py): MVS_GL_OPT = 0 rebuilds round 5's form for A/B runs.
+//   * the bilinear blend is issued tap-outer / channel-inner: round 5 emitted each channel's four dependent v_fma_mix back to back and the
+//     compiler separated them with s_nop (96 per unit: the dependent-VALU hazard of an op_sel source) - eight independent chains interleaved need none
+//   * planar staging through ONE buffer descriptor: channel plane c is a wave-uniform soffset, the position a 32-bit voffset - no 64-bit
+//     address arithmetic per load (2 VALU each), clamp by v_med3 without the canonicalising v_max the fminf / fmaxf pair costs
+//   * the "no tap inside the image" sentinel GL_NONE (0xffff, 0xffff) is neutral for the packed minimum as it stands and, after a packed + 1
+//     (which wraps it to 0), for the maximum: no compare / select per plane in the bounding box; its window position is clamped by one
+//     v_min_u32 (the weights are zero: any finite window value will do) instead of an exec-masked branch per plane
+#ifndef MVS_GL_OPT
+#define MVS_GL_OPT 1
+#endif
+
+// the four taps of one plane into wv[0..7]: t = 8 halves (4 registers) per tap
+#define GL_BLEND8(wv, t00, t01, t10, t11, tp)                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        wv[2 * j] = MVS_FMA_MIX_LO(t00[j], tp.w00, 0.0f);                                              \
+        wv[2 * j + 1] = MVS_FMA_MIX_HI(t00[j], tp.w00, 0.0f);                                          \
+    }                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        wv[2 * j] = MVS_FMA_MIX_LO(t01[j], tp.w01, wv[2 * j]);                                         \
+        wv[2 * j + 1] = MVS_FMA_MIX_HI(t01[j], tp.w01, wv[2 * j + 1]);                                 \
+    }                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        wv[2 * j] = MVS_FMA_MIX_LO(t10[j], tp.w10, wv[2 * j]);                                         \
+        wv[2 * j + 1] = MVS_FMA_MIX_HI(t10[j], tp.w10, wv[2 * j + 1]);                                 \
+    }                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        wv[2 * j] = MVS_FMA_MIX_LO(t11[j], tp.w11, wv[2 * j]);                                         \
+        wv[2 * j + 1] = MVS_FMA_MIX_HI(t11[j], tp.w11, wv[2 * j + 1]);                                 \
+    }
+
 template <typename T, int NOCT, bool KEEP_GROUPS, bool TILED, bool W16, bool DIRECT = false>
 __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __restrict__ ref, const Homography& hm, float fx, float fy,
                                         const float* depth, bool active, int H, int W, unsigned HW, unsigned pc, f32x4* win,
@@ -85,6 +116,17 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
     GTap tp[GL_DCH];
     u16x2 mn = {0xffff, 0xffff}, mx = {0, 0};
     const float cx = 0.5f * (float)(W - 1), cy = 0.5f * (float)(H - 1);
+#if MVS_GL_OPT
+    // mx holds the maximum of (x + 1, y + 1): the sentinel GL_NONE wraps to (0, 0), neutral for it; mn takes the sentinel as it is
+#pragma unroll
+    for (int dd = 0; dd < GL_DCH; ++dd) {
+        tp[dd] = make_gtap(hm, qx, qy, qz, depth[dd], H, W, cx, cy);
+        const u16x2 pkv = gl_as_vec(tp[dd].pk);
+        mn = __builtin_elementwise_min(mn, pkv);
+        mx = __builtin_elementwise_max(mx, (u16x2)(pkv + (u16x2){1, 1}));
+    }
+    if (!active) { mn = (u16x2){0xffff, 0xffff}; mx = (u16x2){0, 0}; }
+#else
 #pragma unroll
     for (int dd = 0; dd < GL_DCH; ++dd) {
         tp[dd] = make_gtap(hm, qx, qy, qz, depth[dd], H, W, cx, cy);
@@ -93,6 +135,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             mx = __builtin_elementwise_max(mx, gl_as_vec(tp[dd].pk));
         }
     }
+#endif
     if constexpr (DIRECT) {
         static_assert(W16 && TILED && std::is_same<T, _Float16>::value, "the direct form reads fp16 octet tiles");
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -171,6 +214,8 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                     wv[2 * j] = __builtin_bit_cast(float, x & 0x3fffffffu);
                     wv[2 * j + 1] = tp[dd].w00;
                 }
+#elif MVS_GL_OPT
+                GL_BLEND8(wv, t[dd][0], t[dd][1], t[dd][2], t[dd][3], tp[dd])
 #else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -211,7 +256,11 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                                    __builtin_elementwise_min(gl_as_vec(rd[2]), gl_as_vec(rd[3])));
     mx = __builtin_elementwise_max(__builtin_elementwise_max(gl_as_vec(rd[4]), gl_as_vec(rd[5])),
                                    __builtin_elementwise_max(gl_as_vec(rd[6]), gl_as_vec(rd[7])));
+#if MVS_GL_OPT
+    const int xmin = mn[0], ymin = mn[1], xmax = (int)mx[0] - 1, ymax = (int)mx[1] - 1;       // mx = maximum of (x + 1, y + 1); 0 = nothing
+#else
     const int xmin = mn[0], ymin = mn[1], xmax = mx[0], ymax = mx[1];
+#endif
     if (xmax < xmin) return;                                    // no tap of the whole tile is inside the source image
     const int wx0 = xmin & ~(GL_XALIGN - 1);
     const int ww = (xmax + 2 - wx0 + GL_XALIGN - 1) & ~(GL_XALIGN - 1);
@@ -224,7 +273,13 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
 #pragma unroll
         for (int dd = 0; dd < GL_DCH; ++dd) {
             const unsigned pk = tp[dd].pk;
+#if MVS_GL_OPT
+            // a 2x2 block inside the window sits at <= n - ww - 2; GL_NONE (weights zero) lands far beyond and is clamped there
+            const unsigned raw = ((pk >> 16) - (unsigned)ymin) * (unsigned)ww + ((pk & 0xffffu) - (unsigned)wx0);
+            pos[dd] = raw < (unsigned)(n - ww - 2) ? raw : (unsigned)(n - ww - 2);
+#else
             pos[dd] = pk == GL_NONE ? 0u : ((pk >> 16) - (unsigned)ymin) * (unsigned)ww + ((pk & 0xffffu) - (unsigned)wx0);
+#endif
         }
         const float inv_ww = __builtin_amdgcn_rcpf((float)ww) * 1.000001f;   // row = floor((i + 0.5) / ww): exact for i < 2^16
         const unsigned gbase = (unsigned)ymin * (unsigned)W + (unsigned)wx0;
@@ -243,10 +298,37 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rf[c] = rf_in[c];
             }
+#if MVS_GL_OPT
+            // planar maps: one descriptor over the octet's 8 channel planes; plane c = wave-uniform soffset, position = 32-bit voffset
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(so), 0, (int)(8u * HW * (unsigned)sizeof(T)), 0x00020000);
+            const unsigned planeb = HW * (unsigned)sizeof(T);
+#endif
 #pragma unroll 1
             for (int i = tid; i < n; i += 256) {
                 const int row = (int)(((float)i + 0.5f) * inv_ww);
                 const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;    // (ymin+row)*W + wx0 + (i - row*ww)
+#if MVS_GL_OPT
+                if constexpr (!TILED) {
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        if constexpr (sizeof(T) == 4)
+                            v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, (int)(g * 4u), (int)((unsigned)c * planeb), 0));
+                        else
+                            v[c] = to_f32(__builtin_bit_cast(T, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(srs, (int)(g * 2u), (int)((unsigned)c * planeb), 0)));
+                    }
+                    if (W16) {
+                        h8 hv;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) hv[c] = (_Float16)__builtin_amdgcn_fmed3f(v[c], -65504.0f, 65504.0f);
+                        win16[i] = hv;
+                    } else {
+                        win[i] = f32x4{v[0], v[1], v[2], v[3]};
+                        win[GL_CAP + i] = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                    continue;
+                }
+#endif
                 if constexpr (W16 && TILED && std::is_same<T, _Float16>::value) {
                     // fp16 octet tiles (what a producer-side emitter hands over, mvs_conv2d3x3_tiles_fwd with out_dtype fp16): the window
                     // position IS the 16-byte run in HBM - staging is a copy, no conversion, no clamp (round 5)
@@ -277,6 +359,9 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4* w0 = reinterpret_cast<const u32x4*>(win16) + pos[dd];
                         const u32x4 t00 = w0[0], t01 = w0[1], t10 = w0[ww], t11 = w0[ww + 1];
+#if MVS_GL_OPT
+                        GL_BLEND8(wv, t00, t01, t10, t11, tp[dd])
+#else
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {            // 4 v_fma_mix_f32 per channel, no conversion instructions
                             float a = MVS_FMA_MIX_LO(t00[j], tp[dd].w00, 0.0f);
@@ -288,6 +373,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                             b = MVS_FMA_MIX_HI(t10[j], tp[dd].w10, b);
                             wv[2 * j + 1] = MVS_FMA_MIX_HI(t11[j], tp[dd].w11, b);
                         }
+#endif
                     } else {
                         const f32x4* w0 = win + pos[dd];
                         const f32x4 a0 = w0[0], a1 = w0[1], b0 = w0[ww], b1 = w0[ww + 1];

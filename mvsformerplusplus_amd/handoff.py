@@ -58,15 +58,19 @@ class TiledFeatureHead(nn.Module):
         """An empty hand-off tensor [B, V, Cout/8, H, W, 8] for `forward(..., out=buf, view=v)` to fill view by view."""
         return ops.PackedFeatures(torch.empty(B, V, self.conv.out_channels // 8, H, W, 8, dtype=self.dtype, device=device))
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor, out: Optional[ops.PackedFeatures] = None, view: Optional[int] = None) -> ops.PackedFeatures:
         """x [B, Cin, H, W] (one view, the reference's eval loop) with `out` + `view`: fills out[:, view] and returns `out`;
         x [B, V, Cin, H, W] or [B*V, Cin, H, W] without `out`: all views at once -> a new PackedFeatures [B, V | 1, Cout/8, H, W, 8]."""
-        if self.training and (self.bn is not None or x.requires_grad or any(p.requires_grad for p in self.conv.parameters())):
-            # inference-only (round 6, ADVICE r5): the kernel folds the BatchNorm's RUNNING statistics and has no backward - in a model put
-            # into train() it would silently detach the feature side and use eval-mode BatchNorm
-            raise RuntimeError("TiledFeatureHead is an inference-time emitter (folded running BatchNorm statistics, no autograd): call .eval() on it, "
-                               "or keep the reference's Conv2d / BatchNorm2d / Swish + ops.pack_features while training")
+        if (self.bn is not None and self.bn.training) or (torch.is_grad_enabled() and x.requires_grad):
+            # inference-only (round 6, ADVICE r5): the kernel folds the BatchNorm's RUNNING statistics and has no backward - inside a model put
+            # into train() it would silently use eval-mode BatchNorm and detach the feature side
+            raise RuntimeError("TiledFeatureHead is an inference-time emitter (folded running BatchNorm statistics, no autograd): put the wrapped "
+                               "BatchNorm2d into eval() and call it under torch.no_grad(), or keep the reference's Conv2d / BatchNorm2d / Swish + "
+                               "ops.pack_features while training")
+        with torch.no_grad():
+            return self._forward(x, out, view)
+
+    def _forward(self, x, out, view):
         wp, b = self._params(x.device)
         co = self.conv.out_channels
         if out is not None:

@@ -26,6 +26,17 @@ def build(verbose=False):
     lib = os.path.join(OUT, "libmvs_hip_emu_%s.so" % tag)
     if os.path.exists(lib):
         return lib
+    # one builder at a time (pytest -n N: every worker's session fixture lands here at once and they would delete each other's objects)
+    import fcntl
+    with open(os.path.join(OUT, ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return lib if os.path.exists(lib) else _build_locked(srcs, tag, lib, verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(srcs, tag, lib, verbose):
     for old in glob.glob(os.path.join(OUT, "libmvs_hip_emu_*.so")):
         os.remove(old)
     objs = []

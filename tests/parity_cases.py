@@ -793,6 +793,16 @@ def case_vis_cnn(device):
             assert vis.shape == ent.shape
             err = float((cpu(vis) - ref).abs().max())
             assert err <= tol, (N, H, W, prec, err)
+            if prec in ("f16", "f16mix"):
+                # round 6: these formats run the wave-autonomous kernel (vis_cnn_wave_kernel); the round-5 block form (one tile per wave, a
+                # workgroup barrier per row) computes the same MFMAs in the same order: bit-identical
+                import os
+                os.environ["MVS_VIS_BLOCK"] = "1"
+                try:
+                    vis_b = ops.vis_weight(dev(ent, device), st._vis_params(torch.device(device) if isinstance(device, str) else device), _lib.PRECISIONS[prec])
+                finally:
+                    del os.environ["MVS_VIS_BLOCK"]
+                assert torch.equal(cpu(vis_b), cpu(vis)), ("wave form vs block form", N, H, W, prec, float((cpu(vis_b) - cpu(vis)).abs().max()))
 
 
 def case_gather_variants(device, quick=False):
