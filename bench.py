@@ -16,12 +16,12 @@ fp32 features, all-"Normal" regularisers, synthetic features / cameras and seede
 statistics (no dataset or checkpoint exists offline).
 
 Arithmetic: warp, correlation, visibility, heads and every accumulation in fp32; the precision policy of the stages is the PRODUCT
-DEFAULT "stagemix" (module.DEFAULT_STAGE_POLICY, round 5): the coarse stages (D = 32 / 16, whose depth schedules the next stage's
-hypotheses) fp32-equivalent - split-bf16 regulariser and visibility CNN (three MFMA terms), exact gather -, the fine stages (D = 8 / 4,
-~75 % of the time) in "f16mix": fp16 activation tensors; fp16 hi + lo weights = two MFMA terms per product on the 8- / 16-channel layers,
-one fp16 term on conv4..conv7 and in the visibility CNN; fp16 source windows and kept correlations in the gather - no narrower than the
-bf16 autocast the reference's own GPU path runs these layers under (test.py:250).  `--conv-precision bf16x3` selects the fp32-equivalent
-format on every stage, `f16mix` round 4's uniform fp16 default.  `parity` = this run's refined depth against the fp32 CPU oracle on the
+DEFAULT "auto" (module.DEFAULT_CASCADE_POLICY, round 6): the head reads the depth range it is handed and runs "f16mix" on every stage while
+depth_max / depth_min stays below half the ratio at which the inverse-depth schedule degenerates (this workload: 2.2 against 12.6) - fp16
+activation tensors; fp16 hi + lo weights = two MFMA terms per product on the 8- / 16-channel layers, one fp16 term on conv4..conv7 and in the
+visibility CNN; fp16 source windows and kept correlations in the gather: no narrower than the bf16 autocast the reference's own GPU path runs
+these layers under (test.py:250) - and round 5's "stagemix" beyond it (coarse stages fp32-equivalent: split-bf16 regulariser and visibility CNN,
+exact gather), reported here as `exact_coarse_mode`.  `--conv-precision bf16x3` selects the fp32-equivalent format on every stage.  `parity` = this run's refined depth against the fp32 CPU oracle on the
 same inputs (bar 1e-3).
 
 The reference views of a step are issued round-robin on `--streams` HIP streams (default 4 since round 5 - graph replay and the default
@@ -417,7 +417,7 @@ def main():
         "f16x2": "f16x2: U-Net activations (cost volume included) stored as fp16, weights as fp16 hi + lo, two MFMA terms per product on "
                  "v_mfma_f32_16x16x32_f16, fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the "
                  "regulariser under bf16 autocast, test.py:250)",
-        "f16mix": "f16mix (round 4's default, opt-in): fp16 U-Net activations as in f16x2; weights fp16 hi + lo (two MFMA terms) on the 8- / 16-channel layers, "
+        "f16mix": "f16mix (every stage): fp16 U-Net activations as in f16x2; weights fp16 hi + lo (two MFMA terms) on the 8- / 16-channel layers, "
                   "ONE fp16 term on the 32- / 64-channel layers conv4..conv7 (no measurable change of the depth error, scripts/study_weight_precision.py); "
                   "fp32 accumulation; warp / correlation / visibility / heads in fp32 (the reference's GPU path runs the regulariser under bf16 autocast, "
                   "test.py:250)",
@@ -429,9 +429,12 @@ def main():
                     "accumulation everywhere (the reference's GPU path runs the regulariser under bf16 autocast, test.py:250)",
         "fp32": "fp32-exact MFMA contraction"}[prec0]
     result["dtype"] = DTYPE_TEXT[prec0]
-    if a.conv_precision == "auto":
-        result["config"]["conv_precision"] = ("auto (opt-in): chose '%s' for this workload's depth range (depth_max / depth_min = 2.2 against the critical 12.6); " % prec0
+    if getattr(head, "_auto", False):
+        result["config"]["conv_precision"] = ("auto (the cascade's default policy since round 6: the uniform fp16 format while depth_max / depth_min stays below half the ratio at which the "
+                                              "inverse-depth schedule degenerates, the exact coarse stages of 'stagemix' otherwise): chose '%s' for this workload's depth range "
+                                              "(depth_max / depth_min = %.2f against the critical 12.6); " % (prec0, float(dv.max() / dv.min()))
                                               + result["config"]["conv_precision"])
+        result["config"]["precision_policy"] = "auto -> " + prec0
     if prec0 in ("f16x2", "f16mix", "f16", "stagemix"):
         result["config"]["gather_pass2"] = ("second gather on every stage (--no-keep-correlations)" if a.no_keep_correlations else
                                             "stream of the per-view correlations kept by pass 1 (fp32 on the exact coarse stages from D = 16 on, fp16 "
@@ -627,8 +630,23 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             result["fp32_equivalent_mode"] = {"error": repr(e)}
-        # ... and rounds 3-4's default, the uniform fp16 format on every stage (opt-in since round 5: it leaves the 1e-3 bar on ill-conditioned
-        # depth ranges) - what the exact coarse stages of the default policy cost on this workload
+        # ... and, when the default policy ("auto") chose the uniform fp16 format for this depth range, what its other branch - the exact coarse
+        # stages of "stagemix", which it takes on ill-conditioned ranges such as BASELINE cfg4 / cfg5's - costs on the same inputs
+        if getattr(head, "_auto", False) and head.fusions[0].precision_policy != "stagemix":
+            try:
+                headx = build_head(device, conv_precision="stagemix")
+                n2 = max(2, a.steps // 4)
+                tx, outx, _ = side_leg(headx, n2)
+                result["exact_coarse_mode"] = {"conv_precision": "stagemix", "value": R / tx, "unit": "ref-views/s", "ms_per_ref_view": tx / R * 1e3, "steps": n2,
+                                               "default_vs_this_refined_depth_rel_l1": float(((out["refined_depth"] - outx["refined_depth"]).abs() / outx["refined_depth"].abs()).mean()),
+                                               "note": "coarse stages (D = 32 / 16) fp32-equivalent: split-bf16 regulariser and visibility CNN, exact gather; fine stages f16mix - the branch the "
+                                                       "default policy takes when depth_max / depth_min exceeds half the critical ratio (round 5's unconditional default)"}
+                del headx, outx
+                torch.cuda.empty_cache()
+            except Exception as e:
+                result["exact_coarse_mode"] = {"error": repr(e)}
+        # ... and rounds 3-4's default, the uniform fp16 format on every stage (it leaves the 1e-3 bar on ill-conditioned
+        # depth ranges) - what the exact coarse stages cost on this workload, when they are what the headline ran
         if head.fusions[0].precision_policy == "stagemix":
             try:
                 head16 = build_head(device, conv_precision="f16mix")
@@ -642,26 +660,26 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 result["uniform_f16mix_mode"] = {"error": repr(e)}
-            # ... and the default policy fed with the hand-off a producer-side emitter gives it: the SAME features of
-            # stages 3-4 (the fp16 gather forms) as fp16 octet tiles, where a tap of 8 channels is one 16-byte run and the gather needs no LDS
-            # window (gather_lds.h, MVS_GL_DIRECT16); packed here by mvs_pack_features outside the timed region, like every input
-            if a.feat_layout == "planar" and a.feat_dtype == "fp32":
-                try:
-                    from mvsformerplusplus_amd import ops as _ops
-                    sets_t = [({k: (_ops.pack_features(v, torch.float16) if k in ("stage3", "stage4") else v) for k, v in f.items()}, p, d) for f, p, d in sets]
-                    n2 = max(2, a.steps // 4)
-                    tt, outt, _ = side_leg(head, n2, use_sets=sets_t)
-                    result["fp16_tiles_handoff_mode"] = {"features": "stages 3-4 as fp16 octet tiles [B,V,C/8,H,W,8] (TiledFeatureHead / mvs_conv2d3x3_tiles_fwd with fp16 output, or "
-                                                                     "mvs_pack_features), stages 1-2 as in the headline", "value": R / tt, "unit": "ref-views/s",
-                                                         "ms_per_ref_view": tt / R * 1e3, "steps": n2,
-                                                         "default_vs_this_refined_depth_rel_l1": float(((out["refined_depth"] - outt["refined_depth"]).abs() / outt["refined_depth"].abs()).mean()),
-                                                         "note": "same source-window values as the headline (its fp16 windows hold exactly these values); the REFERENCE view's features are "
-                                                                 "additionally rounded to fp16 here (planar fp32 keeps them fp32: ~3e-6 depth difference); the gather of stages 3-4 reads "
-                                                                 "the taps straight from the tiles, four 16-byte buffer loads per plane and octet, no bounding box / window / barrier"}
-                    del sets_t, outt
-                    torch.cuda.empty_cache()
-                except Exception as e:
-                    result["fp16_tiles_handoff_mode"] = {"error": repr(e)}
+        # ... and the default policy fed with the hand-off a producer-side emitter gives it: the SAME features of
+        # stages 3-4 (the fp16 gather forms) as fp16 octet tiles, where a tap of 8 channels is one 16-byte run and the gather needs no LDS
+        # window (gather_lds.h, MVS_GL_DIRECT16); packed here by mvs_pack_features outside the timed region, like every input
+        if a.feat_layout == "planar" and a.feat_dtype == "fp32":
+            try:
+                from mvsformerplusplus_amd import ops as _ops
+                sets_t = [({k: (_ops.pack_features(v, torch.float16) if k in ("stage3", "stage4") else v) for k, v in f.items()}, p, d) for f, p, d in sets]
+                n2 = max(2, a.steps // 4)
+                tt, outt, _ = side_leg(head, n2, use_sets=sets_t)
+                result["fp16_tiles_handoff_mode"] = {"features": "stages 3-4 as fp16 octet tiles [B,V,C/8,H,W,8] (TiledFeatureHead / mvs_conv2d3x3_tiles_fwd with fp16 output, or "
+                                                                 "mvs_pack_features), stages 1-2 as in the headline", "value": R / tt, "unit": "ref-views/s",
+                                                     "ms_per_ref_view": tt / R * 1e3, "steps": n2,
+                                                     "default_vs_this_refined_depth_rel_l1": float(((out["refined_depth"] - outt["refined_depth"]).abs() / outt["refined_depth"].abs()).mean()),
+                                                     "note": "same source-window values as the headline (its fp16 windows hold exactly these values); the REFERENCE view's features are "
+                                                             "additionally rounded to fp16 here (planar fp32 keeps them fp32: ~3e-6 depth difference); the gather of stages 3-4 reads "
+                                                             "the taps straight from the tiles, four 16-byte buffer loads per plane and octet, no bounding box / window / barrier"}
+                del sets_t, outt
+                torch.cuda.empty_cache()
+            except Exception as e:
+                result["fp16_tiles_handoff_mode"] = {"error": repr(e)}
 
     # ---- extra (round 5): the SHIPPED regulariser mix (stage-1 transformer + PE3D - what released checkpoints run) on the same
     #      inputs, outside the timed headline: value + its own parity against the oracle ----

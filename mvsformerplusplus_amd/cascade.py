@@ -35,7 +35,7 @@ class CascadeDepthHead(nn.Module):
         self.cost_reg_type = list(args.get("cost_reg_type", ["Normal"] * len(self.ndepths)))
         self.use_pe3d = args.get("use_pe3d", False)
         self.fusions = nn.ModuleList([StageNet(args, self.ndepths[i], i) for i in range(len(self.ndepths))])
-        self._auto = args.get("conv_precision") == "auto"
+        self._auto = args.get("conv_precision", M.DEFAULT_CASCADE_POLICY) == "auto"     # round 6: the default when args name no format / policy
         self._auto_seen: Dict[int, tuple] = {}         # id(tensor) -> (weakref, version, decision)
 
     def set_view_group(self, group, shard_mode: str = "auto") -> None:
@@ -46,7 +46,7 @@ class CascadeDepthHead(nn.Module):
             f.view_group = group
             f.shard_mode = shard_mode
 
-    # conv_precision="auto" (opt-in): the uniform fp16 format where the depth range makes it safe, the exact coarse stages elsewhere.
+    # conv_precision="auto" (the cascade's default since round 6): the uniform fp16 format where the depth range makes it safe, the exact coarse stages elsewhere.
     AUTO_SAFETY = 0.5          # fraction of the critical range ratio up to which "f16mix" is chosen
 
     def _auto_policy(self, depth_values: torch.Tensor) -> str:

@@ -136,7 +136,8 @@ class StageNet(nn.Module):
     @conv_precision.setter
     def conv_precision(self, policy: str) -> None:
         self.precision_policy = policy
-        self._conv_precision, self.gather_precision = resolve_stage_precision(policy, self.ndepth, self.args.get("model_th", 8))
+        self._conv_precision, self.gather_precision = resolve_stage_precision(policy, self.ndepth, self.args.get("model_th", 8),
+                                                                              bool(self.args.get("final_stage", False)))
 
     # ---- packed parameters ----
     def _vis_params(self, device):

@@ -19,8 +19,6 @@
 // x0 - 1 + c (c = 0..63); an MFMA tile is 16 consecutive columns of one row, wave w owns tile w.
 // Zero padding follows the reference exactly: every layer's OUTPUT is forced to zero outside the image (the next
 // Conv2d pads its input with zeros there), which is not the same as convolving zero-padded entropy.
-#include <cstdlib>
-
 #include "mvs_common.h"
 
 namespace mvs {
@@ -385,263 +383,11 @@ __global__ __launch_bounds__(256) void vis_cnn_kernel(const float* __restrict__ 
     for (; i < i1; ++i) general(i);                                           // drain
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave-autonomous form (round 6) of the one-term fp16 visibility CNN (MVS_PREC_F16 / _F16MIX: the fine stages of the default policy).
-//
-// The block form above gives every wave ONE 16-column MFMA tile of a 60-column strip and synchronises the four waves with a workgroup
-// barrier per image row: 11 MFMAs (176 matrix-pipe cycles) between two barriers.  PMC on the stage-4 launch (profiles/r05_pmc_pipe_per_stage.txt):
-// MFMA 30 % busy, VALU 45 %, LDS 48 %, waves 38 % of their cycles parked - a row takes ~540 cycles per SIMD for 176 cycles of matrix work.
-// Here a WAVE owns the whole strip: all four tiles of a row, its own two LDS rings (17 KB), no workgroup barrier anywhere - an LDS
-// instruction stream of one wave executes in order, so a row written in iteration i is visible to the reads of iteration i + 1 - and 44
-// independent MFMAs per row to schedule.  The entropy window is read straight from global memory one row ahead (12 dwords per lane and row,
-// L1-resident) instead of through a block-wide LDS tile.  Same arithmetic, same operand order as the block form: bit-identical results.
-// A block is just VS_NW independent waves (neighbouring strips of one row segment).
-// ------------------------------------------------------------------------------------------------
-#ifndef MVS_VIS_WAVE
-#define MVS_VIS_WAVE 1
-#endif
-constexpr int VS_NW = 4;
-
-// layer-2 and layer-3 rows of ALL FOUR tiles of a strip, one fp16 weight term: eight independent accumulator chains; the eight operand
-// reads of step s + 1 are in flight under the eight MFMAs (128 matrix-pipe cycles) of step s
-template <int SLOT2, int SLOT3>
-__device__ __forceinline__ void vs_two_layer_rows4(const char* lds1, const char* lds2, int laneoff0, int tapsel, const vs_bf16x8* w2h, const vs_bf16x8* w3h,
-                                                   f32x4* a, f32x4* c) {
-    constexpr int POSB = VsL<true>::POSB;
-    vs_f16x8 cb[4], cc[4], nb[4], nc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        cb[t] = *reinterpret_cast<const vs_f16x8*>(lds1 + vs_step_off<SLOT2, POSB>(laneoff0 + t * (16 * POSB), tapsel, 0));
-        cc[t] = *reinterpret_cast<const vs_f16x8*>(lds2 + vs_step_off<SLOT3, POSB>(laneoff0 + t * (16 * POSB), tapsel, 0));
-    }
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        if (s < 4) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                nb[t] = *reinterpret_cast<const vs_f16x8*>(lds1 + vs_step_off<SLOT2, POSB>(laneoff0 + t * (16 * POSB), tapsel, s + 1));
-                nc[t] = *reinterpret_cast<const vs_f16x8*>(lds2 + vs_step_off<SLOT3, POSB>(laneoff0 + t * (16 * POSB), tapsel, s + 1));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vs_f16x8, w2h[s]), cb[t], a[t], 0, 0, 0);
-            c[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vs_f16x8, w3h[s]), cc[t], c[t], 0, 0, 0);
-        }
-        if (s < 4) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { cb[t] = nb[t]; cc[t] = nc[t]; }
-        }
-    }
-}
-
-__global__ __launch_bounds__(64 * VS_NW) void vis_cnn_wave_kernel(const float* __restrict__ ent, const float* __restrict__ w1 /*[9][16]*/,
-                                                                  const float* __restrict__ b1, const void* __restrict__ wp2, const float* __restrict__ b2,
-                                                                  const void* __restrict__ wp3, const float* __restrict__ b3, const float* __restrict__ w4,
-                                                                  const float* __restrict__ b4, float* __restrict__ vis, int H, int W, int SH, int nstrips) {
-    HIP_DYNAMIC_SHARED(float4, lds4)
-    constexpr int POSB = VsL<true>::POSB, PLANE = VsL<true>::PLANE, LAYER = VsL<true>::LAYER;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int strip = (int)blockIdx.x * VS_NW + wave;
-    if (strip >= nstrips) return;                                  // wave-uniform; the kernel has no workgroup barrier
-    char* lds1 = reinterpret_cast<char*>(lds4) + wave * (2 * LAYER);
-    char* lds2 = lds1 + LAYER;
-    const int li = lane & 15, g = lane >> 4;
-    const int x0 = strip * VS_TW, r0 = (int)blockIdx.y * SH;
-    const int r1 = r0 + SH < H ? r0 + SH : H;
-    const float* e = ent + (size_t)blockIdx.z * H * W;
-    float* vo = vis + (size_t)blockIdx.z * H * W;
-
-    // ---- register-resident parameters (one fp16 term per weight) ----
-    vs_bf16x8 w2h[5], w3h[5];
-    {
-        const vs_bf16x8* q2 = reinterpret_cast<const vs_bf16x8*>(wp2) + lane;
-        const vs_bf16x8* q3 = reinterpret_cast<const vs_bf16x8*>(wp3) + lane;
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            w2h[t] = q2[(t * 2) * 64];
-            w3h[t] = q3[(t * 2) * 64];
-#ifndef MVS_NO_OPAQUE_VEC
-            asm volatile("" : "+" MVS_OPAQUE_VEC(w2h[t]), "+" MVS_OPAQUE_VEC(w3h[t]));
-#endif
-        }
-    }
-    vs_f16x8 w1a = {0, 0, 0, 0, 0, 0, 0, 0};                        // layer 1 as one K = 18 MFMA per tile (see the block form)
-    f32x4 b1q;
-    {
-        const int kh = g < 3 ? g : 0;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const _Float16 wv = g < 3 ? (_Float16)w1[(kh * 3 + kw) * 16 + li] : (_Float16)0.0f;
-            w1a[kw] = wv;
-            w1a[3 + kw] = wv;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b1q[r] = b1[4 * g + r];
-    }
-    float b2v[4], b3v[4], w4v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        b2v[r] = b2[4 * g + r];
-        b3v[r] = g < 2 ? b3[4 * g + r] : 0.0f;
-        w4v[r] = g < 2 ? w4[4 * g + r] : 0.0f;
-    }
-    const float bias4 = b4[0];
-
-    // ---- entropy window: lane (li, g) of tile t reads row i - 1 + min(g, 2), image columns x0 - 3 + 16 t + li + {0, 1, 2}.  One descriptor
-    //      over the view's map: rows outside the image are fetched at an out-of-range offset (zeros from the range check); columns outside
-    //      it alias a neighbouring row and are zeroed by a select - only in the strips that touch the left / right image border ----
-    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e), 0, (int)((unsigned)H * (unsigned)W * 4u), 0x00020000);
-    const int gsel = g < 3 ? g : 2;
-    const int colb = (x0 - 3 + li) * 4;                             // byte offset of column x0 - 3 + li (may be negative: wraps out of range on row 0)
-    const bool edge = x0 < 3 || x0 + 64 > W;
-    bool colok[4][3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int xe = x0 - 3 + 16 * t + li + kw;
-            colok[t][kw] = xe >= 0 && xe < W;
-        }
-    float eb[4][3];
-    auto fetch = [&](int i) __attribute__((always_inline)) {         // the window of layer-1 row i
-        const int y = i - 1 + gsel;
-        const unsigned voff = (unsigned)y < (unsigned)H ? (unsigned)(y * W * 4 + colb) : 0x80000000u;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-                eb[t][kw] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ers, (int)(voff + (unsigned)((16 * t + kw) * 4)), 0, 0));
-    };
-
-    const int tapsel = g >> 1;
-    const int laneoff0 = (g & 1) * PLANE + li * POSB;                // + 16 t POSB: B-operand reads of tile t
-    const int wr0 = (g >> 1) * PLANE + li * POSB + (g & 1) * 8;      // + 16 t POSB: epilogue stores of tile t
-    const int i0 = r0 - 2, i1 = r1 + 4;                            // iterations i0 .. i1-1 (layer-1 rows i0 .. r1+1 are needed)
-
-    // layer-1 row i of tile t from its (border-masked) window
-    auto layer1 = [&](int t, int i, const float* ew, int ph) __attribute__((always_inline)) {
-        typedef float vs_f32x2 __attribute__((ext_vector_type(2)));
-        typedef _Float16 vs_f16x2 __attribute__((ext_vector_type(2)));
-        typedef unsigned vs_u32x4 __attribute__((ext_vector_type(4)));
-        const float e0 = ew[0], e1 = ew[1], e2 = ew[2];
-        const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((vs_f32x2){e0, e1}, vs_f16x2));     // [hi0, hi1]
-        const float l0 = MVS_FMA_MIX_LO(p0, -1.0f, e0), l1 = MVS_FMA_MIX_HI(p0, -1.0f, e1);                           // e - (float)hi
-        const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((vs_f32x2){e2, l0}, vs_f16x2));     // [hi2, lo0]
-        const float l2 = MVS_FMA_MIX_LO(p1, -1.0f, e2);
-        const unsigned p2 = __builtin_bit_cast(unsigned, __builtin_convertvector((vs_f32x2){l1, l2}, vs_f16x2));     // [lo1, lo2]
-        const vs_f16x8 bop = __builtin_bit_cast(vs_f16x8, (vs_u32x4){p0, p1, p2, 0u});
-        const f32x4 r1v = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1a, bop, b1q, 0, 0, 0);
-        const int xa1 = x0 - 2 + 16 * t + li;
-        const bool in = xa1 >= 0 && xa1 < W && i >= 0 && i < H;
-        float a[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = fmaxf(r1v[r], 0.0f);
-        *reinterpret_cast<vs_f16x4*>(lds1 + wr0 + t * (16 * POSB) + ph * (VS_P * POSB)) = vs_mask4(vs_cvt4(a), in);
-    };
-    auto store2 = [&](int t, int yb, const f32x4& acc2, int ph2) __attribute__((always_inline)) {      // layer-2 row yb of tile t -> ring 2
-        const int xb = x0 - 1 + 16 * t + li;
-        const bool in = xb >= 0 && xb < W && yb >= 0 && yb < H;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc2[r], 0.0f);
-        *reinterpret_cast<vs_f16x4*>(lds2 + wr0 + t * (16 * POSB) + ph2 * (VS_P * POSB)) = vs_mask4(vs_cvt4(v), in);
-    };
-    auto store3 = [&](int t, int yc, const f32x4& acc3) __attribute__((always_inline)) {               // layer-3 row yc of tile t: 1x1 + sigmoid
-        float part = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part += fmaxf(acc3[r], 0.0f) * w4v[r];                   // rows 8..15 of the tile: zero weights
-        part += __shfl_xor(part, 16);
-        const int c2 = 16 * t + li, xc = x0 + c2;
-        if (g == 0 && c2 < VS_TW && xc < W && yc < r1) {
-            const float z = part + bias4;
-            vo[(size_t)yc * W + xc] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z * 1.4426950408889634f));
-        }
-    };
-    auto iteration = [&](auto phase, auto steady, int i) __attribute__((always_inline)) {
-        constexpr int PH = decltype(phase)::value;                  // == i & 3: ring slot of row i + k is (PH + k) & 3
-        constexpr bool STEADY = decltype(steady)::value != 0;       // every stage has a row to produce: no range logic, no branches
-        constexpr int S2 = (PH + 1) & 3, S3 = (PH + 3) & 3;          // slots of rows i-3 and i-5
-        const bool doA = STEADY || i <= r1 + 1;
-        const int yb = i - 2, yc = i - 4;
-        const bool doB = STEADY || (yb >= r0 - 1 && yb <= r1), doC = STEADY || yc >= r0;
-        // this row's window is in eb; the next row's loads go out before it is consumed
-        float ec[4][3];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) ec[t][kw] = (edge && !colok[t][kw]) ? 0.0f : eb[t][kw];
-        if (STEADY || i + 1 <= r1 + 1) fetch(i + 1);
-        if constexpr (STEADY) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) layer1(t, i, ec[t], PH);
-            f32x4 acc2[4], acc3[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc2[t] = (f32x4){b2v[0], b2v[1], b2v[2], b2v[3]};
-                acc3[t] = (f32x4){b3v[0], b3v[1], b3v[2], b3v[3]};
-            }
-            vs_two_layer_rows4<S2, S3>(lds1, lds2, laneoff0, tapsel, w2h, w3h, acc2, acc3);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) store2(t, yb, acc2[t], (PH + 2) & 3);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) store3(t, yc, acc3[t]);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (doA) layer1(t, i, ec[t], PH);
-                const int laneoff = laneoff0 + t * (16 * POSB);
-                f32x4 acc2 = {b2v[0], b2v[1], b2v[2], b2v[3]}, acc3 = {b3v[0], b3v[1], b3v[2], b3v[3]};
-                if (doB && doC) vs_two_layer_rows<S2, S3, true, true>(lds1, lds2, laneoff, tapsel, w2h, w2h, w3h, w3h, acc2, acc3);
-                else if (doB) acc2 = vs_layer_row<S2, true, true>(lds1, laneoff, tapsel, w2h, w2h, acc2);
-                else if (doC) acc3 = vs_layer_row<S3, true, true>(lds2, laneoff, tapsel, w3h, w3h, acc3);
-                if (doB) store2(t, yb, acc2, (PH + 2) & 3);
-                if (doC) store3(t, yc, acc3);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                             // no instruction on the GPU (the wave runs in lockstep); the host emulator's lanes meet here
-    };
-    auto general = [&](int i) __attribute__((always_inline)) {
-        switch (i & 3) {
-            case 0: iteration(VsInt<0>(), VsInt<0>(), i); break;
-            case 1: iteration(VsInt<1>(), VsInt<0>(), i); break;
-            case 2: iteration(VsInt<2>(), VsInt<0>(), i); break;
-            default: iteration(VsInt<3>(), VsInt<0>(), i); break;
-        }
-    };
-    fetch(i0);
-    int i = i0;
-    for (; i < i1 && (i < r0 + 4 || (i & 3) != 0); ++i) general(i);          // warm-up rows, then up to the next multiple of four
-    for (; i + 3 <= r1; i += 4) {                                             // steady state (the last of the four must still prefetch row i + 4 <= r1 + 1)
-        iteration(VsInt<0>(), VsInt<1>(), i);
-        iteration(VsInt<1>(), VsInt<1>(), i + 1);
-        iteration(VsInt<2>(), VsInt<1>(), i + 2);
-        iteration(VsInt<3>(), VsInt<1>(), i + 3);
-    }
-    for (; i < i1; ++i) general(i);                                           // drain
-}
-
-static int vis_weight_wave(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
-                           const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st) {
-    constexpr int LDS = VS_NW * 2 * VsL<true>::LAYER;
-    const int strips = (int)ceil_div(W, VS_TW), bx = (int)ceil_div(strips, VS_NW);
-    // segment height: a wave's run time ~ (SH + 6) row iterations; the launch takes ceil(waves / resident waves) of those back to back
-    const long long resident = (long long)(160 * 1024 / LDS) * VS_NW * 256;
-    int segs = (int)ceil_div(H, VS_SH_MAX), SH = (int)ceil_div(H, segs);
-    long long best = -1;
-    for (int sg = (int)ceil_div(H, VS_SH_MAX); sg <= (H + 7) / 8; ++sg) {
-        const int sh = (int)ceil_div(H, sg);
-        const long long rounds = ((long long)bx * VS_NW * N * ceil_div(H, sh) + resident - 1) / resident;
-        const long long cost = rounds * (sh + 6);
-        if (best < 0 || cost < best) { best = cost; segs = (int)ceil_div(H, sh); SH = sh; }
-    }
-    if (LDS > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_cnn_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipLaunchKernelGGL(vis_cnn_wave_kernel, dim3(bx, segs, N), dim3(64 * VS_NW), LDS, st, entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, H, W, SH, strips);
-    return check_launch("vis_cnn_wave_kernel");
-}
+// (Round 6 measured a wave-autonomous form of the one-term fp16 CNN - a wave owns a whole 60-column strip: four MFMA tiles per row, private
+// LDS rings, the entropy window straight from global memory, no workgroup barrier; bit-identical on the emulator - at 233 VGPRs / 70 KB of
+// LDS it ran two waves per SIMD and 15 % SLOWER than the block form above (101 vs 88 us per stage-3/4 launch, profiles/r06_vis_wave_ab.txt):
+// the kernel's cost is the SUM of its pipes' work - 40 us of MFMA issue, 53 us of LDS operand traffic (one ds_read_b128 per MFMA at 16 output
+// channels), 21 us of VALU per launch - not its barriers.  The kernel is in git history, commit "visibility CNN: wave-autonomous kernel".)
 
 template <bool F16, bool ONE = false>
 static int vis_weight_stream_t(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
@@ -670,13 +416,7 @@ static int vis_weight_stream_t(const float* entropy, const float* w1, const floa
 // (MVS_PREC_F16 / MVS_PREC_F16MIX)
 int vis_weight_stream_bf16x3(const float* entropy, const float* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                              const float* b3, const float* w4, const float* b4, float* vis, int N, int H, int W, hipStream_t st, int f16) {
-    if (f16 == 2) {
-#if MVS_VIS_WAVE
-        const bool block_form = getenv("MVS_VIS_BLOCK") != nullptr;                 // A/B switch (read per call: tests flip it): the round-5 block form
-        if (!block_form) return vis_weight_wave(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
-#endif
-        return vis_weight_stream_t<true, true>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
-    }
+    if (f16 == 2) return vis_weight_stream_t<true, true>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
     return f16 ? vis_weight_stream_t<true>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st)
                : vis_weight_stream_t<false>(entropy, w1, b1, w2, b2, w3, b3, w4, b4, vis, N, H, W, st);
 }

@@ -60,14 +60,23 @@ DEFAULT_STAGE_POLICY = "stagemix"
 # handed (cascade.CascadeDepthHead._auto_policy: depth_max / depth_min against the ratio at which the inverse-depth schedule degenerates);
 # a StageNet used on its own (patch_model: the reference's loop hands it hypotheses, not the range) resolves "auto" like "stagemix".
 STAGE_POLICIES = ("stagemix", "auto")
+# Round 6: the CASCADE's default (cascade.CascadeDepthHead built from args without "conv_precision") is "auto" - the head sees the depth range
+# and pays the exact coarse stages only where the range makes the schedule ill-conditioned (BASELINE cfg4 / cfg5's literal 0.5 .. 10: "stagemix";
+# DTU-like ranges, ratio 2.2: uniform "f16mix", 5e-5 from the fp32 oracle).  Both branches hold the 1e-3 bar (parity_cases.case_auto_policy,
+# case_cascade_vs_oracle_finite).  A StageNet on its own keeps DEFAULT_STAGE_POLICY: it is handed hypotheses, never the range.
+DEFAULT_CASCADE_POLICY = "auto"
 
 
-def resolve_stage_precision(policy: str, ndepth: int, model_th: int = 8):
+def resolve_stage_precision(policy: str, ndepth: int, model_th: int = 8, final_stage: bool = False):
     """(conv_precision, gather_precision) of a stage under `policy` = args["conv_precision"]: "stagemix" (above) or one format for every
     stage.  gather_precision "f16" = fp16 source windows + fp16 kept correlations (the fp16 formats); "f32" = fp32 windows, pass 2 exact
-    (fp32 kept correlations or a second gather) - "bf16x3" / "fp32" and the coarse stages of "stagemix"."""
+    (fp32 kept correlations or a second gather) - "bf16x3" / "fp32" and the coarse stages of "stagemix".
+    final_stage (round 6, args["final_stage"]): the caller states that this stage's depth schedules NO further stage - a StageNet used on
+    its own (SURVEY 8d Track S, BASELINE cfg1) or the last stage of a cascade whose ndepth exceeds model_th.  The policies then give it the
+    fine stages' format: the exactness of the coarse stages exists because the cascade amplifies THEIR noise through the next stage's
+    hypotheses (scripts/study_stage_mix.py); a stage with no successor only carries its own 5e-5."""
     if policy in ("stagemix", "auto"):
-        return ("bf16x3", "f32") if ndepth > model_th else (DEFAULT_PRECISION, "f16")
+        return ("bf16x3", "f32") if (ndepth > model_th and not final_stage) else (DEFAULT_PRECISION, "f16")
     if policy in F16_FORMATS:
         return policy, "f16"
     return policy, "f32"

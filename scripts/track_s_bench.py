@@ -14,8 +14,8 @@ dev = torch.device("cuda:0")
 ARGS = {"base_ch": [8, 8, 8, 8], "depth_type": ["ce"] * 4, "fusion_type": "cnn", "cost_reg_type": ["Normal"] * 4}
 for name, H, W, V, D, reps in (("cfg1  640x512  V=3 D=48 ", 512, 640, 3, 48, 20), ("TrackS 1152x1536 V=3 D=192", 1152, 1536, 3, 192, 5),
                                ("TrackS 1152x1536 V=5 D=192", 1152, 1536, 5, 192, 5)):
-    for prec in (None, "f16mix"):
-        st = StageNet(dict(ARGS, **({"conv_precision": prec} if prec else {})), D, 3)
+    for prec in (None, "final_stage", "f16mix"):       # the default policy; the same with args["final_stage"] (round 6); the explicit fp16 format
+        st = StageNet(dict(ARGS, **({"final_stage": True} if prec == "final_stage" else {"conv_precision": prec} if prec else {})), D, 3)
         st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 5), strict=True)
         st = st.eval().to(dev)
         st.return_prob_volumes = True
@@ -36,7 +36,7 @@ for name, H, W, V, D, reps in (("cfg1  640x512  V=3 D=48 ", 512, 640, 3, 48, 20)
         # SURVEY 8d byte model: features once + hypotheses + volume write + regulariser R = 51 floats / voxel (CostRegNet) + head 2 reads + outputs
         algo = V * 8 * H * W * 4 + nvox * 4 + 8 * nvox * 4 + 51 * nvox * 4 + 2 * nvox * 4 + 2 * H * W * 4
         print("%s %-8s %8.2f ms per StageNet call   %.2f GB algorithmic (SURVEY 8d)  ->  %.0f GB/s = %.1f %% of 8 TB/s   peak memory %.1f GB" % (
-            name, st.precision_policy if prec is None else prec, ms, algo / 1e9, algo / ms / 1e6, algo / ms / 1e6 / 80.0, torch.cuda.max_memory_allocated() / 1e9), flush=True)
+            name, (st.precision_policy if prec is None else "final_st" if prec == "final_stage" else prec), ms, algo / 1e9, algo / ms / 1e6, algo / ms / 1e6 / 80.0, torch.cuda.max_memory_allocated() / 1e9), flush=True)
         del st, feats, hyp
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()

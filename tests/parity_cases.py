@@ -793,16 +793,6 @@ def case_vis_cnn(device):
             assert vis.shape == ent.shape
             err = float((cpu(vis) - ref).abs().max())
             assert err <= tol, (N, H, W, prec, err)
-            if prec in ("f16", "f16mix"):
-                # round 6: these formats run the wave-autonomous kernel (vis_cnn_wave_kernel); the round-5 block form (one tile per wave, a
-                # workgroup barrier per row) computes the same MFMAs in the same order: bit-identical
-                import os
-                os.environ["MVS_VIS_BLOCK"] = "1"
-                try:
-                    vis_b = ops.vis_weight(dev(ent, device), st._vis_params(torch.device(device) if isinstance(device, str) else device), _lib.PRECISIONS[prec])
-                finally:
-                    del os.environ["MVS_VIS_BLOCK"]
-                assert torch.equal(cpu(vis_b), cpu(vis)), ("wave form vs block form", N, H, W, prec, float((cpu(vis_b) - cpu(vis)).abs().max()))
 
 
 def case_gather_variants(device, quick=False):
@@ -1334,13 +1324,16 @@ BASELINE_CFGS = {
 }
 
 
-def case_baseline_cfg1(device, prec=None):
+def case_baseline_cfg1(device, prec=None, final_stage=False):
     """configs[0] / Track S: one StageNet, stage_idx 3 (C = G = 8), 640x512, V = 3, D = 48 fronto-parallel hypotheses
-    linspace(425, 935) -> CostRegNet (D > 8) with the 3x3x3 head."""
+    linspace(425, 935) -> CostRegNet (D > 8) with the 3x3x3 head.  final_stage: args["final_stage"] = True (round 6) - the default policy
+    then runs this stand-alone stage in the fine stages' fp16 format instead of the exact coarse-stage one; same 1e-3 bar."""
     from mvsformerplusplus_amd.cost_volume import StageNet
     H, W, V, D = 512, 640, 3, 48
-    st = StageNet(with_prec(ARGS, prec), D, 3)
+    st = StageNet(dict(with_prec(ARGS, prec), final_stage=True) if final_stage else with_prec(ARGS, prec), D, 3)
     assert st.precision_policy == eff(prec)
+    if final_stage and prec is None:
+        assert (st.conv_precision, st.gather_precision) == ("f16mix", "f16")
     st.load_state_dict(synth.seeded_state_dict(synth.state_dict_manifest(st.state_dict()), 5), strict=True)
     st = st.eval().to(device)
     cams = synth.make_cameras(V, H, W, baseline=20.0, seed=0)

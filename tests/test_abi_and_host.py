@@ -46,6 +46,20 @@ def test_product_default_precision():
     assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("stagemix", "f16mix", "f16")
 
 
+def test_final_stage_policy():
+    """args["final_stage"] (round 6): a stage whose depth schedules no further stage takes the fine stages' format under the
+    policies even when ndepth > model_th (Track S / BASELINE cfg1: StageNet(args, 48, 3) on its own); explicit formats are untouched."""
+    from mvsformerplusplus_amd.cost_volume import StageNet
+    base = {"base_ch": [8] * 4, "depth_type": ["ce"] * 4}
+    n = StageNet(dict(base), 48, 3)
+    assert (n.precision_policy, n.conv_precision, n.gather_precision) == ("stagemix", "bf16x3", "f32")
+    f = StageNet(dict(base, final_stage=True), 48, 3)
+    assert (f.precision_policy, f.conv_precision, f.gather_precision) == ("stagemix", "f16mix", "f16")
+    assert StageNet(dict(base, final_stage=True, conv_precision="auto"), 48, 3).conv_precision == "f16mix"
+    x = StageNet(dict(base, final_stage=True, conv_precision="bf16x3"), 48, 3)
+    assert (x.conv_precision, x.gather_precision) == ("bf16x3", "f32")
+
+
 def test_auto_policy_decisions():
     """conv_precision="auto" (opt-in): the decision rule of CascadeDepthHead._auto_policy on host tensors (no kernel runs): uniform "f16mix" while
     depth_max / depth_min <= half the critical ratio (ndepths[0] - 1) / ratio[1] + 1, "stagemix" beyond it, for the linear schedule, for
@@ -69,6 +83,25 @@ def test_auto_policy_decisions():
     t[:, -1] = 9000.0                                                                               # in-place change = a new version = a new decision
     assert h._auto_policy(t) == "stagemix"
     assert CascadeDepthHead(dict(args, inverse_depth=False))._auto_policy(torch.linspace(425.0, 931.0, 192)[None]) == "stagemix"
+    # a NEW tensor that the allocator places at the address of a freed one (fresh tensors all have version 0) must get its own
+    # decision - round 5's cache was keyed on (data_ptr, version, shape) and handed a 0.5 .. 10 scene the "f16mix" of a DTU scene
+    src_dtu, src_wide, reused = torch.linspace(425.0, 931.0, 192)[None], torch.linspace(0.5, 10.0, 192)[None], 0
+    for k in range(64):
+        dtu = src_dtu.clone()
+        assert h._auto_policy(dtu) == "f16mix"
+        ptr = dtu.data_ptr()
+        del dtu
+        wide = src_wide.clone()
+        reused += int(wide.data_ptr() == ptr)
+        assert h._auto_policy(wide) == "stagemix", "stale decision for a tensor at a reused address"
+        del wide
+    print("address reuse reproduced in %d of 64 rounds" % reused)      # (the CPU allocator reuses the block every time here; not asserted)
+    # the default of a cascade built without conv_precision IS this policy (round 6); a StageNet on its own keeps the exact coarse stages
+    d = CascadeDepthHead({k: v for k, v in args.items() if k != "conv_precision"})
+    assert d._auto and [f.precision_policy for f in d.fusions] == ["stagemix"] * 4
+    with torch.inference_mode():                       # inference tensors carry no version counter: decided from the values every call
+        it = torch.linspace(425.0, 931.0, 192)[None].clone()
+        assert h._auto_policy(it) == "f16mix" and h._auto_policy(it) == "f16mix"
 
 
 def test_header_matches_binding_table():

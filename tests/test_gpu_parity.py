@@ -215,6 +215,12 @@ def test_baseline_cfg1_stage4_d48(prec):
     print("cfg1 %s: depth rel-L1 %.2e, prob_volume max abs %.2e" % (P.eff(prec), r, pe))
 
 
+def test_baseline_cfg1_final_stage():
+    """The same stand-alone stage with args["final_stage"]: the default policy's fp16 format, same bar."""
+    r, pe = P.case_baseline_cfg1(DEV, None, final_stage=True)
+    print("cfg1 final_stage (f16mix): depth rel-L1 %.2e, prob_volume max abs %.2e" % (r, pe))
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
 def test_baseline_cfgs_small_vs_oracle(name, prec):
