@@ -82,6 +82,12 @@ constexpr bool gl_direct_v = (MVS_GL_DIRECT16 != 0) && W16 && TILED && std::is_s
 #ifndef MVS_GL_OPT
 #define MVS_GL_OPT 1
 #endif
+#ifndef MVS_GL_SB
+#define MVS_GL_SB 2                // planar staging: rounds of 256 window positions whose loads are issued back to back before any is consumed (1: round-5 order)
+#endif
+#ifndef MVS_GL_ABL
+#define MVS_GL_ABL 0               // measurement only (scripts/gather_ablate.py; results are wrong): 1 no window loads (zeros staged), 2 no staging at all,
+#endif                             // 3 no window reads in the gather, 4 no blend arithmetic, 5 no bounding-box reduction (a fixed window), 6 no tap projection
 
 // the four taps of one plane into wv[0..7]: t = 8 halves (4 registers) per tap
 #define GL_BLEND8(wv, t00, t01, t10, t11, tp)                                                          \
@@ -120,7 +126,12 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
     // mx holds the maximum of (x + 1, y + 1): the sentinel GL_NONE wraps to (0, 0), neutral for it; mn takes the sentinel as it is
 #pragma unroll
     for (int dd = 0; dd < GL_DCH; ++dd) {
+#if MVS_GL_ABL == 6
+        tp[dd].pk = ((unsigned)(int)fy << 16) | (unsigned)(int)fx; tp[dd].w00 = depth[dd]; tp[dd].w01 = qx; tp[dd].w10 = 0.25f; tp[dd].w11 = 0.25f;
+        if ((int)fx > W - 2 || (int)fy > H - 2) tp[dd].pk = 0;
+#else
         tp[dd] = make_gtap(hm, qx, qy, qz, depth[dd], H, W, cx, cy);
+#endif
         const u16x2 pkv = gl_as_vec(tp[dd].pk);
         mn = __builtin_elementwise_min(mn, pkv);
         mx = __builtin_elementwise_max(mx, (u16x2)(pkv + (u16x2){1, 1}));
@@ -146,18 +157,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             tofs[dd] = pk == GL_NONE ? 0u : ((pk >> 16) * (unsigned)W + (pk & 0xffffu)) * 16u;
         }
         const int rowb = W * 16;                                 // wave-uniform: the lower tap row through soffset
-#if MVS_GL_DIRECT16 == 4
-        // Column sharing (measurement variant): where the next lane's left column IS this lane's right column (tofs[lane + 1] == tofs + 16 - the
-        // usual case at a view scale near 1), the right column comes from that lane's registers (DPP wave_shl:1) and only the remaining lanes
-        // load it (the masked load overwrites the shifted values in place).  Every lane of the wave takes part in the shifts: no early return;
-        // lanes without work hold valid taps of a clamped pixel.
-        bool share[GL_DCH];
-#pragma unroll
-        for (int dd = 0; dd < GL_DCH; ++dd)
-            share[dd] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)tofs[dd], 0x130, 0xf, 0xf, true) == tofs[dd] + 16u;
-#else
         if (!active) return;
-#endif
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) {
             unsigned oofs = gl_octet_offset(o, HW);
@@ -177,9 +177,6 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 (void)rs; (void)rowb;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[dd][k] = u32x4{tofs[dd], tofs[dd] + (unsigned)k, tofs[dd] ^ 0x3c003c00u, 0x3c003c00u};
-#elif MVS_GL_DIRECT16 == 4
-                t[dd][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], 0, 0);
-                t[dd][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], rowb, 0);
 #else
                 t[dd][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tofs[dd], 0, 0);
                 t[dd][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), 0, 0);
@@ -187,21 +184,6 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                 t[dd][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), rowb, 0);
 #endif
             }
-#if MVS_GL_DIRECT16 == 4
-#pragma unroll
-            for (int dd = 0; dd < GL_DCH; ++dd) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    t[dd][1][j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t[dd][0][j], 0x130, 0xf, 0xf, true);
-                    t[dd][3][j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t[dd][2][j], 0x130, 0xf, 0xf, true);
-                }
-                if (!share[dd]) {
-                    t[dd][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), 0, 0);
-                    t[dd][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tofs[dd] + 16u), rowb, 0);
-                }
-            }
-            if (!active) continue;
-#endif
 #pragma unroll
             for (int c = 0; c < 8; ++c) rf[c] *= wscale;
 #pragma unroll
@@ -247,6 +229,17 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
         }
         return;
     }
+#if MVS_GL_ABL == 5
+    {
+        __syncthreads();
+        const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)tp[0].pk);
+        const unsigned bx = (p0 & 0xffffu) > 8u ? (p0 & 0xffffu) - 8u : 0u, by = (p0 >> 16) > 2u ? (p0 >> 16) - 2u : 0u;
+        mn = gl_as_vec((by << 16) | bx);
+        mx = gl_as_vec(((by + 9u) << 16) | (bx + 81u));
+#pragma unroll
+        for (int dd = 0; dd < GL_DCH; ++dd) tp[dd].pk = ((by + 1u + (unsigned)(lane & 3)) << 16) | (bx + 1u + (unsigned)(lane & 63));
+    }
+#else
     mn = gl_wave_reduce<false>(mn);                               // lane 63 holds the wave's result
     mx = gl_wave_reduce<true>(mx);
     unsigned* rd = red + (unit & 1) * 8;
@@ -256,6 +249,7 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                                    __builtin_elementwise_min(gl_as_vec(rd[2]), gl_as_vec(rd[3])));
     mx = __builtin_elementwise_max(__builtin_elementwise_max(gl_as_vec(rd[4]), gl_as_vec(rd[5])),
                                    __builtin_elementwise_max(gl_as_vec(rd[6]), gl_as_vec(rd[7])));
+#endif
 #if MVS_GL_OPT
     const int xmin = mn[0], ymin = mn[1], xmax = (int)mx[0] - 1, ymax = (int)mx[1] - 1;       // mx = maximum of (x + 1, y + 1); 0 = nothing
 #else
@@ -303,8 +297,59 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
             const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(so), 0, (int)(8u * HW * (unsigned)sizeof(T)), 0x00020000);
             const unsigned planeb = HW * (unsigned)sizeof(T);
 #endif
+            int istart = tid;
+#if MVS_GL_OPT && MVS_GL_ABL == 0
+            if constexpr (!TILED) {
+                // Round 6 (profiles/r06_gather_ablation.txt): the rolled loop below - load 8 dwords, wait, convert, ds_write - exposed one global-memory
+                // latency per round of 256 positions, two or three rounds per unit between two barriers: 19-36 % of a fine-stage pass.  Here the loads
+                // of MVS_GL_SB rounds are all in flight before the first is consumed (8 VGPRs per extra round).  Measured (profiles/r06_gather_staging_rounds_ab.txt):
+                // stage-4 pass 1 -4 %, pass 2 -5 %; at C = 16 the extra registers cost the keeping pass its fourth wave per SIMD (+12 %), at C >= 32 nothing
+                // moves: one octet per unit only.  (The ablation's 19-36 % are mostly the HBM time of the feature maps themselves, which the
+                // barrier-separated phases of four resident blocks overlap imperfectly - not a latency two rounds in flight could hide.)
+                constexpr int SBR = NOCT == 1 ? MVS_GL_SB : 1;
 #pragma unroll 1
-            for (int i = tid; i < n; i += 256) {
+                for (int i0 = tid; i0 < n; i0 += 256 * SBR) {
+                    float v[SBR][8];
+#pragma unroll
+                    for (int k = 0; k < SBR; ++k) {
+                        const int i = i0 + 256 * k;
+                        if (i < n) {
+                            const int row = (int)(((float)i + 0.5f) * inv_ww);
+                            const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                if constexpr (sizeof(T) == 4)
+                                    v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, (int)(g * 4u), (int)((unsigned)c * planeb), 0));
+                                else
+                                    v[k][c] = to_f32(__builtin_bit_cast(T, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(srs, (int)(g * 2u), (int)((unsigned)c * planeb), 0)));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < SBR; ++k) {
+                        const int i = i0 + 256 * k;
+                        if (i < n) {
+                            if (W16) {
+                                h8 hv;
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) hv[c] = (_Float16)__builtin_amdgcn_fmed3f(v[k][c], -65504.0f, 65504.0f);
+                                win16[i] = hv;
+                            } else {
+                                win[i] = f32x4{v[k][0], v[k][1], v[k][2], v[k][3]};
+                                win[GL_CAP + i] = f32x4{v[k][4], v[k][5], v[k][6], v[k][7]};
+                            }
+                        }
+                    }
+                }
+                istart = n;
+            }
+#endif
+#pragma unroll 1
+            for (int i = istart; i < (MVS_GL_ABL == 2 ? 0 : n); i += 256) {
+#if MVS_GL_ABL == 1
+                if (W16) { h8 hz; for (int c = 0; c < 8; ++c) hz[c] = (_Float16)(float)(i & 7); win16[i] = hz; } else { win[i] = f32x4{1, 2, 3, 4}; win[GL_CAP + i] = f32x4{1, 2, 3, 4}; }
+                continue;
+#endif
                 const int row = (int)(((float)i + 0.5f) * inv_ww);
                 const unsigned g = gbase + (unsigned)row * (unsigned)(W - ww) + (unsigned)i;    // (ymin+row)*W + wx0 + (i - row*ww)
 #if MVS_GL_OPT
@@ -358,8 +403,15 @@ __device__ __forceinline__ void gl_unit(const T* __restrict__ src, const T* __re
                     if (W16) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4* w0 = reinterpret_cast<const u32x4*>(win16) + pos[dd];
+#if MVS_GL_ABL == 3
+                        const u32x4 t00 = {pos[dd], 0x3c003c00u, 0x3c003c00u, pos[dd]}, t01 = t00, t10 = {0x3c003c00u, pos[dd], pos[dd], 0x3c003c00u}, t11 = t10;
+#else
                         const u32x4 t00 = w0[0], t01 = w0[1], t10 = w0[ww], t11 = w0[ww + 1];
-#if MVS_GL_OPT
+#endif
+#if MVS_GL_ABL == 4
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { wv[2 * j] = __builtin_bit_cast(float, (t00[j] ^ t01[j] ^ t10[j] ^ t11[j]) & 0x3fffffffu); wv[2 * j + 1] = tp[dd].w00; }
+#elif MVS_GL_OPT
                         GL_BLEND8(wv, t00, t01, t10, t11, tp[dd])
 #else
 #pragma unroll
