@@ -3,11 +3,11 @@
 # Usage: gpurun --timeout 1800 -- 'bash scripts/gpu_round.sh <tag>'
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r05}
+ROOT=$(pwd); OUT=gpurun_out; TAG=${1:-r06}
 mkdir -p $OUT
 export PYTHONDONTWRITEBYTECODE=1
 echo "== pytest -m gpu =="
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/pytest_gpu.log
 echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
 # PMC first: bench.py's roofline.traffic / whole_path.frac_pmc read profiles/pmc_traffic.json, which must describe THIS build's kernels
@@ -20,13 +20,13 @@ mkdir -p $OUT/profiles_$TAG
 python scripts/pmc_traffic.py $OUT/pmc_$TAG $OUT/profiles_$TAG/pmc_traffic.json $OUT/profiles_$TAG/${TAG}_pmc_fetch_write_raw.json
 cp $OUT/profiles_$TAG/pmc_traffic.json profiles/pmc_traffic.json
 echo "== bench (driver's command) =="
-timeout 900 python bench.py --steps 20 --warmup 5 --profile-table > $OUT/bench.json 2> $OUT/bench.err
+timeout 1500 python bench.py --steps 20 --warmup 5 --profile-table > $OUT/bench.json 2> $OUT/bench.err
 grep -v "amdgpu.ids" $OUT/bench.err | tail -45
 python - <<'PY'
 import json
 r = json.loads(open('gpurun_out/bench.json').read().strip().splitlines()[-1])
 print({k: r[k] for k in ('value', 'ms_per_step', 'ms_per_ref_view') if k in r})
-for k in ('latency', 'whole_path', 'roofline', 'cpu_baseline', 'parity', 'fp32_equivalent_mode', 'uniform_f16mix_mode', 'fp16_tiles_handoff_mode', 'shipped', 'feature_emitter'):
+for k in ('latency', 'whole_path', 'roofline', 'cpu_baseline', 'torch_rocm_composite', 'parity', 'exact_coarse_mode', 'fp32_equivalent_mode', 'uniform_f16mix_mode', 'fp16_tiles_handoff_mode', 'shipped', 'feature_emitter'):
     print(k, r.get(k))
 print('gather', r.get('gather_roofline', {}).get('all_passes'))
 PY
@@ -95,6 +95,15 @@ grep -v "amdgpu.ids" $OUT/bench_bf16x3.err > $OUT/profiles_$TAG/${TAG}_bench_ker
 grep -v "amdgpu.ids" $OUT/bench.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table.txt
 grep -v "amdgpu.ids" $OUT/bench_shipped.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_shipped.txt
 rm -rf $OUT/prof_$TAG $OUT/prof1_$TAG $OUT/pmc_$TAG
+echo "== bench, the exact-coarse branch of the default policy (--conv-precision stagemix) =="
+timeout 600 python bench.py --steps 10 --warmup 3 --profile-table --no-train-leg --no-cpu-baseline --no-shipped-leg --conv-precision stagemix > $OUT/bench_stagemix.json 2> $OUT/bench_stagemix.err
+python -c "
+import json; r = json.loads(open('gpurun_out/bench_stagemix.json').read().strip().splitlines()[-1]); print('stagemix', r['value'], r['ms_per_ref_view'], r['latency']['single_stream_ms_per_ref_view'])"
+cp $OUT/bench_stagemix.json $OUT/profiles_$TAG/${TAG}_bench_1gpu_stagemix.json
+grep -v "amdgpu.ids" $OUT/bench_stagemix.err > $OUT/profiles_$TAG/${TAG}_bench_kernel_table_stagemix.txt
+echo "== Track S (one StageNet at a literal D) and the U-Net layer table =="
+timeout 600 python scripts/track_s_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/profiles_$TAG/${TAG}_track_s.txt
+timeout 300 python scripts/bench_unet_layers.py 2>&1 | grep -v amdgpu.ids | tee $OUT/profiles_$TAG/${TAG}_unet_layers.txt
 echo "== PMC pipe utilisation per kernel (three counter passes over a short bench run) =="
 bash scripts/gpu_pmc_bench.sh $TAG --no-train-leg --no-shipped-leg --issue eager --views-per-step 8 > $OUT/pmc_pipe.log 2>&1
 cp $OUT/pmc_$TAG/summary.txt $OUT/profiles_$TAG/${TAG}_pmc_pipe_utilisation.txt
