@@ -791,6 +791,10 @@ def composite_baseline(head, feats, projs, dv, out, shipped=False):
     compared with it as a second parity read-out (same device, other kernels)."""
     from oracle import ref_path as O
     dev = dv.device
+    # MIOpen's default find mode spends ~2 minutes benchmarking every convolution shape of the cascade in the first pass; "FAST" (immediate mode) picks the
+    # same-speed kernels here (measured: 24.9 vs 24.8 ref-views/s steady state, warm-up 0.45 s vs 124 s; scripts/gpu_r6k.sh).  Only this leg uses MIOpen
+    # (the product path has no MIOpen call), and the library reads the variable at its first convolution: set here unless the caller chose a mode.
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     sds = [{k: v.detach().to(dev) for k, v in st.state_dict().items()} for st in head.fusions]
     f = {k: (v.unpack() if hasattr(v, "unpack") else v).float() for k, v in feats.items()}
 
@@ -817,8 +821,10 @@ def composite_baseline(head, feats, projs, dv, out, shipped=False):
                       "then the median of three passes: %s ms" % (warm, " / ".join("%.1f" % (t * 1e3) for t in ts)),
             "peak_memory_gb": torch.cuda.max_memory_allocated() / 1e9,
             "hip_path_vs_this_refined_depth_rel_l1": float(((d - r).abs() / r.abs()).mean()),
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"),
             "note": "oracle/ref_path.py (the CPU restatement of models/cost_volume.py:51-133 + module.py regularisers + the cascade loop) with its "
-                    "tensors on cuda:0: stock PyTorch-ROCm composite kernels, the baseline a patch_model user starts from"}
+                    "tensors on cuda:0: stock PyTorch-ROCm composite kernels, the baseline a patch_model user starts from (MIOpen immediate mode unless "
+                    "MIOPEN_FIND_MODE is set: the exhaustive default costs a 2-minute first pass for the same steady state)"}
 
 
 def emitter_leg(device, V):
